@@ -1,0 +1,171 @@
+/*
+ * tempest_hip.h -- C ABI of libtempest_hip.so: the MI355X (gfx950) persistent-SMC hot path.
+ *
+ * Drop-in boundary for the numerics of minaskar/tempest v0.2.1 (reference file:line cited per
+ * entry point, relative to the reference tree).  The reference is pure Python/NumPy and has no FFI
+ * of its own; these are the calls its four step plugins (tempest/steps/ *.py) and its StateManager
+ * (tempest/state_manager.py) would bind if their NumPy bodies were replaced (INTEGRATION.md shows
+ * the ctypes stubs).  Host code above this boundary: tempest_amd/ (Python, mirrors the reference's
+ * Sampler / steps API).
+ *
+ * Conventions
+ *  - extern "C"; every function returns 0 on success, <0 on error; tph_last_error() returns the
+ *    thread-local message of the last failure.
+ *  - tph_ctx owns the persistent particle history and all scratch; every other pointer is a
+ *    BORROWED raw pointer valid for the call only.  `_dev` = device pointer, `_host` = host pointer.
+ *  - Particle arrays are structure-of-arrays, dimension-major: a[j*ld + i] is coordinate j of
+ *    particle i (ld >= n).  All reals are FP64, indices int64, labels int32.
+ *  - All work is enqueued on the hipStream_t given to tph_ctx_create / tph_set_stream (pass the
+ *    caller framework's current stream so its own kernels are ordered with ours).  Functions whose
+ *    outputs are `_host` synchronise that stream before returning; all others are asynchronous.
+ *  - One ctx per device, not re-entrant.
+ *  - Randomness is counter-based Philox4x32-10: (seed, tick, tag, item, draw) -> bits, so results do
+ *    not depend on launch geometry or on how particles are sharded (item = global particle index =
+ *    item0 + local index).  The reference's global NumPy RNG (mcmc.py:169,236,243,307 ...) cannot be
+ *    reproduced on a GPU; parity for RNG-consuming steps is as pure functions of the draws.
+ */
+#ifndef TEMPEST_HIP_H
+#define TEMPEST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tph_ctx tph_ctx;
+
+#define TPH_VERSION 100
+
+/* proposal kernels (tempest/config.py:135-137: only these two exist in the reference) */
+#define TPH_KERNEL_TPCN 0
+#define TPH_KERNEL_RWM 1
+
+/* per-dimension boundary flags (tempest/mcmc.py:326-411) */
+#define TPH_BC_STRICT 0
+#define TPH_BC_PERIODIC 1
+#define TPH_BC_REFLECTIVE 2
+
+/* history array keys for tph_history_read / tph_history_ptr */
+#define TPH_KEY_U 0
+#define TPH_KEY_X 1
+#define TPH_KEY_LOGL 2
+#define TPH_KEY_LOGMIX 3
+
+const char* tph_last_error(void);
+int tph_version(void);
+
+/* ---- context ------------------------------------------------------------------------------- */
+int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void* hip_stream, tph_ctx** out);
+int tph_ctx_destroy(tph_ctx* ctx);
+int tph_set_stream(tph_ctx* ctx, void* hip_stream);
+int tph_synchronize(tph_ctx* ctx);
+
+/* ---- persistent ensemble: StateManager history (state_manager.py:171-176,356-416) ------------
+ * tph_history_append = commit_current_to_history for the array keys u, x, logl, plus the cached
+ * per-particle log-mixture  C_s = log sum_t n_t exp(beta_t l_s - logZ_t)  (state_manager.py:466-471,
+ * kept up to the common -log N_h) updated incrementally: one logaddexp term for the old particles,
+ * the full T-term fold for the n new ones.  n_global is n_t of the mixture (the iteration's particle
+ * count over all shards; = n on one GPU). */
+int tph_history_append(tph_ctx* ctx, const double* u_dev, const double* x_dev, const double* logl_dev,
+                       int64_t n, int64_t ld, double beta, double logz, int64_t n_global);
+int64_t tph_history_size(const tph_ctx* ctx);        /* N_h held by this ctx */
+int tph_history_iterations(const tph_ctx* ctx);      /* T */
+int tph_history_clear(tph_ctx* ctx);
+/* copy rows [off, off+n) to host: u/x as [n_dim][n] (dimension-major), logl/logmix as [n] */
+int tph_history_read(tph_ctx* ctx, int key, int64_t off, int64_t n, double* out_host);
+/* device base pointer and leading dimension (capacity) of a history array */
+int tph_history_ptr(tph_ctx* ctx, int key, void** dev_ptr, int64_t* ld);
+/* replace the history wholesale (resume / tests): arrays [n_dim][n] / [n] on host, tables of length T */
+int tph_history_load(tph_ctx* ctx, const double* u_host, const double* x_host, const double* logl_host,
+                     int64_t n, int T, const double* beta_t, const double* logz_t, const int64_t* n_t_local,
+                     const int64_t* n_t_global);
+
+/* ---- reweighting (state_manager.py:418-480, steps/reweight.py:88-118, tools.py:120-135) -------
+ * For each trial beta_b:  v_s = beta_b*l_s - C_s ;  out[b] = (max_s v, sum_s e^{v-max}, sum_s e^{2(v-max)}).
+ * Then ESS = s1^2/s2 (tools.py:134-135) and logZ = max + log s1 (state_manager.py:475; the two
+ * log N_h cancel).  nb <= 16.  _dev leaves the triples on the device (for the cross-GPU merge),
+ * _host synchronises and returns them. */
+int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int nb, double* out_dev /*[nb][3]*/);
+int tph_reweight_eval(tph_ctx* ctx, const double* betas_host, int nb, double* out_host /*[nb][3]*/);
+/* normalised weights w_s = e^{beta l_s - C_s - vmax}/s1 for all N_h particles (reweight.py:106,328) */
+int tph_weights(tph_ctx* ctx, double beta, double vmax, double s1, double* w_dev);
+/* unnormalised log-weights beta*l - C + log(n_h_global)  (state_manager.py:473) */
+int tph_logw(tph_ctx* ctx, double beta, int64_t n_h_global, double* logw_dev);
+
+/* ---- generic reductions on a device vector ---------------------------------------------------- */
+/* out_host = (sum w, sum w^2, max w) */
+int tph_sum_sq_max(tph_ctx* ctx, const double* w_dev, int64_t n, double* out_host /*[3]*/);
+
+/* ---- trimming (tools.py:10-55) ----------------------------------------------------------------
+ * Decides the percentile threshold exactly as the reference's 99->0 walk over a `bins`-point grid:
+ * out = (threshold, kept_sum, kept_count, ess_total).  Weights must be normalised. */
+int tph_trim_threshold(tph_ctx* ctx, const double* w_dev, int64_t n, double ess, int bins,
+                       double* out_dev /*[4]*/, double* out_host /*[4] or NULL*/);
+
+/* ---- resampling (tools.py:178-228, steps/resample.py:52-99) ----------------------------------- */
+/* inclusive prefix sum of w (optionally masked: w_s < *thr_dev -> 0) */
+int tph_cdf(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev /*or NULL*/, double* cdf_dev);
+/* idx_i = #{k : cdf_k < (u0+i0+i)/size_global}   (strict walk of tools.py:222-226) */
+int tph_resample_systematic(tph_ctx* ctx, const double* cdf_dev, int64_t n, int64_t n_out, int64_t i0,
+                            int64_t size_global, double u0, double renorm, int64_t* idx_dev);
+/* idx_i = #{k : cdf_k/cdf_last <= U_i}, U_i = Philox(seed, tick, tag, item0+i)  (np.random.choice) */
+int tph_resample_multinomial(tph_ctx* ctx, const double* cdf_dev, int64_t n, int64_t n_out, uint64_t seed,
+                             uint32_t tick, uint32_t tag, int64_t item0, int64_t* idx_dev);
+/* u_out[j][i] = u_hist[j][idx_i] etc. (steps/resample.py:86-99) */
+int tph_gather(tph_ctx* ctx, const int64_t* idx_dev, int64_t n_out, double* u_out, double* x_out,
+               double* logl_out, int64_t ld_out);
+/* multiplicity of each history row among factor*(*kept_count_dev) multinomial draws from cdf (modes.py:196-201);
+ * kept_count_dev NULL = n_draw_max draws.  The count stays on the device: no host sync. */
+int tph_multinomial_counts(tph_ctx* ctx, const double* cdf_dev, int64_t n, const double* kept_count_dev, int factor,
+                           int64_t n_draw_max, uint64_t seed, uint32_t tick, uint32_t tag, int32_t* counts_dev);
+
+/* ---- mutation (steps/mutate.py:76-200, mcmc.py:142-411) ---------------------------------------- */
+/* u ~ U(0,1)^d (mutate.py:102) */
+int tph_prior_draw(tph_ctx* ctx, double* u_dev, int64_t n, int64_t ld, uint64_t seed, uint32_t tick, int64_t item0);
+/* rows with +-inf logl replaced by uniformly chosen finite rows; stats_dev = (n_finite, n) (mutate.py:122-148) */
+int tph_inf_repair(tph_ctx* ctx, double* u_dev, double* x_dev, double* logl_dev, int64_t n, int64_t ld,
+                   uint64_t seed, uint32_t tick, int64_t item0, double* stats_dev /*[2]*/);
+/* proposals for all particles (mcmc.py:225-249 tpCN, :301-312 RWM) incl. boundary handling and the
+ * redraw-until-in-bounds loop; maha_u/maha_up receive (u-mu)^T S^-1 (u-mu) at u and u' (tpCN). */
+int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const int32_t* assign_dev, int64_t n, int64_t ld,
+                int K, const double* means_dev, const double* chol_dev, const double* inv_dev,
+                const double* dof_dev, const double* sigmas_dev, const uint8_t* bc_dev,
+                uint64_t seed, uint32_t tick, int64_t item0,
+                double* uprime_dev, double* maha_u_dev, double* maha_up_dev);
+/* Metropolis step (mcmc.py:163-177 with the factor of :251-279): masked overwrite of u,x,logl and
+ * per-rank sums  sums_dev = (n_accepted, sum alpha_0 .. sum alpha_{K-1}). */
+int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, double* x_dev, double* logl_dev,
+               const double* uprime_dev, const double* xprime_dev, const double* loglprime_dev,
+               const double* maha_u_dev, const double* maha_up_dev, const int32_t* assign_dev,
+               int64_t n, int64_t ld, int K, const double* dof_dev,
+               uint64_t seed, uint32_t tick, int64_t item0, double* sums_dev /*[1+K]*/);
+/* sigma adaptation + adaptive stopping rule (mcmc.py:104-140,180-194,281-288,320-323) from GLOBAL sums.
+ * state_dev[6]: [0]=iteration (in/out) [1]=done flag [2]=accepted fraction [3]=mean alpha
+ *            [4]=mean(sigma)/sigma_0 [5]=adaptive step target ; counts_dev = particles per cluster (global). */
+int tph_adapt(tph_ctx* ctx, int kernel, const double* sums_dev, const double* counts_dev, int K,
+              double n_global, int n_dim, int n_steps, int n_max, double* sigmas_dev, double* state_dev);
+int tph_cluster_counts(tph_ctx* ctx, const int32_t* assign_dev, int64_t n, int K, double* counts_dev);
+
+/* ---- proposal fit (student.py:6-116 effective form, modes.py:58-119,131-288) -------------------- */
+/* From multiplicities counts_s over the first n history rows (labels_dev NULL = one global mode):
+ * per mode k: mean = per-dimension median, cov = MLE covariance + diag(var)/n of the up-sampled set,
+ * then chol/inv with the 1e-6 ridge on failure.  Outputs [K][d], [K][d][d] x3 on the device. */
+int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int32_t* labels_dev, int64_t n, int K,
+                  double* means_dev, double* covs_dev, double* chol_dev, double* inv_dev);
+/* Cholesky + inverse of K d x d matrices with the reference's ridge rule (modes.py:105-119) */
+int tph_chol_inv(tph_ctx* ctx, double* covs_dev, int K, double* chol_dev, double* inv_dev);
+
+/* ---- volume variation (tools.py:58-117) ---------------------------------------------------------
+ * stage 1: weighted mean and covariance of the history's u with weights w (device -> host, tiny);
+ * stage 2 (after the host's rank check / inverse, d x d): 0.25 * sum w^2 clip(d2-n,+-1e6)^2 partial. */
+int tph_weighted_moments(tph_ctx* ctx, const double* w_dev, int64_t n, double* mean_cov_dev /*[d + d*d]*/);
+int tph_weighted_cov_centered(tph_ctx* ctx, const double* w_dev, int64_t n, const double* mean_dev,
+                              double* cov_dev /*[d*d]*/);
+int tph_cv_sum(tph_ctx* ctx, const double* w_dev, int64_t n, const double* mean_dev, const double* covinv_dev,
+               double* out_dev /*[1]: sum w^2 dev^2*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+"""ctypes binding of libtempest_hip.so (C ABI: include/tempest_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails this
+module raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C tempest_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtempest_hip.so")
+
+c_i64 = C.c_int64
+c_u64 = C.c_uint64
+c_u32 = C.c_uint32
+c_dbl = C.c_double
+c_int = C.c_int
+ptr = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/tempest_hip.h one to one
+SIGNATURES = {
+    "tph_last_error": (C.c_char_p, []),
+    "tph_version": (c_int, []),
+    "tph_ctx_create": (c_int, [c_int, c_int, c_i64, ptr, C.POINTER(ptr)]),
+    "tph_ctx_destroy": (c_int, [ptr]),
+    "tph_set_stream": (c_int, [ptr, ptr]),
+    "tph_synchronize": (c_int, [ptr]),
+    "tph_history_append": (c_int, [ptr, ptr, ptr, ptr, c_i64, c_i64, c_dbl, c_dbl, c_i64]),
+    "tph_history_size": (c_i64, [ptr]),
+    "tph_history_iterations": (c_int, [ptr]),
+    "tph_history_clear": (c_int, [ptr]),
+    "tph_history_read": (c_int, [ptr, c_int, c_i64, c_i64, ptr]),
+    "tph_history_ptr": (c_int, [ptr, c_int, C.POINTER(ptr), C.POINTER(c_i64)]),
+    "tph_history_load": (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, ptr, ptr, ptr, ptr]),
+    "tph_reweight_partials": (c_int, [ptr, ptr, c_int, ptr]),
+    "tph_reweight_eval": (c_int, [ptr, ptr, c_int, ptr]),
+    "tph_weights": (c_int, [ptr, c_dbl, c_dbl, c_dbl, ptr]),
+    "tph_logw": (c_int, [ptr, c_dbl, c_i64, ptr]),
+    "tph_sum_sq_max": (c_int, [ptr, ptr, c_i64, ptr]),
+    "tph_trim_threshold": (c_int, [ptr, ptr, c_i64, c_dbl, c_int, ptr, ptr]),
+    "tph_cdf": (c_int, [ptr, ptr, c_i64, ptr, ptr]),
+    "tph_resample_systematic": (c_int, [ptr, ptr, c_i64, c_i64, c_i64, c_i64, c_dbl, c_dbl, ptr]),
+    "tph_resample_multinomial": (c_int, [ptr, ptr, c_i64, c_i64, c_u64, c_u32, c_u32, c_i64, ptr]),
+    "tph_gather": (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr, c_i64]),
+    "tph_multinomial_counts": (c_int, [ptr, ptr, c_i64, ptr, c_int, c_i64, c_u64, c_u32, c_u32, ptr]),
+    "tph_prior_draw": (c_int, [ptr, ptr, c_i64, c_i64, c_u64, c_u32, c_i64]),
+    "tph_inf_repair": (c_int, [ptr, ptr, ptr, ptr, c_i64, c_i64, c_u64, c_u32, c_i64, ptr]),
+    "tph_propose": (c_int, [ptr, c_int, ptr, ptr, c_i64, c_i64, c_int, ptr, ptr, ptr, ptr, ptr, ptr,
+                            c_u64, c_u32, c_i64, ptr, ptr, ptr]),
+    "tph_accept": (c_int, [ptr, c_int, c_dbl, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i64, c_i64,
+                           c_int, ptr, c_u64, c_u32, c_i64, ptr]),
+    "tph_adapt": (c_int, [ptr, c_int, ptr, ptr, c_int, c_dbl, c_int, c_int, c_int, ptr, ptr]),
+    "tph_cluster_counts": (c_int, [ptr, ptr, c_i64, c_int, ptr]),
+    "tph_fit_modes": (c_int, [ptr, ptr, ptr, c_i64, c_int, ptr, ptr, ptr, ptr]),
+    "tph_chol_inv": (c_int, [ptr, ptr, c_int, ptr, ptr]),
+    "tph_weighted_moments": (c_int, [ptr, ptr, c_i64, ptr]),
+    "tph_weighted_cov_centered": (c_int, [ptr, ptr, c_i64, ptr, ptr]),
+    "tph_cv_sum": (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr]),
+}
+
+
+class TempestHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load(path=None):
+    """Load the shared library and attach prototypes.  Raises if it is missing or incomplete."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise TempestHipError(
+            f"{p} not found: the HIP extension is not built (run `make -C tempest_amd/csrc`). "
+            "tempest_amd has no CPU fallback.")
+    lib = C.CDLL(p)
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing:
+        raise TempestHipError(f"{p} lacks symbols declared in include/tempest_hip.h: {missing}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().tph_last_error()
+        raise TempestHipError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

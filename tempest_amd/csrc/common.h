@@ -1,0 +1,203 @@
+// Shared host/device helpers for libtempest_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include <math.h>
+#include <string>
+#include <vector>
+
+#include "../../include/tempest_hip.h"
+
+// ------------------------------------------------------------------------------------------ errors
+void tph_set_error(const char* fmt, ...);
+
+#define TPH_HIP(call)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      tph_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));       \
+      return -1;                                                                                \
+    }                                                                                           \
+  } while (0)
+
+#define TPH_REQUIRE(cond, ...)                                                                  \
+  do {                                                                                          \
+    if (!(cond)) {                                                                              \
+      tph_set_error(__VA_ARGS__);                                                               \
+      return -2;                                                                                \
+    }                                                                                           \
+  } while (0)
+
+#define TPH_LAUNCH_CHECK() TPH_HIP(hipGetLastError())
+
+// -------------------------------------------------------------------------------------------- ctx
+constexpr int TPH_MAX_NB = 16;          // trial betas per reweight pass
+constexpr int TPH_RED_BLOCKS = 2048;    // 256 CUs x 8 blocks: grid cap of the streaming reductions
+constexpr int TPH_RED_THREADS = 256;
+constexpr int TPH_WAVE = 64;
+
+struct tph_ctx {
+  int device = 0;
+  int d = 0;
+  hipStream_t stream = nullptr;
+  // history, dimension-major with leading dimension `cap`
+  int64_t cap = 0, size = 0;
+  double *u = nullptr, *x = nullptr, *logl = nullptr, *cmix = nullptr;
+  // iteration table (host mirrors + device copy of (beta_t, -logZ_t + log n_t))
+  std::vector<double> beta_t, logz_t;
+  std::vector<int64_t> n_local_t, n_global_t;
+  double* table_dev = nullptr;  // [2][table_cap]: beta_t, a_t = log n_t - logZ_t ... see ctx.hip
+  int table_cap = 0;
+  // scratch
+  double* partials = nullptr;       // streaming-reduction block partials
+  size_t partials_bytes = 0;
+  double* small_dev = nullptr;      // small device results (<= 4096 doubles)
+  double* pinned = nullptr;         // pinned host staging (<= 4096 doubles)
+  void* scratch = nullptr;          // big scratch (sort buffers, scans), grown on demand
+  size_t scratch_bytes = 0;
+};
+
+int tph_scratch_reserve(tph_ctx* ctx, size_t bytes);
+
+// --------------------------------------------------------------------------------- device helpers
+#if defined(__HIPCC__)
+
+// np.logaddexp (numpy/core/src/npymath: npy_logaddexp) restated
+__device__ __forceinline__ double tph_logaddexp(double x, double y) {
+  if (x == y) return x + 0.6931471805599453094;  // also equal infinities
+  double t = x - y;
+  if (t > 0) return x + log1p(exp(-t));
+  if (t <= 0) return y + log1p(exp(t));
+  return t;  // NaN
+}
+
+// ---- Philox4x32-10 (twin of oracle/philox.py) ----
+struct tph_u4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ tph_u4 tph_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                             uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return tph_u4{c0, c1, c2, c3};
+}
+
+constexpr uint32_t TPH_TAG_PRIOR = 1, TPH_TAG_NORMAL = 2, TPH_TAG_GAMMA = 3, TPH_TAG_ACCEPT = 4,
+                   TPH_TAG_RESAMPLE = 5, TPH_TAG_UPSAMPLE = 6, TPH_TAG_REPAIR = 7;
+
+__device__ __forceinline__ double tph_k53(uint32_t hi, uint32_t lo) {
+  uint64_t k = ((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6);
+  return (double)k;
+}
+
+struct tph_rng {
+  uint32_t k0, k1, tick, tag, item;
+  __device__ tph_rng(uint64_t seed, uint32_t tick_, uint32_t tag_, uint64_t item_)
+      : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), tick(tick_), tag(tag_), item((uint32_t)item_) {}
+  // two U[0,1)
+  __device__ __forceinline__ void uniform2(uint32_t draw, double& a, double& b) const {
+    tph_u4 r = tph_philox(item, draw, tick, tag, k0, k1);
+    a = tph_k53(r.x, r.y) * 0x1.0p-53;
+    b = tph_k53(r.z, r.w) * 0x1.0p-53;
+  }
+  // two N(0,1), Box-Muller with u1 in (0,1]
+  __device__ __forceinline__ void normal2(uint32_t draw, double& z0, double& z1) const {
+    tph_u4 r = tph_philox(item, draw, tick, tag, k0, k1);
+    double u1 = (tph_k53(r.x, r.y) + 1.0) * 0x1.0p-53;
+    double u2 = tph_k53(r.z, r.w) * 0x1.0p-53;
+    double rad = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincos(6.283185307179586476925 * u2, &s, &c);
+    z0 = rad * c;
+    z1 = rad * s;
+  }
+};
+
+// Gamma(shape,1), Marsaglia-Tsang; attempt a uses draws 2a (normal) and 2a+1 (uniform); shape<1 boosted.
+__device__ inline double tph_gamma_mt(const tph_rng& g, double shape) {
+  const int max_attempts = 64;
+  bool boost = shape < 1.0;
+  double a = boost ? shape + 1.0 : shape;
+  double d = a - 1.0 / 3.0;
+  double c = 1.0 / sqrt(9.0 * d);
+  double out = d;
+  for (int att = 0; att < max_attempts; ++att) {
+    double x, x1, uu, u1;
+    g.normal2(2 * att, x, x1);
+    g.uniform2(2 * att + 1, uu, u1);
+    uu += 0x1.0p-53;
+    double v = 1.0 + c * x;
+    v = v * v * v;
+    if (v > 0.0 && log(uu) < 0.5 * x * x + d - d * v + d * log(v)) {
+      out = d * v;
+      break;
+    }
+  }
+  if (boost) {
+    double ub, u1;
+    g.uniform2(2 * max_attempts, ub, u1);
+    ub += 0x1.0p-53;
+    out *= pow(ub, 1.0 / shape);
+  }
+  return out;
+}
+
+// ---- wave / block reductions (wave64) ----
+__device__ __forceinline__ double tph_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double tph_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+
+// block-wide sum; result valid in thread 0.  `sh` must hold blockDim.x/64 doubles.
+__device__ __forceinline__ double tph_block_sum(double v, double* sh) {
+  v = tph_wave_sum(v);
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  if (wid == 0) {
+    int nw = (blockDim.x + 63) >> 6;
+    v = lane < nw ? sh[lane] : 0.0;
+    v = tph_wave_sum(v);
+  }
+  return v;
+}
+__device__ __forceinline__ double tph_block_max(double v, double* sh) {
+  v = tph_wave_max(v);
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  if (wid == 0) {
+    int nw = (blockDim.x + 63) >> 6;
+    v = lane < nw ? sh[lane] : -DBL_MAX;
+    v = tph_wave_max(v);
+  }
+  return v;
+}
+
+#endif  // __HIPCC__
+
+static inline int tph_grid_for(int64_t n, int threads, int per_thread = 1, int cap = TPH_RED_BLOCKS) {
+  int64_t b = (n + (int64_t)threads * per_thread - 1) / ((int64_t)threads * per_thread);
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}

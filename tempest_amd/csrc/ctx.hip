@@ -1,0 +1,279 @@
+// Context + persistent particle history (reference: tempest/state_manager.py:171-176,267-320,356-416)
+// and the cached log-mixture denominator of the MIS weights (state_manager.py:466-471).
+#include "common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[1024] = "";
+
+void tph_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* tph_last_error(void) { return g_err; }
+extern "C" int tph_version(void) { return TPH_VERSION; }
+
+int tph_scratch_reserve(tph_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_bytes) return 0;
+  size_t nb = ctx->scratch_bytes ? ctx->scratch_bytes : (size_t)1 << 20;
+  while (nb < bytes) nb *= 2;
+  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->scratch) TPH_HIP(hipFree(ctx->scratch));
+  ctx->scratch = nullptr;
+  ctx->scratch_bytes = 0;
+  TPH_HIP(hipMalloc(&ctx->scratch, nb));
+  ctx->scratch_bytes = nb;
+  return 0;
+}
+
+static int table_reserve(tph_ctx* ctx, int T) {
+  if (T <= ctx->table_cap) return 0;
+  int nc = ctx->table_cap ? ctx->table_cap : 256;
+  while (nc < T) nc *= 2;
+  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->table_dev) TPH_HIP(hipFree(ctx->table_dev));
+  ctx->table_dev = nullptr;
+  TPH_HIP(hipMalloc((void**)&ctx->table_dev, sizeof(double) * 3 * (size_t)nc));
+  ctx->table_cap = nc;
+  return 0;
+}
+
+// upload (beta_t, logZ_t, log n_t) for t < T
+static int table_upload(tph_ctx* ctx) {
+  int T = (int)ctx->beta_t.size();
+  if (T == 0) return 0;
+  if (table_reserve(ctx, T)) return -1;
+  std::vector<double> h(3 * (size_t)ctx->table_cap, 0.0);
+  for (int t = 0; t < T; ++t) {
+    h[t] = ctx->beta_t[t];
+    h[ctx->table_cap + t] = ctx->logz_t[t];
+    h[2 * (size_t)ctx->table_cap + t] = log((double)ctx->n_global_t[t]);
+  }
+  // synchronous copy: the table is tiny and the host vector is about to go out of scope
+  TPH_HIP(hipMemcpyAsync(ctx->table_dev, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream));
+  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+static int history_reserve(tph_ctx* ctx, int64_t need) {
+  if (need <= ctx->cap) return 0;
+  int64_t nc = ctx->cap ? ctx->cap : 1024;
+  while (nc < need) nc *= 2;
+  nc = (nc + 255) / 256 * 256;
+  double *nu = nullptr, *nx = nullptr, *nl = nullptr, *nm = nullptr;
+  size_t d = (size_t)ctx->d;
+  TPH_HIP(hipMalloc((void**)&nu, sizeof(double) * d * nc));
+  TPH_HIP(hipMalloc((void**)&nx, sizeof(double) * d * nc));
+  TPH_HIP(hipMalloc((void**)&nl, sizeof(double) * nc));
+  TPH_HIP(hipMalloc((void**)&nm, sizeof(double) * nc));
+  if (ctx->size > 0) {
+    size_t w = sizeof(double) * (size_t)ctx->size;
+    TPH_HIP(hipMemcpy2DAsync(nu, sizeof(double) * nc, ctx->u, sizeof(double) * ctx->cap, w, d,
+                             hipMemcpyDeviceToDevice, ctx->stream));
+    TPH_HIP(hipMemcpy2DAsync(nx, sizeof(double) * nc, ctx->x, sizeof(double) * ctx->cap, w, d,
+                             hipMemcpyDeviceToDevice, ctx->stream));
+    TPH_HIP(hipMemcpyAsync(nl, ctx->logl, w, hipMemcpyDeviceToDevice, ctx->stream));
+    TPH_HIP(hipMemcpyAsync(nm, ctx->cmix, w, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->u) TPH_HIP(hipFree(ctx->u));
+  if (ctx->x) TPH_HIP(hipFree(ctx->x));
+  if (ctx->logl) TPH_HIP(hipFree(ctx->logl));
+  if (ctx->cmix) TPH_HIP(hipFree(ctx->cmix));
+  ctx->u = nu; ctx->x = nx; ctx->logl = nl; ctx->cmix = nm;
+  ctx->cap = nc;
+  return 0;
+}
+
+extern "C" int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void* hip_stream, tph_ctx** out) {
+  TPH_REQUIRE(out != nullptr, "tph_ctx_create: out is NULL");
+  TPH_REQUIRE(n_dim > 0 && n_dim <= 4096, "tph_ctx_create: n_dim=%d out of range", n_dim);
+  int ndev = 0;
+  TPH_HIP(hipGetDeviceCount(&ndev));
+  TPH_REQUIRE(device >= 0 && device < ndev, "tph_ctx_create: device %d not present (%d visible)", device, ndev);
+  TPH_HIP(hipSetDevice(device));
+  tph_ctx* c = new tph_ctx();
+  c->device = device;
+  c->d = n_dim;
+  c->stream = (hipStream_t)hip_stream;
+  c->partials_bytes = sizeof(double) * (size_t)TPH_RED_BLOCKS * 64;
+  if (hipMalloc((void**)&c->partials, c->partials_bytes) != hipSuccess ||
+      hipMalloc((void**)&c->small_dev, sizeof(double) * 4096) != hipSuccess ||
+      hipHostMalloc((void**)&c->pinned, sizeof(double) * 4096) != hipSuccess) {
+    tph_set_error("tph_ctx_create: scratch allocation failed");
+    delete c;
+    return -1;
+  }
+  if (capacity_hint > 0 && history_reserve(c, capacity_hint)) {
+    delete c;
+    return -1;
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int tph_ctx_destroy(tph_ctx* ctx) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  void* bufs[] = {ctx->u, ctx->x, ctx->logl, ctx->cmix, ctx->table_dev, ctx->partials, ctx->small_dev, ctx->scratch};
+  for (void* b : bufs) (void)hipFree(b);
+  (void)hipHostFree(ctx->pinned);
+  delete ctx;
+  return 0;
+}
+
+extern "C" int tph_set_stream(tph_ctx* ctx, void* hip_stream) {
+  TPH_REQUIRE(ctx, "tph_set_stream: ctx is NULL");
+  ctx->stream = (hipStream_t)hip_stream;
+  return 0;
+}
+
+extern "C" int tph_synchronize(tph_ctx* ctx) {
+  TPH_REQUIRE(ctx, "tph_synchronize: ctx is NULL");
+  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int64_t tph_history_size(const tph_ctx* ctx) { return ctx ? ctx->size : -1; }
+extern "C" int tph_history_iterations(const tph_ctx* ctx) { return ctx ? (int)ctx->beta_t.size() : -1; }
+
+extern "C" int tph_history_clear(tph_ctx* ctx) {
+  TPH_REQUIRE(ctx, "tph_history_clear: ctx is NULL");
+  ctx->size = 0;
+  ctx->beta_t.clear(); ctx->logz_t.clear(); ctx->n_local_t.clear(); ctx->n_global_t.clear();
+  return 0;
+}
+
+// K1: log-mixture update.  Old rows fold in the one new term; new rows fold all T terms in
+// iteration order, i.e. the same left-to-right fold np.logaddexp.reduce performs.
+// HBM: old rows 24 B (read l, C; write C); new rows 16 B + T table terms (scalar loads).
+__global__ void __launch_bounds__(256) k_logmix_append(const double* __restrict__ logl, double* __restrict__ cmix,
+                                                       int64_t size_old, int64_t size_new,
+                                                       const double* __restrict__ table, int tcap, int T) {
+  const double* beta = table;
+  const double* logz = table + tcap;
+  const double* logn = table + 2 * (size_t)tcap;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const double bT = beta[T - 1], zT = logz[T - 1], nT = logn[T - 1];
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < size_new; s += stride) {
+    double l = logl[s];
+    if (s < size_old) {
+      cmix[s] = tph_logaddexp(cmix[s], l * bT - zT + nT);
+    } else {
+      double acc = l * beta[0] - logz[0] + logn[0];
+      for (int t = 1; t < T; ++t) acc = tph_logaddexp(acc, l * beta[t] - logz[t] + logn[t]);
+      cmix[s] = acc;
+    }
+  }
+}
+
+static int launch_logmix(tph_ctx* ctx, int64_t size_old, int64_t size_new) {
+  int T = (int)ctx->beta_t.size();
+  int grid = tph_grid_for(size_new, 256);
+  hipLaunchKernelGGL(k_logmix_append, dim3(grid), dim3(256), 0, ctx->stream, ctx->logl, ctx->cmix, size_old,
+                     size_new, ctx->table_dev, ctx->table_cap, T);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tph_history_append(tph_ctx* ctx, const double* u_dev, const double* x_dev, const double* logl_dev,
+                                  int64_t n, int64_t ld, double beta, double logz, int64_t n_global) {
+  TPH_REQUIRE(ctx, "tph_history_append: ctx is NULL");
+  TPH_REQUIRE(n > 0 && ld >= n, "tph_history_append: bad n=%lld ld=%lld", (long long)n, (long long)ld);
+  TPH_REQUIRE(u_dev && x_dev && logl_dev, "tph_history_append: NULL array");
+  TPH_REQUIRE(n_global >= n, "tph_history_append: n_global < n");
+  TPH_HIP(hipSetDevice(ctx->device));
+  if (history_reserve(ctx, ctx->size + n)) return -1;
+  size_t w = sizeof(double) * (size_t)n;
+  TPH_HIP(hipMemcpy2DAsync(ctx->u + ctx->size, sizeof(double) * ctx->cap, u_dev, sizeof(double) * ld, w, ctx->d,
+                           hipMemcpyDeviceToDevice, ctx->stream));
+  TPH_HIP(hipMemcpy2DAsync(ctx->x + ctx->size, sizeof(double) * ctx->cap, x_dev, sizeof(double) * ld, w, ctx->d,
+                           hipMemcpyDeviceToDevice, ctx->stream));
+  TPH_HIP(hipMemcpyAsync(ctx->logl + ctx->size, logl_dev, w, hipMemcpyDeviceToDevice, ctx->stream));
+  ctx->beta_t.push_back(beta);
+  ctx->logz_t.push_back(logz);
+  ctx->n_local_t.push_back(n);
+  ctx->n_global_t.push_back(n_global);
+  if (table_upload(ctx)) return -1;
+  int64_t old = ctx->size;
+  ctx->size += n;
+  return launch_logmix(ctx, old, ctx->size);
+}
+
+extern "C" int tph_history_load(tph_ctx* ctx, const double* u_host, const double* x_host, const double* logl_host,
+                                int64_t n, int T, const double* beta_t, const double* logz_t,
+                                const int64_t* n_t_local, const int64_t* n_t_global) {
+  TPH_REQUIRE(ctx, "tph_history_load: ctx is NULL");
+  TPH_REQUIRE(n >= 0 && T >= 0, "tph_history_load: bad sizes");
+  TPH_HIP(hipSetDevice(ctx->device));
+  tph_history_clear(ctx);
+  int64_t tot = 0;
+  for (int t = 0; t < T; ++t) {
+    ctx->beta_t.push_back(beta_t[t]);
+    ctx->logz_t.push_back(logz_t[t]);
+    ctx->n_local_t.push_back(n_t_local[t]);
+    ctx->n_global_t.push_back(n_t_global ? n_t_global[t] : n_t_local[t]);
+    tot += n_t_local[t];
+  }
+  TPH_REQUIRE(tot == n, "tph_history_load: sum(n_t)=%lld != n=%lld", (long long)tot, (long long)n);
+  if (n == 0) return 0;
+  if (history_reserve(ctx, n)) return -1;
+  size_t w = sizeof(double) * (size_t)n;
+  if (u_host)
+    TPH_HIP(hipMemcpy2DAsync(ctx->u, sizeof(double) * ctx->cap, u_host, w, w, ctx->d, hipMemcpyHostToDevice, ctx->stream));
+  if (x_host)
+    TPH_HIP(hipMemcpy2DAsync(ctx->x, sizeof(double) * ctx->cap, x_host, w, w, ctx->d, hipMemcpyHostToDevice, ctx->stream));
+  TPH_REQUIRE(logl_host, "tph_history_load: logl is NULL");
+  TPH_HIP(hipMemcpyAsync(ctx->logl, logl_host, w, hipMemcpyHostToDevice, ctx->stream));
+  if (table_upload(ctx)) return -1;
+  ctx->size = n;
+  if (launch_logmix(ctx, 0, n)) return -1;
+  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int tph_history_read(tph_ctx* ctx, int key, int64_t off, int64_t n, double* out_host) {
+  TPH_REQUIRE(ctx && out_host, "tph_history_read: NULL argument");
+  TPH_REQUIRE(off >= 0 && n >= 0 && off + n <= ctx->size, "tph_history_read: range [%lld,%lld) outside history of %lld",
+              (long long)off, (long long)(off + n), (long long)ctx->size);
+  if (n == 0) return 0;
+  TPH_HIP(hipSetDevice(ctx->device));
+  size_t w = sizeof(double) * (size_t)n;
+  switch (key) {
+    case TPH_KEY_U:
+    case TPH_KEY_X: {
+      const double* src = (key == TPH_KEY_U ? ctx->u : ctx->x) + off;
+      TPH_HIP(hipMemcpy2DAsync(out_host, w, src, sizeof(double) * ctx->cap, w, ctx->d, hipMemcpyDeviceToHost, ctx->stream));
+      break;
+    }
+    case TPH_KEY_LOGL:
+      TPH_HIP(hipMemcpyAsync(out_host, ctx->logl + off, w, hipMemcpyDeviceToHost, ctx->stream));
+      break;
+    case TPH_KEY_LOGMIX:
+      TPH_HIP(hipMemcpyAsync(out_host, ctx->cmix + off, w, hipMemcpyDeviceToHost, ctx->stream));
+      break;
+    default:
+      TPH_REQUIRE(false, "tph_history_read: unknown key %d", key);
+  }
+  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int tph_history_ptr(tph_ctx* ctx, int key, void** dev_ptr, int64_t* ld) {
+  TPH_REQUIRE(ctx && dev_ptr, "tph_history_ptr: NULL argument");
+  switch (key) {
+    case TPH_KEY_U: *dev_ptr = ctx->u; break;
+    case TPH_KEY_X: *dev_ptr = ctx->x; break;
+    case TPH_KEY_LOGL: *dev_ptr = ctx->logl; break;
+    case TPH_KEY_LOGMIX: *dev_ptr = ctx->cmix; break;
+    default: TPH_REQUIRE(false, "tph_history_ptr: unknown key %d", key);
+  }
+  if (ld) *ld = ctx->cap;
+  return 0;
+}

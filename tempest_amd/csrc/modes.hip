@@ -1,0 +1,688 @@
+// Weight trimming, proposal fit (median + covariance of the up-sampled set, Cholesky/inverse) and the
+// volume-variation diagnostic.
+// Reference: tempest/tools.py:10-55 (trim_weights), :58-117 (volume_variation); tempest/student.py:6-116
+// (fit_mvstud; effective form = per-dimension median, MLE covariance + diag(var)/n, nu=inf -- SURVEY.md F5);
+// tempest/modes.py:58-119 (chol/inv with ridge), :131-288 (x4 multinomial up-sampling then fit).
+#include "common.h"
+
+#include <cstring>
+#include <cstdlib>
+#include <rocprim/rocprim.hpp>
+
+// ---- generic inclusive scan (same 3-pass scheme as resample.hip, with an optional square) ----------
+namespace {
+constexpr int ST = 256, SI = 8, STILE = ST * SI;
+
+__device__ __forceinline__ double wave_scan(double v) {
+  int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+template <bool SQ>
+__global__ void __launch_bounds__(ST) k_tile_sums(const double* __restrict__ w, int64_t n, double* __restrict__ tiles) {
+  int64_t base = (int64_t)blockIdx.x * STILE + (int64_t)threadIdx.x * SI;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < SI; ++k)
+    if (base + k < n) { double v = w[base + k]; s += SQ ? v * v : v; }
+  __shared__ double sh[ST / 64];
+  s = tph_block_sum(s, sh);
+  if (threadIdx.x == 0) tiles[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(1024) k_tile_offsets(double* __restrict__ tiles, int64_t ntiles, double* __restrict__ total) {
+  int64_t per = (ntiles + 1023) / 1024;
+  int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
+  double s = 0.0;
+  for (int64_t i = lo; i < hi; ++i) s += tiles[i];
+  __shared__ double wsum[16];
+  double inc = wave_scan(s);
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  if (wid == 0) {
+    double v = lane < 16 ? wsum[lane] : 0.0;
+    v = wave_scan(v);
+    if (lane < 16) wsum[lane] = v;
+  }
+  __syncthreads();
+  double excl = inc - s + (wid > 0 ? wsum[wid - 1] : 0.0);
+  for (int64_t i = lo; i < hi; ++i) { double t = tiles[i]; tiles[i] = excl; excl += t; }
+  if (threadIdx.x == 1023 && total) *total = wsum[15];
+}
+
+template <bool SQ>
+__global__ void __launch_bounds__(ST) k_scan_apply(const double* __restrict__ w, int64_t n, const double* __restrict__ tiles,
+                                                   double* __restrict__ out) {
+  int64_t base = (int64_t)blockIdx.x * STILE + (int64_t)threadIdx.x * SI;
+  double v[SI];
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < SI; ++k) {
+    double x = base + k < n ? w[base + k] : 0.0;
+    s += SQ ? x * x : x;
+    v[k] = s;
+  }
+  __shared__ double wsum[ST / 64];
+  double inc = wave_scan(s);
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  double off = tiles[blockIdx.x];
+  for (int k = 0; k < wid; ++k) off += wsum[k];
+  off += inc - s;
+#pragma unroll
+  for (int k = 0; k < SI; ++k)
+    if (base + k < n) out[base + k] = off + v[k];
+}
+
+template <bool SQ>
+int scan_incl(tph_ctx* ctx, const double* in, int64_t n, double* tiles, double* out, double* total_dev) {
+  int64_t ntiles = (n + STILE - 1) / STILE;
+  hipLaunchKernelGGL(k_tile_sums<SQ>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, in, n, tiles);
+  hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, ctx->stream, tiles, ntiles, total_dev);
+  hipLaunchKernelGGL(k_scan_apply<SQ>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, in, n, tiles, out);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------- trimming
+// All `bins` candidates of the reference's 99 -> 0 percentile walk at once on the sorted weights S with
+// prefix sums P1 (of S) and P2 (of S^2): candidate i keeps {w >= thr_i}; it passes if
+// ESS(kept)/ESS(all) >= ess; the answer is the largest passing i (tools.py:42-53).
+__device__ __forceinline__ void trim_candidate(const double* __restrict__ S, int64_t n, int bins, double step, int i,
+                                               double& thr, int64_t& first_kept) {
+  double p = (i == bins - 1 && bins > 1) ? 99.0 : __dmul_rn((double)i, step);   // np.linspace(0, 99, bins)[i]
+  double q = p / 100.0;                                                         // np.percentile: q / 100
+  // numpy _compute_virtual_index(n, q, 1, 1) = n*q + (1 + q*(1-1-1)) - 1, evaluated without contraction
+  double vi = __dadd_rn(__dadd_rn(__dmul_rn((double)n, q), __dadd_rn(1.0, __dmul_rn(q, -1.0))), -1.0);
+  if (vi >= (double)(n - 1)) thr = S[n - 1];
+  else if (vi < 0.0) thr = S[0];
+  else {
+    double pf = floor(vi);
+    int64_t pi = (int64_t)pf;
+    double g = vi - pf;
+    double a = S[pi], b = S[pi + 1];
+    double diff = b - a;   // numpy _lerp
+    thr = (g >= 0.5) ? __dadd_rn(b, -__dmul_rn(diff, __dadd_rn(1.0, -g))) : __dadd_rn(a, __dmul_rn(diff, g));
+  }
+  int64_t lo = 0, hi = n;  // first k with S[k] >= thr
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (S[mid] < thr) lo = mid + 1; else hi = mid; }
+  first_kept = lo;
+}
+
+__global__ void __launch_bounds__(256) k_trim_candidates(const double* __restrict__ S, const double* __restrict__ P1,
+                                                         const double* __restrict__ P2, int64_t n, double ess, int bins,
+                                                         double* __restrict__ out) {
+  __shared__ int best;
+  if (threadIdx.x == 0) best = 0;   // i = 0 keeps everything and always passes
+  __syncthreads();
+  const double tot1 = P1[n - 1], tot2 = P2[n - 1];
+  const double ess_total = (tot1 * tot1) / tot2;
+  const double step = bins > 1 ? 99.0 / (double)(bins - 1) : 0.0;
+  for (int i = threadIdx.x; i < bins; i += blockDim.x) {
+    double thr; int64_t lo;
+    trim_candidate(S, n, bins, step, i, thr, lo);
+    double k1 = tot1 - (lo > 0 ? P1[lo - 1] : 0.0);
+    double k2 = tot2 - (lo > 0 ? P2[lo - 1] : 0.0);
+    if (((k1 * k1) / k2) / ess_total >= ess) atomicMax(&best, i);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double thr; int64_t lo;
+    trim_candidate(S, n, bins, step, best, thr, lo);
+    out[0] = thr;
+    out[1] = tot1 - (lo > 0 ? P1[lo - 1] : 0.0);
+    out[2] = (double)(n - lo);
+    out[3] = ess_total;
+  }
+}
+
+extern "C" int tph_trim_threshold(tph_ctx* ctx, const double* w_dev, int64_t n, double ess, int bins, double* out_dev,
+                                  double* out_host) {
+  TPH_REQUIRE(ctx && w_dev && out_dev && n > 0 && bins >= 1, "tph_trim_threshold: bad argument");
+  size_t temp_bytes = 0;
+  double* nullk = nullptr;
+  TPH_HIP(rocprim::radix_sort_keys(nullptr, temp_bytes, w_dev, nullk, (size_t)n, 0, 64, ctx->stream));
+  int64_t ntiles = (n + STILE - 1) / STILE;
+  size_t a_tiles = ((size_t)ntiles * sizeof(double) + 255) / 256 * 256;
+  size_t a_n = ((size_t)n * sizeof(double) + 255) / 256 * 256;
+  size_t a_tmp = (temp_bytes + 255) / 256 * 256;
+  if (tph_scratch_reserve(ctx, a_tiles + 3 * a_n + a_tmp)) return -1;
+  char* base = (char*)ctx->scratch;
+  double* tiles = (double*)base;
+  double* S = (double*)(base + a_tiles);
+  double* P1 = (double*)(base + a_tiles + a_n);
+  double* P2 = (double*)(base + a_tiles + 2 * a_n);
+  void* tmp = base + a_tiles + 3 * a_n;
+  TPH_HIP(rocprim::radix_sort_keys(tmp, temp_bytes, w_dev, S, (size_t)n, 0, 64, ctx->stream));
+  if (scan_incl<false>(ctx, S, n, tiles, P1, nullptr)) return -1;
+  if (scan_incl<true>(ctx, S, n, tiles, P2, nullptr)) return -1;
+  hipLaunchKernelGGL(k_trim_candidates, dim3(1), dim3(256), 0, ctx->stream, S, P1, P2, n, ess, bins, out_dev);
+  TPH_LAUNCH_CHECK();
+  if (out_host) {
+    TPH_HIP(hipMemcpyAsync(ctx->pinned, out_dev, sizeof(double) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; ++i) out_host[i] = ctx->pinned[i];
+  }
+  return 0;
+}
+
+// -------------------------------------------------------------------------- weighted first moments
+// sums[0] = sum wt ; sums[1+j] = sum wt * u_j   (wt = counts or real weights, optional label filter)
+template <typename WT>
+__global__ void __launch_bounds__(256) k_wsum(const double* __restrict__ hu, int64_t cap, int d, const WT* __restrict__ wt,
+                                              const int32_t* __restrict__ labels, int label, int64_t n,
+                                              double* __restrict__ partials) {
+  // grid: (row blocks, 1 + d): blockIdx.y == 0 -> sum of weights, else coordinate blockIdx.y-1
+  const int col = blockIdx.y;
+  const double* src = col ? hu + (size_t)(col - 1) * cap : nullptr;
+  double s = 0.0;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (labels && labels[i] != label) continue;
+    double w = (double)wt[i];
+    s += col ? w * src[i] : w;
+  }
+  __shared__ double sh[4];
+  s = tph_block_sum(s, sh);
+  if (threadIdx.x == 0) partials[(size_t)blockIdx.x * gridDim.y + col] = s;
+}
+
+__global__ void __launch_bounds__(256) k_colsum2(const double* __restrict__ partials, int nblocks, int ncol,
+                                                 double* __restrict__ out) {
+  int c = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partials[(size_t)b * ncol + c];
+  __shared__ double sh[4];
+  s = tph_block_sum(s, sh);
+  if (threadIdx.x == 0) out[c] = s;
+}
+
+// mean_j = sums[1+j] / sums[0]
+__global__ void k_mean_from_sums(const double* __restrict__ sums, int d, double* __restrict__ mean) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < d) mean[j] = sums[1 + j] / sums[0];
+}
+
+// --------------------------------------------------------------- centred weighted second moments
+// C[a][b] = sum_s wt_s (u_a - m_a)(u_b - m_b).  Tile of 64 rows staged in LDS ([d][64] + weights);
+// each thread owns a strided set of (a,b) pairs.  Block partials [blocks][d*d] reduced by k_colsum2.
+constexpr int COV_ROWS = 64;
+constexpr int COV_LD = 65;  // padded row: conflict-free ds_read_b64 across pairs
+template <typename WT>
+__global__ void __launch_bounds__(256) k_wcov(const double* __restrict__ hu, int64_t cap, int d, const WT* __restrict__ wt,
+                                              const int32_t* __restrict__ labels, int label, int64_t n,
+                                              const double* __restrict__ mean, double* __restrict__ partials) {
+  extern __shared__ double sh[];
+  double* xs = sh;                               // [d][64]
+  double* ws = sh + (size_t)d * COV_LD;          // [64]
+  const int npairs = d * d;
+  double* mine = partials + (size_t)blockIdx.x * npairs;
+  // per-thread accumulators for pairs tid, tid+256, ...  (kept in LDS-free registers via small loop)
+  // pairs per thread can be large for big d; accumulate into global partials at the end of each tile
+  // would be slow, so we keep up to 40 accumulators (d <= 100 -> 10000/256 = 40)
+  double acc[40];
+#pragma unroll
+  for (int k = 0; k < 40; ++k) acc[k] = 0.0;
+  const int64_t ntiles = (n + COV_ROWS - 1) / COV_ROWS;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t r0 = t * COV_ROWS;
+    __syncthreads();
+    for (int e = threadIdx.x; e < d * COV_ROWS; e += blockDim.x) {
+      int j = e / COV_ROWS, r = e % COV_ROWS;
+      int64_t i = r0 + r;
+      xs[j * COV_LD + r] = i < n ? hu[(size_t)j * cap + i] - mean[j] : 0.0;
+    }
+    if (threadIdx.x < COV_ROWS) {
+      int64_t i = r0 + threadIdx.x;
+      double w = 0.0;
+      if (i < n && (!labels || labels[i] == label)) w = (double)wt[i];
+      ws[threadIdx.x] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 40; ++k) {
+      int pidx = threadIdx.x + k * 256;
+      if (pidx < npairs) {
+        int a = pidx / d, b = pidx % d;
+        if (b <= a) {  // lower triangle only; mirrored at the end
+          const double* xa = xs + a * COV_LD;
+          const double* xb = xs + b * COV_LD;
+          double s = 0.0;
+#pragma unroll 8
+          for (int r = 0; r < COV_ROWS; ++r) s += ws[r] * xa[r] * xb[r];
+          acc[k] += s;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 40; ++k) {
+    int pidx = threadIdx.x + k * 256;
+    if (pidx < npairs) mine[pidx] = acc[k];
+  }
+}
+
+// symmetrise the lower triangle and (optionally) apply student.py:62-63:
+//   Sigma = C/n + diag(C/n)/n      (np.cov*(n-1)/n + diag(np.var)/n)
+__global__ void k_cov_finish(const double* __restrict__ csum, const double* __restrict__ sums, int d, int student,
+                             double* __restrict__ cov) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d * d) return;
+  int a = e / d, b = e % d;
+  double v = a >= b ? csum[a * d + b] : csum[b * d + a];
+  if (student == 1) {
+    double ntot = sums[0];
+    v = v / ntot;
+    if (a == b) v = v + v / ntot;
+  } else if (student == 2) {
+    v = v / sums[0];   // tools.py:94: weights normalised to sum 1
+  }
+  cov[e] = v;
+}
+
+static int moments_launch_cov(tph_ctx* ctx, const void* wt, bool wt_is_int, const int32_t* labels, int label, int64_t n,
+                              const double* mean_dev, const double* sums_dev, int student, double* cov_dev,
+                              double* partials, int nblk) {
+  const int d = ctx->d;
+  TPH_REQUIRE(d * d <= 40 * 256, "covariance kernel supports n_dim <= 101 (got %d)", d);
+  size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS);
+  if (wt_is_int) {
+    if (lds > 64 * 1024)
+      TPH_HIP(hipFuncSetAttribute((const void*)k_wcov<int32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_wcov<int32_t>, dim3(nblk), dim3(256), lds, ctx->stream, ctx->u, ctx->cap, d, (const int32_t*)wt,
+                       labels, label, n, mean_dev, partials);
+  } else {
+    if (lds > 64 * 1024)
+      TPH_HIP(hipFuncSetAttribute((const void*)k_wcov<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_wcov<double>, dim3(nblk), dim3(256), lds, ctx->stream, ctx->u, ctx->cap, d, (const double*)wt, labels,
+                       label, n, mean_dev, partials);
+  }
+  double* csum = partials + (size_t)nblk * d * d;
+  hipLaunchKernelGGL(k_colsum2, dim3(d * d), dim3(256), 0, ctx->stream, partials, nblk, d * d, csum);
+  hipLaunchKernelGGL(k_cov_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum, sums_dev, d, student, cov_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+static int cov_blocks(int64_t n) {
+  int64_t t = (n + COV_ROWS - 1) / COV_ROWS;
+  return (int)(t < 512 ? (t < 1 ? 1 : t) : 512);
+}
+
+// -------------------------------------------------------------------- exact weighted median select
+// Per (dimension j, target rank t in {lower, upper middle}): two 12-bit histogram levels over the
+// exact binary expansion of u in [0,1] (u*4096 and the subtraction of the integer digit are exact in
+// FP64), then the <= MED_CAP entries of the final bin are collected and the order statistic is found
+// exactly.  Multiplicities are the up-sampling counts.
+constexpr int MED_BINS = 4096;
+constexpr int MED_CAP = 2048;
+
+__device__ __forceinline__ void med_digits(double u, int& d1, int& d2) {
+  double a = u * 4096.0;
+  double f1 = floor(a);
+  if (f1 > 4095.0) f1 = 4095.0;
+  if (f1 < 0.0) f1 = 0.0;
+  double b = (a - f1) * 4096.0;
+  double f2 = floor(b);
+  if (f2 > 4095.0) f2 = 4095.0;
+  if (f2 < 0.0) f2 = 0.0;
+  d1 = (int)f1;
+  d2 = (int)f2;
+}
+
+// level 1: hist1[j][bin] += count
+__global__ void __launch_bounds__(256) k_med_hist1(const double* __restrict__ hu, int64_t cap, const int32_t* __restrict__ cnt,
+                                                   const int32_t* __restrict__ labels, int label, int64_t n,
+                                                   unsigned int* __restrict__ hist1) {
+  __shared__ unsigned int h[MED_BINS];
+  const int j = blockIdx.y;
+  for (int b = threadIdx.x; b < MED_BINS; b += blockDim.x) h[b] = 0;
+  __syncthreads();
+  const double* src = hu + (size_t)j * cap;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int c = cnt[i];
+    if (c == 0 || (labels && labels[i] != label)) continue;
+    int d1, d2;
+    med_digits(src[i], d1, d2);
+    atomicAdd(&h[d1], (unsigned int)c);
+  }
+  __syncthreads();
+  unsigned int* g = hist1 + (size_t)j * MED_BINS;
+  for (int b = threadIdx.x; b < MED_BINS; b += blockDim.x)
+    if (h[b]) atomicAdd(&g[b], h[b]);
+}
+
+// pick the bin holding each target rank.  sel[j][t] = {bin1, bin2, rank_in_bin(after level), _}
+// level==1 reads hist1[j][.] ; level==2 reads hist2[j][t][.]
+__global__ void __launch_bounds__(64) k_med_select(const unsigned int* __restrict__ hist, int level,
+                                                   const double* __restrict__ sums, long long* __restrict__ sel) {
+  const int j = blockIdx.x, t = blockIdx.y;
+  if (threadIdx.x != 0) return;
+  long long* s = sel + ((size_t)j * 2 + t) * 4;
+  long long rank;
+  if (level == 1) {
+    long long ntot = (long long)sums[0];
+    long long r_lo = (ntot - 1) / 2, r_hi = ntot / 2;   // equal when ntot is odd
+    rank = t == 0 ? r_lo : r_hi;
+  } else {
+    rank = s[2];
+  }
+  const unsigned int* h = level == 1 ? hist + (size_t)j * MED_BINS : hist + ((size_t)j * 2 + t) * MED_BINS;
+  long long cum = 0;
+  int b = 0;
+  for (; b < MED_BINS; ++b) {
+    long long c = h[b];
+    if (rank < cum + c) break;
+    cum += c;
+  }
+  if (b >= MED_BINS) b = MED_BINS - 1;
+  s[level - 1] = b;
+  s[2] = rank - cum;
+}
+
+// level 2: hist2[j][t][bin2] += count for rows whose first digit is the target's
+__global__ void __launch_bounds__(256) k_med_hist2(const double* __restrict__ hu, int64_t cap, const int32_t* __restrict__ cnt,
+                                                   const int32_t* __restrict__ labels, int label, int64_t n,
+                                                   const long long* __restrict__ sel, unsigned int* __restrict__ hist2) {
+  __shared__ unsigned int h[2 * MED_BINS];
+  const int j = blockIdx.y;
+  for (int b = threadIdx.x; b < 2 * MED_BINS; b += blockDim.x) h[b] = 0;
+  __syncthreads();
+  const int b0 = (int)sel[((size_t)j * 2 + 0) * 4], b1 = (int)sel[((size_t)j * 2 + 1) * 4];
+  const double* src = hu + (size_t)j * cap;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int c = cnt[i];
+    if (c == 0 || (labels && labels[i] != label)) continue;
+    int d1, d2;
+    med_digits(src[i], d1, d2);
+    if (d1 == b0) atomicAdd(&h[d2], (unsigned int)c);
+    if (d1 == b1) atomicAdd(&h[MED_BINS + d2], (unsigned int)c);
+  }
+  __syncthreads();
+  unsigned int* g = hist2 + (size_t)j * 2 * MED_BINS;
+  for (int b = threadIdx.x; b < 2 * MED_BINS; b += blockDim.x)
+    if (h[b]) atomicAdd(&g[b], h[b]);
+}
+
+// collect (value, count) of the rows in each target's final bin
+__global__ void __launch_bounds__(256) k_med_collect(const double* __restrict__ hu, int64_t cap, const int32_t* __restrict__ cnt,
+                                                     const int32_t* __restrict__ labels, int label, int64_t n,
+                                                     const long long* __restrict__ sel, double* __restrict__ vals,
+                                                     int* __restrict__ cnts, int* __restrict__ fill) {
+  const int j = blockIdx.y;
+  const long long* s0 = sel + ((size_t)j * 2 + 0) * 4;
+  const long long* s1 = sel + ((size_t)j * 2 + 1) * 4;
+  const int a0 = (int)s0[0], a1 = (int)s0[1], c0 = (int)s1[0], c1 = (int)s1[1];
+  const double* src = hu + (size_t)j * cap;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int c = cnt[i];
+    if (c == 0 || (labels && labels[i] != label)) continue;
+    double v = src[i];
+    int d1, d2;
+    med_digits(v, d1, d2);
+    if (d1 == a0 && d2 == a1) {
+      int slot = atomicAdd(&fill[j * 2 + 0], 1);
+      if (slot < MED_CAP) { vals[((size_t)j * 2 + 0) * MED_CAP + slot] = v; cnts[((size_t)j * 2 + 0) * MED_CAP + slot] = c; }
+    }
+    if (d1 == c0 && d2 == c1) {
+      int slot = atomicAdd(&fill[j * 2 + 1], 1);
+      if (slot < MED_CAP) { vals[((size_t)j * 2 + 1) * MED_CAP + slot] = v; cnts[((size_t)j * 2 + 1) * MED_CAP + slot] = c; }
+    }
+  }
+}
+
+// exact order statistic inside the collected bin; median_j = (v_lo + v_hi)/2 (np.median)
+__global__ void __launch_bounds__(256) k_med_finish(const long long* __restrict__ sel, const double* __restrict__ vals,
+                                                    const int* __restrict__ cnts, const int* __restrict__ fill,
+                                                    double* __restrict__ median, int* __restrict__ overflow) {
+  const int j = blockIdx.x;
+  __shared__ double res[2];
+  __shared__ double sv[MED_CAP];
+  __shared__ int sc[MED_CAP];
+  for (int t = 0; t < 2; ++t) {
+    const long long* s = sel + ((size_t)j * 2 + t) * 4;
+    int m = fill[j * 2 + t];
+    long long rank = s[2];
+    __syncthreads();
+    if (threadIdx.x == 0) res[t] = ((double)s[0] + (double)s[1] / 4096.0) / 4096.0;  // bin edge if overflow / empty
+    if (m > MED_CAP) { if (threadIdx.x == 0) atomicAdd(overflow, 1); m = 0; }
+    for (int e = threadIdx.x; e < m; e += blockDim.x) {
+      sv[e] = vals[((size_t)j * 2 + t) * MED_CAP + e];
+      sc[e] = cnts[((size_t)j * 2 + t) * MED_CAP + e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < m; e += blockDim.x) {
+      double v = sv[e];
+      long long below = 0, eq = 0;
+      for (int f = 0; f < m; ++f) {
+        double o = sv[f];
+        below += o < v ? sc[f] : 0;
+        eq += o == v ? sc[f] : 0;
+      }
+      if (below <= rank && rank < below + eq) res[t] = v;  // all writers hold the same value
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) median[j] = (res[0] + res[1]) / 2.0;
+}
+
+// -------------------------------------------------------------------------- Cholesky + inverse
+// One block per mode.  LinAlgError <=> a non-positive (or NaN) pivot; then the reference adds
+// max(1e-6, 1e-6*|trace|) to the diagonal and retries (student.py:75-79, modes.py:111-119).
+// inv = L^-T L^-1 with W = L^-1 in scratch.
+__global__ void __launch_bounds__(256) k_chol_inv(double* __restrict__ covs, int d, double* __restrict__ chols,
+                                                  double* __restrict__ invs, double* __restrict__ work) {
+  double* A = covs + (size_t)blockIdx.x * d * d;
+  double* L = chols + (size_t)blockIdx.x * d * d;
+  double* Ainv = invs + (size_t)blockIdx.x * d * d;
+  double* W = work + (size_t)blockIdx.x * d * d;
+  __shared__ int fail;
+  __shared__ double piv;
+  for (int round = 0; round < 3; ++round) {
+    __syncthreads();
+    if (threadIdx.x == 0) fail = 0;
+    for (int e = threadIdx.x; e < d * d; e += blockDim.x) L[e] = 0.0;
+    __syncthreads();
+    for (int j = 0; j < d; ++j) {
+      if (threadIdx.x == 0) {
+        double s = A[j * d + j];
+        for (int k = 0; k < j; ++k) s -= L[j * d + k] * L[j * d + k];
+        if (!(s > 0.0)) fail = 1;
+        piv = sqrt(s);
+        L[j * d + j] = piv;
+      }
+      __syncthreads();
+      if (fail) break;
+      for (int i = j + 1 + threadIdx.x; i < d; i += blockDim.x) {
+        double s = A[i * d + j];
+        for (int k = 0; k < j; ++k) s -= L[i * d + k] * L[j * d + k];
+        L[i * d + j] = s / piv;
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+    if (!fail || round == 2) break;
+    if (threadIdx.x == 0) {
+      double tr = 0.0;
+      for (int j = 0; j < d; ++j) tr += A[j * d + j];
+      double reg = fmax(1e-6, 1e-6 * fabs(tr));
+      for (int j = 0; j < d; ++j) A[j * d + j] += reg;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {  // column c of W solves L y = e_c
+    for (int i = 0; i < d; ++i) {
+      if (i < c) { W[i * d + c] = 0.0; continue; }
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = c; k < i; ++k) s -= L[i * d + k] * W[k * d + c];
+      W[i * d + c] = s / L[i * d + i];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < d * d; e += blockDim.x) {
+    int i = e / d, j = e % d;
+    int m = i > j ? i : j;
+    double s = 0.0;
+    for (int k = m; k < d; ++k) s += W[k * d + i] * W[k * d + j];
+    Ainv[e] = s;
+  }
+}
+
+extern "C" int tph_chol_inv(tph_ctx* ctx, double* covs_dev, int K, double* chol_dev, double* inv_dev) {
+  TPH_REQUIRE(ctx && covs_dev && chol_dev && inv_dev && K >= 1, "tph_chol_inv: bad argument");
+  size_t need = sizeof(double) * (size_t)K * ctx->d * ctx->d;
+  if (tph_scratch_reserve(ctx, need)) return -1;
+  hipLaunchKernelGGL(k_chol_inv, dim3(K), dim3(256), 0, ctx->stream, covs_dev, ctx->d, chol_dev, inv_dev, (double*)ctx->scratch);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ fit_modes
+extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int32_t* labels_dev, int64_t n, int K,
+                             double* means_dev, double* covs_dev, double* chol_dev, double* inv_dev) {
+  TPH_REQUIRE(ctx && counts_dev && means_dev && covs_dev && chol_dev && inv_dev, "tph_fit_modes: NULL argument");
+  TPH_REQUIRE(n > 0 && n <= ctx->size && K >= 1, "tph_fit_modes: bad sizes");
+  TPH_REQUIRE(K == 1 || labels_dev, "tph_fit_modes: K>1 needs labels");
+  const int d = ctx->d;
+  const int nblk = cov_blocks(n);
+  const int rblk = tph_grid_for(n, 256, 4, 512);
+  // scratch layout
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
+  size_t o_part = take(sizeof(double) * ((size_t)nblk * d * d + (size_t)d * d));      // cov partials + column sums
+  size_t o_part1 = take(sizeof(double) * (size_t)rblk * (1 + d));                      // first-moment partials
+  size_t o_sums = take(sizeof(double) * (1 + d));
+  size_t o_mean = take(sizeof(double) * d);
+  size_t o_h1 = take(sizeof(unsigned int) * (size_t)d * MED_BINS);
+  size_t o_h2 = take(sizeof(unsigned int) * (size_t)d * 2 * MED_BINS);
+  size_t o_sel = take(sizeof(long long) * (size_t)d * 2 * 4);
+  size_t o_vals = take(sizeof(double) * (size_t)d * 2 * MED_CAP);
+  size_t o_cnts = take(sizeof(int) * (size_t)d * 2 * MED_CAP);
+  size_t o_fill = take(sizeof(int) * ((size_t)d * 2 + 1));
+  if (tph_scratch_reserve(ctx, o)) return -1;
+  char* base = (char*)ctx->scratch;
+  double* part = (double*)(base + o_part);
+  double* part1 = (double*)(base + o_part1);
+  double* sums = (double*)(base + o_sums);
+  double* mean = (double*)(base + o_mean);
+  unsigned int* h1 = (unsigned int*)(base + o_h1);
+  unsigned int* h2 = (unsigned int*)(base + o_h2);
+  long long* sel = (long long*)(base + o_sel);
+  double* vals = (double*)(base + o_vals);
+  int* cnts = (int*)(base + o_cnts);
+  int* fill = (int*)(base + o_fill);
+  int* overflow = fill + (size_t)d * 2;
+  for (int k = 0; k < K; ++k) {
+    const int32_t* lab = K > 1 ? labels_dev : nullptr;
+    // first moments -> arithmetic mean (centre of np.cov)
+    hipLaunchKernelGGL(k_wsum<int32_t>, dim3(rblk, 1 + d), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, d, counts_dev, lab, k, n,
+                       part1);
+    hipLaunchKernelGGL(k_colsum2, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums);
+    hipLaunchKernelGGL(k_mean_from_sums, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, sums, d, mean);
+    // covariance (student.py:62-63)
+    if (moments_launch_cov(ctx, counts_dev, true, lab, k, n, mean, sums, 1, covs_dev + (size_t)k * d * d, part, nblk)) return -1;
+    // per-dimension median (student.py:61)
+    TPH_HIP(hipMemsetAsync(h1, 0, sizeof(unsigned int) * (size_t)d * MED_BINS, ctx->stream));
+    TPH_HIP(hipMemsetAsync(h2, 0, sizeof(unsigned int) * (size_t)d * 2 * MED_BINS, ctx->stream));
+    TPH_HIP(hipMemsetAsync(fill, 0, sizeof(int) * ((size_t)d * 2 + 1), ctx->stream));
+    dim3 hg(tph_grid_for(n, 256, 8, 256), d);
+    hipLaunchKernelGGL(k_med_hist1, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, h1);
+    hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(64), 0, ctx->stream, h1, 1, sums, sel);
+    hipLaunchKernelGGL(k_med_hist2, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, sel, h2);
+    hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(64), 0, ctx->stream, h2, 2, sums, sel);
+    hipLaunchKernelGGL(k_med_collect, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, sel, vals, cnts, fill);
+    hipLaunchKernelGGL(k_med_finish, dim3(d), dim3(256), 0, ctx->stream, sel, vals, cnts, fill, means_dev + (size_t)k * d, overflow);
+    TPH_LAUNCH_CHECK();
+  }
+  return tph_chol_inv(ctx, covs_dev, K, chol_dev, inv_dev);
+}
+
+// ------------------------------------------------------------------------------ volume variation
+extern "C" int tph_weighted_moments(tph_ctx* ctx, const double* w_dev, int64_t n, double* mean_cov_dev) {
+  TPH_REQUIRE(ctx && w_dev && mean_cov_dev && n > 0 && n <= ctx->size, "tph_weighted_moments: bad argument");
+  const int d = ctx->d;
+  const int nblk = cov_blocks(n);
+  const int rblk = tph_grid_for(n, 256, 4, 512);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
+  size_t o_part = take(sizeof(double) * ((size_t)nblk * d * d + (size_t)d * d));
+  size_t o_part1 = take(sizeof(double) * (size_t)rblk * (1 + d));
+  size_t o_sums = take(sizeof(double) * (1 + d));
+  if (tph_scratch_reserve(ctx, o)) return -1;
+  char* base = (char*)ctx->scratch;
+  double* part = (double*)(base + o_part);
+  double* part1 = (double*)(base + o_part1);
+  double* sums = (double*)(base + o_sums);
+  hipLaunchKernelGGL(k_wsum<double>, dim3(rblk, 1 + d), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, d, w_dev,
+                     (const int32_t*)nullptr, 0, n, part1);
+  hipLaunchKernelGGL(k_colsum2, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums);
+  // tools.py:94-96: weights are normalised first, so mean = sum(w u)/sum(w)
+  hipLaunchKernelGGL(k_mean_from_sums, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, sums, d, mean_cov_dev);
+  TPH_LAUNCH_CHECK();
+  return moments_launch_cov(ctx, w_dev, false, nullptr, 0, n, mean_cov_dev, sums, 2, mean_cov_dev + d, part, nblk);
+}
+
+extern "C" int tph_weighted_cov_centered(tph_ctx* ctx, const double* w_dev, int64_t n, const double* mean_dev, double* cov_dev) {
+  TPH_REQUIRE(ctx && w_dev && mean_dev && cov_dev && n > 0 && n <= ctx->size, "tph_weighted_cov_centered: bad argument");
+  const int d = ctx->d;
+  const int nblk = cov_blocks(n);
+  size_t need = sizeof(double) * ((size_t)nblk * d * d + (size_t)d * d);
+  if (tph_scratch_reserve(ctx, need)) return -1;
+  return moments_launch_cov(ctx, w_dev, false, nullptr, 0, n, mean_dev, nullptr, 0, cov_dev, (double*)ctx->scratch, nblk);
+}
+
+// sum_s w_s^2 clip(d2_s - n_dim, +-1e6)^2 with d2 the Mahalanobis distance (tools.py:111-115).
+// One lane per row, its centred coordinates in LDS as [d][64]; Sigma^-1 read with wave-uniform loads.
+__global__ void __launch_bounds__(64) k_cv_sum(const double* __restrict__ hu, int64_t cap, int d, const double* __restrict__ w,
+                                               int64_t n, const double* __restrict__ mean, const double* __restrict__ P,
+                                               double* __restrict__ partials) {
+  extern __shared__ double sh[];
+  double* xc = sh + threadIdx.x;
+  double acc = 0.0;
+  const int64_t ntiles = (n + 63) / 64;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    int64_t i = t * 64 + threadIdx.x;
+    if (i < n) {
+      for (int j = 0; j < d; ++j) xc[j * 64] = hu[(size_t)j * cap + i] - mean[j];
+      double d2 = 0.0;
+      for (int r = 0; r < d; ++r) {
+        double s = 0.0;
+        for (int j = 0; j < d; ++j) s += P[r * d + j] * xc[j * 64];
+        d2 += xc[r * 64] * s;
+      }
+      double dev = fmin(fmax(d2 - (double)d, -1e6), 1e6);
+      double ww = w[i];
+      acc += (ww * ww) * (dev * dev);
+    }
+  }
+  acc = tph_wave_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+extern "C" int tph_cv_sum(tph_ctx* ctx, const double* w_dev, int64_t n, const double* mean_dev, const double* covinv_dev,
+                          double* out_dev) {
+  TPH_REQUIRE(ctx && w_dev && mean_dev && covinv_dev && out_dev && n > 0 && n <= ctx->size, "tph_cv_sum: bad argument");
+  const int d = ctx->d;
+  int64_t ntiles = (n + 63) / 64;
+  int nblk = (int)(ntiles < 4096 ? ntiles : 4096);
+  if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)nblk)) return -1;
+  double* part = (double*)ctx->scratch;
+  size_t lds = sizeof(double) * (size_t)d * 64;
+  if (lds > 64 * 1024)
+    TPH_HIP(hipFuncSetAttribute((const void*)k_cv_sum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_cv_sum, dim3(nblk), dim3(64), lds, ctx->stream, ctx->u, ctx->cap, d, w_dev, n, mean_dev, covinv_dev, part);
+  hipLaunchKernelGGL(k_colsum2, dim3(1), dim3(256), 0, ctx->stream, part, nblk, 1, out_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}

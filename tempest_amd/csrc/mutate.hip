@@ -1,0 +1,383 @@
+// MCMC mutation of the active particle set.
+// Reference: tempest/steps/mutate.py:76-200 (Mutator.run), tempest/mcmc.py:104-208 (runner loop,
+// adaptive step count), :211-288 (tpCN), :291-323 (RWM), :326-411 (boundary conditions).
+#include "common.h"
+
+// ------------------------------------------------------------------------------- prior draw (beta=0)
+// u ~ U(0,1)^d (mutate.py:102): one Philox call per coordinate pair.
+__global__ void __launch_bounds__(256) k_prior_draw(double* __restrict__ u, int64_t n, int64_t ld, int d, uint64_t seed,
+                                                    uint32_t tick, int64_t item0) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int p = blockIdx.y;
+  if (i >= n) return;
+  tph_rng g(seed, tick, TPH_TAG_PRIOR, (uint64_t)(item0 + i));
+  double a, b;
+  g.uniform2((uint32_t)p, a, b);
+  u[(size_t)(2 * p) * ld + i] = a;
+  if (2 * p + 1 < d) u[(size_t)(2 * p + 1) * ld + i] = b;
+}
+
+extern "C" int tph_prior_draw(tph_ctx* ctx, double* u_dev, int64_t n, int64_t ld, uint64_t seed, uint32_t tick,
+                              int64_t item0) {
+  TPH_REQUIRE(ctx && u_dev && n > 0 && ld >= n, "tph_prior_draw: bad argument");
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)((ctx->d + 1) / 2));
+  hipLaunchKernelGGL(k_prior_draw, grid, dim3(256), 0, ctx->stream, u_dev, n, ld, ctx->d, seed, tick, item0);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------- +-inf repair (mutate.py:122-148)
+__global__ void __launch_bounds__(256) k_flag_finite(const double* __restrict__ logl, int64_t n, double* __restrict__ flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = isinf(logl[i]) ? 0.0 : 1.0;
+}
+__global__ void __launch_bounds__(256) k_finite_list(const double* __restrict__ flag, const double* __restrict__ rank,
+                                                     int64_t n, int64_t* __restrict__ list) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag[i] != 0.0) list[(int64_t)rank[i] - 1] = i;
+}
+__global__ void __launch_bounds__(256) k_inf_repair(double* __restrict__ u, double* __restrict__ x, double* __restrict__ logl,
+                                                    int64_t n, int64_t ld, int d, const double* __restrict__ flag,
+                                                    const double* __restrict__ rank, const int64_t* __restrict__ list,
+                                                    uint64_t seed, uint32_t tick, int64_t item0, double* __restrict__ stats) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t n_fin = (int64_t)rank[n - 1];
+  if (i == 0) { stats[0] = (double)n_fin; stats[1] = (double)n; }
+  if (i >= n || flag[i] != 0.0 || n_fin == 0) return;
+  tph_rng g(seed, tick, TPH_TAG_REPAIR, (uint64_t)(item0 + i));
+  double U, U1;
+  g.uniform2(0, U, U1);
+  int64_t pick = (int64_t)(U * (double)n_fin);
+  if (pick > n_fin - 1) pick = n_fin - 1;
+  int64_t s = list[pick];  // finite rows are never written, infinite rows never read: no hazard
+  for (int j = 0; j < d; ++j) {
+    u[(size_t)j * ld + i] = u[(size_t)j * ld + s];
+    x[(size_t)j * ld + i] = x[(size_t)j * ld + s];
+  }
+  logl[i] = logl[s];
+}
+
+extern "C" int tph_inf_repair(tph_ctx* ctx, double* u_dev, double* x_dev, double* logl_dev, int64_t n, int64_t ld,
+                              uint64_t seed, uint32_t tick, int64_t item0, double* stats_dev) {
+  TPH_REQUIRE(ctx && u_dev && x_dev && logl_dev && stats_dev && n > 0 && ld >= n, "tph_inf_repair: bad argument");
+  // layout inside the big scratch: [tile sums (used by tph_cdf)] ... we take our arrays after a 1 MiB offset
+  size_t tiles_bytes = sizeof(double) * (size_t)((n + 2047) / 2048 + 1);
+  size_t off = (tiles_bytes + 255) / 256 * 256;
+  size_t need = off + sizeof(double) * 3 * (size_t)n;
+  if (tph_scratch_reserve(ctx, need)) return -1;
+  double* flag = (double*)((char*)ctx->scratch + off);
+  double* rank = flag + n;
+  int64_t* list = (int64_t*)(rank + n);
+  unsigned grid = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_flag_finite, dim3(grid), dim3(256), 0, ctx->stream, logl_dev, n, flag);
+  int rc = tph_cdf(ctx, flag, n, nullptr, rank);  // scratch already large enough: no reallocation
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_finite_list, dim3(grid), dim3(256), 0, ctx->stream, flag, rank, n, list);
+  hipLaunchKernelGGL(k_inf_repair, dim3(grid), dim3(256), 0, ctx->stream, u_dev, x_dev, logl_dev, n, ld, ctx->d, flag, rank,
+                     list, seed, tick, item0, stats_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- proposals
+__device__ __forceinline__ double bc_periodic(double v) {  // numpy `v % 1.0` (npy_divmod)
+  double r = fmod(v, 1.0);
+  if (r != 0.0) { if (r < 0.0) r += 1.0; } else r = 0.0;
+  return r;
+}
+__device__ __forceinline__ double bc_reflective(double v) {  // mcmc.py:357-364
+  double nr = floor(v);
+  double rem = v - nr;
+  return fmod(nr, 2.0) == 0.0 ? rem : 1.0 - rem;
+}
+
+constexpr int PROP_THREADS = 64;
+constexpr int PROP_MAX_ATTEMPTS = 256;
+
+// One lane per particle; its z[d] and diff[d] columns live in LDS as [d][64] (conflict-free).
+// tpCN (mcmc.py:225-249): m = diff^T S^-1 diff ; s = 1/Gamma((d+nu)/2, 2/(nu+m)) (one draw, reused across
+// redraws) ; u' = mu + sqrt(1-sigma^2) diff + sigma sqrt(s) L z, redrawn until the strict dims lie in [0,1].
+// RWM (mcmc.py:301-312): u' = u + sigma L z.
+// HBM per particle: read 8d+4, write 8d+16; FLOP 2*(d^2/2) per attempt (+ 2*2*d^2 for the two Mahalanobis forms).
+template <int KERNEL>
+__global__ void __launch_bounds__(PROP_THREADS) k_propose(const double* __restrict__ u, const int32_t* __restrict__ assign,
+                                                          int64_t n, int64_t ld, int d, const double* __restrict__ means,
+                                                          const double* __restrict__ chol, const double* __restrict__ inv,
+                                                          const double* __restrict__ dof, const double* __restrict__ sigmas,
+                                                          const uint8_t* __restrict__ bc, uint64_t seed, uint32_t tick,
+                                                          int64_t item0, double* __restrict__ up,
+                                                          double* __restrict__ maha_u, double* __restrict__ maha_up) {
+  extern __shared__ double sh[];
+  const int tid = threadIdx.x;
+  double* zs = sh + tid;                       // zs[j*64]
+  double* df = sh + (size_t)d * PROP_THREADS + tid;  // df[j*64]
+  int64_t i = (int64_t)blockIdx.x * PROP_THREADS + tid;
+  if (i >= n) return;
+  const int c = assign ? assign[i] : 0;
+  const double* __restrict__ mu = means + (size_t)c * d;
+  const double* __restrict__ L = chol + (size_t)c * d * d;
+  const double* __restrict__ P = inv + (size_t)c * d * d;
+  const double sigma = sigmas[c];
+
+  for (int j = 0; j < d; ++j) {
+    double uj = u[(size_t)j * ld + i];
+    df[j * PROP_THREADS] = (KERNEL == TPH_KERNEL_TPCN) ? uj - mu[j] : uj;
+  }
+  double a_fac = 1.0, b_fac = sigma, m_u = 0.0;
+  if (KERNEL == TPH_KERNEL_TPCN) {
+    for (int r = 0; r < d; ++r) {
+      double acc = 0.0;
+      for (int j = 0; j < d; ++j) acc += P[r * d + j] * df[j * PROP_THREADS];
+      m_u += df[r * PROP_THREADS] * acc;
+    }
+    const double nu = dof[c];
+    tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
+    double gam = tph_gamma_mt(gg, 0.5 * ((double)d + nu)) * (2.0 / (nu + m_u));
+    double s = 1.0 / gam;
+    a_fac = sqrt(1.0 - sigma * sigma);
+    b_fac = sigma * sqrt(s);
+  }
+  tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
+  const int npairs = (d + 1) >> 1;
+  bool ok = false;
+  for (int att = 0; att < PROP_MAX_ATTEMPTS && !ok; ++att) {
+    for (int p = 0; p < npairs; ++p) {
+      double z0, z1;
+      gz.normal2((uint32_t)(att * npairs + p), z0, z1);
+      zs[(2 * p) * PROP_THREADS] = z0;
+      if (2 * p + 1 < d) zs[(2 * p + 1) * PROP_THREADS] = z1;
+    }
+    ok = true;
+    for (int r = d - 1; r >= 0; --r) {  // descending: slot r is free once row r is done
+      double acc = 0.0;
+      for (int j = 0; j <= r; ++j) acc += L[r * d + j] * zs[j * PROP_THREADS];
+      double v;
+      if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * df[r * PROP_THREADS] + b_fac * acc;
+      else v = df[r * PROP_THREADS] + b_fac * acc;
+      const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
+      if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
+      else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
+      else ok = ok && (v >= 0.0) && (v <= 1.0);
+      zs[r * PROP_THREADS] = v;
+    }
+  }
+  if (!ok) {  // the reference would loop forever; after 256 redraws we propose the current point
+    for (int j = 0; j < d; ++j)
+      zs[j * PROP_THREADS] = (KERNEL == TPH_KERNEL_TPCN) ? df[j * PROP_THREADS] + mu[j] : df[j * PROP_THREADS];
+  }
+  double m_up = 0.0;
+  for (int j = 0; j < d; ++j) up[(size_t)j * ld + i] = zs[j * PROP_THREADS];
+  if (KERNEL == TPH_KERNEL_TPCN) {
+    for (int j = 0; j < d; ++j) zs[j * PROP_THREADS] -= mu[j];
+    for (int r = 0; r < d; ++r) {
+      double acc = 0.0;
+      for (int j = 0; j < d; ++j) acc += P[r * d + j] * zs[j * PROP_THREADS];
+      m_up += zs[r * PROP_THREADS] * acc;
+    }
+  }
+  if (maha_u) maha_u[i] = m_u;
+  if (maha_up) maha_up[i] = m_up;
+}
+
+extern "C" int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const int32_t* assign_dev, int64_t n, int64_t ld,
+                           int K, const double* means_dev, const double* chol_dev, const double* inv_dev,
+                           const double* dof_dev, const double* sigmas_dev, const uint8_t* bc_dev, uint64_t seed,
+                           uint32_t tick, int64_t item0, double* uprime_dev, double* maha_u_dev, double* maha_up_dev) {
+  TPH_REQUIRE(ctx && u_dev && uprime_dev && chol_dev && sigmas_dev, "tph_propose: NULL argument");
+  TPH_REQUIRE(n > 0 && ld >= n && K >= 1, "tph_propose: bad sizes");
+  TPH_REQUIRE(kernel == TPH_KERNEL_TPCN || kernel == TPH_KERNEL_RWM, "tph_propose: unknown kernel %d", kernel);
+  if (kernel == TPH_KERNEL_TPCN)
+    TPH_REQUIRE(means_dev && inv_dev && dof_dev && maha_u_dev && maha_up_dev, "tph_propose: tpCN needs means/inv/dof/maha");
+  TPH_REQUIRE(K == 1 || assign_dev, "tph_propose: K>1 needs assignments");
+  size_t lds = sizeof(double) * 2 * (size_t)ctx->d * PROP_THREADS;
+  TPH_REQUIRE(lds <= 160 * 1024, "tph_propose: n_dim=%d needs %zu B of LDS (>160 KiB)", ctx->d, lds);
+  unsigned grid = (unsigned)((n + PROP_THREADS - 1) / PROP_THREADS);
+  if (kernel == TPH_KERNEL_TPCN) {
+    if (lds > 64 * 1024)
+      TPH_HIP(hipFuncSetAttribute((const void*)k_propose<TPH_KERNEL_TPCN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_propose<TPH_KERNEL_TPCN>, dim3(grid), dim3(PROP_THREADS), lds, ctx->stream, u_dev, assign_dev, n, ld,
+                       ctx->d, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick, item0, uprime_dev,
+                       maha_u_dev, maha_up_dev);
+  } else {
+    if (lds > 64 * 1024)
+      TPH_HIP(hipFuncSetAttribute((const void*)k_propose<TPH_KERNEL_RWM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_propose<TPH_KERNEL_RWM>, dim3(grid), dim3(PROP_THREADS), lds, ctx->stream, u_dev, assign_dev, n, ld,
+                       ctx->d, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick, item0, uprime_dev,
+                       maha_u_dev, maha_up_dev);
+  }
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ accept
+constexpr int ACC_THREADS = 256;
+constexpr int ACC_MAX_K_DET = 64;  // deterministic per-cluster block reductions up to this K
+
+// Metropolis step (mcmc.py:163-177): alpha = min(1, exp(beta (l'-l) + factor)), NaN -> 0,
+// factor (tpCN, mcmc.py:251-279) = -A + B with A,B = -0.5 (d+nu) log(1 + m/nu) at u', u.
+// Accepted rows overwrite u, x, logl in place.  Block partials: [block][1+K] = (#accepted, sum alpha_c).
+template <int KERNEL>
+__global__ void __launch_bounds__(ACC_THREADS) k_accept(double beta, double* __restrict__ u, double* __restrict__ x,
+                                                        double* __restrict__ logl, const double* __restrict__ up,
+                                                        const double* __restrict__ xp, const double* __restrict__ lp,
+                                                        const double* __restrict__ maha_u, const double* __restrict__ maha_up,
+                                                        const int32_t* __restrict__ assign, int64_t n, int64_t ld, int d, int K,
+                                                        const double* __restrict__ dof, uint64_t seed, uint32_t tick,
+                                                        int64_t item0, double* __restrict__ partials) {
+  int64_t i = (int64_t)blockIdx.x * ACC_THREADS + threadIdx.x;
+  double alpha = 0.0, acc = 0.0;
+  int c = 0;
+  if (i < n) {
+    c = assign ? assign[i] : 0;
+    double l0 = logl[i], l1 = lp[i];
+    double factor = 0.0;
+    if (KERNEL == TPH_KERNEL_TPCN) {
+      double nu = dof[c];
+      double B = -0.5 * ((double)d + nu) * log(1.0 + maha_u[i] / nu);
+      double A = -0.5 * ((double)d + nu) * log(1.0 + maha_up[i] / nu);
+      factor = -A + B;
+    }
+    double a = exp(beta * (l1 - l0) + factor);
+    a = isnan(a) ? 0.0 : fmin(1.0, a);
+    alpha = a;
+    tph_rng g(seed, tick, TPH_TAG_ACCEPT, (uint64_t)(item0 + i));
+    double U, U1;
+    g.uniform2(0, U, U1);
+    if (U < a) {
+      acc = 1.0;
+      for (int j = 0; j < d; ++j) {
+        u[(size_t)j * ld + i] = up[(size_t)j * ld + i];
+        x[(size_t)j * ld + i] = xp[(size_t)j * ld + i];
+      }
+      logl[i] = l1;
+    }
+  }
+  __shared__ double sh[ACC_THREADS / 64];
+  double* out = partials + (size_t)blockIdx.x * (1 + K);
+  double t = tph_block_sum(acc, sh);
+  if (threadIdx.x == 0) out[0] = t;
+  for (int k = 0; k < K; ++k) {
+    t = tph_block_sum((i < n && c == k) ? alpha : 0.0, sh);
+    if (threadIdx.x == 0) out[1 + k] = t;
+  }
+}
+
+// column sums of the block partials in block order (deterministic): one thread-block per column
+__global__ void __launch_bounds__(256) k_colsum(const double* __restrict__ partials, int nblocks, int ncol,
+                                                double* __restrict__ out) {
+  int cidx = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partials[(size_t)b * ncol + cidx];
+  __shared__ double sh[4];
+  s = tph_block_sum(s, sh);
+  if (threadIdx.x == 0) out[cidx] = s;
+}
+
+extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, double* x_dev, double* logl_dev,
+                          const double* uprime_dev, const double* xprime_dev, const double* loglprime_dev,
+                          const double* maha_u_dev, const double* maha_up_dev, const int32_t* assign_dev, int64_t n,
+                          int64_t ld, int K, const double* dof_dev, uint64_t seed, uint32_t tick, int64_t item0,
+                          double* sums_dev) {
+  TPH_REQUIRE(ctx && u_dev && x_dev && logl_dev && uprime_dev && xprime_dev && loglprime_dev && sums_dev,
+              "tph_accept: NULL argument");
+  TPH_REQUIRE(n > 0 && ld >= n && K >= 1, "tph_accept: bad sizes");
+  TPH_REQUIRE(K == 1 || assign_dev, "tph_accept: K>1 needs assignments");
+  TPH_REQUIRE(K <= 4096, "tph_accept: K=%d too large", K);
+  TPH_REQUIRE(kernel == TPH_KERNEL_TPCN || kernel == TPH_KERNEL_RWM, "tph_accept: unknown kernel %d", kernel);
+  if (kernel == TPH_KERNEL_TPCN) TPH_REQUIRE(maha_u_dev && maha_up_dev && dof_dev, "tph_accept: tpCN needs maha/dof");
+  unsigned grid = (unsigned)((n + ACC_THREADS - 1) / ACC_THREADS);
+  size_t need = sizeof(double) * (size_t)grid * (1 + K);
+  if (tph_scratch_reserve(ctx, need)) return -1;
+  double* partials = (double*)ctx->scratch;
+  if (kernel == TPH_KERNEL_TPCN)
+    hipLaunchKernelGGL(k_accept<TPH_KERNEL_TPCN>, dim3(grid), dim3(ACC_THREADS), 0, ctx->stream, beta, u_dev, x_dev, logl_dev,
+                       uprime_dev, xprime_dev, loglprime_dev, maha_u_dev, maha_up_dev, assign_dev, n, ld, ctx->d, K, dof_dev,
+                       seed, tick, item0, partials);
+  else
+    hipLaunchKernelGGL(k_accept<TPH_KERNEL_RWM>, dim3(grid), dim3(ACC_THREADS), 0, ctx->stream, beta, u_dev, x_dev, logl_dev,
+                       uprime_dev, xprime_dev, loglprime_dev, maha_u_dev, maha_up_dev, assign_dev, n, ld, ctx->d, K, dof_dev,
+                       seed, tick, item0, partials);
+  hipLaunchKernelGGL(k_colsum, dim3(1 + K), dim3(256), 0, ctx->stream, partials, (int)grid, 1 + K, sums_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------- sigma adaptation + stopping rule
+// mcmc.py:180-186 (per-cluster mean alpha), :281-288 / :320-323 (sigma update), :104-140,192-194
+// (adaptive step count incl. the `sigmas[:n_nonempty]` weighting quirk), :196-197 (returned stats).
+__global__ void k_adapt(int kernel, const double* __restrict__ sums, const double* __restrict__ counts, int K, double n_global,
+                        int d, int n_steps, int n_max, double* __restrict__ sigmas, double* __restrict__ state) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int iteration = (int)state[0] + 1;
+  const double sigma_0 = 2.38 / sqrt((double)d);
+  const double rate = 1.0 / (double)(iteration + 1);
+  double alpha_tot = 0.0;
+  for (int c = 0; c < K; ++c) {
+    alpha_tot += sums[1 + c];
+    if (counts[c] > 0.0) {
+      double mean_accept = sums[1 + c] / counts[c];
+      double s = sigmas[c] + rate * (mean_accept - 0.234);
+      if (kernel == TPH_KERNEL_TPCN) s = fmin(fmax(s, 0.0), fmin(sigma_0, 0.99));
+      sigmas[c] = s;
+    }
+  }
+  const double acc = sums[0] / n_global;
+  // weighted average of sigmas[:n_nonempty] with the non-empty cluster sizes (mcmc.py:107-117)
+  double wsum = 0.0, wsig = 0.0, smean = 0.0;
+  int q = 0;
+  for (int c = 0; c < K; ++c) {
+    smean += sigmas[c];
+    if (counts[c] > 0.0) { wsig += sigmas[q] * counts[c]; wsum += counts[c]; ++q; }
+  }
+  const double weighted_sigma = wsig / wsum;
+  const double n_min = (double)n_steps * d;
+  double ratio = sigma_0 / fmax(1e-6, weighted_sigma);
+  double n_adapt = (double)n_steps * d * (0.234 / fmax(0.01, acc)) * (ratio * ratio);
+  double n_final = fmin(fmax(n_min, n_adapt), (double)n_max * d);
+  long long n_int = (long long)n_final;  // int() truncation
+  state[0] = (double)iteration;
+  state[1] = (iteration >= n_int) ? 1.0 : 0.0;
+  state[2] = acc;
+  state[3] = alpha_tot / n_global;
+  state[4] = (smean / K) / sigma_0;
+  state[5] = (double)n_int;
+}
+
+extern "C" int tph_adapt(tph_ctx* ctx, int kernel, const double* sums_dev, const double* counts_dev, int K, double n_global,
+                         int n_dim, int n_steps, int n_max, double* sigmas_dev, double* state_dev) {
+  TPH_REQUIRE(ctx && sums_dev && counts_dev && sigmas_dev && state_dev && K >= 1, "tph_adapt: bad argument");
+  hipLaunchKernelGGL(k_adapt, dim3(1), dim3(64), 0, ctx->stream, kernel, sums_dev, counts_dev, K, n_global, n_dim, n_steps,
+                     n_max, sigmas_dev, state_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+// particles per cluster (mcmc.py:107-112); int atomics: exact and order-independent
+__global__ void __launch_bounds__(256) k_cluster_counts(const int32_t* __restrict__ assign, int64_t n, int K,
+                                                        unsigned long long* __restrict__ cnt) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int c = assign[i];
+    if (c >= 0 && c < K) atomicAdd(&cnt[c], 1ull);
+  }
+}
+__global__ void k_u64_to_double(const unsigned long long* __restrict__ in, int K, double* __restrict__ out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < K) out[c] = (double)in[c];
+}
+
+extern "C" int tph_cluster_counts(tph_ctx* ctx, const int32_t* assign_dev, int64_t n, int K, double* counts_dev) {
+  TPH_REQUIRE(ctx && counts_dev && n > 0 && K >= 1 && K <= 4096, "tph_cluster_counts: bad argument");
+  unsigned long long* cnt = (unsigned long long*)(ctx->small_dev);  // 4096 slots of 8 B
+  TPH_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * (size_t)K, ctx->stream));
+  if (assign_dev) {
+    hipLaunchKernelGGL(k_cluster_counts, dim3(tph_grid_for(n, 256, 4)), dim3(256), 0, ctx->stream, assign_dev, n, K, cnt);
+  } else {
+    unsigned long long one = (unsigned long long)n;
+    TPH_HIP(hipMemcpyAsync(cnt, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream));
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  hipLaunchKernelGGL(k_u64_to_double, dim3((K + 255) / 256), dim3(256), 0, ctx->stream, cnt, K, counts_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,216 @@
+// Resampling of the active set from the weighted history.
+// Reference: tempest/tools.py:178-228 (systematic_resample), tempest/steps/resample.py:52-99
+// (Resampler.run: np.random.choice(p=w) | systematic, then u,x,logl[idx]), tempest/modes.py:196-201
+// (x4 multinomial up-sampling before the proposal fit).
+#include "common.h"
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ __forceinline__ double masked(double w, bool use_thr, double thr) { return (use_thr && !(w >= thr)) ? 0.0 : w; }
+
+// pass 1: sum of each 2048-element tile
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_tile_sums(const double* __restrict__ w, int64_t n,
+                                                                 const double* __restrict__ thr_dev,
+                                                                 double* __restrict__ tile_sums) {
+  const bool use_thr = thr_dev != nullptr;
+  const double thr = use_thr ? thr_dev[0] : 0.0;
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    int64_t i = base + k;
+    if (i < n) s += masked(w[i], use_thr, thr);
+  }
+  __shared__ double sh[SCAN_THREADS / 64];
+  s = tph_block_sum(s, sh);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = s;
+}
+
+// inclusive scan across the lanes of a wave
+__device__ __forceinline__ double wave_incl_scan(double v) {
+  int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// pass 2: exclusive scan of the tile sums, one block of 1024 threads, each owning a contiguous run
+__global__ void __launch_bounds__(1024) k_scan_tile_offsets(double* __restrict__ tile_sums, int64_t ntiles) {
+  int64_t per = (ntiles + 1023) / 1024;
+  int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
+  double s = 0.0;
+  for (int64_t i = lo; i < hi; ++i) s += tile_sums[i];
+  __shared__ double wsum[16];
+  double inc = wave_incl_scan(s);
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  if (wid == 0) {
+    double v = lane < 16 ? wsum[lane] : 0.0;
+    v = wave_incl_scan(v);
+    if (lane < 16) wsum[lane] = v;
+  }
+  __syncthreads();
+  double excl = inc - s + (wid > 0 ? wsum[wid - 1] : 0.0);
+  for (int64_t i = lo; i < hi; ++i) {
+    double t = tile_sums[i];
+    tile_sums[i] = excl;
+    excl += t;
+  }
+}
+
+// pass 3: local inclusive scan + tile offset
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const double* __restrict__ w, int64_t n,
+                                                             const double* __restrict__ thr_dev,
+                                                             const double* __restrict__ tile_offsets,
+                                                             double* __restrict__ cdf) {
+  const bool use_thr = thr_dev != nullptr;
+  const double thr = use_thr ? thr_dev[0] : 0.0;
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  double v[SCAN_ITEMS];
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    int64_t i = base + k;
+    double x = i < n ? masked(w[i], use_thr, thr) : 0.0;
+    s += x;
+    v[k] = s;
+  }
+  __shared__ double wsum[SCAN_THREADS / 64];
+  double inc = wave_incl_scan(s);
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  double off = tile_offsets[blockIdx.x];
+  for (int k = 0; k < wid; ++k) off += wsum[k];
+  off += inc - s;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    int64_t i = base + k;
+    if (i < n) cdf[i] = off + v[k];
+  }
+}
+
+extern "C" int tph_cdf(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev, double* cdf_dev) {
+  TPH_REQUIRE(ctx && w_dev && cdf_dev && n > 0, "tph_cdf: bad argument");
+  int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)ntiles)) return -1;
+  double* tiles = (double*)ctx->scratch;
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, ctx->stream, w_dev, n, thr_dev, tiles);
+  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(1024), 0, ctx->stream, tiles, ntiles);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, ctx->stream, w_dev, n, thr_dev, tiles, cdf_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+// #{k in [0,n) : pred(cdf_k)}, pred monotone (true ... true false ... false)
+template <bool STRICT>
+__device__ __forceinline__ int64_t count_below(const double* __restrict__ cdf, int64_t n, double div, double pos) {
+  int64_t lo = 0, hi = n;  // answer in [lo, hi]
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    double c = cdf[mid] / div;
+    bool below = STRICT ? (c < pos) : (c <= pos);
+    if (below) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256) k_resample_systematic(const double* __restrict__ cdf, int64_t n, int64_t n_out,
+                                                             int64_t i0, int64_t size_global, double u0, double renorm,
+                                                             int64_t* __restrict__ idx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  double pos = (u0 + (double)(i0 + i)) / (double)size_global;
+  int64_t k = count_below<true>(cdf, n, renorm, pos);
+  idx[i] = k < n ? k : n - 1;
+}
+
+extern "C" int tph_resample_systematic(tph_ctx* ctx, const double* cdf_dev, int64_t n, int64_t n_out, int64_t i0,
+                                       int64_t size_global, double u0, double renorm, int64_t* idx_dev) {
+  TPH_REQUIRE(ctx && cdf_dev && idx_dev && n > 0 && n_out > 0, "tph_resample_systematic: bad argument");
+  TPH_REQUIRE(renorm > 0 && size_global >= n_out, "tph_resample_systematic: bad renorm/size");
+  hipLaunchKernelGGL(k_resample_systematic, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx->stream, cdf_dev, n,
+                     n_out, i0, size_global, u0, renorm, idx_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) k_resample_multinomial(const double* __restrict__ cdf, int64_t n, int64_t n_out,
+                                                              uint64_t seed, uint32_t tick, uint32_t tag, int64_t item0,
+                                                              int64_t* __restrict__ idx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  tph_rng g(seed, tick, tag, (uint64_t)(item0 + i));
+  double U, U1;
+  g.uniform2(0, U, U1);
+  int64_t k = count_below<false>(cdf, n, cdf[n - 1], U);
+  idx[i] = k < n ? k : n - 1;
+}
+
+extern "C" int tph_resample_multinomial(tph_ctx* ctx, const double* cdf_dev, int64_t n, int64_t n_out, uint64_t seed,
+                                        uint32_t tick, uint32_t tag, int64_t item0, int64_t* idx_dev) {
+  TPH_REQUIRE(ctx && cdf_dev && idx_dev && n > 0 && n_out > 0, "tph_resample_multinomial: bad argument");
+  hipLaunchKernelGGL(k_resample_multinomial, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx->stream, cdf_dev, n,
+                     n_out, seed, tick, tag, item0, idx_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+// K7: gather rows of the history; coalesced writes, indexed reads
+__global__ void __launch_bounds__(256) k_gather(const double* __restrict__ hu, const double* __restrict__ hx,
+                                                const double* __restrict__ hl, int64_t cap, int d,
+                                                const int64_t* __restrict__ idx, int64_t n_out,
+                                                double* __restrict__ u, double* __restrict__ x, double* __restrict__ l,
+                                                int64_t ld) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  int64_t s = idx[i];
+  for (int j = 0; j < d; ++j) {
+    u[(size_t)j * ld + i] = hu[(size_t)j * cap + s];
+    x[(size_t)j * ld + i] = hx[(size_t)j * cap + s];
+  }
+  l[i] = hl[s];
+}
+
+extern "C" int tph_gather(tph_ctx* ctx, const int64_t* idx_dev, int64_t n_out, double* u_out, double* x_out,
+                          double* logl_out, int64_t ld_out) {
+  TPH_REQUIRE(ctx && idx_dev && u_out && x_out && logl_out, "tph_gather: NULL argument");
+  TPH_REQUIRE(n_out > 0 && ld_out >= n_out && ctx->size > 0, "tph_gather: bad sizes");
+  hipLaunchKernelGGL(k_gather, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx->stream, ctx->u, ctx->x, ctx->logl,
+                     ctx->cap, ctx->d, idx_dev, n_out, u_out, x_out, logl_out, ld_out);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+// multiplicities of `factor * kept_count` multinomial draws (kept_count lives on the device: no host sync)
+__global__ void __launch_bounds__(256) k_multinomial_counts(const double* __restrict__ cdf, int64_t n,
+                                                            const double* __restrict__ kept_count_dev, int factor,
+                                                            int64_t n_draw_max, uint64_t seed, uint32_t tick, uint32_t tag,
+                                                            int32_t* __restrict__ counts) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t n_draw = kept_count_dev ? (int64_t)(kept_count_dev[0]) * factor : n_draw_max;
+  if (r >= n_draw || r >= n_draw_max) return;
+  tph_rng g(seed, tick, tag, (uint64_t)r);
+  double U, U1;
+  g.uniform2(0, U, U1);
+  int64_t k = count_below<false>(cdf, n, cdf[n - 1], U);
+  if (k >= n) k = n - 1;
+  atomicAdd(&counts[k], 1);
+}
+
+extern "C" int tph_multinomial_counts(tph_ctx* ctx, const double* cdf_dev, int64_t n, const double* kept_count_dev,
+                                      int factor, int64_t n_draw_max, uint64_t seed, uint32_t tick, uint32_t tag,
+                                      int32_t* counts_dev) {
+  TPH_REQUIRE(ctx && cdf_dev && counts_dev && n > 0 && n_draw_max > 0, "tph_multinomial_counts: bad argument");
+  TPH_HIP(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * (size_t)n, ctx->stream));
+  hipLaunchKernelGGL(k_multinomial_counts, dim3((unsigned)((n_draw_max + 255) / 256)), dim3(256), 0, ctx->stream, cdf_dev, n,
+                     kept_count_dev, factor, n_draw_max, seed, tick, tag, counts_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}

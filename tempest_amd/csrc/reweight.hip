@@ -1,0 +1,244 @@
+// Tempered reweighting over the whole particle history.
+// Reference: tempest/state_manager.py:418-480 (compute_logw_and_logz), tempest/steps/reweight.py:88-118
+// (_compute_metric_and_weights), tempest/tools.py:120-135 (effective_sample_size).
+//
+// With the cached log-mixture C_s (ctx.hip) one evaluation of a trial beta is a single streaming pass
+//     v_s = beta*l_s - C_s ;  (max v, sum e^{v-max}, sum e^{2(v-max)})
+// over 16 B per historical particle: HBM-bound.  ESS = s1^2/s2, logZ = max + log s1.
+#include "common.h"
+
+struct tph_betas { double b[TPH_MAX_NB]; };
+
+struct trip { double m, s1, s2; };
+
+__device__ __forceinline__ trip trip_merge(trip a, trip b) {
+  double M = fmax(a.m, b.m);
+  double fa = exp(a.m - M), fb = exp(b.m - M);
+  trip r;
+  r.m = M;
+  r.s1 = a.s1 * fa + b.s1 * fb;
+  r.s2 = a.s2 * (fa * fa) + b.s2 * (fb * fb);
+  return r;
+}
+
+__device__ __forceinline__ trip trip_wave_reduce(trip t) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    trip b;
+    b.m = __shfl_down(t.m, o, 64);
+    b.s1 = __shfl_down(t.s1, o, 64);
+    b.s2 = __shfl_down(t.s2, o, 64);
+    t = trip_merge(t, b);
+  }
+  return t;
+}
+
+// block reduce; result valid in thread 0.  sh: 3 * (blockDim/64) doubles.
+__device__ __forceinline__ trip trip_block_reduce(trip t, double* sh) {
+  t = trip_wave_reduce(t);
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) { sh[wid] = t.m; sh[nw + wid] = t.s1; sh[2 * nw + wid] = t.s2; }
+  __syncthreads();
+  if (wid == 0) {
+    if (lane < nw) { t.m = sh[lane]; t.s1 = sh[nw + lane]; t.s2 = sh[2 * nw + lane]; }
+    else { t.m = -DBL_MAX; t.s1 = 0.0; t.s2 = 0.0; }
+    t = trip_wave_reduce(t);
+  }
+  return t;
+}
+
+// One streaming pass for NB trial betas.  Each lane keeps a running (m, s1, s2) per beta and
+// rescales only when a 4-element chunk raises its maximum (about one exp per element).
+// Loads are 16 B/lane (double2) with two independent chunks in flight.
+template <int NB>
+__global__ void __launch_bounds__(TPH_RED_THREADS) k_reweight_reduce(const double* __restrict__ logl,
+                                                                      const double* __restrict__ cmix, int64_t n,
+                                                                      tph_betas betas, double* __restrict__ partials) {
+  double m[NB], s1[NB], s2[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) { m[b] = -DBL_MAX; s1[b] = 0.0; s2[b] = 0.0; }
+
+  const int64_t n2 = n >> 1;
+  const double2* __restrict__ l2 = reinterpret_cast<const double2*>(logl);
+  const double2* __restrict__ c2 = reinterpret_cast<const double2*>(cmix);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += 2 * stride) {
+    double2 la = l2[i], ca = c2[i];
+    double2 lb = make_double2(0.0, 0.0), cb = make_double2(INFINITY, INFINITY);  // v = -inf: contributes 0
+    if (i + stride < n2) { lb = l2[i + stride]; cb = c2[i + stride]; }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const double be = betas.b[b];
+      double v0 = be * la.x - ca.x, v1 = be * la.y - ca.y, v2 = be * lb.x - cb.x, v3 = be * lb.y - cb.y;
+      double vm = fmax(fmax(v0, v1), fmax(v2, v3));
+      if (vm > m[b]) {
+        double f = exp(m[b] - vm);
+        s1[b] *= f;
+        s2[b] *= f * f;
+        m[b] = vm;
+      }
+      double e0 = exp(v0 - m[b]), e1 = exp(v1 - m[b]), e2 = exp(v2 - m[b]), e3 = exp(v3 - m[b]);
+      s1[b] += (e0 + e1) + (e2 + e3);
+      s2[b] += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd tail
+    double l = logl[n - 1], c = cmix[n - 1];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      double v = betas.b[b] * l - c;
+      if (v > m[b]) { double f = exp(m[b] - v); s1[b] *= f; s2[b] *= f * f; m[b] = v; }
+      double e = exp(v - m[b]);
+      s1[b] += e;
+      s2[b] += e * e;
+    }
+  }
+  __shared__ double sh[3 * (TPH_RED_THREADS / 64)];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    trip t = trip_block_reduce(trip{m[b], s1[b], s2[b]}, sh);
+    if (threadIdx.x == 0) {
+      double* p = partials + ((size_t)blockIdx.x * NB + b) * 3;
+      p[0] = t.m; p[1] = t.s1; p[2] = t.s2;
+    }
+  }
+}
+
+// merge the per-block partials of all betas: one block per beta
+__global__ void __launch_bounds__(256) k_reweight_finalize(const double* __restrict__ partials, int nblocks, int nb,
+                                                           double* __restrict__ out) {
+  int b = blockIdx.x;
+  trip t{-DBL_MAX, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+    const double* p = partials + ((size_t)i * nb + b) * 3;
+    t = trip_merge(t, trip{p[0], p[1], p[2]});
+  }
+  __shared__ double sh[3 * 4];
+  t = trip_block_reduce(t, sh);
+  if (threadIdx.x == 0) {
+    if (t.m == -DBL_MAX) t.m = -INFINITY;  // empty input
+    out[b * 3 + 0] = t.m; out[b * 3 + 1] = t.s1; out[b * 3 + 2] = t.s2;
+  }
+}
+
+template <int NB>
+static void launch_reduce(tph_ctx* ctx, int grid, const tph_betas& bt) {
+  hipLaunchKernelGGL(k_reweight_reduce<NB>, dim3(grid), dim3(TPH_RED_THREADS), 0, ctx->stream, ctx->logl, ctx->cmix,
+                     ctx->size, bt, ctx->partials);
+}
+
+extern "C" int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int nb, double* out_dev) {
+  TPH_REQUIRE(ctx && betas_host && out_dev, "tph_reweight_partials: NULL argument");
+  TPH_REQUIRE(nb >= 1 && nb <= TPH_MAX_NB, "tph_reweight_partials: nb=%d outside [1,%d]", nb, TPH_MAX_NB);
+  TPH_REQUIRE(ctx->size > 0, "tph_reweight_partials: empty history");
+  tph_betas bt;
+  for (int i = 0; i < TPH_MAX_NB; ++i) bt.b[i] = i < nb ? betas_host[i] : 0.0;
+  // 4 elements per lane per trip, capped at 2048 blocks (256 CUs x 8) and grid-strided beyond
+  int grid = tph_grid_for(ctx->size, TPH_RED_THREADS, 4);
+  TPH_REQUIRE((size_t)grid * nb * 3 * sizeof(double) <= ctx->partials_bytes, "tph_reweight_partials: scratch too small");
+  switch (nb) {
+    case 1: launch_reduce<1>(ctx, grid, bt); break;
+    case 2: launch_reduce<2>(ctx, grid, bt); break;
+    case 3: launch_reduce<3>(ctx, grid, bt); break;
+    case 4: launch_reduce<4>(ctx, grid, bt); break;
+    case 5: launch_reduce<5>(ctx, grid, bt); break;
+    case 6: launch_reduce<6>(ctx, grid, bt); break;
+    case 7: launch_reduce<7>(ctx, grid, bt); break;
+    case 8: launch_reduce<8>(ctx, grid, bt); break;
+    case 9: launch_reduce<9>(ctx, grid, bt); break;
+    case 10: launch_reduce<10>(ctx, grid, bt); break;
+    case 11: launch_reduce<11>(ctx, grid, bt); break;
+    case 12: launch_reduce<12>(ctx, grid, bt); break;
+    case 13: launch_reduce<13>(ctx, grid, bt); break;
+    case 14: launch_reduce<14>(ctx, grid, bt); break;
+    case 15: launch_reduce<15>(ctx, grid, bt); break;
+    default: launch_reduce<16>(ctx, grid, bt); break;
+  }
+  TPH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_reweight_finalize, dim3(nb), dim3(256), 0, ctx->stream, ctx->partials, grid, nb, out_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tph_reweight_eval(tph_ctx* ctx, const double* betas_host, int nb, double* out_host) {
+  TPH_REQUIRE(out_host, "tph_reweight_eval: out is NULL");
+  int rc = tph_reweight_partials(ctx, betas_host, nb, ctx->small_dev);
+  if (rc) return rc;
+  TPH_HIP(hipMemcpyAsync(ctx->pinned, ctx->small_dev, sizeof(double) * 3 * nb, hipMemcpyDeviceToHost, ctx->stream));
+  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 3 * nb; ++i) out_host[i] = ctx->pinned[i];
+  return 0;
+}
+
+// K3: normalised weights, 24 B per historical particle
+__global__ void __launch_bounds__(256) k_weights(const double* __restrict__ logl, const double* __restrict__ cmix,
+                                                 int64_t n, double beta, double vmax, double s1,
+                                                 double* __restrict__ w) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += stride)
+    w[s] = exp(beta * logl[s] - cmix[s] - vmax) / s1;
+}
+
+extern "C" int tph_weights(tph_ctx* ctx, double beta, double vmax, double s1, double* w_dev) {
+  TPH_REQUIRE(ctx && w_dev, "tph_weights: NULL argument");
+  TPH_REQUIRE(ctx->size > 0, "tph_weights: empty history");
+  hipLaunchKernelGGL(k_weights, dim3(tph_grid_for(ctx->size, 256, 2)), dim3(256), 0, ctx->stream, ctx->logl, ctx->cmix,
+                     ctx->size, beta, vmax, s1, w_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) k_logw(const double* __restrict__ logl, const double* __restrict__ cmix, int64_t n,
+                                              double beta, double lognh, double* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += stride)
+    out[s] = beta * logl[s] - (cmix[s] - lognh);
+}
+
+extern "C" int tph_logw(tph_ctx* ctx, double beta, int64_t n_h_global, double* logw_dev) {
+  TPH_REQUIRE(ctx && logw_dev, "tph_logw: NULL argument");
+  TPH_REQUIRE(ctx->size > 0, "tph_logw: empty history");
+  hipLaunchKernelGGL(k_logw, dim3(tph_grid_for(ctx->size, 256, 2)), dim3(256), 0, ctx->stream, ctx->logl, ctx->cmix,
+                     ctx->size, beta, log((double)n_h_global), logw_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+// (sum w, sum w^2, max w)
+__global__ void __launch_bounds__(256) k_sum_sq_max(const double* __restrict__ w, int64_t n, double* __restrict__ partials) {
+  double a = 0.0, b = 0.0, m = -DBL_MAX;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += stride) {
+    double v = w[s];
+    a += v; b += v * v; m = fmax(m, v);
+  }
+  __shared__ double sh[4];
+  a = tph_block_sum(a, sh);
+  b = tph_block_sum(b, sh);
+  m = tph_block_max(m, sh);
+  if (threadIdx.x == 0) { partials[blockIdx.x * 3] = a; partials[blockIdx.x * 3 + 1] = b; partials[blockIdx.x * 3 + 2] = m; }
+}
+__global__ void __launch_bounds__(256) k_sum_sq_max_final(const double* __restrict__ partials, int nblocks, double* out) {
+  double a = 0.0, b = 0.0, m = -DBL_MAX;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+    a += partials[i * 3]; b += partials[i * 3 + 1]; m = fmax(m, partials[i * 3 + 2]);
+  }
+  __shared__ double sh[4];
+  a = tph_block_sum(a, sh);
+  b = tph_block_sum(b, sh);
+  m = tph_block_max(m, sh);
+  if (threadIdx.x == 0) { out[0] = a; out[1] = b; out[2] = m; }
+}
+
+extern "C" int tph_sum_sq_max(tph_ctx* ctx, const double* w_dev, int64_t n, double* out_host) {
+  TPH_REQUIRE(ctx && w_dev && out_host && n > 0, "tph_sum_sq_max: bad argument");
+  int grid = tph_grid_for(n, 256, 4);
+  hipLaunchKernelGGL(k_sum_sq_max, dim3(grid), dim3(256), 0, ctx->stream, w_dev, n, ctx->partials);
+  hipLaunchKernelGGL(k_sum_sq_max_final, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, ctx->small_dev);
+  TPH_LAUNCH_CHECK();
+  TPH_HIP(hipMemcpyAsync(ctx->pinned, ctx->small_dev, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
+  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 3; ++i) out_host[i] = ctx->pinned[i];
+  return 0;
+}

@@ -1,0 +1,266 @@
+"""Thin Python handle on one `tph_ctx` (one per GPU): every numeric step of the hot path goes
+through libtempest_hip.so here.  torch is only the device-array container (allocation, the current
+HIP stream, the tensors handed to the user's callbacks); no torch op computes anything below.
+
+Layout convention: particle arrays are SoA / dimension-major tensors of shape (n_dim, n) (row j =
+coordinate j of every particle), FP64; index arrays int64; labels int32.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+KERNEL_ID = {"tpcn": 0, "rwm": 1}
+KEY_U, KEY_X, KEY_LOGL, KEY_LOGMIX = 0, 1, 2, 3
+BC_STRICT, BC_PERIODIC, BC_REFLECTIVE = 0, 1, 2
+
+TAG_PRIOR, TAG_NORMAL, TAG_GAMMA, TAG_ACCEPT, TAG_RESAMPLE, TAG_UPSAMPLE, TAG_REPAIR, TAG_SYST = 1, 2, 3, 4, 5, 6, 7, 8
+
+
+def _ptr(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.TempestHipError("expected a device tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.TempestHipError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.TempestHipError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def _hptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class HipContext:
+    """Owns the on-device persistent ensemble (history) for one GPU."""
+
+    def __init__(self, n_dim, device=None, capacity_hint=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.TempestHipError("no GPU visible: tempest_amd has no CPU fallback")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        self.n_dim = int(n_dim)
+        torch.cuda.set_device(self.device)
+        self._ctx = C.c_void_p()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.tph_ctx_create(self.device.index, self.n_dim, int(capacity_hint), C.c_void_p(stream),
+                                      C.byref(self._ctx)), "tph_ctx_create")
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self.lib.tph_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ allocation helpers
+    def empty(self, *shape, dtype=torch.float64):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float64):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def use_current_stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.tph_set_stream(self._ctx, C.c_void_p(s)), "tph_set_stream")
+
+    def synchronize(self):
+        check(self.lib.tph_synchronize(self._ctx), "tph_synchronize")
+
+    # ------------------------------------------------------------------------------ history
+    @property
+    def size(self):
+        return int(self.lib.tph_history_size(self._ctx))
+
+    @property
+    def iterations(self):
+        return int(self.lib.tph_history_iterations(self._ctx))
+
+    def history_append(self, u, x, logl, beta, logz, n_global=None):
+        n = logl.shape[0]
+        ld = u.shape[1]
+        check(self.lib.tph_history_append(self._ctx, _ptr(u, torch.float64), _ptr(x, torch.float64),
+                                          _ptr(logl, torch.float64), n, ld, float(beta), float(logz),
+                                          int(n if n_global is None else n_global)), "tph_history_append")
+
+    def history_clear(self):
+        check(self.lib.tph_history_clear(self._ctx), "tph_history_clear")
+
+    def history_load(self, u, x, logl, beta_t, logz_t, n_t, n_t_global=None):
+        """u, x: host arrays (N_h, d) or None; logl (N_h,)."""
+        logl = np.ascontiguousarray(logl, dtype=np.float64)
+        n = logl.size
+        ut = np.ascontiguousarray(np.asarray(u, dtype=np.float64).T) if u is not None else None
+        xt = np.ascontiguousarray(np.asarray(x, dtype=np.float64).T) if x is not None else None
+        bt = np.ascontiguousarray(beta_t, dtype=np.float64)
+        zt = np.ascontiguousarray(logz_t, dtype=np.float64)
+        nt = np.ascontiguousarray(n_t, dtype=np.int64)
+        ng = np.ascontiguousarray(n_t if n_t_global is None else n_t_global, dtype=np.int64)
+        check(self.lib.tph_history_load(self._ctx, _hptr(ut) if ut is not None else None,
+                                        _hptr(xt) if xt is not None else None, _hptr(logl), n, bt.size,
+                                        _hptr(bt), _hptr(zt), _hptr(nt), _hptr(ng)), "tph_history_load")
+
+    def history_read(self, key, off=0, n=None):
+        """Host copy: (n, d) C-contiguous for u/x, (n,) for logl/logmix."""
+        n = self.size - off if n is None else n
+        if key in (KEY_U, KEY_X):
+            buf = np.empty((self.n_dim, n), dtype=np.float64)
+        else:
+            buf = np.empty((n,), dtype=np.float64)
+        if n > 0:
+            check(self.lib.tph_history_read(self._ctx, key, off, n, _hptr(buf)), "tph_history_read")
+        return np.ascontiguousarray(buf.T) if buf.ndim == 2 else buf
+
+    # --------------------------------------------------------------------------- reweighting
+    def reweight_eval(self, betas):
+        """[(vmax, s1, s2)] per trial beta (host floats; synchronises)."""
+        b = np.ascontiguousarray(np.atleast_1d(betas), dtype=np.float64)
+        out = np.empty((b.size, 3), dtype=np.float64)
+        check(self.lib.tph_reweight_eval(self._ctx, _hptr(b), b.size, _hptr(out)), "tph_reweight_eval")
+        return out
+
+    def reweight_partials(self, betas, out=None):
+        b = np.ascontiguousarray(np.atleast_1d(betas), dtype=np.float64)
+        if out is None:
+            out = self.empty(b.size, 3)
+        check(self.lib.tph_reweight_partials(self._ctx, _hptr(b), b.size, _ptr(out, torch.float64)),
+              "tph_reweight_partials")
+        return out
+
+    def weights(self, beta, vmax, s1, out=None):
+        if out is None:
+            out = self.empty(self.size)
+        check(self.lib.tph_weights(self._ctx, float(beta), float(vmax), float(s1), _ptr(out, torch.float64)),
+              "tph_weights")
+        return out
+
+    def logw(self, beta, n_h_global=None, out=None):
+        if out is None:
+            out = self.empty(self.size)
+        check(self.lib.tph_logw(self._ctx, float(beta), int(self.size if n_h_global is None else n_h_global),
+                                _ptr(out, torch.float64)), "tph_logw")
+        return out
+
+    def sum_sq_max(self, w):
+        out = np.empty(3)
+        check(self.lib.tph_sum_sq_max(self._ctx, _ptr(w, torch.float64), w.numel(), _hptr(out)), "tph_sum_sq_max")
+        return out
+
+    # ------------------------------------------------------------------------------- trimming
+    def trim_threshold(self, w, ess=0.99, bins=1000, sync=False):
+        """Device tensor (threshold, kept_sum, kept_count, ess_total) [+ host copy if sync]."""
+        out = self.empty(4)
+        host = np.empty(4) if sync else None
+        check(self.lib.tph_trim_threshold(self._ctx, _ptr(w, torch.float64), w.numel(), float(ess), int(bins),
+                                          _ptr(out), _hptr(host) if sync else None), "tph_trim_threshold")
+        return (out, host) if sync else out
+
+    # ----------------------------------------------------------------------------- resampling
+    def cdf(self, w, thr=None, out=None):
+        if out is None:
+            out = self.empty(w.numel())
+        check(self.lib.tph_cdf(self._ctx, _ptr(w, torch.float64), w.numel(), _ptr(thr), _ptr(out)), "tph_cdf")
+        return out
+
+    def resample_systematic(self, cdf, n_out, u0, i0=0, size_global=None, renorm=1.0):
+        idx = self.empty(n_out, dtype=torch.int64)
+        check(self.lib.tph_resample_systematic(self._ctx, _ptr(cdf), cdf.numel(), n_out, i0,
+                                               n_out if size_global is None else size_global, float(u0),
+                                               float(renorm), _ptr(idx)), "tph_resample_systematic")
+        return idx
+
+    def resample_multinomial(self, cdf, n_out, seed, tick, tag=TAG_RESAMPLE, item0=0):
+        idx = self.empty(n_out, dtype=torch.int64)
+        check(self.lib.tph_resample_multinomial(self._ctx, _ptr(cdf), cdf.numel(), n_out, seed, tick, tag, item0,
+                                                _ptr(idx)), "tph_resample_multinomial")
+        return idx
+
+    def gather(self, idx, u_out, x_out, logl_out):
+        check(self.lib.tph_gather(self._ctx, _ptr(idx, torch.int64), idx.numel(), _ptr(u_out), _ptr(x_out),
+                                  _ptr(logl_out), u_out.shape[1]), "tph_gather")
+
+    def multinomial_counts(self, cdf, seed, tick, kept_count=None, factor=4, n_draw_max=None, tag=TAG_UPSAMPLE):
+        n = cdf.numel()
+        counts = self.empty(n, dtype=torch.int32)
+        if n_draw_max is None:
+            n_draw_max = factor * n
+        check(self.lib.tph_multinomial_counts(self._ctx, _ptr(cdf), n, _ptr(kept_count), factor, n_draw_max, seed,
+                                              tick, tag, _ptr(counts)), "tph_multinomial_counts")
+        return counts
+
+    # ------------------------------------------------------------------------------- mutation
+    def prior_draw(self, u, seed, tick, item0=0):
+        check(self.lib.tph_prior_draw(self._ctx, _ptr(u, torch.float64), u.shape[1], u.shape[1], seed, tick, item0),
+              "tph_prior_draw")
+
+    def inf_repair(self, u, x, logl, seed, tick, item0=0):
+        stats = self.empty(2)
+        check(self.lib.tph_inf_repair(self._ctx, _ptr(u), _ptr(x), _ptr(logl), logl.numel(), u.shape[1], seed, tick,
+                                      item0, _ptr(stats)), "tph_inf_repair")
+        return stats
+
+    def propose(self, kernel, u, assign, modes, sigmas, bc, seed, tick, item0, uprime, maha_u, maha_up):
+        n = u.shape[1]
+        check(self.lib.tph_propose(self._ctx, KERNEL_ID[kernel], _ptr(u), _ptr(assign, torch.int32) if assign is not None else None,
+                                   n, n, modes.K, _ptr(modes.means_dev), _ptr(modes.chol_dev), _ptr(modes.inv_dev),
+                                   _ptr(modes.dof_dev), _ptr(sigmas), _ptr(bc) if bc is not None else None, seed, tick,
+                                   item0, _ptr(uprime), _ptr(maha_u), _ptr(maha_up)), "tph_propose")
+
+    def accept(self, kernel, beta, u, x, logl, uprime, xprime, loglprime, maha_u, maha_up, assign, K, dof, seed,
+               tick, item0, sums):
+        n = u.shape[1]
+        check(self.lib.tph_accept(self._ctx, KERNEL_ID[kernel], float(beta), _ptr(u), _ptr(x), _ptr(logl),
+                                  _ptr(uprime), _ptr(xprime, torch.float64), _ptr(loglprime, torch.float64),
+                                  _ptr(maha_u), _ptr(maha_up),
+                                  _ptr(assign, torch.int32) if assign is not None else None, n, n, K, _ptr(dof), seed,
+                                  tick, item0, _ptr(sums)), "tph_accept")
+
+    def adapt(self, kernel, sums, counts, K, n_global, n_steps, n_max, sigmas, state):
+        check(self.lib.tph_adapt(self._ctx, KERNEL_ID[kernel], _ptr(sums), _ptr(counts), K, float(n_global),
+                                 self.n_dim, int(n_steps), int(n_max), _ptr(sigmas), _ptr(state)), "tph_adapt")
+
+    def cluster_counts(self, assign, n, K):
+        out = self.empty(K)
+        check(self.lib.tph_cluster_counts(self._ctx, _ptr(assign, torch.int32) if assign is not None else None, n, K,
+                                          _ptr(out)), "tph_cluster_counts")
+        return out
+
+    # --------------------------------------------------------------------------- proposal fit
+    def fit_modes(self, counts, labels=None, K=1, n=None):
+        d = self.n_dim
+        n = self.size if n is None else n
+        means, covs = self.empty(K, d), self.empty(K, d, d)
+        chol, inv = self.empty(K, d, d), self.empty(K, d, d)
+        check(self.lib.tph_fit_modes(self._ctx, _ptr(counts, torch.int32),
+                                     _ptr(labels, torch.int32) if labels is not None else None, n, K, _ptr(means),
+                                     _ptr(covs), _ptr(chol), _ptr(inv)), "tph_fit_modes")
+        return means, covs, chol, inv
+
+    def chol_inv(self, covs):
+        K = covs.shape[0]
+        chol, inv = torch.empty_like(covs), torch.empty_like(covs)
+        check(self.lib.tph_chol_inv(self._ctx, _ptr(covs), K, _ptr(chol), _ptr(inv)), "tph_chol_inv")
+        return chol, inv
+
+    # ------------------------------------------------------------------------ volume variation
+    def weighted_moments(self, w):
+        d = self.n_dim
+        out = self.empty(d + d * d)
+        check(self.lib.tph_weighted_moments(self._ctx, _ptr(w), w.numel(), _ptr(out)), "tph_weighted_moments")
+        return out
+
+    def cv_sum(self, w, mean, covinv):
+        out = self.empty(1)
+        check(self.lib.tph_cv_sum(self._ctx, _ptr(w), w.numel(), _ptr(mean), _ptr(covinv), _ptr(out)), "tph_cv_sum")
+        return out

@@ -1,0 +1,431 @@
+"""HIP kernels (through the C ABI) against the oracle and the reference's golden vectors.
+Run on the GPU box:  python -m pytest tests -m gpu
+Tolerances: FP64 results rtol 1e-10 unless stated (different summation order / libm than NumPy);
+integer / index results bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import mcmc as omc  # noqa: E402
+from oracle import philox as px  # noqa: E402
+from oracle import ps  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda", 0)
+
+
+def ctx_for(d, cap=0):
+    from tempest_amd.device import HipContext
+    return HipContext(d, 0, cap)
+
+
+def soa(a, dev):
+    """(n,d) host -> (d,n) device tensor"""
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64).T)).to(dev)
+
+
+def aos(t):
+    return np.ascontiguousarray(t.cpu().numpy().T)
+
+
+# ------------------------------------------------------------------------------------ RNG
+def test_prior_draw_matches_philox(dev):
+    for d in (1, 2, 5, 10):
+        c = ctx_for(d)
+        n = 1000
+        u = c.empty(d, n)
+        c.prior_draw(u, seed=0x1234567890ABCDEF, tick=7, item0=55)
+        want = omc.prior_draw(n, d, 0x1234567890ABCDEF, 7, 55)
+        np.testing.assert_array_equal(aos(u), want)
+        assert want.min() >= 0 and want.max() < 1
+
+
+# -------------------------------------------------------------------------- reweighting
+def test_logmix_reweight_golden(dev):
+    from tempest_amd.device import KEY_LOGMIX, KEY_LOGL
+    g = load("g1_logw.npz")
+    for k in range(int(g["n_cases"])):
+        logl, bt, zt, nt = g[f"c{k}_logl"], g[f"c{k}_beta_t"], g[f"c{k}_logz_t"], g[f"c{k}_n_t"]
+        c = ctx_for(3)
+        c.history_load(None, None, logl, bt, zt, nt)
+        assert c.size == logl.size and c.iterations == bt.size
+        np.testing.assert_array_equal(c.history_read(KEY_LOGL), logl)
+        cm = c.history_read(KEY_LOGMIX)
+        np.testing.assert_allclose(cm, ps.log_mixture(logl, bt, zt, nt), rtol=1e-12, atol=1e-12, equal_nan=True)
+        nh = int(nt.sum())
+        for j in range(4):
+            bf = float(g[f"c{k}_b{j}_beta"])
+            ref_lw = g[f"c{k}_b{j}_logw_unnorm"]
+            lw = c.logw(bf, nh).cpu().numpy()
+            np.testing.assert_allclose(lw, ref_lw, rtol=1e-11, atol=1e-10, equal_nan=True)
+            if not np.all(np.isfinite(ref_lw)):
+                continue
+            m, s1, s2 = c.reweight_eval([bf])[0]
+            np.testing.assert_allclose(m + np.log(s1), g[f"c{k}_b{j}_logz"], rtol=1e-11, atol=1e-10)
+            w_ref = np.exp(g[f"c{k}_b{j}_logw"])
+            np.testing.assert_allclose(s1 * s1 / s2, ps.effective_sample_size(w_ref), rtol=1e-10)
+            w = c.weights(bf, m, s1).cpu().numpy()
+            np.testing.assert_allclose(w, w_ref, rtol=1e-9, atol=1e-300)
+        c.close()
+
+
+def test_nan_rows_propagate_like_reference(dev):
+    # -inf log-likelihood at an iteration with beta_t = 0 gives 0*(-inf) = NaN in the reference
+    g = load("g1_logw.npz")
+    k = 3
+    logl, bt, zt, nt = g[f"c{k}_logl"], g[f"c{k}_beta_t"], g[f"c{k}_logz_t"], g[f"c{k}_n_t"]
+    assert np.isinf(logl).any()
+    c = ctx_for(3)
+    c.history_load(None, None, logl, bt, zt, nt)
+    m, s1, s2 = c.reweight_eval([0.3])[0]
+    assert np.isnan(g[f"c{k}_b2_logz"]) and np.isnan(m + np.log(s1))
+
+
+def test_history_append_incremental(dev):
+    from tempest_amd.device import KEY_LOGMIX, KEY_U, KEY_X
+    rs = np.random.RandomState(0)
+    d, n = 4, 777
+    c = ctx_for(d)           # no capacity hint: exercises growth
+    betas, logzs, us, xs, ls = [], [], [], [], []
+    for t in range(9):
+        u = rs.rand(n + t, d); x = 20 * u - 10
+        l = -0.5 * np.sum(x ** 2, axis=1)
+        beta, logz = (0.0 if t < 2 else 0.1 * t), -1.5 * t
+        c.history_append(soa(u, dev), soa(x, dev), torch.from_numpy(l).to(dev), beta, logz)
+        betas.append(beta); logzs.append(logz); us.append(u); xs.append(x); ls.append(l)
+        nt = np.array([len(v) for v in ls])
+        want = ps.log_mixture(np.concatenate(ls), betas, logzs, nt)
+        np.testing.assert_allclose(c.history_read(KEY_LOGMIX), want, rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(c.history_read(KEY_U), np.concatenate(us))
+    np.testing.assert_array_equal(c.history_read(KEY_X), np.concatenate(xs))
+    np.testing.assert_array_equal(c.history_read(KEY_X, 10, 5), np.concatenate(xs)[10:15])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 4097, 1_000_003, 6_000_000])
+def test_reweight_sizes_and_batching(dev, n):
+    rs = np.random.RandomState(n % 1000)
+    T = 16
+    nt = np.full(T, n // T, dtype=np.int64); nt[-1] += n - nt.sum()
+    nt = nt[nt > 0]; T = nt.size
+    bt = np.linspace(0, 1, T) ** 2
+    zt = -np.linspace(0, 30, T)
+    logl = -rs.chisquare(10, size=n) * (1 + rs.rand(n))
+    c = ctx_for(2)
+    c.history_load(None, None, logl, bt, zt, nt)
+    cm = ps.log_mixture(logl, bt, zt, nt)
+    betas = np.array([0.0, 1e-4, 0.05, 0.37, 0.9, 1.0, 0.2, 0.21, 0.22, 0.23, 0.5, 0.51, 0.52, 0.53, 0.54])
+    batch = c.reweight_eval(betas)
+    for b, row in zip(betas[:4], batch[:4]):
+        m, s1, s2 = ps.reweight_triple(logl, cm, b)
+        np.testing.assert_allclose(row[0] + np.log(row[1]), m + np.log(s1), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(row[1] ** 2 / row[2], s1 ** 2 / s2, rtol=1e-10)
+    for i, b in enumerate(betas):      # a batch is the same as one evaluation per beta
+        one = c.reweight_eval([b])[0]
+        np.testing.assert_allclose(one[0] + np.log(one[1]), batch[i][0] + np.log(batch[i][1]), rtol=1e-13)
+        np.testing.assert_allclose(one[1] ** 2 / one[2], batch[i][1] ** 2 / batch[i][2], rtol=1e-12)
+    # determinism: bitwise identical on repeat
+    np.testing.assert_array_equal(c.reweight_eval(betas), batch)
+    # ESS decreases with beta past the last stored beta, ESS(w uniform)=N: sanity of the domain properties
+    if n > 100:
+        w = c.weights(0.37, *batch[3][:2])
+        s = c.sum_sq_max(w)
+        np.testing.assert_allclose(s[0], 1.0, rtol=1e-10)
+        np.testing.assert_allclose(1.0 / s[1], batch[3][1] ** 2 / batch[3][2], rtol=1e-10)
+
+
+# --------------------------------------------------------------------------- resampling
+@pytest.mark.parametrize("n", [1, 7, 2048, 2049, 100_003, 3_000_001])
+def test_cdf(dev, n):
+    rs = np.random.RandomState(1)
+    w = np.exp(rs.randn(n))
+    c = ctx_for(1)
+    wt = torch.from_numpy(w).to(dev)
+    cdf = c.cdf(wt).cpu().numpy()
+    np.testing.assert_allclose(cdf, np.cumsum(w), rtol=1e-12)
+    assert np.all(np.diff(cdf) >= 0)
+    thr = torch.tensor([1.0], dtype=torch.float64, device=dev)
+    cdfm = c.cdf(wt, thr).cpu().numpy()
+    np.testing.assert_allclose(cdfm, np.cumsum(np.where(w >= 1.0, w, 0.0)), rtol=1e-12, atol=1e-300)
+
+
+def test_systematic_golden(dev):
+    g = load("g4_resample.npz")
+    c = ctx_for(1)
+    for k in range(int(g["n_cases"])):
+        w = g[f"c{k}_w"]
+        size = int(g[f"c{k}_size"])
+        cdf = c.cdf(torch.from_numpy(w).to(dev))
+        tot = float(w.sum())
+        renorm = tot if abs(tot - 1.0) > ps.SQRTEPS else 1.0
+        idx = c.resample_systematic(cdf, size, float(g[f"c{k}_u0"]), renorm=renorm).cpu().numpy()
+        np.testing.assert_array_equal(idx, g[f"c{k}_idx"])
+
+
+def test_multinomial_vs_oracle_and_gather(dev):
+    from tempest_amd.device import TAG_RESAMPLE
+    rs = np.random.RandomState(3)
+    d, nh, n_out = 3, 50_000, 20_000
+    u = rs.rand(nh, d); x = 20 * u - 10; logl = -np.sum(x ** 2, axis=1)
+    w = np.exp(rs.randn(nh) * 2); w /= w.sum()
+    c = ctx_for(d)
+    c.history_load(u, x, logl, [0.0], [0.0], [nh])
+    cdf = c.cdf(torch.from_numpy(w).to(dev))
+    idx = c.resample_multinomial(cdf, n_out, seed=99, tick=5, item0=1000)
+    U = px.uniform1(99, np.arange(n_out) + 1000, 5, TAG_RESAMPLE)
+    want = ps.multinomial_resample(w, U)
+    got = idx.cpu().numpy()
+    mism = np.nonzero(got != want)[0]
+    assert mism.size <= 2, mism.size     # only draws within 1 ulp of a cdf boundary may differ (scan order)
+    uo, xo, lo = c.empty(d, n_out), c.empty(d, n_out), c.empty(n_out)
+    c.gather(idx, uo, xo, lo)
+    np.testing.assert_array_equal(aos(uo), u[got])
+    np.testing.assert_array_equal(aos(xo), x[got])
+    np.testing.assert_array_equal(lo.cpu().numpy(), logl[got])
+    # distributional: counts track the weights
+    counts = np.bincount(got, minlength=nh)
+    top = np.argsort(w)[-50:]
+    np.testing.assert_allclose(counts[top].sum() / n_out, w[top].sum(), rtol=0.05)
+
+
+# ------------------------------------------------------------------------------ trimming
+def test_trim_threshold_golden(dev):
+    g = load("g2_tools.npz")
+    c = ctx_for(1)
+    for k in range(4):
+        w = g[f"ess{k}_w"]
+        wn = w / w.sum()
+        for j in range(3):
+            ess, bins = g[f"trim{k}_{j}_cfg"]
+            _, out = c.trim_threshold(torch.from_numpy(wn).to(dev), float(ess), int(bins), sync=True)
+            thr, ksum, kcnt, ess_total = out
+            mask = wn >= thr
+            np.testing.assert_array_equal(np.nonzero(mask)[0], g[f"trim{k}_{j}_idx"])
+            assert int(kcnt) == g[f"trim{k}_{j}_idx"].size
+            np.testing.assert_allclose(wn[mask] / ksum, g[f"trim{k}_{j}_w"], rtol=1e-12)
+            np.testing.assert_allclose(ess_total, ps.effective_sample_size(w), rtol=1e-12)
+
+
+def test_trim_large_vs_oracle(dev):
+    rs = np.random.RandomState(4)
+    w = np.exp(3 * rs.randn(1_500_000)); w /= w.sum()
+    c = ctx_for(1)
+    _, out = c.trim_threshold(torch.from_numpy(w).to(dev), 0.99, 1000, sync=True)
+    thr, ksum, kcnt = ps.trim_threshold_sorted(w, 0.99, 1000)
+    assert out[0] == thr and int(out[2]) == kcnt
+    np.testing.assert_allclose(out[1], ksum, rtol=1e-12)
+
+
+# ------------------------------------------------------------------------- proposal fit
+def test_fit_modes_vs_golden_and_oracle(dev):
+    g = load("g7_modes.npz")
+    u, w, idx = g["fg_u"], g["fg_w"], g["fg_idx"]
+    n, d = u.shape
+    c = ctx_for(d)
+    c.history_load(u, u, np.zeros(n), [0.0], [0.0], [n])
+    counts = np.bincount(idx, minlength=n).astype(np.int32)
+    means, covs, chol, inv = c.fit_modes(torch.from_numpy(counts).to(dev))
+    np.testing.assert_allclose(means.cpu().numpy(), g["fg_means"], rtol=1e-14)
+    np.testing.assert_allclose(covs.cpu().numpy(), g["fg_covs"], rtol=1e-10)
+    np.testing.assert_allclose(chol.cpu().numpy(), g["fg_chol"], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(inv.cpu().numpy(), g["fg_inv"], rtol=1e-8)
+    # per-label fit (modes.py:131-219)
+    labels = g["fp_labels"].astype(np.int32)
+    counts = np.zeros(n, dtype=np.int32)
+    for cidx in range(3):
+        sel = np.nonzero(labels == cidx)[0]
+        counts += np.bincount(sel[g[f"fp_idx{cidx}"]], minlength=n).astype(np.int32)
+    means, covs, chol, inv = c.fit_modes(torch.from_numpy(counts).to(dev), torch.from_numpy(labels).to(dev), K=3)
+    np.testing.assert_allclose(means.cpu().numpy(), g["fp_means"], rtol=1e-14)
+    np.testing.assert_allclose(covs.cpu().numpy(), g["fp_covs"], rtol=1e-10)
+    np.testing.assert_allclose(inv.cpu().numpy(), g["fp_inv"], rtol=1e-8)
+
+
+def test_fit_modes_large_narrow_with_duplicates(dev):
+    rs = np.random.RandomState(8)
+    n, d = 300_000, 10
+    base = 0.5 + 2e-3 * rs.randn(n // 3, d) @ np.triu(rs.rand(d, d))
+    u = np.concatenate([base, base, base])[rs.permutation(n)]     # exact duplicates, as rejected moves leave
+    u[:, 0] = np.clip(np.abs(1e-9 * rs.randn(n)), 0, 1)            # a coordinate piled against the bound
+    w = np.exp(rs.randn(n)); w /= w.sum()
+    c = ctx_for(d)
+    c.history_load(u, u, np.zeros(n), [0.0], [0.0], [n])
+    cdf = c.cdf(torch.from_numpy(w).to(dev))
+    counts = c.multinomial_counts(cdf, seed=5, tick=1, factor=4)
+    cn = counts.cpu().numpy()
+    assert cn.sum() == 4 * n
+    U = px.uniform1(5, np.arange(4 * n), 1, px.TAG_UPSAMPLE)
+    want_counts = np.bincount(ps.multinomial_resample(w, U), minlength=n)
+    assert np.abs(cn - want_counts).sum() <= 4
+    means, covs, chol, inv = c.fit_modes(counts)
+    mu, Sig, _ = ps.median_cov_from_counts(u, cn)
+    np.testing.assert_allclose(means.cpu().numpy()[0], mu, rtol=1e-14, atol=0)
+    np.testing.assert_allclose(covs.cpu().numpy()[0], Sig, rtol=1e-9, atol=1e-22)
+    L = chol.cpu().numpy()[0]
+    np.testing.assert_allclose(L @ L.T, covs.cpu().numpy()[0], rtol=1e-10, atol=1e-22)
+
+
+def test_chol_inv_ridge(dev):
+    rs = np.random.RandomState(2)
+    d = 6
+    A = rs.randn(d, d); good = A @ A.T + 0.1 * np.eye(d)
+    v = rs.randn(d, 1); singular = v @ v.T                       # rank 1 -> LinAlgError -> ridge
+    covs = np.stack([good, singular, np.zeros((d, d))])
+    want_cov, want_chol, want_inv = ps.mode_statistics(np.zeros((3, d)), covs)
+    c = ctx_for(d)
+    ct = torch.from_numpy(covs.copy()).to(dev)
+    chol, inv = c.chol_inv(ct)
+    np.testing.assert_allclose(ct.cpu().numpy(), want_cov, rtol=1e-14)
+    np.testing.assert_allclose(chol.cpu().numpy(), want_chol, rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(inv.cpu().numpy()[0], want_inv[0], rtol=1e-9)
+    np.testing.assert_allclose(inv.cpu().numpy()[2], want_inv[2], rtol=1e-9)
+
+
+def test_volume_variation_golden(dev):
+    g = load("g2_tools.npz")
+    for key in ("vv0", "vv4"):
+        x, w = g[f"{key}_x"], g[f"{key}_w"]
+        n, d = x.shape
+        wn = w / w.sum()
+        c = ctx_for(d)
+        c.history_load(x, x, np.zeros(n), [0.0], [0.0], [n])
+        wt = torch.from_numpy(wn).to(dev)
+        mc = c.weighted_moments(wt).cpu().numpy()
+        mean, cov = mc[:d], mc[d:].reshape(d, d)
+        np.testing.assert_allclose(mean, np.sum(x * wn[:, None], axis=0), rtol=1e-12)
+        xc = x - mean
+        np.testing.assert_allclose(cov, xc.T @ (xc * wn[:, None]), rtol=1e-9, atol=1e-20)
+        assert np.linalg.matrix_rank(cov) == d
+        cinv = np.linalg.inv(cov)
+        s = c.cv_sum(wt, torch.from_numpy(mean).to(dev), torch.from_numpy(cinv).to(dev)).cpu().numpy()[0]
+        np.testing.assert_allclose(0.5 * np.sqrt(s), g[key], rtol=1e-8)
+
+
+# ----------------------------------------------------------------------------- mutation
+class _Modes:
+    def __init__(self, means, chol, inv, dof, dev):
+        self.K = means.shape[0]
+        self.means_dev = torch.from_numpy(means).to(dev)
+        self.chol_dev = torch.from_numpy(chol).to(dev)
+        self.inv_dev = torch.from_numpy(inv).to(dev)
+        self.dof_dev = torch.from_numpy(dof).to(dev)
+
+
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+@pytest.mark.parametrize("bc", [None, "mixed"])
+def test_propose_accept_adapt_vs_oracle(dev, kernel, bc):
+    rs = np.random.RandomState(17)
+    d, n, K = 7, 5000, 3
+    means = 0.5 + 0.1 * rs.randn(K, d)
+    covs = np.empty((K, d, d))
+    for k in range(K):
+        A = rs.randn(d, d) * 0.08
+        covs[k] = A @ A.T + 1e-3 * np.eye(d)
+    _, chol, inv = ps.mode_statistics(means, covs)
+    dof = np.array([1e6, 4.0, 25.0])
+    sigmas = np.array([0.9, 0.5, 0.2]) * (2.38 / np.sqrt(d) if kernel == "rwm" else 1.0)
+    assign = rs.randint(K, size=n).astype(np.int32)
+    u = np.clip(means[assign] + 0.2 * rs.randn(n, d), 0.01, 0.99)   # many land near the walls -> redraws
+    flags = omc.bc_flags(d, [1], [4]) if bc else omc.bc_flags(d)
+    seed, tick, item0 = 4242, 11, 100_000
+    want_up, want_mu, want_mup = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, flags, seed, tick, item0)
+    c = ctx_for(d)
+    modes = _Modes(means, chol, inv, dof, dev)
+    up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+    ut = soa(u, dev)
+    at = torch.from_numpy(assign).to(dev)
+    st = torch.from_numpy(sigmas).to(dev)
+    ft = torch.from_numpy(flags).to(dev)
+    c.propose(kernel, ut, at, modes, st, ft, seed, tick, item0, up, mu_, mup)
+    got_up = aos(up)
+    np.testing.assert_allclose(got_up, want_up, rtol=1e-11, atol=1e-13)
+    strict = np.nonzero(flags == 0)[0]
+    assert np.all((got_up[:, strict] >= 0) & (got_up[:, strict] <= 1))
+    assert np.all((got_up >= 0) & (got_up <= 1))
+    if kernel == "tpcn":
+        np.testing.assert_allclose(mu_.cpu().numpy(), want_mu, rtol=1e-10)
+        np.testing.assert_allclose(mup.cpu().numpy(), want_mup, rtol=1e-9, atol=1e-9)
+    # accept
+    x = 20 * u - 10
+    logl = -0.5 * np.sum(x ** 2, axis=1) * 0.05
+    xp = 20 * want_up - 10
+    loglp = -0.5 * np.sum(xp ** 2, axis=1) * 0.05
+    loglp[::97] = np.nan; loglp[1::101] = -np.inf; loglp[2::103] = np.inf
+    beta = 0.6
+    alpha, mask = omc.accept(kernel, beta, logl, loglp, want_mu, want_mup, dof, assign, d, seed, tick + 1, item0)
+    xt, lt = soa(x, dev), torch.from_numpy(logl.copy()).to(dev)
+    upt, xpt, lpt = soa(want_up, dev), soa(xp, dev), torch.from_numpy(loglp).to(dev)
+    sums = c.empty(1 + K)
+    c.accept(kernel, beta, ut, xt, lt, upt, xpt, lpt, torch.from_numpy(want_mu).to(dev),
+             torch.from_numpy(want_mup).to(dev), at, K, modes.dof_dev, seed, tick + 1, item0, sums)
+    s = sums.cpu().numpy()
+    assert s[0] == mask.sum()
+    for k in range(K):
+        np.testing.assert_allclose(s[1 + k], alpha[assign == k].sum(), rtol=1e-10)
+    np.testing.assert_array_equal(aos(ut), np.where(mask[:, None], want_up, u))
+    np.testing.assert_array_equal(aos(xt), np.where(mask[:, None], xp, x))
+    np.testing.assert_array_equal(lt.cpu().numpy(), np.where(mask, loglp, logl))
+    assert not mask[::97].any() and not mask[1::101].any()
+    # adapt + stopping rule
+    counts = c.cluster_counts(at, n, K)
+    np.testing.assert_array_equal(counts.cpu().numpy(), np.bincount(assign, minlength=K))
+    state = c.zeros(6)
+    state[0] = 4.0
+    c.adapt(kernel, sums, counts, K, n, 2, 40, st, state)
+    ws, done, acc, target = omc.adapt(kernel, alpha, mask, assign, K, sigmas, 5, d, 2, 40)
+    np.testing.assert_allclose(st.cpu().numpy(), ws, rtol=1e-12)
+    sh = state.cpu().numpy()
+    assert sh[0] == 5 and bool(sh[1]) == bool(done) and int(sh[5]) == target
+    np.testing.assert_allclose(sh[2], acc, rtol=1e-14)
+    np.testing.assert_allclose(sh[3], alpha.mean(), rtol=1e-10)
+    np.testing.assert_allclose(sh[4], ws.mean() / (2.38 / np.sqrt(d)), rtol=1e-12)
+
+
+def test_propose_golden_pure_function(dev):
+    # single-cluster-per-lane golden vectors drawn by the reference itself: check the deterministic
+    # parts (Mahalanobis, acceptance factor) against its outputs
+    g = load("g6_mcmc.npz")
+    u, a = g["u"], g["assign"].astype(np.int32)
+    n, d = u.shape
+    c = ctx_for(d)
+    modes = _Modes(g["means"], g["chol"], g["inv"], g["dof"], dev)
+    up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+    c.propose("tpcn", soa(u, dev), torch.from_numpy(a).to(dev), modes, torch.from_numpy(g["tpcn_sigmas"]).to(dev),
+              None, 1, 1, 0, up, mu_, mup)
+    np.testing.assert_allclose(mu_.cpu().numpy(), ps.mahalanobis(u, g["means"], g["inv"], a), rtol=1e-10)
+    fac = ps.tpcn_acceptance_factor(u, aos(up), g["means"], g["inv"], g["dof"], a)
+    nu = g["dof"][a]
+    dev_fac = 0.5 * (d + nu) * (np.log1p(mup.cpu().numpy() / nu) - np.log1p(mu_.cpu().numpy() / nu))
+    np.testing.assert_allclose(dev_fac, fac, rtol=1e-6, atol=1e-9)
+
+
+def test_inf_repair_vs_oracle(dev):
+    rs = np.random.RandomState(6)
+    d, n = 3, 10_000
+    u = rs.rand(n, d); x = 20 * u - 10
+    logl = -0.5 * np.sum(x ** 2, axis=1)
+    logl[x[:, 0] > 5] = -np.inf
+    logl[x[:, 1] < -8] = np.inf
+    wu, wx, wl, nfin = omc.inf_repair(u, x, logl, 77, 3, 500)
+    c = ctx_for(d)
+    ut, xt, lt = soa(u, dev), soa(x, dev), torch.from_numpy(logl.copy()).to(dev)
+    stats = c.inf_repair(ut, xt, lt, 77, 3, 500).cpu().numpy()
+    assert stats[0] == nfin and stats[1] == n
+    np.testing.assert_array_equal(aos(ut), wu)
+    np.testing.assert_array_equal(aos(xt), wx)
+    np.testing.assert_array_equal(lt.cpu().numpy(), wl)
+    assert np.all(np.isfinite(lt.cpu().numpy()))
