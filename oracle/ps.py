@@ -98,11 +98,12 @@ def trim_weights(samples, weights, ess=0.99, bins=1000):
     return samples[mask], wt
 
 
-def trim_threshold_sorted(weights, ess=0.99, bins=1000):
+def trim_threshold_sorted(weights, ess=0.99, bins=1000, normalized=False):
     """The same decision as trim_weights taken the way the device takes it: one sort,
     suffix sums, all `bins` candidates at once.  Returns (threshold, kept_sum, kept_count)."""
     w = np.asarray(weights, dtype=np.float64)
-    w = w / w.sum()
+    if not normalized:
+        w = w / w.sum()
     s = np.sort(w)
     n = s.size
     t1 = np.cumsum(s[::-1])[::-1]

@@ -100,8 +100,8 @@ __device__ __forceinline__ void trim_candidate(const double* __restrict__ S, int
                                                double& thr, int64_t& first_kept) {
   double p = (i == bins - 1 && bins > 1) ? 99.0 : __dmul_rn((double)i, step);   // np.linspace(0, 99, bins)[i]
   double q = p / 100.0;                                                         // np.percentile: q / 100
-  // numpy _compute_virtual_index(n, q, 1, 1) = n*q + (1 + q*(1-1-1)) - 1, evaluated without contraction
-  double vi = __dadd_rn(__dadd_rn(__dmul_rn((double)n, q), __dadd_rn(1.0, __dmul_rn(q, -1.0))), -1.0);
+  // numpy method 'linear': virtual index = (n - 1) * q  (lib/_function_base_impl.py, _QuantileMethods)
+  double vi = __dmul_rn((double)(n - 1), q);
   if (vi >= (double)(n - 1)) thr = S[n - 1];
   else if (vi < 0.0) thr = S[0];
   else {
@@ -175,7 +175,8 @@ extern "C" int tph_trim_threshold(tph_ctx* ctx, const double* w_dev, int64_t n, 
 }
 
 // -------------------------------------------------------------------------- weighted first moments
-// sums[0] = sum wt ; sums[1+j] = sum wt * u_j   (wt = counts or real weights, optional label filter)
+// sums[0] = sum wt ; sums[1+j] = sum wt * u_j ; range[2j], range[2j+1] = min, max of u_j over rows with wt > 0
+// (wt = counts or real weights, optional label filter)
 template <typename WT>
 __global__ void __launch_bounds__(256) k_wsum(const double* __restrict__ hu, int64_t cap, int d, const WT* __restrict__ wt,
                                               const int32_t* __restrict__ labels, int label, int64_t n,
@@ -183,16 +184,46 @@ __global__ void __launch_bounds__(256) k_wsum(const double* __restrict__ hu, int
   // grid: (row blocks, 1 + d): blockIdx.y == 0 -> sum of weights, else coordinate blockIdx.y-1
   const int col = blockIdx.y;
   const double* src = col ? hu + (size_t)(col - 1) * cap : nullptr;
-  double s = 0.0;
+  double s = 0.0, mn = DBL_MAX, mx = -DBL_MAX;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     if (labels && labels[i] != label) continue;
     double w = (double)wt[i];
-    s += col ? w * src[i] : w;
+    if (col) {
+      double v = src[i];
+      s += w * v;
+      if (w > 0.0) { mn = fmin(mn, v); mx = fmax(mx, v); }
+    } else {
+      s += w;
+    }
   }
   __shared__ double sh[4];
   s = tph_block_sum(s, sh);
-  if (threadIdx.x == 0) partials[(size_t)blockIdx.x * gridDim.y + col] = s;
+  mx = tph_block_max(mx, sh);
+  mn = -tph_block_max(-mn, sh);
+  if (threadIdx.x == 0) {
+    double* p = partials + ((size_t)blockIdx.x * gridDim.y + col) * 3;
+    p[0] = s; p[1] = mn; p[2] = mx;
+  }
+}
+
+// reduce the (sum, min, max) block partials: one block per column
+__global__ void __launch_bounds__(256) k_wsum_final(const double* __restrict__ partials, int nblocks, int ncol,
+                                                    double* __restrict__ sums, double* __restrict__ range) {
+  int c = blockIdx.x;
+  double s = 0.0, mn = DBL_MAX, mx = -DBL_MAX;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    const double* p = partials + ((size_t)b * ncol + c) * 3;
+    s += p[0]; mn = fmin(mn, p[1]); mx = fmax(mx, p[2]);
+  }
+  __shared__ double sh[4];
+  s = tph_block_sum(s, sh);
+  mx = tph_block_max(mx, sh);
+  mn = -tph_block_max(-mn, sh);
+  if (threadIdx.x == 0) {
+    sums[c] = s;
+    if (c > 0 && range) { range[2 * (c - 1)] = mn; range[2 * (c - 1) + 1] = mx; }
+  }
 }
 
 __global__ void __launch_bounds__(256) k_colsum2(const double* __restrict__ partials, int nblocks, int ncol,
@@ -318,32 +349,38 @@ static int cov_blocks(int64_t n) {
 }
 
 // -------------------------------------------------------------------- exact weighted median select
-// Per (dimension j, target rank t in {lower, upper middle}): two 12-bit histogram levels over the
-// exact binary expansion of u in [0,1] (u*4096 and the subtraction of the integer digit are exact in
-// FP64), then the <= MED_CAP entries of the final bin are collected and the order statistic is found
-// exactly.  Multiplicities are the up-sampling counts.
+// Per (dimension j, target rank t in {lower, upper middle}): two 4096-bin histogram levels over the
+// coordinate's data range (2^24 bins in all), then the <= MED_CAP entries of the final bin are
+// collected and the order statistic is found exactly.  Multiplicities are the up-sampling counts.
 constexpr int MED_BINS = 4096;
 constexpr int MED_CAP = 2048;
 
-__device__ __forceinline__ void med_digits(double u, int& d1, int& d2) {
-  double a = u * 4096.0;
+// Monotone (not necessarily exact) two-level bin of u inside the data range [lo, hi] of its coordinate:
+// selection only needs the same non-decreasing map in every pass.
+__device__ __forceinline__ void med_digits(double u, double lo, double scale, int& d1, int& d2) {
+  double a = (u - lo) * scale;
   double f1 = floor(a);
   if (f1 > 4095.0) f1 = 4095.0;
-  if (f1 < 0.0) f1 = 0.0;
+  if (!(f1 >= 0.0)) f1 = 0.0;
   double b = (a - f1) * 4096.0;
   double f2 = floor(b);
   if (f2 > 4095.0) f2 = 4095.0;
-  if (f2 < 0.0) f2 = 0.0;
+  if (!(f2 >= 0.0)) f2 = 0.0;
   d1 = (int)f1;
   d2 = (int)f2;
+}
+__device__ __forceinline__ double med_scale(double lo, double hi) {
+  double w = hi - lo;
+  return w > 0.0 ? 4096.0 / w : 0.0;
 }
 
 // level 1: hist1[j][bin] += count
 __global__ void __launch_bounds__(256) k_med_hist1(const double* __restrict__ hu, int64_t cap, const int32_t* __restrict__ cnt,
                                                    const int32_t* __restrict__ labels, int label, int64_t n,
-                                                   unsigned int* __restrict__ hist1) {
+                                                   const double* __restrict__ range, unsigned int* __restrict__ hist1) {
   __shared__ unsigned int h[MED_BINS];
   const int j = blockIdx.y;
+  const double lo = range[2 * j], scale = med_scale(range[2 * j], range[2 * j + 1]);
   for (int b = threadIdx.x; b < MED_BINS; b += blockDim.x) h[b] = 0;
   __syncthreads();
   const double* src = hu + (size_t)j * cap;
@@ -352,7 +389,7 @@ __global__ void __launch_bounds__(256) k_med_hist1(const double* __restrict__ hu
     int c = cnt[i];
     if (c == 0 || (labels && labels[i] != label)) continue;
     int d1, d2;
-    med_digits(src[i], d1, d2);
+    med_digits(src[i], lo, scale, d1, d2);
     atomicAdd(&h[d1], (unsigned int)c);
   }
   __syncthreads();
@@ -392,9 +429,11 @@ __global__ void __launch_bounds__(64) k_med_select(const unsigned int* __restric
 // level 2: hist2[j][t][bin2] += count for rows whose first digit is the target's
 __global__ void __launch_bounds__(256) k_med_hist2(const double* __restrict__ hu, int64_t cap, const int32_t* __restrict__ cnt,
                                                    const int32_t* __restrict__ labels, int label, int64_t n,
-                                                   const long long* __restrict__ sel, unsigned int* __restrict__ hist2) {
+                                                   const double* __restrict__ range, const long long* __restrict__ sel,
+                                                   unsigned int* __restrict__ hist2) {
   __shared__ unsigned int h[2 * MED_BINS];
   const int j = blockIdx.y;
+  const double lo = range[2 * j], scale = med_scale(range[2 * j], range[2 * j + 1]);
   for (int b = threadIdx.x; b < 2 * MED_BINS; b += blockDim.x) h[b] = 0;
   __syncthreads();
   const int b0 = (int)sel[((size_t)j * 2 + 0) * 4], b1 = (int)sel[((size_t)j * 2 + 1) * 4];
@@ -404,7 +443,7 @@ __global__ void __launch_bounds__(256) k_med_hist2(const double* __restrict__ hu
     int c = cnt[i];
     if (c == 0 || (labels && labels[i] != label)) continue;
     int d1, d2;
-    med_digits(src[i], d1, d2);
+    med_digits(src[i], lo, scale, d1, d2);
     if (d1 == b0) atomicAdd(&h[d2], (unsigned int)c);
     if (d1 == b1) atomicAdd(&h[MED_BINS + d2], (unsigned int)c);
   }
@@ -417,9 +456,10 @@ __global__ void __launch_bounds__(256) k_med_hist2(const double* __restrict__ hu
 // collect (value, count) of the rows in each target's final bin
 __global__ void __launch_bounds__(256) k_med_collect(const double* __restrict__ hu, int64_t cap, const int32_t* __restrict__ cnt,
                                                      const int32_t* __restrict__ labels, int label, int64_t n,
-                                                     const long long* __restrict__ sel, double* __restrict__ vals,
-                                                     int* __restrict__ cnts, int* __restrict__ fill) {
+                                                     const double* __restrict__ range, const long long* __restrict__ sel,
+                                                     double* __restrict__ vals, int* __restrict__ cnts, int* __restrict__ fill) {
   const int j = blockIdx.y;
+  const double lo = range[2 * j], scale = med_scale(range[2 * j], range[2 * j + 1]);
   const long long* s0 = sel + ((size_t)j * 2 + 0) * 4;
   const long long* s1 = sel + ((size_t)j * 2 + 1) * 4;
   const int a0 = (int)s0[0], a1 = (int)s0[1], c0 = (int)s1[0], c1 = (int)s1[1];
@@ -430,7 +470,7 @@ __global__ void __launch_bounds__(256) k_med_collect(const double* __restrict__ 
     if (c == 0 || (labels && labels[i] != label)) continue;
     double v = src[i];
     int d1, d2;
-    med_digits(v, d1, d2);
+    med_digits(v, lo, scale, d1, d2);
     if (d1 == a0 && d2 == a1) {
       int slot = atomicAdd(&fill[j * 2 + 0], 1);
       if (slot < MED_CAP) { vals[((size_t)j * 2 + 0) * MED_CAP + slot] = v; cnts[((size_t)j * 2 + 0) * MED_CAP + slot] = c; }
@@ -443,10 +483,12 @@ __global__ void __launch_bounds__(256) k_med_collect(const double* __restrict__ 
 }
 
 // exact order statistic inside the collected bin; median_j = (v_lo + v_hi)/2 (np.median)
-__global__ void __launch_bounds__(256) k_med_finish(const long long* __restrict__ sel, const double* __restrict__ vals,
-                                                    const int* __restrict__ cnts, const int* __restrict__ fill,
-                                                    double* __restrict__ median, int* __restrict__ overflow) {
+__global__ void __launch_bounds__(256) k_med_finish(const long long* __restrict__ sel, const double* __restrict__ range,
+                                                    const double* __restrict__ vals, const int* __restrict__ cnts,
+                                                    const int* __restrict__ fill, double* __restrict__ median,
+                                                    int* __restrict__ overflow) {
   const int j = blockIdx.x;
+  const double lo = range[2 * j], width = range[2 * j + 1] - range[2 * j];
   __shared__ double res[2];
   __shared__ double sv[MED_CAP];
   __shared__ int sc[MED_CAP];
@@ -455,7 +497,7 @@ __global__ void __launch_bounds__(256) k_med_finish(const long long* __restrict_
     int m = fill[j * 2 + t];
     long long rank = s[2];
     __syncthreads();
-    if (threadIdx.x == 0) res[t] = ((double)s[0] + (double)s[1] / 4096.0) / 4096.0;  // bin edge if overflow / empty
+    if (threadIdx.x == 0) res[t] = lo + width * (((double)s[0] + (double)s[1] / 4096.0) / 4096.0);  // bin edge if overflow
     if (m > MED_CAP) { if (threadIdx.x == 0) atomicAdd(overflow, 1); m = 0; }
     for (int e = threadIdx.x; e < m; e += blockDim.x) {
       sv[e] = vals[((size_t)j * 2 + t) * MED_CAP + e];
@@ -561,8 +603,9 @@ extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int3
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
   size_t o_part = take(sizeof(double) * ((size_t)nblk * d * d + (size_t)d * d));      // cov partials + column sums
-  size_t o_part1 = take(sizeof(double) * (size_t)rblk * (1 + d));                      // first-moment partials
+  size_t o_part1 = take(sizeof(double) * (size_t)rblk * (1 + d) * 3);                  // first-moment partials
   size_t o_sums = take(sizeof(double) * (1 + d));
+  size_t o_range = take(sizeof(double) * 2 * d);
   size_t o_mean = take(sizeof(double) * d);
   size_t o_h1 = take(sizeof(unsigned int) * (size_t)d * MED_BINS);
   size_t o_h2 = take(sizeof(unsigned int) * (size_t)d * 2 * MED_BINS);
@@ -575,6 +618,7 @@ extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int3
   double* part = (double*)(base + o_part);
   double* part1 = (double*)(base + o_part1);
   double* sums = (double*)(base + o_sums);
+  double* range = (double*)(base + o_range);
   double* mean = (double*)(base + o_mean);
   unsigned int* h1 = (unsigned int*)(base + o_h1);
   unsigned int* h2 = (unsigned int*)(base + o_h2);
@@ -588,7 +632,7 @@ extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int3
     // first moments -> arithmetic mean (centre of np.cov)
     hipLaunchKernelGGL(k_wsum<int32_t>, dim3(rblk, 1 + d), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, d, counts_dev, lab, k, n,
                        part1);
-    hipLaunchKernelGGL(k_colsum2, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums);
+    hipLaunchKernelGGL(k_wsum_final, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums, range);
     hipLaunchKernelGGL(k_mean_from_sums, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, sums, d, mean);
     // covariance (student.py:62-63)
     if (moments_launch_cov(ctx, counts_dev, true, lab, k, n, mean, sums, 1, covs_dev + (size_t)k * d * d, part, nblk)) return -1;
@@ -597,12 +641,12 @@ extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int3
     TPH_HIP(hipMemsetAsync(h2, 0, sizeof(unsigned int) * (size_t)d * 2 * MED_BINS, ctx->stream));
     TPH_HIP(hipMemsetAsync(fill, 0, sizeof(int) * ((size_t)d * 2 + 1), ctx->stream));
     dim3 hg(tph_grid_for(n, 256, 8, 256), d);
-    hipLaunchKernelGGL(k_med_hist1, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, h1);
+    hipLaunchKernelGGL(k_med_hist1, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, range, h1);
     hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(64), 0, ctx->stream, h1, 1, sums, sel);
-    hipLaunchKernelGGL(k_med_hist2, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, sel, h2);
+    hipLaunchKernelGGL(k_med_hist2, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, range, sel, h2);
     hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(64), 0, ctx->stream, h2, 2, sums, sel);
-    hipLaunchKernelGGL(k_med_collect, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, sel, vals, cnts, fill);
-    hipLaunchKernelGGL(k_med_finish, dim3(d), dim3(256), 0, ctx->stream, sel, vals, cnts, fill, means_dev + (size_t)k * d, overflow);
+    hipLaunchKernelGGL(k_med_collect, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, range, sel, vals, cnts, fill);
+    hipLaunchKernelGGL(k_med_finish, dim3(d), dim3(256), 0, ctx->stream, sel, range, vals, cnts, fill, means_dev + (size_t)k * d, overflow);
     TPH_LAUNCH_CHECK();
   }
   return tph_chol_inv(ctx, covs_dev, K, chol_dev, inv_dev);
@@ -617,7 +661,7 @@ extern "C" int tph_weighted_moments(tph_ctx* ctx, const double* w_dev, int64_t n
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
   size_t o_part = take(sizeof(double) * ((size_t)nblk * d * d + (size_t)d * d));
-  size_t o_part1 = take(sizeof(double) * (size_t)rblk * (1 + d));
+  size_t o_part1 = take(sizeof(double) * (size_t)rblk * (1 + d) * 3);
   size_t o_sums = take(sizeof(double) * (1 + d));
   if (tph_scratch_reserve(ctx, o)) return -1;
   char* base = (char*)ctx->scratch;
@@ -626,7 +670,7 @@ extern "C" int tph_weighted_moments(tph_ctx* ctx, const double* w_dev, int64_t n
   double* sums = (double*)(base + o_sums);
   hipLaunchKernelGGL(k_wsum<double>, dim3(rblk, 1 + d), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, d, w_dev,
                      (const int32_t*)nullptr, 0, n, part1);
-  hipLaunchKernelGGL(k_colsum2, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums);
+  hipLaunchKernelGGL(k_wsum_final, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums, (double*)nullptr);
   // tools.py:94-96: weights are normalised first, so mean = sum(w u)/sum(w)
   hipLaunchKernelGGL(k_mean_from_sums, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, sums, d, mean_cov_dev);
   TPH_LAUNCH_CHECK();

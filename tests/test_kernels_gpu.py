@@ -225,7 +225,7 @@ def test_trim_large_vs_oracle(dev):
     w = np.exp(3 * rs.randn(1_500_000)); w /= w.sum()
     c = ctx_for(1)
     _, out = c.trim_threshold(torch.from_numpy(w).to(dev), 0.99, 1000, sync=True)
-    thr, ksum, kcnt = ps.trim_threshold_sorted(w, 0.99, 1000)
+    thr, ksum, kcnt = ps.trim_threshold_sorted(w, 0.99, 1000, normalized=True)
     assert out[0] == thr and int(out[2]) == kcnt
     np.testing.assert_allclose(out[1], ksum, rtol=1e-12)
 
@@ -364,7 +364,7 @@ def test_propose_accept_adapt_vs_oracle(dev, kernel, bc):
     logl = -0.5 * np.sum(x ** 2, axis=1) * 0.05
     xp = 20 * want_up - 10
     loglp = -0.5 * np.sum(xp ** 2, axis=1) * 0.05
-    loglp[::97] = np.nan; loglp[1::101] = -np.inf; loglp[2::103] = np.inf
+    loglp[2::103] = np.inf; loglp[1::101] = -np.inf; loglp[::97] = np.nan
     beta = 0.6
     alpha, mask = omc.accept(kernel, beta, logl, loglp, want_mu, want_mup, dof, assign, d, seed, tick + 1, item0)
     xt, lt = soa(x, dev), torch.from_numpy(logl.copy()).to(dev)
