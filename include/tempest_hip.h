@@ -160,6 +160,9 @@ int tph_chol_inv(tph_ctx* ctx, double* covs_dev, int K, double* chol_dev, double
  * stage 1: weighted mean and covariance of the history's u with weights w (device -> host, tiny);
  * stage 2 (after the host's rank check / inverse, d x d): 0.25 * sum w^2 clip(d2-n,+-1e6)^2 partial. */
 int tph_weighted_moments(tph_ctx* ctx, const double* w_dev, int64_t n, double* mean_cov_dev /*[d + d*d]*/);
+/* sums_dev = (sum w, sum w u_0 .. sum w u_{d-1}) over the first n history rows (per-rank partial sums) */
+int tph_weighted_sums(tph_ctx* ctx, const double* w_dev, int64_t n, double* sums_dev /*[1+d]*/);
+/* cov_dev[a][b] = sum_s w_s (u_a - mean_a)(u_b - mean_b)  (raw per-rank sums, not divided by sum w) */
 int tph_weighted_cov_centered(tph_ctx* ctx, const double* w_dev, int64_t n, const double* mean_dev,
                               double* cov_dev /*[d*d]*/);
 int tph_cv_sum(tph_ctx* ctx, const double* w_dev, int64_t n, const double* mean_dev, const double* covinv_dev,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "tph_fit_modes": (c_int, [ptr, ptr, ptr, c_i64, c_int, ptr, ptr, ptr, ptr]),
     "tph_chol_inv": (c_int, [ptr, ptr, c_int, ptr, ptr]),
     "tph_weighted_moments": (c_int, [ptr, ptr, c_i64, ptr]),
+    "tph_weighted_sums": (c_int, [ptr, ptr, c_i64, ptr]),
     "tph_weighted_cov_centered": (c_int, [ptr, ptr, c_i64, ptr, ptr]),
     "tph_cv_sum": (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr]),
 }

@@ -1,0 +1,84 @@
+"""Cross-GPU glue: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on the GPU
+box, "gloo" in the CPU tests).  Particles are sharded; the history never moves.  Only three kinds of
+traffic exist:
+  * scalars: the (max, s1, s2) reweight partials (all-gather + log-sum-exp merge), per-cluster alpha
+    sums / counts, moment sums (all-reduce SUM);
+  * histograms of the distributed median select (all-reduce SUM);
+  * the resample shuffle (all-to-all-v of the selected rows).
+With world_size == 1 every method is a no-op / identity.
+"""
+import numpy as np
+
+
+def merge_triples_host(parts):
+    """Merge per-rank reweight partials [(m, s1, s2)] -> global, per trial beta.
+    parts: array (G, nb, 3).  logsumexp-style: M = max m_g ; s1 = sum s1_g e^{m_g-M} ; s2 = sum s2_g e^{2(m_g-M)}."""
+    parts = np.asarray(parts, dtype=np.float64)
+    m = parts[:, :, 0]
+    M = np.max(m, axis=0)
+    with np.errstate(invalid="ignore", over="ignore"):
+        f = np.exp(m - M[None, :])
+        f = np.where(np.isneginf(m) & np.isneginf(M)[None, :], 0.0, f)
+        s1 = np.sum(parts[:, :, 1] * f, axis=0)
+        s2 = np.sum(parts[:, :, 2] * f * f, axis=0)
+    return np.stack([M, s1, s2], axis=1)
+
+
+class Comm:
+    """Thin wrapper over an initialised torch.distributed process group (or a single process)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.group = group
+        self.world_size = self._dist.get_world_size(group) if self._dist else 1
+        self.rank = self._dist.get_rank(group) if self._dist else 0
+
+    @property
+    def active(self):
+        return self.world_size > 1
+
+    def all_reduce_sum(self, t):
+        """In-place SUM all-reduce of a tensor (device tensor -> RCCL; CPU tensor -> gloo)."""
+        if self.active:
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def sum_int(self, n):
+        if not self.active:
+            return int(n)
+        import torch
+        t = torch.tensor([int(n)], dtype=torch.int64)
+        if self._dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        self._dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+    def all_gather(self, t):
+        """Stack equal-shape tensors of all ranks along a new leading axis."""
+        import torch
+        if not self.active:
+            return t.unsqueeze(0)
+        out = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self._dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out
+
+    def merge_triples(self, part):
+        """part: (nb, 3) tensor of this rank's (max, s1, s2) -> global (nb, 3) host array."""
+        allp = self.all_gather(part)
+        return merge_triples_host(allp.cpu().numpy())
+
+    def all_to_all_rows(self, send, send_counts, recv_counts):
+        """all-to-all-v of row blocks: `send` is (n_send, width) ordered by destination rank."""
+        import torch
+        recv = torch.empty((int(sum(recv_counts)), send.shape[1]), dtype=send.dtype, device=send.device)
+        if not self.active:
+            recv.copy_(send)
+            return recv
+        self._dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=[int(c) for c in recv_counts],
+                                     input_split_sizes=[int(c) for c in send_counts], group=self.group)
+        return recv
+
+    def barrier(self):
+        if self.active:
+            self._dist.barrier(group=self.group)

@@ -677,6 +677,19 @@ extern "C" int tph_weighted_moments(tph_ctx* ctx, const double* w_dev, int64_t n
   return moments_launch_cov(ctx, w_dev, false, nullptr, 0, n, mean_cov_dev, sums, 2, mean_cov_dev + d, part, nblk);
 }
 
+extern "C" int tph_weighted_sums(tph_ctx* ctx, const double* w_dev, int64_t n, double* sums_dev) {
+  TPH_REQUIRE(ctx && w_dev && sums_dev && n > 0 && n <= ctx->size, "tph_weighted_sums: bad argument");
+  const int d = ctx->d;
+  const int rblk = tph_grid_for(n, 256, 4, 512);
+  if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)rblk * (1 + d) * 3)) return -1;
+  double* part1 = (double*)ctx->scratch;
+  hipLaunchKernelGGL(k_wsum<double>, dim3(rblk, 1 + d), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, d, w_dev,
+                     (const int32_t*)nullptr, 0, n, part1);
+  hipLaunchKernelGGL(k_wsum_final, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums_dev, (double*)nullptr);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int tph_weighted_cov_centered(tph_ctx* ctx, const double* w_dev, int64_t n, const double* mean_dev, double* cov_dev) {
   TPH_REQUIRE(ctx && w_dev && mean_dev && cov_dev && n > 0 && n <= ctx->size, "tph_weighted_cov_centered: bad argument");
   const int d = ctx->d;

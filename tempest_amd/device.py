@@ -260,6 +260,18 @@ class HipContext:
         check(self.lib.tph_weighted_moments(self._ctx, _ptr(w), w.numel(), _ptr(out)), "tph_weighted_moments")
         return out
 
+    def weighted_sums(self, w):
+        out = self.empty(1 + self.n_dim)
+        check(self.lib.tph_weighted_sums(self._ctx, _ptr(w), w.numel(), _ptr(out)), "tph_weighted_sums")
+        return out
+
+    def weighted_cov_centered(self, w, mean):
+        d = self.n_dim
+        out = self.empty(d * d)
+        check(self.lib.tph_weighted_cov_centered(self._ctx, _ptr(w), w.numel(), _ptr(mean.contiguous()), _ptr(out)),
+              "tph_weighted_cov_centered")
+        return out
+
     def cv_sum(self, w, mean, covinv):
         out = self.empty(1)
         check(self.lib.tph_cv_sum(self._ctx, _ptr(w), w.numel(), _ptr(mean), _ptr(covinv), _ptr(out)), "tph_cv_sum")

@@ -1,0 +1,95 @@
+"""Mutation step (reference: tempest/steps/mutate.py:76-200): fresh prior draws while beta = 0
+(with the +-inf-likelihood repair and its logZ correction), MCMC on the device otherwise."""
+import math
+
+import numpy as np
+
+from ..mcmc import DeviceMCMC
+
+
+class Mutator:
+    def __init__(self, state, prior_transform, log_likelihood, pbar=None, n_particles: int = 256, n_dim: int = 1,
+                 n_steps: int = 10, n_max_steps: int = 1000, sampler: str = "tpcn", periodic=None, reflective=None,
+                 have_blobs: bool = False, rng=None, device_callbacks=None):
+        """`prior_transform(u)` / `log_likelihood(x) -> (logl, blobs)` follow the reference's conventions unless
+        `device_callbacks=(prior_dev, like_dev)` is given: SoA tensor -> SoA tensor / (n,) tensor (set by SamplerCore)."""
+        self.state = state
+        self.prior_transform = prior_transform
+        self.log_likelihood = log_likelihood
+        self.pbar = pbar
+        self.n_particles = n_particles
+        self.n_dim = n_dim
+        self.n_steps = n_steps
+        self.n_max_steps = n_max_steps
+        self.sampler = sampler
+        self.periodic = periodic
+        self.reflective = reflective
+        self.have_blobs = have_blobs
+        self.rng = rng
+        self.device_callbacks = device_callbacks
+
+    def _rng(self):
+        if self.rng is None:
+            from ..mcmc import PhiloxStream
+            self.rng = PhiloxStream(np.random.randint(0, 2 ** 62))
+        return self.rng
+
+    def _callbacks(self):
+        if self.device_callbacks is not None:
+            return self.device_callbacks
+        import torch
+        dev = self.state.device
+
+        def prior_dev(up):      # reference convention: one row at a time on the host (mcmc.py:157)
+            uh = np.ascontiguousarray(up.cpu().numpy().T)
+            xh = np.array([self.prior_transform(r) for r in uh])
+            return torch.from_numpy(np.ascontiguousarray(xh.T)).to(dev)
+
+        def like_dev(xp):
+            xh = np.ascontiguousarray(xp.cpu().numpy().T)
+            ll, _ = self.log_likelihood(xh)
+            return torch.from_numpy(np.ascontiguousarray(ll, dtype=np.float64)).to(dev)
+        return prior_dev, like_dev
+
+    def run(self, mode_stats) -> None:
+        import torch
+        st = self.state
+        ctx = st.ctx
+        ctx.use_current_stream()
+        rng = self._rng()
+        prior_dev, like_dev = self._callbacks()
+        comm = st.comm
+        active = comm is not None and comm.active
+        n = self.n_particles                      # rows held by this rank
+        n_global = n * (comm.world_size if active else 1)
+        item0 = n * (comm.rank if active else 0)
+        beta = st.get_current("beta")
+        if beta == 0.0:
+            u = ctx.empty(self.n_dim, n)
+            ctx.prior_draw(u, rng.seed, rng.next(), item0)
+            x = prior_dev(u)
+            logl = like_dev(x).clone()
+            x = x.clone() if x.data_ptr() == u.data_ptr() else x
+            calls = st.get_current("calls") + n_global
+            stats = ctx.inf_repair(u, x, logl, rng.seed, rng.next(), item0)    # in place; finite rows untouched
+            if active:
+                comm.all_reduce_sum(stats)
+            n_fin, n_tot = stats.cpu().numpy()
+            st.update_current({"u": u, "x": x, "logl": logl,
+                               "assignments": torch.zeros(n, dtype=torch.int32, device=st.device), "calls": calls,
+                               "steps": 1, "acceptance": 1.0, "efficiency": 1.0}, copy=False)
+            if n_fin < n_tot:     # logZ correction for the prior mass without finite likelihood (mutate.py:144-148)
+                with np.errstate(divide="ignore"):
+                    st.set_current("logz", st.get_current("logz") + float(np.log(n_fin / n_tot)))
+            return
+
+        if self.have_blobs:
+            raise NotImplementedError("blobs are not carried on the GPU path (vectorize=True forbids them)")
+        u, x, logl = st.dev("u"), st.dev("x"), st.dev("logl")
+        run = DeviceMCMC(ctx, "rwm" if self.sampler == "rwm" else "tpcn", beta, mode_stats, like_dev, prior_dev,
+                         self.n_steps, self.n_max_steps, self.periodic, self.reflective, rng=rng, comm=comm,
+                         item0=item0, n_global=n_global, progress_bar=self.pbar)
+        efficiency, acceptance, steps, mcmc_calls = run.run(u, x, logl, st.dev("assignments"))
+        st.update_current({"efficiency": efficiency, "acceptance": acceptance, "steps": steps,
+                           "calls": st.get_current("calls") + mcmc_calls})
+        _ = math  # noqa: F841

@@ -1,0 +1,69 @@
+"""Training step: fit the proposal statistics for the mutation kernels from the weighted history
+(reference: tempest/steps/train.py:65-127; tempest/modes.py; tempest/student.py -- effective form).
+
+Everything after the weights stays on the device and needs no host synchronisation:
+trim threshold (sort + prefix sums, tools.py:10-55) -> masked prefix sum -> x4 multinomial up-sampling as
+multiplicities (modes.py:196-201) -> per-dimension median, covariance, Cholesky and inverse.
+"""
+import numpy as np
+
+from ..modes import ModeStatistics
+from .resample import _as_device_weights
+
+
+class Trainer:
+    def __init__(self, state, pbar=None, clusterer=None, cluster_every: int = 1, clustering: bool = True,
+                 TRIM_ESS: float = 512, TRIM_BINS: int = 10, DOF_FALLBACK: float = 1.0, rng=None):
+        self.state = state
+        self.pbar = pbar
+        self.clusterer = clusterer
+        self.cluster_every = cluster_every
+        self.clustering = clustering
+        self.TRIM_ESS = TRIM_ESS
+        self.TRIM_BINS = TRIM_BINS
+        self.DOF_FALLBACK = DOF_FALLBACK
+        self.rng = rng
+
+    def _rng(self):
+        if self.rng is None:
+            from ..mcmc import PhiloxStream
+            self.rng = PhiloxStream(np.random.randint(0, 2 ** 62))
+        return self.rng
+
+    def run(self, weights) -> ModeStatistics:
+        import torch
+        st = self.state
+        n_dim = st.n_dim
+        if st.get_current("beta") == 0.0:    # dummy statistics, unused at beta = 0 (train.py:80-88)
+            return ModeStatistics(np.zeros((1, n_dim)), np.eye(n_dim).reshape(1, n_dim, n_dim),
+                                  np.array([self.DOF_FALLBACK]), device=st.ctx)
+        ctx = st.ctx
+        ctx.use_current_stream()
+        rng = self._rng()
+        w = _as_device_weights(weights, ctx)
+        n_h = w.numel()
+        comm = st.comm
+        if comm is not None and comm.active:
+            from ..sharding import fit_modes_sharded
+            ms = fit_modes_sharded(st, w, self.TRIM_ESS, self.TRIM_BINS, self.DOF_FALLBACK, rng)
+        elif self.clustering and self.clusterer is not None:
+            it = st.get_current("iter")
+            thr = ctx.trim_threshold(w, self.TRIM_ESS, self.TRIM_BINS)
+            refit = (it % self.cluster_every == 0) or it == 0
+            labels, K = self.clusterer.fit_predict_device(st, w, thr, refit, rng)
+            wt = torch.where(w >= thr[0], w, torch.zeros_like(w))
+            ms = ModeStatistics._fit(ctx, wt, n_h, labels if K > 1 else None, K, rng.seed, rng.next(),
+                                     self.DOF_FALLBACK, 4)
+            for _ in range(K):
+                rng.next()
+        else:
+            thr = ctx.trim_threshold(w, self.TRIM_ESS, self.TRIM_BINS)        # (threshold, kept_sum, kept_count, ess)
+            cdf = ctx.cdf(w, thr[0:1])
+            counts = ctx.multinomial_counts(cdf, rng.seed, rng.next(), kept_count=thr[2:3], factor=4,
+                                            n_draw_max=4 * n_h)
+            means, covs, chol, inv = ctx.fit_modes(counts, None, 1, n_h)
+            dof = torch.full((1,), float(self.DOF_FALLBACK), dtype=torch.float64, device=ctx.device)
+            ms = ModeStatistics(None, None, None, _dev=(ctx, means, covs, chol, inv, dof))
+        if self.pbar is not None:
+            self.pbar.update_stats(dict(K=ms.K))
+        return ms
