@@ -1,0 +1,207 @@
+"""Headline benchmark: particle-mutation-steps/s of the persistent-SMC loop on 10-D Rosenbrock
+(BASELINE.json), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full Persistent Sampling iteration (reweight -> train -> resample -> mutate -> commit) of
+`tempest_amd.Sampler` on the README Rosenbrock target (coefficient 10, prior U(-10,10)^10), 131 072 particles
+per GPU (BASELINE config 4 = 1 048 576 particles over 8 GPUs; weak scaling).  `value` = particle-mutation-steps
+(sum over the timed iterations of MCMC steps x global particles, the reference's `calls` bookkeeping,
+mcmc.py:89) / wall time, user likelihood included, inputs resident in HBM.
+
+Also in the JSON line:
+  roofline      the reweight reduction kernel (north_star's named kernel) on a 1.07 GB synthetic history
+                (outside the 256 MB Infinity Cache): algorithmic 16 B per historical particle /
+                HIP-event average launch duration, against 8 TB/s.
+  cpu_baseline  the NumPy oracle sampler ("port") on the host cores, bounded sample, same target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ANALYTIC_LOGZ = 5 * np.log(np.pi / np.sqrt(10.0)) - 10 * np.log(20.0)      # -29.9901
+HBM_PEAK_GBS = 8000.0                                                       # MI355X_MICROARCH.md
+
+
+def rosenbrock_torch(x):
+    return -(10.0 * (x[:, ::2] ** 2.0 - x[:, 1::2]) ** 2.0 + (x[:, ::2] - 1.0) ** 2.0).sum(dim=1)
+
+
+def rosenbrock_numpy(x):
+    return -np.sum(10.0 * (x[:, ::2] ** 2.0 - x[:, 1::2]) ** 2.0 + (x[:, ::2] - 1.0) ** 2.0, axis=1)
+
+
+def prior20(u):
+    return 20 * u - 10
+
+
+def reweight_roofline(device, n_rows):
+    """HIP-event timing of the reduction kernel on a synthetic history of n_rows (16 B each)."""
+    import torch
+    from tempest_amd.device import HipContext
+    T = 64
+    rs = np.random.RandomState(0)
+    n_t = np.full(T, n_rows // T, dtype=np.int64)
+    n_t[-1] += n_rows - n_t.sum()
+    # logl ~ -chi2_10 * (1 + t/T), generated in blocks to bound host memory
+    logl = np.empty(n_rows)
+    off = 0
+    for t in range(T):
+        logl[off:off + n_t[t]] = -rs.chisquare(10, size=n_t[t]) * (1 + t / T)
+        off += n_t[t]
+    ctx = HipContext(1, device)
+    ctx.history_load(None, None, logl, np.linspace(0, 1, T) ** 2, -np.linspace(0, 30, T), n_t)
+    del logl
+    ms = [ctx.reweight_time(0.37, 1, 20) for _ in range(5)]
+    avg_ms = float(np.median(ms))
+    m, s1, s2 = ctx.reweight_eval([0.37])[0]
+    ctx.close()
+    torch.cuda.empty_cache()
+    algo_bytes = 16.0 * n_rows
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_reweight_pmc.json")
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc))
+            if rec.get("n_rows") == n_rows:
+                traffic = rec.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_reweight_reduce<1>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(avg_ms, 5), "history_rows": n_rows,
+            "check_ess": float(s1 * s1 / s2)}
+
+
+def cpu_baseline(budget_s=20.0):
+    """Oracle (NumPy port of the reference algorithm) on the host: 10-D Rosenbrock, N=4096, as many PS
+    iterations as fit the time budget (at least the 3 warm-up + 2 annealing ones)."""
+    from oracle.sampler import OracleSampler
+    try:
+        import threadpoolctl
+        threads = max(d.get("num_threads", 1) for d in threadpoolctl.threadpool_info()) if threadpoolctl.threadpool_info() else 1
+    except Exception:
+        threads = 1
+    n_cpu = 4096
+    s = OracleSampler(prior20, rosenbrock_numpy, 10, n_cpu, seed=0)
+    t0 = time.perf_counter()
+    it = 0
+    while (time.perf_counter() - t0 < budget_s or it < 5) and it < 60:
+        s.sample()
+        it += 1
+    wall = time.perf_counter() - t0
+    return {"value": round(s.pms / wall, 1), "unit": "particle-mutation-steps/s", "cores": int(threads), "kind": "port",
+            "sample": f"oracle.sampler.OracleSampler, 10-D Rosenbrock, N={n_cpu}, first {it} PS iterations "
+                      f"({s.pms} particle-mutation-steps in {wall:.1f} s; host has {os.cpu_count()} cores, "
+                      f"NumPy/BLAS threads={threads})",
+            "phase_seconds": {k: round(v, 2) for k, v in s.timing.items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--particles-per-gpu", type=int, default=131072)
+    ap.add_argument("--roofline-rows", type=int, default=67_108_864)      # 1.07 GB of (logl, logmix)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-finish", action="store_true", help="skip running on to termination for logZ")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--roofline-only", action="store_true", help="only the reweight-kernel microbench (for rocprofv3 --pmc)")
+    a = ap.parse_args()
+    if a.roofline_only:
+        print(json.dumps({"roofline": reweight_roofline(int(os.environ.get("LOCAL_RANK", "0")), a.roofline_rows)}))
+        return
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    import tempest_amd as tp
+    n_local = a.particles_per_gpu
+    n_global = n_local * world
+    n_total = 4 * n_global                                                  # n_total = 4 N
+    s = tp.Sampler(prior20, rosenbrock_torch, 10, n_particles=n_global, vectorize=True, clustering=False,
+                   random_state=a.seed, backend="torch", batch_prior=True, device=local_rank)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        s.sample()
+    sync()
+    it0 = len(s.state._scalars["steps"])
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        s.sample()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    steps_t = np.asarray(s.state._scalars["steps"][it0:])
+    beta_t = np.asarray(s.state._scalars["beta"][it0:])
+    pms = float(np.sum(steps_t[beta_t > 0])) * n_global
+    value = pms / dt
+
+    extra = {"timed_mcmc_steps": int(np.sum(steps_t[beta_t > 0])), "timed_iterations": int(a.steps),
+             "beta_range": [float(beta_t.min()), float(beta_t.max())],
+             "reweight_evals_per_iteration": round(s._core.reweighter.n_evals / max(1, len(s.state._scalars["beta"])), 1)}
+    if not a.no_finish:
+        # run on to the reference's stopping rule for the evidence (untimed)
+        core = s._core
+        core.n_total = n_total
+        guard = 0
+        while core._not_termination() and guard < 400:
+            s.sample()
+            guard += 1
+        _, logz = core._logz_at(1.0)
+        extra.update({"logz": logz, "logz_abs_err_vs_analytic": abs(logz - ANALYTIC_LOGZ),
+                      "analytic_logz": float(ANALYTIC_LOGZ), "iterations_total": len(s.state._scalars["beta"]),
+                      "reference_logz_ensemble_N1000": {"mean": -29.804, "std": 0.115, "seeds": 16,
+                                                        "source": "tests/golden/ref_ensembles.json"}})
+    out = {"metric": "particle-mutation-steps/s (whole job), 10-D Rosenbrock", "value": value,
+           "unit": "particle-mutation-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"rosenbrock10d_n{n_local}_per_gpu (BASELINE config 4 shard: {n_global} particles global)",
+                      "n_dim": 10, "particles_per_gpu": n_local, "particles_global": n_global, "sample": "tpcn",
+                      "resample": "mult", "clustering": False, "n_total": n_total, "step": "one PS iteration"}}
+    out.update(extra)
+    if rank == 0:
+        if not a.no_roofline:
+            out["roofline"] = reweight_roofline(local_rank, a.roofline_rows)
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

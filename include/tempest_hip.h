@@ -88,6 +88,9 @@ int tph_history_load(tph_ctx* ctx, const double* u_host, const double* x_host, c
  * _host synchronises and returns them. */
 int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int nb, double* out_dev /*[nb][3]*/);
 int tph_reweight_eval(tph_ctx* ctx, const double* betas_host, int nb, double* out_host /*[nb][3]*/);
+/* measurement aid: average duration (ms, HIP events on the ctx stream) of `reps` back-to-back launches of the
+ * reduction kernel alone for nb trial betas */
+int tph_reweight_time(tph_ctx* ctx, double beta, int nb, int reps, double* avg_ms_host);
 /* normalised weights w_s = e^{beta l_s - C_s - vmax}/s1 for all N_h particles (reweight.py:106,328) */
 int tph_weights(tph_ctx* ctx, double beta, double vmax, double s1, double* w_dev);
 /* unnormalised log-weights beta*l - C + log(n_h_global)  (state_manager.py:473) */

@@ -128,15 +128,7 @@ static void launch_reduce(tph_ctx* ctx, int grid, const tph_betas& bt) {
                      ctx->size, bt, ctx->partials);
 }
 
-extern "C" int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int nb, double* out_dev) {
-  TPH_REQUIRE(ctx && betas_host && out_dev, "tph_reweight_partials: NULL argument");
-  TPH_REQUIRE(nb >= 1 && nb <= TPH_MAX_NB, "tph_reweight_partials: nb=%d outside [1,%d]", nb, TPH_MAX_NB);
-  TPH_REQUIRE(ctx->size > 0, "tph_reweight_partials: empty history");
-  tph_betas bt;
-  for (int i = 0; i < TPH_MAX_NB; ++i) bt.b[i] = i < nb ? betas_host[i] : 0.0;
-  // 4 elements per lane per trip, capped at 2048 blocks (256 CUs x 8) and grid-strided beyond
-  int grid = tph_grid_for(ctx->size, TPH_RED_THREADS, 4);
-  TPH_REQUIRE((size_t)grid * nb * 3 * sizeof(double) <= ctx->partials_bytes, "tph_reweight_partials: scratch too small");
+static void launch_reduce_nb(tph_ctx* ctx, int grid, const tph_betas& bt, int nb) {
   switch (nb) {
     case 1: launch_reduce<1>(ctx, grid, bt); break;
     case 2: launch_reduce<2>(ctx, grid, bt); break;
@@ -155,6 +147,18 @@ extern "C" int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int
     case 15: launch_reduce<15>(ctx, grid, bt); break;
     default: launch_reduce<16>(ctx, grid, bt); break;
   }
+}
+
+extern "C" int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int nb, double* out_dev) {
+  TPH_REQUIRE(ctx && betas_host && out_dev, "tph_reweight_partials: NULL argument");
+  TPH_REQUIRE(nb >= 1 && nb <= TPH_MAX_NB, "tph_reweight_partials: nb=%d outside [1,%d]", nb, TPH_MAX_NB);
+  TPH_REQUIRE(ctx->size > 0, "tph_reweight_partials: empty history");
+  tph_betas bt;
+  for (int i = 0; i < TPH_MAX_NB; ++i) bt.b[i] = i < nb ? betas_host[i] : 0.0;
+  // 4 elements per lane per trip, capped at 2048 blocks (256 CUs x 8) and grid-strided beyond
+  int grid = tph_grid_for(ctx->size, TPH_RED_THREADS, 4);
+  TPH_REQUIRE((size_t)grid * nb * 3 * sizeof(double) <= ctx->partials_bytes, "tph_reweight_partials: scratch too small");
+  launch_reduce_nb(ctx, grid, bt, nb);
   TPH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_reweight_finalize, dim3(nb), dim3(256), 0, ctx->stream, ctx->partials, grid, nb, out_dev);
   TPH_LAUNCH_CHECK();
@@ -168,6 +172,30 @@ extern "C" int tph_reweight_eval(tph_ctx* ctx, const double* betas_host, int nb,
   TPH_HIP(hipMemcpyAsync(ctx->pinned, ctx->small_dev, sizeof(double) * 3 * nb, hipMemcpyDeviceToHost, ctx->stream));
   TPH_HIP(hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < 3 * nb; ++i) out_host[i] = ctx->pinned[i];
+  return 0;
+}
+
+// HIP-event timing of the streaming reduction alone (no finalize, no host work between launches):
+// what bench.py reports as the kernel's average launch duration.
+extern "C" int tph_reweight_time(tph_ctx* ctx, double beta, int nb, int reps, double* avg_ms_host) {
+  TPH_REQUIRE(ctx && avg_ms_host && reps > 0, "tph_reweight_time: bad argument");
+  TPH_REQUIRE(nb >= 1 && nb <= TPH_MAX_NB && ctx->size > 0, "tph_reweight_time: bad nb / empty history");
+  tph_betas bt;
+  for (int i = 0; i < TPH_MAX_NB; ++i) bt.b[i] = beta * (1.0 - 0.01 * i);
+  int grid = tph_grid_for(ctx->size, TPH_RED_THREADS, 4);
+  hipEvent_t e0, e1;
+  TPH_HIP(hipEventCreate(&e0));
+  TPH_HIP(hipEventCreate(&e1));
+  launch_reduce_nb(ctx, grid, bt, nb);  // warm
+  TPH_HIP(hipEventRecord(e0, ctx->stream));
+  for (int r = 0; r < reps; ++r) launch_reduce_nb(ctx, grid, bt, nb);
+  TPH_HIP(hipEventRecord(e1, ctx->stream));
+  TPH_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  TPH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  TPH_HIP(hipEventDestroy(e0));
+  TPH_HIP(hipEventDestroy(e1));
+  *avg_ms_host = (double)ms / reps;
   return 0;
 }
 

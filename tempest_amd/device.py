@@ -138,6 +138,12 @@ class HipContext:
               "tph_reweight_partials")
         return out
 
+    def reweight_time(self, beta=0.37, nb=1, reps=20):
+        """Average launch duration (ms) of the reduction kernel, HIP events on the ctx stream."""
+        out = C.c_double(0.0)
+        check(self.lib.tph_reweight_time(self._ctx, float(beta), int(nb), int(reps), C.byref(out)), "tph_reweight_time")
+        return out.value
+
     def weights(self, beta, vmax, s1, out=None):
         if out is None:
             out = self.empty(self.size)
