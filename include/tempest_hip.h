@@ -115,6 +115,13 @@ int tph_resample_systematic(tph_ctx* ctx, const double* cdf_dev, int64_t n, int6
 /* idx_i = #{k : cdf_k/cdf_last <= U_i}, U_i = Philox(seed, tick, tag, item0+i)  (np.random.choice) */
 int tph_resample_multinomial(tph_ctx* ctx, const double* cdf_dev, int64_t n, int64_t n_out, uint64_t seed,
                              uint32_t tick, uint32_t tag, int64_t item0, int64_t* idx_dev);
+/* Sharded variant: of the n_slots GLOBAL output slots, the ones whose position in the global cumulative weight
+ * falls in this rank's span [w_before, w_upto) get idx = local row, all others -1 (scheme 0 multinomial, 1 systematic).
+ * Every rank evaluates the same counter-based draws, so the spans partition the slots without communication.
+ * is_last: bit 0 set on the rank owning the last span, bit 1 on the rank owning the first. */
+int tph_resample_select(tph_ctx* ctx, const double* cdf_dev, int64_t n, int64_t n_slots, int scheme, uint64_t seed,
+                        uint32_t tick, uint32_t tag, double u0, double w_before, double w_upto, double w_total,
+                        int is_last, int64_t* idx_dev);
 /* u_out[j][i] = u_hist[j][idx_i] etc. (steps/resample.py:86-99) */
 int tph_gather(tph_ctx* ctx, const int64_t* idx_dev, int64_t n_out, double* u_out, double* x_out,
                double* logl_out, int64_t ld_out);

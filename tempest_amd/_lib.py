@@ -42,6 +42,7 @@ SIGNATURES = {
     "tph_cdf": (c_int, [ptr, ptr, c_i64, ptr, ptr]),
     "tph_resample_systematic": (c_int, [ptr, ptr, c_i64, c_i64, c_i64, c_i64, c_dbl, c_dbl, ptr]),
     "tph_resample_multinomial": (c_int, [ptr, ptr, c_i64, c_i64, c_u64, c_u32, c_u32, c_i64, ptr]),
+    "tph_resample_select": (c_int, [ptr, ptr, c_i64, c_i64, c_int, c_u64, c_u32, c_u32, c_dbl, c_dbl, c_dbl, c_dbl, c_int, ptr]),
     "tph_gather": (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr, c_i64]),
     "tph_multinomial_counts": (c_int, [ptr, ptr, c_i64, ptr, c_int, c_i64, c_u64, c_u32, c_u32, ptr]),
     "tph_prior_draw": (c_int, [ptr, ptr, c_i64, c_i64, c_u64, c_u32, c_i64]),

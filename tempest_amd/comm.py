@@ -38,10 +38,20 @@ class Comm:
     def active(self):
         return self.world_size > 1
 
+    @property
+    def _stage_on_host(self):
+        """gloo (the CPU-test backend) cannot move device tensors for every collective: stage through the host."""
+        return self._dist is not None and self._dist.get_backend(self.group) == "gloo"
+
     def all_reduce_sum(self, t):
         """In-place SUM all-reduce of a tensor (device tensor -> RCCL; CPU tensor -> gloo)."""
         if self.active:
-            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+            if t.is_cuda and self._stage_on_host:
+                h = t.cpu()
+                self._dist.all_reduce(h, op=self._dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
         return t
 
     def sum_int(self, n):
@@ -59,9 +69,23 @@ class Comm:
         import torch
         if not self.active:
             return t.unsqueeze(0)
+        if self._stage_on_host:
+            h = t.detach().cpu().contiguous()
+            parts = [torch.empty_like(h) for _ in range(self.world_size)]
+            self._dist.all_gather(parts, h, group=self.group)
+            return torch.stack(parts).to(t.device)
         out = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         self._dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         return out
+
+    def all_to_all_counts(self, send_counts):
+        """send_counts[r] rows go to rank r -> recv_counts[r] rows come from rank r (int64 tensor on the host)."""
+        import torch
+        sc = send_counts.detach().to(torch.int64)
+        if not self.active:
+            return sc.cpu()
+        allc = self.all_gather(sc)                  # (G, G): row = sender
+        return allc[:, self.rank].cpu()
 
     def merge_triples(self, part):
         """part: (nb, 3) tensor of this rank's (max, s1, s2) -> global (nb, 3) host array."""
@@ -75,9 +99,31 @@ class Comm:
         if not self.active:
             recv.copy_(send)
             return recv
+        if self._stage_on_host:                    # gloo: exchange as a list of per-peer CPU blocks
+            sh = send.detach().cpu()
+            so = np.concatenate([[0], np.cumsum(send_counts)]).astype(int)
+            outs = [torch.empty((int(c), send.shape[1]), dtype=send.dtype) for c in recv_counts]
+            ins = [sh[so[r]:so[r + 1]].contiguous() for r in range(self.world_size)]
+            self._dist.all_to_all(outs, ins, group=self.group) if self._has_gloo_all_to_all() else self._p2p_all_to_all(outs, ins)
+            return torch.cat(outs).to(send.device)
         self._dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=[int(c) for c in recv_counts],
                                      input_split_sizes=[int(c) for c in send_counts], group=self.group)
         return recv
+
+    @staticmethod
+    def _has_gloo_all_to_all():
+        return False          # ProcessGroupGloo lacks list all_to_all: use point-to-point
+
+    def _p2p_all_to_all(self, outs, ins):
+        reqs = []
+        for r in range(self.world_size):
+            if r == self.rank:
+                outs[r].copy_(ins[r])
+                continue
+            reqs.append(self._dist.isend(ins[r], r, group=self.group))
+            reqs.append(self._dist.irecv(outs[r], r, group=self.group))
+        for q in reqs:
+            q.wait()
 
     def barrier(self):
         if self.active:

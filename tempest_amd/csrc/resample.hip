@@ -162,6 +162,48 @@ extern "C" int tph_resample_multinomial(tph_ctx* ctx, const double* cdf_dev, int
   return 0;
 }
 
+// Sharded selection (multi-GPU): every rank walks ALL n_slots global output slots (the draws are a pure
+// function of (seed, tick, slot), so every rank sees the same ones) and keeps those whose position falls in
+// its own span [w_before, w_upto) of the global cumulative weight; idx_out[i] = local row or -1.
+// scheme 0 = multinomial (position U_i * w_total, `<=` walk), 1 = systematic ((u0+i)/n_slots * w_total, `<` walk).
+// is_last: bit 0 = this rank owns the last span, bit 1 = the first.
+__global__ void __launch_bounds__(256) k_resample_select(const double* __restrict__ cdf, int64_t n, int64_t n_slots,
+                                                         int scheme, uint64_t seed, uint32_t tick, uint32_t tag, double u0,
+                                                         double w_before, double w_upto, double w_total, int is_last,
+                                                         int64_t* __restrict__ idx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots) return;
+  double p;
+  if (scheme == 0) {
+    tph_rng g(seed, tick, tag, (uint64_t)i);
+    double U, U1;
+    g.uniform2(0, U, U1);
+    p = U * w_total;
+  } else {
+    p = (u0 + (double)i) / (double)n_slots * w_total;
+  }
+  // span membership uses the same boundaries on every rank (computed from the all-gathered totals), so the
+  // spans partition the slots: multinomial row = #{cum <= p}, systematic row = #{cum < p}
+  const bool first = (is_last & 2) != 0, last = (is_last & 1) != 0;
+  bool mine = scheme == 0 ? ((first || p >= w_before) && (last || p < w_upto))
+                          : ((first || p > w_before) && (last || p <= w_upto));
+  if (!mine) { idx[i] = -1; return; }
+  double q = p - w_before;
+  int64_t k = scheme == 0 ? count_below<false>(cdf, n, 1.0, q) : count_below<true>(cdf, n, 1.0, q);
+  idx[i] = k < n ? k : n - 1;
+}
+
+extern "C" int tph_resample_select(tph_ctx* ctx, const double* cdf_dev, int64_t n, int64_t n_slots, int scheme,
+                                   uint64_t seed, uint32_t tick, uint32_t tag, double u0, double w_before, double w_upto,
+                                   double w_total, int is_last, int64_t* idx_dev) {
+  TPH_REQUIRE(ctx && cdf_dev && idx_dev && n > 0 && n_slots > 0, "tph_resample_select: bad argument");
+  TPH_REQUIRE(scheme == 0 || scheme == 1, "tph_resample_select: scheme must be 0 (multinomial) or 1 (systematic)");
+  hipLaunchKernelGGL(k_resample_select, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, ctx->stream, cdf_dev, n,
+                     n_slots, scheme, seed, tick, tag, u0, w_before, w_upto, w_total, is_last, idx_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
 // K7: gather rows of the history; coalesced writes, indexed reads
 __global__ void __launch_bounds__(256) k_gather(const double* __restrict__ hu, const double* __restrict__ hx,
                                                 const double* __restrict__ hl, int64_t cap, int d,

@@ -192,6 +192,14 @@ class HipContext:
                                                 _ptr(idx)), "tph_resample_multinomial")
         return idx
 
+    def resample_select(self, cdf, n_slots, scheme, seed, tick, u0, w_before, w_upto, w_total, is_last,
+                        tag=TAG_RESAMPLE):
+        idx = self.empty(n_slots, dtype=torch.int64)
+        check(self.lib.tph_resample_select(self._ctx, _ptr(cdf), cdf.numel(), n_slots, int(scheme), seed, tick, tag,
+                                           float(u0), float(w_before), float(w_upto), float(w_total), int(is_last),
+                                           _ptr(idx)), "tph_resample_select")
+        return idx
+
     def gather(self, idx, u_out, x_out, logl_out):
         check(self.lib.tph_gather(self._ctx, _ptr(idx, torch.int64), idx.numel(), _ptr(u_out), _ptr(x_out),
                                   _ptr(logl_out), u_out.shape[1]), "tph_gather")

@@ -1,0 +1,138 @@
+"""Worker bodies for the multi-process tests (spawned by torch.multiprocessing)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def comm_cpu_worker(rank, world, port, out_dir):
+    """gloo / CPU tensors: the collectives of tempest_amd.comm against a single-process oracle."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from oracle import ps
+    from tempest_amd.comm import Comm
+    _init(rank, world, port)
+    comm = Comm()
+    assert comm.active and comm.world_size == world and comm.rank == rank
+    rs = np.random.RandomState(0)               # same data on every rank; each takes its shard
+    n = 4000
+    logl = -rs.chisquare(5, size=n) * 3
+    bt, zt, nt = np.array([0.0, 0.2, 0.6]), np.array([0.0, -2.0, -5.0]), np.array([n // 2, n // 4, n - n // 2 - n // 4])
+    cm = ps.log_mixture(logl, bt, zt, nt)
+    betas = [0.0, 0.3, 1.0]
+    sl = slice(rank * n // world, (rank + 1) * n // world)
+    part = torch.tensor([ps.reweight_triple(logl[sl], cm[sl], b) for b in betas], dtype=torch.float64)
+    merged = comm.merge_triples(part)
+    for b, row in zip(betas, merged):
+        m, s1, s2 = ps.reweight_triple(logl, cm, b)
+        np.testing.assert_allclose(row[0] + np.log(row[1]), m + np.log(s1), rtol=1e-13)
+        np.testing.assert_allclose(row[1] ** 2 / row[2], s1 ** 2 / s2, rtol=1e-12)
+    # a rank with no finite rows must not poison the merge
+    empty = torch.tensor([[-np.inf, 0.0, 0.0]], dtype=torch.float64)
+    one = torch.tensor([[1.5, 2.0, 3.0]], dtype=torch.float64)
+    mm = comm.merge_triples(empty if rank == 0 else one)
+    np.testing.assert_allclose(mm[0], [1.5, 2.0 * (world - 1), 3.0 * (world - 1)])
+    # sums
+    t = torch.tensor([float(rank + 1), 2.0], dtype=torch.float64)
+    comm.all_reduce_sum(t)
+    assert t.tolist() == [world * (world + 1) / 2, 2.0 * world]
+    assert comm.sum_int(10 + rank) == sum(10 + r for r in range(world))
+    # all-to-all-v of rows: rank r sends (r + d + 1) rows tagged (r, d) to rank d
+    rows, counts = [], []
+    for d in range(world):
+        k = rank + d + 1
+        counts.append(k)
+        rows.append(torch.full((k, 3), float(10 * rank + d), dtype=torch.float64))
+    send = torch.cat(rows)
+    rc = comm.all_to_all_counts(torch.tensor(counts))
+    assert rc.tolist() == [s + rank + 1 for s in range(world)]
+    recv = comm.all_to_all_rows(send, counts, rc.tolist())
+    want = torch.cat([torch.full((s + rank + 1, 3), float(10 * s + rank), dtype=torch.float64) for s in range(world)])
+    assert torch.equal(recv, want)
+    comm.barrier()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def sharded_gpu_worker(rank, world, port, out_dir):
+    """2 ranks sharing cuda:0 over gloo (host-staged collectives): sharded resampling partitions the slots,
+    and a sharded Sampler run reproduces the analytic evidence."""
+    import json
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    _init(rank, world, port)
+    import tempest_amd as tp
+    from tempest_amd.comm import Comm
+    from tempest_amd.device import HipContext
+    from tempest_amd.mcmc import PhiloxStream
+    from tempest_amd.sharding import resample_sharded
+    from tempest_amd.state_manager import StateManager
+    dev = torch.device("cuda", 0)
+    comm = Comm()
+    res = {}
+    # ---- sharded resampling: every slot gets exactly one row; frequencies follow the global weights
+    for scheme in ("mult", "syst"):
+        d, nh, n_local = 3, 5000, 4000
+        rs = np.random.RandomState(100 + rank)
+        st = StateManager(d, device=0, comm=comm)
+        u = rs.rand(nh, d)
+        tag = np.full(nh, float(rank))                      # logl carries (rank, row) so rows can be traced
+        st.ctx.history_load(u, 20 * u - 10, tag * 1e6 + np.arange(nh), [0.0], [0.0], [nh], [nh * world])
+        w = np.exp(rs.randn(nh) * (1.0 + rank))
+        tot = torch.tensor([w.sum()], dtype=torch.float64)
+        comm.all_reduce_sum(tot)
+        wn = w / float(tot)
+        ut, xt, lt = resample_sharded(st, torch.from_numpy(wn).to(dev), scheme, PhiloxStream(7), n_local)
+        assert ut.shape == (d, n_local) and xt.shape == (d, n_local) and lt.shape == (n_local,)
+        ids = lt.cpu().numpy()
+        src_rank = (ids // 1e6).astype(int)
+        src_row = (ids % 1e6).astype(int)
+        np.testing.assert_allclose(xt.cpu().numpy(), 20 * ut.cpu().numpy() - 10, rtol=1e-15)
+        # rows really are the source rank's rows
+        for r in range(world):
+            ur = np.random.RandomState(100 + r).rand(nh, d)
+            sel = src_rank == r
+            np.testing.assert_array_equal(ut.cpu().numpy().T[sel], ur[src_row[sel]])
+        res[scheme] = {"from0": int((src_rank == 0).sum()), "w0": None}
+        # share of slots drawn from rank 0 ~ its share of the global weight
+        w_all = comm.all_gather(torch.tensor([wn.sum()], dtype=torch.float64)).reshape(-1).numpy()
+        cnt = torch.tensor([float((src_rank == 0).sum())], dtype=torch.float64)
+        comm.all_reduce_sum(cnt)
+        frac0 = float(cnt) / (n_local * world)
+        assert abs(frac0 - w_all[0]) < 0.03, (scheme, frac0, w_all)
+        res[scheme]["w0"] = float(w_all[0]); res[scheme]["frac0"] = frac0
+    # ---- a sharded run end to end
+    mean = torch.linspace(-2, 2, 6, dtype=torch.float64, device=dev)
+
+    def loglike(x):
+        return -0.5 * ((x - mean) ** 2).sum(dim=1) - 3.0 * float(np.log(2 * np.pi))
+    logzs = []
+    for seed in range(3):
+        s = tp.Sampler(lambda uu: 20 * uu - 10, loglike, 6, n_particles=512, vectorize=True, clustering=False,
+                       random_state=seed, device=0)
+        assert s.state.comm is not None and s._core.n_local == 256
+        s.run(n_total=2048, progress=False)
+        logzs.append(s.evidence()[0])
+        assert s.state.ctx.size == 256 * len(s.state.get_history("beta"))
+    res["logz"] = logzs
+    res["analytic"] = float(-6 * np.log(20.0))
+    assert all(abs(z - res["analytic"]) < 0.35 for z in logzs), logzs
+    zt = torch.tensor(logzs, dtype=torch.float64)
+    z0 = zt.clone()
+    comm.all_reduce_sum(zt)
+    assert torch.allclose(zt, world * z0, rtol=0, atol=1e-12)            # every rank holds the same evidence
+    json.dump(res, open(os.path.join(out_dir, f"res{rank}.json"), "w"))
+    comm.barrier()
+    dist.destroy_process_group()
+    _ = HipContext

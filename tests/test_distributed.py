@@ -1,0 +1,61 @@
+"""Multi-process tests of the sharded path.  CPU part: gloo, world_size 2 (runs without a GPU).
+GPU part (marked gpu): two ranks sharing cuda:0 over gloo, exercising the sharded kernels end to end."""
+import os
+import socket
+
+import pytest
+
+torch = pytest.importorskip("torch")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(fn, world, tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(fn, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+
+
+def test_comm_collectives_gloo_world2(tmp_path):
+    from tests._dist_workers import comm_cpu_worker
+    _spawn(comm_cpu_worker, 2, tmp_path)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_comm_collectives_gloo_world3(tmp_path):
+    from tests._dist_workers import comm_cpu_worker
+    _spawn(comm_cpu_worker, 3, tmp_path)
+    assert len(os.listdir(tmp_path)) == 3
+
+
+def test_merge_triples_host_matches_single_pass():
+    import numpy as np
+    from oracle import ps
+    from tempest_amd.comm import merge_triples_host
+    rs = np.random.RandomState(3)
+    logl = -rs.chisquare(4, size=9000) * 5
+    cm = ps.log_mixture(logl, [0.0, 0.5], [0.0, -3.0], [4000, 5000])
+    parts = np.array([[ps.reweight_triple(logl[i::8], cm[i::8], b) for b in (0.1, 0.9)] for i in range(8)])
+    merged = merge_triples_host(parts)
+    for j, b in enumerate((0.1, 0.9)):
+        m, s1, s2 = ps.reweight_triple(logl, cm, b)
+        np.testing.assert_allclose(merged[j][0] + np.log(merged[j][1]), m + np.log(s1), rtol=1e-13)
+        np.testing.assert_allclose(merged[j][1] ** 2 / merged[j][2], s1 ** 2 / s2, rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_sharded_sampler_two_ranks_one_gpu(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    from tests._dist_workers import sharded_gpu_worker
+    _spawn(sharded_gpu_worker, 2, tmp_path)
+    r0 = json.load(open(tmp_path / "res0.json"))
+    r1 = json.load(open(tmp_path / "res1.json"))
+    assert r0["logz"] == r1["logz"]
+    print(r0)
