@@ -151,6 +151,8 @@ class SamplerCore:
         # random_state seeds the counter-based stream; without it the seed is taken from NumPy's global
         # stream, so `np.random.seed(k)` makes a run reproducible the way it does for the reference
         seed = config.random_state if config.random_state is not None else int(np.random.randint(0, 2 ** 62))
+        if comm is not None and comm.active:      # every rank must walk the same counter-based stream
+            seed = comm.sum_int(seed if comm.rank == 0 else 0)
         self.rng = PhiloxStream(seed)
         self.callbacks = None
 
