@@ -178,6 +178,28 @@ int tph_weighted_cov_centered(tph_ctx* ctx, const double* w_dev, int64_t n, cons
 int tph_cv_sum(tph_ctx* ctx, const double* w_dev, int64_t n, const double* mean_dev, const double* covinv_dev,
                double* out_dev /*[1]: sum w^2 dev^2*/);
 
+/* ---- clustering working set (cluster.py) ---------------------------------------------------------------
+ * The hierarchical GMM runs on a compact, [0,1]-normalised SoA copy x[j*ld+i] of the kept (trimmed) history rows. */
+/* idx = ascending history rows with w >= *thr_dev (their number is the kept_count of tph_trim_threshold) */
+int tph_compact_indices(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev, int64_t* idx_dev);
+/* out[j][i] = (u_hist[j][idx_i] - shift_j) * scale_j (shift NULL = copy), wout[i] = w[idx_i] (cluster.py:373-379) */
+int tph_gather_u_affine(tph_ctx* ctx, const int64_t* idx_dev, int64_t m, const double* shift_dev, const double* scale_dev,
+                        const double* w_dev, double* out_dev, int64_t ld, double* wout_dev);
+int tph_affine(tph_ctx* ctx, double* x_dev, int64_t ld, int64_t n, const double* shift_dev, const double* scale_dev);
+/* sums (1+d) [+ range (2d): min,max of rows with w>0] and raw centred second moments of an explicit SoA array */
+int tph_x_weighted_sums(tph_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, const double* w_dev, double* sums_dev,
+                        double* range_dev /*or NULL*/);
+int tph_x_weighted_cov(tph_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, const double* w_dev, const double* mean_dev,
+                       double* cov_dev);
+/* Gaussian-mixture pass over the rows with labels[i]==label (labels NULL = all).  params per component:
+ * [log-weight term, mean(d), precision(d*d), logdet].  mode 0: wr[k][i] = sw_i w_k N_k / (sum_k w_k N_k + eps) and
+ * stats = (sum sw log(p+1e-10), sum log(p+1e-10), #rows) (cluster.py:178-198,287-304,330-340); mode 1: wr[i] = sw_i min_k
+ * maha_k (k-means++ seeding, :146-157); mode 2: label_out[i] = argmax_k term_k + logN_k (:306-328,600-696).
+ * shift/scale (NULL = none): rows are normalised on the fly as (x - shift_j) * scale_j. */
+int tph_gmm_estep(tph_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, const double* sw_dev, const int32_t* labels_dev,
+                  int label, int K, const double* params_dev, int mode, double eps, const double* shift_dev,
+                  const double* scale_dev, double* wr_dev, int32_t* label_out_dev, double* stats_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -367,11 +367,49 @@ def g8_inf_repair():
     np.savez_compressed(os.path.join(OUT, "g8_inf_repair.npz"), **out)
 
 
+def g10_cluster():
+    """HierarchicalGaussianMixture / GaussianMixture of the reference on seeded synthetic sets: number of clusters,
+    labels, fitted two-component parameters, BICs (distributional pins: the seeding RNG cannot be reproduced)."""
+    from tempest.cluster import GaussianMixture, HierarchicalGaussianMixture
+    out = {}
+    rs = np.random.RandomState(77)
+    sets = {}
+    # two well separated blobs in 3-D, weighted
+    a = 0.3 + 0.03 * rs.randn(300, 3); b = 0.7 + 0.04 * rs.randn(200, 3)
+    sets["two"] = (np.clip(np.vstack([a, b]), 0, 1), np.exp(0.3 * rs.randn(500)), np.r_[np.zeros(300), np.ones(200)])
+    # four modes in 4-D (config-3 shape: +-offset in the first two coordinates)
+    pts, lab = [], []
+    for k, (sx, sy) in enumerate([(-1, -1), (-1, 1), (1, -1), (1, 1)]):
+        c = np.array([0.5 + 0.2 * sx, 0.5 + 0.2 * sy, 0.5, 0.5])
+        pts.append(c + 0.02 * rs.randn(250, 4)); lab.append(np.full(250, k))
+    sets["four"] = (np.vstack(pts), np.ones(1000), np.concatenate(lab))
+    # one Gaussian blob: must not split
+    sets["one"] = (0.5 + 0.05 * rs.randn(600, 3), np.exp(0.5 * rs.randn(600)), np.zeros(600))
+    for name, (X, w, truth) in sets.items():
+        out[f"{name}_X"], out[f"{name}_w"], out[f"{name}_truth"] = X, w, truth
+        h = HierarchicalGaussianMixture(n_init=1, max_iterations=1000, min_points=None, threshold_modifier=1.0,
+                                        covariance_type="full", verbose=False, normalize=True)
+        h.fit(X, w)
+        out[f"{name}_K"] = h.n_clusters_
+        out[f"{name}_labels"] = h.labels_
+        out[f"{name}_pred"] = h.predict(X)
+        out[f"{name}_weights"] = h.cluster_weights_
+        out[f"{name}_centers"] = np.array(h.cluster_centers_)
+    X, w, _ = sets["two"]
+    for K in (1, 2):
+        g = GaussianMixture(n_components=K, random_state=42).fit(X, w)
+        order = np.argsort(g.means_[:, 0])
+        out[f"gmm{K}_weights"], out[f"gmm{K}_means"], out[f"gmm{K}_covs"] = g.weights_[order], g.means_[order], g.covariances_[order]
+        out[f"gmm{K}_lower"], out[f"gmm{K}_bic"], out[f"gmm{K}_niter"] = g.lower_bound_, g.bic(X), g.n_iter_
+        out[f"gmm{K}_pred"] = np.argsort(order)[g.predict(X)]
+    np.savez_compressed(os.path.join(OUT, "g10_cluster.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     import tempest
     print("reference", tempest.__version__, "numpy", np.__version__)
-    for fn in (g1_logw, g2_tools, g3_reweighter, g4_resample, g5_boundaries, g6_mcmc, g7_modes, g8_inf_repair):
+    for fn in (g1_logw, g2_tools, g3_reweighter, g4_resample, g5_boundaries, g6_mcmc, g7_modes, g8_inf_repair, g10_cluster):
         fn()
         print("wrote", fn.__name__)
 

@@ -58,6 +58,12 @@ SIGNATURES = {
     "tph_weighted_moments": (c_int, [ptr, ptr, c_i64, ptr]),
     "tph_weighted_sums": (c_int, [ptr, ptr, c_i64, ptr]),
     "tph_weighted_cov_centered": (c_int, [ptr, ptr, c_i64, ptr, ptr]),
+    "tph_compact_indices": (c_int, [ptr, ptr, c_i64, ptr, ptr]),
+    "tph_gather_u_affine": (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr, ptr, c_i64, ptr]),
+    "tph_affine": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr]),
+    "tph_x_weighted_sums": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr, ptr]),
+    "tph_x_weighted_cov": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr, ptr]),
+    "tph_gmm_estep": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr, c_int, c_int, ptr, c_int, c_dbl, ptr, ptr, ptr, ptr, ptr]),
     "tph_cv_sum": (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr]),
 }
 

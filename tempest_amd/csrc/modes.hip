@@ -321,19 +321,21 @@ __global__ void k_cov_finish(const double* __restrict__ csum, const double* __re
 
 static int moments_launch_cov(tph_ctx* ctx, const void* wt, bool wt_is_int, const int32_t* labels, int label, int64_t n,
                               const double* mean_dev, const double* sums_dev, int student, double* cov_dev,
-                              double* partials, int nblk) {
+                              double* partials, int nblk, const double* xsrc = nullptr, int64_t xld = 0) {
   const int d = ctx->d;
+  const double* src = xsrc ? xsrc : ctx->u;
+  const int64_t src_ld = xsrc ? xld : ctx->cap;
   TPH_REQUIRE(d * d <= 40 * 256, "covariance kernel supports n_dim <= 101 (got %d)", d);
   size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS);
   if (wt_is_int) {
     if (lds > 64 * 1024)
       TPH_HIP(hipFuncSetAttribute((const void*)k_wcov<int32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_wcov<int32_t>, dim3(nblk), dim3(256), lds, ctx->stream, ctx->u, ctx->cap, d, (const int32_t*)wt,
+    hipLaunchKernelGGL(k_wcov<int32_t>, dim3(nblk), dim3(256), lds, ctx->stream, src, src_ld, d, (const int32_t*)wt,
                        labels, label, n, mean_dev, partials);
   } else {
     if (lds > 64 * 1024)
       TPH_HIP(hipFuncSetAttribute((const void*)k_wcov<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_wcov<double>, dim3(nblk), dim3(256), lds, ctx->stream, ctx->u, ctx->cap, d, (const double*)wt, labels,
+    hipLaunchKernelGGL(k_wcov<double>, dim3(nblk), dim3(256), lds, ctx->stream, src, src_ld, d, (const double*)wt, labels,
                        label, n, mean_dev, partials);
   }
   double* csum = partials + (size_t)nblk * d * d;
@@ -688,6 +690,30 @@ extern "C" int tph_weighted_sums(tph_ctx* ctx, const double* w_dev, int64_t n, d
   hipLaunchKernelGGL(k_wsum_final, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums_dev, (double*)nullptr);
   TPH_LAUNCH_CHECK();
   return 0;
+}
+
+// the same two reductions on an explicit SoA array x[j*ld + i] (the clustering working set)
+extern "C" int tph_x_weighted_sums(tph_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, const double* w_dev,
+                                   double* sums_dev, double* range_dev) {
+  TPH_REQUIRE(ctx && x_dev && w_dev && sums_dev && n > 0 && ld >= n, "tph_x_weighted_sums: bad argument");
+  const int d = ctx->d;
+  const int rblk = tph_grid_for(n, 256, 4, 512);
+  if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)rblk * (1 + d) * 3)) return -1;
+  double* part1 = (double*)ctx->scratch;
+  hipLaunchKernelGGL(k_wsum<double>, dim3(rblk, 1 + d), dim3(256), 0, ctx->stream, x_dev, ld, d, w_dev, (const int32_t*)nullptr, 0,
+                     n, part1);
+  hipLaunchKernelGGL(k_wsum_final, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums_dev, range_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tph_x_weighted_cov(tph_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, const double* w_dev,
+                                  const double* mean_dev, double* cov_dev) {
+  TPH_REQUIRE(ctx && x_dev && w_dev && mean_dev && cov_dev && n > 0 && ld >= n, "tph_x_weighted_cov: bad argument");
+  const int d = ctx->d;
+  const int nblk = cov_blocks(n);
+  if (tph_scratch_reserve(ctx, sizeof(double) * ((size_t)nblk * d * d + (size_t)d * d))) return -1;
+  return moments_launch_cov(ctx, w_dev, false, nullptr, 0, n, mean_dev, nullptr, 0, cov_dev, (double*)ctx->scratch, nblk, x_dev, ld);
 }
 
 extern "C" int tph_weighted_cov_centered(tph_ctx* ctx, const double* w_dev, int64_t n, const double* mean_dev, double* cov_dev) {

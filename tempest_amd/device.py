@@ -94,6 +94,12 @@ class HipContext:
                                           _ptr(logl, torch.float64), n, ld, float(beta), float(logz),
                                           int(n if n_global is None else n_global)), "tph_history_append")
 
+    def history_ptr(self, key):
+        """(device pointer, leading dimension) of a history array."""
+        p, ld = C.c_void_p(), C.c_int64()
+        check(self.lib.tph_history_ptr(self._ctx, key, C.byref(p), C.byref(ld)), "tph_history_ptr")
+        return p.value, ld.value
+
     def history_clear(self):
         check(self.lib.tph_history_clear(self._ctx), "tph_history_clear")
 
@@ -266,6 +272,48 @@ class HipContext:
         chol, inv = torch.empty_like(covs), torch.empty_like(covs)
         check(self.lib.tph_chol_inv(self._ctx, _ptr(covs), K, _ptr(chol), _ptr(inv)), "tph_chol_inv")
         return chol, inv
+
+    # ----------------------------------------------------------------------------- clustering
+    def compact_indices(self, w, thr, m):
+        idx = self.empty(m, dtype=torch.int64)
+        check(self.lib.tph_compact_indices(self._ctx, _ptr(w), w.numel(), _ptr(thr), _ptr(idx)), "tph_compact_indices")
+        return idx
+
+    def gather_u_affine(self, idx, shift=None, scale=None, w=None):
+        m = idx.numel()
+        out = self.empty(self.n_dim, m)
+        wout = self.empty(m)
+        check(self.lib.tph_gather_u_affine(self._ctx, _ptr(idx, torch.int64), m, _ptr(shift), _ptr(scale), _ptr(w),
+                                           _ptr(out), m, _ptr(wout)), "tph_gather_u_affine")
+        return out, wout
+
+    def affine(self, x, shift, scale):
+        check(self.lib.tph_affine(self._ctx, _ptr(x), x.shape[1], x.shape[1], _ptr(shift), _ptr(scale)), "tph_affine")
+
+    def x_weighted_sums(self, x, w, with_range=False):
+        sums = self.empty(1 + self.n_dim)
+        rng = self.empty(2 * self.n_dim) if with_range else None
+        check(self.lib.tph_x_weighted_sums(self._ctx, _ptr(x), x.shape[1], x.shape[1], _ptr(w), _ptr(sums), _ptr(rng)),
+              "tph_x_weighted_sums")
+        return (sums, rng) if with_range else sums
+
+    def x_weighted_cov(self, x, w, mean):
+        cov = self.empty(self.n_dim * self.n_dim)
+        check(self.lib.tph_x_weighted_cov(self._ctx, _ptr(x), x.shape[1], x.shape[1], _ptr(w), _ptr(mean), _ptr(cov)),
+              "tph_x_weighted_cov")
+        return cov
+
+    def gmm_estep(self, x, sw, labels, label, params, K, mode, eps=1e-10, wr=None, label_out=None, stats=None,
+                  shift=None, scale=None, n=None, ld=None):
+        """x: (d, n) SoA tensor, or a raw device pointer (int) with explicit n and ld (e.g. the history)."""
+        if isinstance(x, int):
+            xp = x
+        else:
+            xp, n, ld = _ptr(x), x.shape[1], x.shape[1]
+        check(self.lib.tph_gmm_estep(self._ctx, xp, ld, n, _ptr(sw), _ptr(labels, torch.int32) if labels is not None else None,
+                                     int(label), int(K), _ptr(params), int(mode), float(eps), _ptr(shift), _ptr(scale), _ptr(wr),
+                                     _ptr(label_out, torch.int32) if label_out is not None else None, _ptr(stats)),
+              "tph_gmm_estep")
 
     # ------------------------------------------------------------------------ volume variation
     def weighted_moments(self, w):

@@ -87,7 +87,7 @@ class ModeStatistics:
             counts = torch.zeros(n, dtype=torch.int32, device=ctx.device)
             for k in range(K):
                 wk = torch.where(labels_dev == k, w_dev, torch.zeros_like(w_dev))      # masking: data movement only
-                nk = int((labels_dev == k).sum().item())
+                nk = int(((labels_dev == k) & (w_dev > 0)).sum().item())      # rows of the label that survived trimming
                 if nk == 0:
                     continue
                 cdf = ctx.cdf(wk)

@@ -65,7 +65,7 @@ class Resampler:
             u, x, logl = ctx.empty(d, n), ctx.empty(d, n), ctx.empty(n)
             ctx.gather(idx, u, x, logl)
         if self.clustering and self.clusterer is not None:
-            assign = self.clusterer.predict_device(u)
+            assign = self.clusterer.predict_device(u.contiguous(), st.ctx)
         else:
             assign = torch.zeros(logl.shape[0], dtype=torch.int32, device=st.device)
         st.update_current({"u": u, "x": x, "logl": logl, "assignments": assign}, copy=False)

@@ -51,11 +51,19 @@ class Trainer:
             thr = ctx.trim_threshold(w, self.TRIM_ESS, self.TRIM_BINS)
             refit = (it % self.cluster_every == 0) or it == 0
             labels, K = self.clusterer.fit_predict_device(st, w, thr, refit, rng)
-            wt = torch.where(w >= thr[0], w, torch.zeros_like(w))
-            ms = ModeStatistics._fit(ctx, wt, n_h, labels if K > 1 else None, K, rng.seed, rng.next(),
-                                     self.DOF_FALLBACK, 4)
-            for _ in range(K):
-                rng.next()
+            if K > 1:
+                wt = torch.where(w >= thr[0], w, torch.zeros_like(w))       # trimmed weights, history order
+                tick = rng.next()
+                for _ in range(K - 1):
+                    rng.next()
+                ms = ModeStatistics._fit(ctx, wt, n_h, labels, K, rng.seed, tick, self.DOF_FALLBACK, 4)
+            else:
+                cdf = ctx.cdf(w, thr[0:1])
+                counts = ctx.multinomial_counts(cdf, rng.seed, rng.next(), kept_count=thr[2:3], factor=4,
+                                                n_draw_max=4 * n_h)
+                means, covs, chol, inv = ctx.fit_modes(counts, None, 1, n_h)
+                dof = torch.full((1,), float(self.DOF_FALLBACK), dtype=torch.float64, device=ctx.device)
+                ms = ModeStatistics(None, None, None, _dev=(ctx, means, covs, chol, inv, dof))
         else:
             thr = ctx.trim_threshold(w, self.TRIM_ESS, self.TRIM_BINS)        # (threshold, kept_sum, kept_count, ess)
             cdf = ctx.cdf(w, thr[0:1])
