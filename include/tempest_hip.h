@@ -60,6 +60,9 @@ int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void* hip_strea
 int tph_ctx_destroy(tph_ctx* ctx);
 int tph_set_stream(tph_ctx* ctx, void* hip_stream);
 int tph_synchronize(tph_ctx* ctx);
+/* option 0 (TPH_OPT_FORCE_GENERIC): 1 = always run the generic any-n_dim kernels (tests compare both variants) */
+#define TPH_OPT_FORCE_GENERIC 0
+int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- persistent ensemble: StateManager history (state_manager.py:171-176,356-416) ------------
  * tph_history_append = commit_current_to_history for the array keys u, x, logl, plus the cached

@@ -229,6 +229,8 @@ class SamplerCore:
             it = self.state.get_current("iter")
             if (it - t0) % int(save_every) == 0 and it != t0:
                 self.save_sampler_state(self.config.output_dir / f"{self.config.output_label}_{it}.state")
+        if getattr(self, "profile", False):
+            return self._execute_iteration_profiled()
         weights = self.reweighter.run()
         mode_stats = self.trainer.run(weights)
         self.resampler.run(weights)
@@ -236,6 +238,26 @@ class SamplerCore:
         self._update_progress_bar()
         self.state.commit_current_to_history()
         return self.state.get_current()
+
+    def _execute_iteration_profiled(self):
+        """Same pipeline with a device synchronisation after each phase; accumulates wall seconds in self.timing
+        (diagnostics only: the synchronisations remove the overlap the normal path has)."""
+        import time
+        import torch
+        dev = self.state.device
+
+        def lap(name, t0):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            self.timing[name] += t1 - t0
+            return t1
+        t = time.perf_counter()
+        weights = self.reweighter.run(); t = lap("reweight", t)
+        mode_stats = self.trainer.run(weights); t = lap("train", t)
+        self.resampler.run(weights); t = lap("resample", t)
+        self.mutator.run(mode_stats); t = lap("mutate", t)
+        self.state.commit_current_to_history(); lap("commit", t)
+        return None
 
     def _logz_at(self, beta):
         m, s1, s2 = self.state.reweight_eval([beta])[0]

@@ -134,6 +134,15 @@ extern "C" int tph_set_stream(tph_ctx* ctx, void* hip_stream) {
   return 0;
 }
 
+extern "C" int tph_set_option(tph_ctx* ctx, int option, int value) {
+  TPH_REQUIRE(ctx, "tph_set_option: ctx is NULL");
+  switch (option) {
+    case 0: ctx->force_generic = value; break;   // TPH_OPT_FORCE_GENERIC
+    default: TPH_REQUIRE(false, "tph_set_option: unknown option %d", option);
+  }
+  return 0;
+}
+
 extern "C" int tph_synchronize(tph_ctx* ctx) {
   TPH_REQUIRE(ctx, "tph_synchronize: ctx is NULL");
   TPH_HIP(hipStreamSynchronize(ctx->stream));

@@ -243,25 +243,44 @@ __global__ void k_mean_from_sums(const double* __restrict__ sums, int d, double*
 }
 
 // --------------------------------------------------------------- centred weighted second moments
-// C[a][b] = sum_s wt_s (u_a - m_a)(u_b - m_b).  Tile of 64 rows staged in LDS ([d][64] + weights);
-// each thread owns a strided set of (a,b) pairs.  Block partials [blocks][d*d] reduced by k_colsum2.
+// C[a][b] = sum_s wt_s (u_a - m_a)(u_b - m_b), lower triangle only (npl = d(d+1)/2 pairs).  A tile of 64 rows is
+// staged in LDS ([d][65] padded + weights); thread t owns row slice t % S of the tile and the pairs
+// t / S + k * (256 / S): for small d (few pairs) the 64 rows are split over S lanes per pair so that all 256
+// threads work.  Block partials [blocks * S][npl] are reduced in fixed order by k_colsum2 (deterministic).
 constexpr int COV_ROWS = 64;
-constexpr int COV_LD = 65;  // padded row: conflict-free ds_read_b64 across pairs
+constexpr int COV_LD = 65;   // padded row: conflict-free ds_read_b64 across pairs
+constexpr int COV_NPT = 20;  // pairs per thread: 20 * 256 >= 5050 = npl(d = 100)
+
+__host__ __device__ inline int cov_slices(int npl) {
+  int S = 1;
+  while (S < 16 && npl * (S * 2) <= 256) S *= 2;
+  return S;
+}
+
 template <typename WT>
 __global__ void __launch_bounds__(256) k_wcov(const double* __restrict__ hu, int64_t cap, int d, const WT* __restrict__ wt,
                                               const int32_t* __restrict__ labels, int label, int64_t n,
                                               const double* __restrict__ mean, double* __restrict__ partials) {
   extern __shared__ double sh[];
-  double* xs = sh;                               // [d][64]
+  double* xs = sh;                               // [d][65]
   double* ws = sh + (size_t)d * COV_LD;          // [64]
-  const int npairs = d * d;
-  double* mine = partials + (size_t)blockIdx.x * npairs;
-  // per-thread accumulators for pairs tid, tid+256, ...  (kept in LDS-free registers via small loop)
-  // pairs per thread can be large for big d; accumulate into global partials at the end of each tile
-  // would be slow, so we keep up to 40 accumulators (d <= 100 -> 10000/256 = 40)
-  double acc[40];
+  const int npl = d * (d + 1) / 2;
+  const int S = cov_slices(npl);
+  const int slots = 256 / S;
+  const int slice = threadIdx.x % S, pslot = threadIdx.x / S;
+  const int rows_per = COV_ROWS / S, r_lo = slice * rows_per;
+  int pa[COV_NPT], pb[COV_NPT];
+  double acc[COV_NPT];
 #pragma unroll
-  for (int k = 0; k < 40; ++k) acc[k] = 0.0;
+  for (int k = 0; k < COV_NPT; ++k) {
+    acc[k] = 0.0;
+    int p = pslot + k * slots;
+    int a = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= p) ++a;
+    while (a * (a + 1) / 2 > p) --a;
+    pa[k] = a;
+    pb[k] = p - a * (a + 1) / 2;
+  }
   const int64_t ntiles = (n + COV_ROWS - 1) / COV_ROWS;
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int64_t r0 = t * COV_ROWS;
@@ -279,25 +298,22 @@ __global__ void __launch_bounds__(256) k_wcov(const double* __restrict__ hu, int
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 40; ++k) {
-      int pidx = threadIdx.x + k * 256;
-      if (pidx < npairs) {
-        int a = pidx / d, b = pidx % d;
-        if (b <= a) {  // lower triangle only; mirrored at the end
-          const double* xa = xs + a * COV_LD;
-          const double* xb = xs + b * COV_LD;
-          double s = 0.0;
-#pragma unroll 8
-          for (int r = 0; r < COV_ROWS; ++r) s += ws[r] * xa[r] * xb[r];
-          acc[k] += s;
-        }
+    for (int k = 0; k < COV_NPT; ++k) {
+      if (pslot + k * slots < npl) {
+        const double* xa = xs + pa[k] * COV_LD + r_lo;
+        const double* xb = xs + pb[k] * COV_LD + r_lo;
+        const double* wr = ws + r_lo;
+        double s = 0.0;
+        for (int r = 0; r < rows_per; ++r) s += wr[r] * xa[r] * xb[r];
+        acc[k] += s;
       }
     }
   }
+  double* mine = partials + ((size_t)blockIdx.x * S + slice) * npl;
 #pragma unroll
-  for (int k = 0; k < 40; ++k) {
-    int pidx = threadIdx.x + k * 256;
-    if (pidx < npairs) mine[pidx] = acc[k];
+  for (int k = 0; k < COV_NPT; ++k) {
+    int p = pslot + k * slots;
+    if (p < npl) mine[p] = acc[k];
   }
 }
 
@@ -308,7 +324,8 @@ __global__ void k_cov_finish(const double* __restrict__ csum, const double* __re
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d * d) return;
   int a = e / d, b = e % d;
-  double v = a >= b ? csum[a * d + b] : csum[b * d + a];
+  int hi = a >= b ? a : b, lo = a >= b ? b : a;
+  double v = csum[hi * (hi + 1) / 2 + lo];
   if (student == 1) {
     double ntot = sums[0];
     v = v / ntot;
@@ -325,7 +342,9 @@ static int moments_launch_cov(tph_ctx* ctx, const void* wt, bool wt_is_int, cons
   const int d = ctx->d;
   const double* src = xsrc ? xsrc : ctx->u;
   const int64_t src_ld = xsrc ? xld : ctx->cap;
-  TPH_REQUIRE(d * d <= 40 * 256, "covariance kernel supports n_dim <= 101 (got %d)", d);
+  const int npl = d * (d + 1) / 2;
+  const int S = cov_slices(npl);
+  TPH_REQUIRE(npl <= COV_NPT * 256, "covariance kernel supports n_dim <= 100 (got %d)", d);
   size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS);
   if (wt_is_int) {
     if (lds > 64 * 1024)
@@ -338,8 +357,8 @@ static int moments_launch_cov(tph_ctx* ctx, const void* wt, bool wt_is_int, cons
     hipLaunchKernelGGL(k_wcov<double>, dim3(nblk), dim3(256), lds, ctx->stream, src, src_ld, d, (const double*)wt, labels,
                        label, n, mean_dev, partials);
   }
-  double* csum = partials + (size_t)nblk * d * d;
-  hipLaunchKernelGGL(k_colsum2, dim3(d * d), dim3(256), 0, ctx->stream, partials, nblk, d * d, csum);
+  double* csum = partials + (size_t)nblk * S * npl;
+  hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, partials, nblk * S, npl, csum);
   hipLaunchKernelGGL(k_cov_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum, sums_dev, d, student, cov_dev);
   TPH_LAUNCH_CHECK();
   return 0;
@@ -347,7 +366,13 @@ static int moments_launch_cov(tph_ctx* ctx, const void* wt, bool wt_is_int, cons
 
 static int cov_blocks(int64_t n) {
   int64_t t = (n + COV_ROWS - 1) / COV_ROWS;
-  return (int)(t < 512 ? (t < 1 ? 1 : t) : 512);
+  return (int)(t < 2048 ? (t < 1 ? 1 : t) : 2048);
+}
+// doubles of scratch the covariance stage needs: block partials (<= nblk * 16 slices * npl <= nblk * 256 for small d,
+// nblk * npl otherwise) + the reduced triangle
+static size_t cov_scratch_doubles(int d, int nblk) {
+  int npl = d * (d + 1) / 2;
+  return (size_t)nblk * cov_slices(npl) * npl + (size_t)npl;
 }
 
 // -------------------------------------------------------------------- exact weighted median select
@@ -401,31 +426,46 @@ __global__ void __launch_bounds__(256) k_med_hist1(const double* __restrict__ hu
 }
 
 // pick the bin holding each target rank.  sel[j][t] = {bin1, bin2, rank_in_bin(after level), _}
-// level==1 reads hist1[j][.] ; level==2 reads hist2[j][t][.]
-__global__ void __launch_bounds__(64) k_med_select(const unsigned int* __restrict__ hist, int level,
+// level==1 reads hist1[j][.] ; level==2 reads hist2[j][t][.].  256 threads x 16 bins + a block scan.
+__global__ void __launch_bounds__(256) k_med_select(const unsigned int* __restrict__ hist, int level,
                                                    const double* __restrict__ sums, long long* __restrict__ sel) {
   const int j = blockIdx.x, t = blockIdx.y;
-  if (threadIdx.x != 0) return;
   long long* s = sel + ((size_t)j * 2 + t) * 4;
   long long rank;
   if (level == 1) {
     long long ntot = (long long)sums[0];
-    long long r_lo = (ntot - 1) / 2, r_hi = ntot / 2;   // equal when ntot is odd
-    rank = t == 0 ? r_lo : r_hi;
+    rank = t == 0 ? (ntot - 1) / 2 : ntot / 2;   // equal when ntot is odd
   } else {
     rank = s[2];
   }
   const unsigned int* h = level == 1 ? hist + (size_t)j * MED_BINS : hist + ((size_t)j * 2 + t) * MED_BINS;
-  long long cum = 0;
-  int b = 0;
-  for (; b < MED_BINS; ++b) {
-    long long c = h[b];
-    if (rank < cum + c) break;
-    cum += c;
+  constexpr int PER = MED_BINS / 256;
+  long long mine = 0;
+  for (int b = 0; b < PER; ++b) mine += h[threadIdx.x * PER + b];
+  __shared__ long long cum[256];
+  cum[threadIdx.x] = mine;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {            // inclusive Hillis-Steele scan
+    long long v = threadIdx.x >= o ? cum[threadIdx.x - o] : 0;
+    __syncthreads();
+    cum[threadIdx.x] += v;
+    __syncthreads();
   }
-  if (b >= MED_BINS) b = MED_BINS - 1;
-  s[level - 1] = b;
-  s[2] = rank - cum;
+  const long long before = cum[threadIdx.x] - mine;
+  const bool owner = rank >= before && rank < cum[threadIdx.x];
+  const bool overflow_owner = threadIdx.x == 255 && rank >= cum[255];   // rank beyond the histogram: last bin
+  if (owner || overflow_owner) {
+    long long c = before;
+    int b = 0;
+    for (; b < PER; ++b) {
+      long long hb = h[threadIdx.x * PER + b];
+      if (rank < c + hb) break;
+      c += hb;
+    }
+    if (b >= PER) { b = PER - 1; c -= h[threadIdx.x * PER + b]; }
+    s[level - 1] = threadIdx.x * PER + b;
+    s[2] = rank - c;
+  }
 }
 
 // level 2: hist2[j][t][bin2] += count for rows whose first digit is the target's
@@ -604,7 +644,7 @@ extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int3
   // scratch layout
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
-  size_t o_part = take(sizeof(double) * ((size_t)nblk * d * d + (size_t)d * d));      // cov partials + column sums
+  size_t o_part = take(sizeof(double) * cov_scratch_doubles(d, nblk));                  // cov partials + column sums
   size_t o_part1 = take(sizeof(double) * (size_t)rblk * (1 + d) * 3);                  // first-moment partials
   size_t o_sums = take(sizeof(double) * (1 + d));
   size_t o_range = take(sizeof(double) * 2 * d);
@@ -644,9 +684,9 @@ extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int3
     TPH_HIP(hipMemsetAsync(fill, 0, sizeof(int) * ((size_t)d * 2 + 1), ctx->stream));
     dim3 hg(tph_grid_for(n, 256, 8, 256), d);
     hipLaunchKernelGGL(k_med_hist1, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, range, h1);
-    hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(64), 0, ctx->stream, h1, 1, sums, sel);
+    hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(256), 0, ctx->stream, h1, 1, sums, sel);
     hipLaunchKernelGGL(k_med_hist2, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, range, sel, h2);
-    hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(64), 0, ctx->stream, h2, 2, sums, sel);
+    hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(256), 0, ctx->stream, h2, 2, sums, sel);
     hipLaunchKernelGGL(k_med_collect, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, range, sel, vals, cnts, fill);
     hipLaunchKernelGGL(k_med_finish, dim3(d), dim3(256), 0, ctx->stream, sel, range, vals, cnts, fill, means_dev + (size_t)k * d, overflow);
     TPH_LAUNCH_CHECK();
@@ -662,7 +702,7 @@ extern "C" int tph_weighted_moments(tph_ctx* ctx, const double* w_dev, int64_t n
   const int rblk = tph_grid_for(n, 256, 4, 512);
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
-  size_t o_part = take(sizeof(double) * ((size_t)nblk * d * d + (size_t)d * d));
+  size_t o_part = take(sizeof(double) * cov_scratch_doubles(d, nblk));
   size_t o_part1 = take(sizeof(double) * (size_t)rblk * (1 + d) * 3);
   size_t o_sums = take(sizeof(double) * (1 + d));
   if (tph_scratch_reserve(ctx, o)) return -1;
@@ -712,7 +752,7 @@ extern "C" int tph_x_weighted_cov(tph_ctx* ctx, const double* x_dev, int64_t ld,
   TPH_REQUIRE(ctx && x_dev && w_dev && mean_dev && cov_dev && n > 0 && ld >= n, "tph_x_weighted_cov: bad argument");
   const int d = ctx->d;
   const int nblk = cov_blocks(n);
-  if (tph_scratch_reserve(ctx, sizeof(double) * ((size_t)nblk * d * d + (size_t)d * d))) return -1;
+  if (tph_scratch_reserve(ctx, sizeof(double) * cov_scratch_doubles(d, nblk))) return -1;
   return moments_launch_cov(ctx, w_dev, false, nullptr, 0, n, mean_dev, nullptr, 0, cov_dev, (double*)ctx->scratch, nblk, x_dev, ld);
 }
 
@@ -720,7 +760,7 @@ extern "C" int tph_weighted_cov_centered(tph_ctx* ctx, const double* w_dev, int6
   TPH_REQUIRE(ctx && w_dev && mean_dev && cov_dev && n > 0 && n <= ctx->size, "tph_weighted_cov_centered: bad argument");
   const int d = ctx->d;
   const int nblk = cov_blocks(n);
-  size_t need = sizeof(double) * ((size_t)nblk * d * d + (size_t)d * d);
+  size_t need = sizeof(double) * cov_scratch_doubles(d, nblk);
   if (tph_scratch_reserve(ctx, need)) return -1;
   return moments_launch_cov(ctx, w_dev, false, nullptr, 0, n, mean_dev, nullptr, 0, cov_dev, (double*)ctx->scratch, nblk);
 }

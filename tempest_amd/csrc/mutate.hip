@@ -179,6 +179,116 @@ __global__ void __launch_bounds__(PROP_THREADS) k_propose(const double* __restri
   if (maha_up) maha_up[i] = m_up;
 }
 
+// Small-dimension variant (d <= 16 known at compile time): everything in registers, loops fully unrolled, so
+// one lane's independent Philox / Box-Muller / matvec chains overlap (the active set is far smaller than the
+// chip's thread capacity, so instruction-level parallelism is what hides latency here).  Same operation order
+// as the generic kernel above.
+template <int KERNEL, int D>
+__global__ void __launch_bounds__(256) k_propose_reg(const double* __restrict__ u, const int32_t* __restrict__ assign,
+                                                     int64_t n, int64_t ld, const double* __restrict__ means,
+                                                     const double* __restrict__ chol, const double* __restrict__ inv,
+                                                     const double* __restrict__ dof, const double* __restrict__ sigmas,
+                                                     const uint8_t* __restrict__ bc, uint64_t seed, uint32_t tick,
+                                                     int64_t item0, double* __restrict__ up, double* __restrict__ maha_u,
+                                                     double* __restrict__ maha_up) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = assign ? assign[i] : 0;
+  const double* __restrict__ mu = means + (size_t)c * D;
+  const double* __restrict__ L = chol + (size_t)c * D * D;
+  const double* __restrict__ P = inv + (size_t)c * D * D;
+  const double sigma = sigmas[c];
+  double df[D], z[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    double uj = u[(size_t)j * ld + i];
+    df[j] = (KERNEL == TPH_KERNEL_TPCN) ? uj - mu[j] : uj;
+  }
+  double a_fac = 1.0, b_fac = sigma, m_u = 0.0;
+  if (KERNEL == TPH_KERNEL_TPCN) {
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < D; ++j) acc += P[r * D + j] * df[j];
+      m_u += df[r] * acc;
+    }
+    const double nu = dof[c];
+    tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
+    double gam = tph_gamma_mt(gg, 0.5 * ((double)D + nu)) * (2.0 / (nu + m_u));
+    a_fac = sqrt(1.0 - sigma * sigma);
+    b_fac = sigma * sqrt(1.0 / gam);
+  }
+  tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
+  constexpr int NP = (D + 1) / 2;
+  bool ok = false;
+  for (int att = 0; att < PROP_MAX_ATTEMPTS && !ok; ++att) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      double z0, z1;
+      gz.normal2((uint32_t)(att * NP + p), z0, z1);
+      z[2 * p] = z0;
+      if (2 * p + 1 < D) z[2 * p + 1] = z1;
+    }
+    ok = true;
+#pragma unroll
+    for (int r = D - 1; r >= 0; --r) {
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j <= r; ++j) acc += L[r * D + j] * z[j];
+      double v;
+      if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * df[r] + b_fac * acc;
+      else v = df[r] + b_fac * acc;
+      const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
+      if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
+      else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
+      else ok = ok && (v >= 0.0) && (v <= 1.0);
+      z[r] = v;
+    }
+  }
+  if (!ok) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) z[j] = (KERNEL == TPH_KERNEL_TPCN) ? df[j] + mu[j] : df[j];
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) up[(size_t)j * ld + i] = z[j];
+  double m_up = 0.0;
+  if (KERNEL == TPH_KERNEL_TPCN) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) z[j] -= mu[j];
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < D; ++j) acc += P[r * D + j] * z[j];
+      m_up += z[r] * acc;
+    }
+  }
+  if (maha_u) maha_u[i] = m_u;
+  if (maha_up) maha_up[i] = m_up;
+}
+
+template <int KERNEL, int D>
+static void launch_propose_reg(tph_ctx* ctx, const double* u, const int32_t* assign, int64_t n, int64_t ld,
+                               const double* means, const double* chol, const double* inv, const double* dof,
+                               const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick, int64_t item0,
+                               double* up, double* mu_, double* mup) {
+  hipLaunchKernelGGL((k_propose_reg<KERNEL, D>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, u, assign, n, ld,
+                     means, chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup);
+}
+
+#define TPH_PROPOSE_CASE(DD)                                                                                       \
+  case DD:                                                                                                         \
+    if (kernel == TPH_KERNEL_TPCN)                                                                                 \
+      launch_propose_reg<TPH_KERNEL_TPCN, DD>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, \
+                                              sigmas_dev, bc_dev, seed, tick, item0, uprime_dev, maha_u_dev,       \
+                                              maha_up_dev);                                                        \
+    else                                                                                                           \
+      launch_propose_reg<TPH_KERNEL_RWM, DD>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev,  \
+                                             sigmas_dev, bc_dev, seed, tick, item0, uprime_dev, maha_u_dev,        \
+                                             maha_up_dev);                                                         \
+    break;
+
 extern "C" int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const int32_t* assign_dev, int64_t n, int64_t ld,
                            int K, const double* means_dev, const double* chol_dev, const double* inv_dev,
                            const double* dof_dev, const double* sigmas_dev, const uint8_t* bc_dev, uint64_t seed,
@@ -189,6 +299,16 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const 
   if (kernel == TPH_KERNEL_TPCN)
     TPH_REQUIRE(means_dev && inv_dev && dof_dev && maha_u_dev && maha_up_dev, "tph_propose: tpCN needs means/inv/dof/maha");
   TPH_REQUIRE(K == 1 || assign_dev, "tph_propose: K>1 needs assignments");
+  if (ctx->d <= 16 && !ctx->force_generic) {
+    switch (ctx->d) {
+      TPH_PROPOSE_CASE(1) TPH_PROPOSE_CASE(2) TPH_PROPOSE_CASE(3) TPH_PROPOSE_CASE(4) TPH_PROPOSE_CASE(5)
+      TPH_PROPOSE_CASE(6) TPH_PROPOSE_CASE(7) TPH_PROPOSE_CASE(8) TPH_PROPOSE_CASE(9) TPH_PROPOSE_CASE(10)
+      TPH_PROPOSE_CASE(11) TPH_PROPOSE_CASE(12) TPH_PROPOSE_CASE(13) TPH_PROPOSE_CASE(14) TPH_PROPOSE_CASE(15)
+      TPH_PROPOSE_CASE(16)
+    }
+    TPH_LAUNCH_CHECK();
+    return 0;
+  }
   size_t lds = sizeof(double) * 2 * (size_t)ctx->d * PROP_THREADS;
   TPH_REQUIRE(lds <= 160 * 1024, "tph_propose: n_dim=%d needs %zu B of LDS (>160 KiB)", ctx->d, lds);
   unsigned grid = (unsigned)((n + PROP_THREADS - 1) / PROP_THREADS);

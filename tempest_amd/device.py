@@ -75,6 +75,9 @@ class HipContext:
         s = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.tph_set_stream(self._ctx, C.c_void_p(s)), "tph_set_stream")
 
+    def set_option(self, option, value):
+        check(self.lib.tph_set_option(self._ctx, int(option), int(value)), "tph_set_option")
+
     def synchronize(self):
         check(self.lib.tph_synchronize(self._ctx), "tph_synchronize")
 

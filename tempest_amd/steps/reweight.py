@@ -53,19 +53,58 @@ class Reweighter:
         self.BETA_RTOL = BETA_RTOL
         self.METRIC_ATOL = METRIC_ATOL
         self.METRIC_ATOL_CV = METRIC_ATOL_CV
-        self.n_evals = 0          # trial betas evaluated (each = one pass over the history)
+        self.n_evals = 0          # trial betas evaluated
+        self.n_passes = 0         # passes over the history (a pass evaluates up to 16 betas)
+        self.batch_depth = 4      # bisection levels evaluated per pass (1 = one beta per pass, as the reference)
         self._cache = {}
 
-    # ------------------------------------------------------------------ one trial beta
+    # ------------------------------------------------------------------ trial betas
+    def _eval_many(self, betas):
+        """Evaluate the not-yet-known betas of `betas` in ONE pass over the history (<= 16 per pass)."""
+        todo = []
+        for b in betas:
+            if b not in self._cache and b not in todo:
+                todo.append(b)
+        for i in range(0, len(todo), 16):
+            chunk = todo[i:i + 16]
+            res = self.state.reweight_eval(chunk)
+            self.n_passes += 1
+            for b, (m, s1, s2) in zip(chunk, res):
+                self._cache[b] = (float(m), float(s1), float(s2), float(s1 * s1 / s2))
+                self.n_evals += 1
+
     def _eval(self, beta: float):
         """(vmax, s1, s2, ess) at beta, memoised within one run() (the reference re-evaluates the final
         beta several times; the result is identical)."""
         hit = self._cache.get(beta)
         if hit is None:
-            m, s1, s2 = self.state.reweight_eval([beta])[0]
-            hit = self._cache[beta] = (float(m), float(s1), float(s2), float(s1 * s1 / s2))
-            self.n_evals += 1
+            self._eval_many([beta])
+            hit = self._cache[beta]
         return hit
+
+    @staticmethod
+    def _midpoint_tree(lo: float, hi: float, depth: int):
+        """All midpoints a bisection started on [lo, hi] can visit in its next `depth` levels, computed with the
+        reference's own expression (hi + lo) * 0.5 on the exact bracket ends, so they are bit-identical to the
+        sequential ones whatever the decisions turn out to be (exact-bisection batching)."""
+        out, level = [], [(lo, hi)]
+        for _ in range(depth):
+            nxt = []
+            for a, b in level:
+                mid = (b + a) * 0.5
+                out.append(mid)
+                nxt.append((a, mid))
+                nxt.append((mid, b))
+            level = nxt
+        return out
+
+    def _prefetch(self, lo: float, hi: float, extra=()):
+        """Before the sequential logic asks for the midpoint of [lo, hi]: evaluate the coming `batch_depth`
+        levels of candidates in one pass (15 betas for depth 4) unless that midpoint is already known."""
+        mid = (hi + lo) * 0.5
+        if self.batch_depth > 1 and mid not in self._cache:
+            depth = self.batch_depth if not extra else min(self.batch_depth, 3)
+            self._eval_many(list(extra) + self._midpoint_tree(lo, hi, depth))
 
     def _weights_dev(self, beta: float):
         m, s1, _, _ = self._eval(beta)
@@ -99,6 +138,8 @@ class Reweighter:
         beta, aux = None, None
         for _ in range(self._MAX_BISECTION_ITERATIONS):
             beta = (beta_max + beta_min) * 0.5
+            if not dynamic:
+                self._prefetch(beta_min, beta_max)
             metric_val, aux = metric_fn(beta)
             if not np.isfinite(metric_val):
                 metric_val = 1e10
@@ -122,6 +163,8 @@ class Reweighter:
     def _find_ess_bracket(self, beta_current: float, ess_target: float) -> tuple:
         """reweight.py:225-297: (low, high) with ESS(low) >= target > ESS(high); equal when no crossing."""
         beta_low, beta_high = beta_current, 1.0
+        if self.batch_depth > 1:      # both ends and the first levels of the bracket search in one pass
+            self._prefetch(beta_low, beta_high, extra=(beta_current, 1.0))
         if self._eval(beta_current)[3] <= ess_target:
             return beta_current, beta_current
         if self._eval(1.0)[3] >= ess_target:
@@ -130,6 +173,7 @@ class Reweighter:
             beta_mid = (beta_high + beta_low) * 0.5
             if (beta_high - beta_low) <= self._tol(beta_low, beta_high):
                 break
+            self._prefetch(beta_low, beta_high)
             if self._eval(beta_mid)[3] >= ess_target:
                 beta_low = beta_mid
             else:

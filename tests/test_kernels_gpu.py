@@ -327,9 +327,10 @@ class _Modes:
 
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
 @pytest.mark.parametrize("bc", [None, "mixed"])
-def test_propose_accept_adapt_vs_oracle(dev, kernel, bc):
+@pytest.mark.parametrize("variant", ["registers_d7", "generic_d7", "generic_d19"])
+def test_propose_accept_adapt_vs_oracle(dev, kernel, bc, variant):
     rs = np.random.RandomState(17)
-    d, n, K = 7, 5000, 3
+    d, n, K = (19 if variant.endswith("19") else 7), 5000, 3
     means = 0.5 + 0.1 * rs.randn(K, d)
     covs = np.empty((K, d, d))
     for k in range(K):
@@ -344,6 +345,8 @@ def test_propose_accept_adapt_vs_oracle(dev, kernel, bc):
     seed, tick, item0 = 4242, 11, 100_000
     want_up, want_mu, want_mup = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, flags, seed, tick, item0)
     c = ctx_for(d)
+    if variant.startswith("generic"):
+        c.set_option(0, 1)          # TPH_OPT_FORCE_GENERIC: the any-n_dim LDS kernel instead of the d<=16 register one
     modes = _Modes(means, chol, inv, dof, dev)
     up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
     ut = soa(u, dev)

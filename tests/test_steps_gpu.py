@@ -37,6 +37,7 @@ def test_reweighter_decisions_match_reference():
     from tempest_amd.steps import Reweighter
     g = np.load(os.path.join(G, "g3_reweighter.npz"))
     for k in range(int(g["n_cases"])):
+      for depth in (1, 4):          # one beta per pass (as the reference) and exact-bisection batching: same decisions
         n_p, er, vv, bp = g[f"c{k}_cfg"]
         st = _state_from_history(g[f"c{k}_u"], g[f"c{k}_logl"], g[f"c{k}_beta_t"], g[f"c{k}_logz_t"], g[f"c{k}_n_t"])
         assert st.get_history_length() == len(g[f"c{k}_beta_t"])
@@ -45,11 +46,12 @@ def test_reweighter_decisions_match_reference():
                         volume_variation=None if vv < 0 else float(vv), ESS_TOLERANCE=C.ESS_TOLERANCE,
                         BETA_TOLERANCE=C.BETA_TOLERANCE, BETA_RTOL=C.BETA_RTOL, METRIC_ATOL=C.METRIC_ATOL,
                         METRIC_ATOL_CV=C.METRIC_ATOL_CV)
+        rw.batch_depth = depth
         trace = []
         orig = rw._eval
 
         def traced(beta, _o=orig, _t=trace):
-            if beta not in rw._cache:
+            if beta not in _t:
                 _t.append(beta)
             return _o(beta)
         rw._eval = traced
@@ -65,6 +67,8 @@ def test_reweighter_decisions_match_reference():
         if vv < 0:
             ref_trace = [b for i, b in enumerate(g[f"c{k}_trace"]) if b not in g[f"c{k}_trace"][:i]]
             assert trace == ref_trace, (k, tag)
+            if depth == 4 and len(ref_trace) > 6:
+                assert rw.n_passes < len(ref_trace) / 2          # several bisection levels per pass
 
 
 def test_reweighter_first_iteration_contract():
