@@ -126,14 +126,14 @@ struct tph_rng {
 };
 
 // Gamma(shape,1), Marsaglia-Tsang; attempt a uses draws 2a (normal) and 2a+1 (uniform); shape<1 boosted.
-__device__ inline double tph_gamma_mt(const tph_rng& g, double shape) {
+__device__ inline double tph_gamma_mt(const tph_rng& g, double shape, int first_attempt = 0) {
   const int max_attempts = 64;
   bool boost = shape < 1.0;
   double a = boost ? shape + 1.0 : shape;
   double d = a - 1.0 / 3.0;
   double c = 1.0 / sqrt(9.0 * d);
   double out = d;
-  for (int att = 0; att < max_attempts; ++att) {
+  for (int att = first_attempt; att < max_attempts; ++att) {
     double x, x1, uu, u1;
     g.normal2(2 * att, x, x1);
     g.uniform2(2 * att + 1, uu, u1);

@@ -179,11 +179,202 @@ __global__ void __launch_bounds__(PROP_THREADS) k_propose(const double* __restri
   if (maha_up) maha_up[i] = m_up;
 }
 
+// ---- multi-lane proposals: LPP lanes cooperate on one particle ---------------------------------------------
+// The active set (1e5-1e6 particles) is far smaller than the chip's 524 288 thread slots and each particle needs
+// O(d^2) FP64 work plus ~d/2 Philox/Box-Muller draws, so one lane per particle leaves the SIMDs latency-bound.
+// Here a group of LPP lanes (a power of two <= 64, inside one wave) shares a particle: lane q draws normal pair q
+// (and two lanes draw the Gamma candidate's normal and uniform in the same instruction stream), rows of the
+// Sigma^-1 / L products are dealt round-robin to the lanes, partial sums meet by xor-shuffles.  The draws are the
+// same counter-based ones as in the one-lane kernels, so results agree to rounding (different summation tree).
+constexpr int ML_THREADS = 256;
+
+template <int LPP>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int o = LPP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int LPP>
+__device__ __forceinline__ int group_and(int v) {
+#pragma unroll
+  for (int o = LPP / 2; o > 0; o >>= 1) v &= __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int KERNEL, int LPP>
+__global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restrict__ u, const int32_t* __restrict__ assign,
+                                                           int64_t n, int64_t ld, int d, const double* __restrict__ means,
+                                                           const double* __restrict__ chol, const double* __restrict__ inv,
+                                                           const double* __restrict__ dof, const double* __restrict__ sigmas,
+                                                           const uint8_t* __restrict__ bc, uint64_t seed, uint32_t tick,
+                                                           int64_t item0, double* __restrict__ up,
+                                                           double* __restrict__ maha_u, double* __restrict__ maha_up) {
+  extern __shared__ double sh[];
+  constexpr int PPB = ML_THREADS / LPP;
+  const int l = threadIdx.x % LPP, p = threadIdx.x / LPP;
+  double* zs = sh + (size_t)p * d;                    // z, later the proposal
+  double* df = sh + (size_t)PPB * d + (size_t)p * d;  // u - mu (tpCN) or u (RWM)
+  const int64_t i = (int64_t)blockIdx.x * PPB + p;
+  const bool live = i < n;
+  const int64_t ii = live ? i : n - 1;               // dead groups shadow the last particle, never store
+  const int c = assign ? assign[ii] : 0;
+  const double* __restrict__ mu = means + (size_t)c * d;
+  const double* __restrict__ L = chol + (size_t)c * d * d;
+  const double* __restrict__ P = inv + (size_t)c * d * d;
+  const double sigma = sigmas[c];
+  const int npairs = (d + 1) >> 1;
+
+  for (int j = l; j < d; j += LPP) {
+    double uj = u[(size_t)j * ld + ii];
+    df[j] = (KERNEL == TPH_KERNEL_TPCN) ? uj - mu[j] : uj;
+  }
+  __syncthreads();
+  double a_fac = 1.0, b_fac = sigma, m_u = 0.0;
+  double nu = 0.0, gshape = 1.0;
+  if (KERNEL == TPH_KERNEL_TPCN) {
+    double part = 0.0;
+    for (int r = l; r < d; r += LPP) {
+      const double* Pr = P + (size_t)r * d;
+      double acc = 0.0;
+      for (int j = 0; j < d; ++j) acc += Pr[j] * df[j];
+      part += df[r] * acc;
+    }
+    m_u = group_sum<LPP>(part);
+    nu = dof[c];
+    gshape = 0.5 * ((double)d + nu);
+    a_fac = sqrt(1.0 - sigma * sigma);
+  }
+  // first attempt: normal pairs (tag NORMAL, draws 0..npairs-1) and, for tpCN, the Gamma candidate
+  // (tag GAMMA: draw 0 = normal, draw 1 = uniform) are generated by different lanes at once
+  const uint64_t item = (uint64_t)(item0 + ii);
+  tph_rng gz(seed, tick, TPH_TAG_NORMAL, item);
+  tph_rng gg(seed, tick, TPH_TAG_GAMMA, item);
+  double g_x = 0.0, g_logu = 0.0;
+  const int nq = npairs + (KERNEL == TPH_KERNEL_TPCN ? 2 : 0);
+  for (int q = l; q < nq; q += LPP) {
+    const bool is_norm = q < npairs;
+    const tph_rng& g = is_norm ? gz : gg;
+    const uint32_t draw = is_norm ? (uint32_t)q : (uint32_t)(q - npairs);
+    tph_u4 r = tph_philox(g.item, draw, g.tick, g.tag, g.k0, g.k1);
+    double a = tph_k53(r.x, r.y), b = tph_k53(r.z, r.w);
+    if (q == npairs + 1) {                       // Gamma uniform: (k + 1) * 2^-53 in (0, 1]
+      g_logu = log((a + 1.0) * 0x1.0p-53);
+    } else {                                      // Box-Muller
+      double rad = sqrt(-2.0 * log((a + 1.0) * 0x1.0p-53));
+      double sn, cs;
+      sincos(6.283185307179586476925 * (b * 0x1.0p-53), &sn, &cs);
+      if (is_norm) {
+        zs[2 * q] = rad * cs;
+        if (2 * q + 1 < d) zs[2 * q + 1] = rad * sn;
+      } else {
+        g_x = rad * cs;
+      }
+    }
+  }
+  if (KERNEL == TPH_KERNEL_TPCN) {
+    // bring the candidate's two pieces to every lane of the group (owners: lanes npairs % LPP, (npairs+1) % LPP)
+    g_x = group_sum<LPP>(g_x);
+    g_logu = group_sum<LPP>(g_logu);
+    double gam;
+    if (gshape < 1.0) {
+      gam = tph_gamma_mt(gg, gshape);            // boosted small-shape path: serial (d = 1 and nu < 1 only)
+    } else {
+      const double dd = gshape - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * dd);
+      double v = 1.0 + cc * g_x;
+      v = v * v * v;
+      if (v > 0.0 && g_logu < 0.5 * g_x * g_x + dd - dd * v + dd * log(v)) gam = dd * v;
+      else gam = tph_gamma_mt(gg, gshape, 1);    // rare: continue with attempt 1, 2, ... as the one-lane kernels do
+    }
+    gam *= 2.0 / (nu + m_u);
+    b_fac = sigma * sqrt(1.0 / gam);
+  }
+  __syncthreads();
+
+  int ok = 0;
+  for (int att = 0; att < PROP_MAX_ATTEMPTS; ++att) {
+    if (att > 0) {
+      if (!ok) {
+        for (int q = l; q < npairs; q += LPP) {
+          double z0, z1;
+          gz.normal2((uint32_t)(att * npairs + q), z0, z1);
+          zs[2 * q] = z0;
+          if (2 * q + 1 < d) zs[2 * q + 1] = z1;
+        }
+      }
+      __syncthreads();
+    }
+    // rows of L z for this lane; results parked in registers until every lane has read z
+    double mine[8];
+    int okl = 1;
+    if (!ok) {
+      int k = 0;
+      for (int r = l; r < d; r += LPP, ++k) {
+        const double* Lr = L + (size_t)r * d;
+        double acc = 0.0;
+        for (int j = 0; j <= r; ++j) acc += Lr[j] * zs[j];
+        double v;
+        if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * df[r] + b_fac * acc;
+        else v = df[r] + b_fac * acc;
+        const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
+        if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
+        else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
+        else okl = okl && (v >= 0.0) && (v <= 1.0);
+        if (k < 8) mine[k] = v;
+      }
+    }
+    __syncthreads();
+    if (!ok) {
+      int k = 0;
+      for (int r = l; r < d; r += LPP, ++k) if (k < 8) zs[r] = mine[k];
+      ok = group_and<LPP>(okl);
+    }
+    if (__syncthreads_and(ok)) break;
+  }
+  if (!ok) {  // redraw cap reached: propose the current point
+    for (int j = l; j < d; j += LPP) zs[j] = (KERNEL == TPH_KERNEL_TPCN) ? df[j] + mu[j] : df[j];
+  }
+  __syncthreads();
+  if (live)
+    for (int j = l; j < d; j += LPP) up[(size_t)j * ld + i] = zs[j];
+  double m_up = 0.0;
+  if (KERNEL == TPH_KERNEL_TPCN) {
+    __syncthreads();
+    for (int j = l; j < d; j += LPP) zs[j] -= mu[j];
+    __syncthreads();
+    double part = 0.0;
+    for (int r = l; r < d; r += LPP) {
+      const double* Pr = P + (size_t)r * d;
+      double acc = 0.0;
+      for (int j = 0; j < d; ++j) acc += Pr[j] * zs[j];
+      part += zs[r] * acc;
+    }
+    m_up = group_sum<LPP>(part);
+  }
+  if (live && l == 0) {
+    if (maha_u) maha_u[i] = m_u;
+    if (maha_up) maha_up[i] = m_up;
+  }
+}
+
+template <int KERNEL, int LPP>
+static int launch_propose_ml(tph_ctx* ctx, const double* u, const int32_t* assign, int64_t n, int64_t ld, const double* means,
+                             const double* chol, const double* inv, const double* dof, const double* sigmas,
+                             const uint8_t* bc, uint64_t seed, uint32_t tick, int64_t item0, double* up, double* mu_,
+                             double* mup) {
+  constexpr int PPB = ML_THREADS / LPP;
+  size_t lds = sizeof(double) * 2 * (size_t)PPB * ctx->d;
+  hipLaunchKernelGGL((k_propose_ml<KERNEL, LPP>), dim3((unsigned)((n + PPB - 1) / PPB)), dim3(ML_THREADS), lds, ctx->stream, u,
+                     assign, n, ld, ctx->d, means, chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup);
+  return 0;
+}
+
 // Small-dimension variant (d <= 16 known at compile time): everything in registers, loops fully unrolled, so
-// one lane's independent Philox / Box-Muller / matvec chains overlap (the active set is far smaller than the
-// chip's thread capacity, so instruction-level parallelism is what hides latency here).  Same operation order
-// as the generic kernel above.
-template <int KERNEL, int D>
+// one lane's independent Philox / Box-Muller / matvec chains overlap.  The redraw-until-in-bounds loop
+// (mcmc.py:239-249) is run as a block-level WORK LIST: after each attempt the particles still out of bounds are
+// compacted into an LDS list and dealt to the first lanes again, so the cost follows the total number of redraws
+// instead of 64 x the worst lane of every wave (early iterations redraw ~30 % of the proposals).
+// Same draws and operation order as the generic kernel above.
+template <int KERNEL, int D, bool ONE_MODE>
 __global__ void __launch_bounds__(256) k_propose_reg(const double* __restrict__ u, const int32_t* __restrict__ assign,
                                                      int64_t n, int64_t ld, const double* __restrict__ means,
                                                      const double* __restrict__ chol, const double* __restrict__ inv,
@@ -191,81 +382,120 @@ __global__ void __launch_bounds__(256) k_propose_reg(const double* __restrict__ 
                                                      const uint8_t* __restrict__ bc, uint64_t seed, uint32_t tick,
                                                      int64_t item0, double* __restrict__ up, double* __restrict__ maha_u,
                                                      double* __restrict__ maha_up) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int c = assign ? assign[i] : 0;
-  const double* __restrict__ mu = means + (size_t)c * D;
-  const double* __restrict__ L = chol + (size_t)c * D * D;
-  const double* __restrict__ P = inv + (size_t)c * D * D;
-  const double sigma = sigmas[c];
-  double df[D], z[D];
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    double uj = u[(size_t)j * ld + i];
-    df[j] = (KERNEL == TPH_KERNEL_TPCN) ? uj - mu[j] : uj;
-  }
-  double a_fac = 1.0, b_fac = sigma, m_u = 0.0;
-  if (KERNEL == TPH_KERNEL_TPCN) {
-#pragma unroll
-    for (int r = 0; r < D; ++r) {
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < D; ++j) acc += P[r * D + j] * df[j];
-      m_u += df[r] * acc;
-    }
-    const double nu = dof[c];
-    tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
-    double gam = tph_gamma_mt(gg, 0.5 * ((double)D + nu)) * (2.0 / (nu + m_u));
-    a_fac = sqrt(1.0 - sigma * sigma);
-    b_fac = sigma * sqrt(1.0 / gam);
-  }
-  tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
+  __shared__ double s_bfac[256];
+  __shared__ int s_list[2][256];
+  __shared__ int s_count[2];
+  const int64_t base = (int64_t)blockIdx.x * 256;
   constexpr int NP = (D + 1) / 2;
-  bool ok = false;
-  for (int att = 0; att < PROP_MAX_ATTEMPTS && !ok; ++att) {
+  // ---- phase A: every particle of the block: Mahalanobis at u and the Gamma scale (one draw, reused by redraws)
+  {
+    const int64_t i = base + threadIdx.x;
+    if (threadIdx.x == 0) { s_count[0] = 0; s_count[1] = 0; }
+    double b_fac = 0.0;
+    if (i < n) {
+      const int c = ONE_MODE ? 0 : assign[i];
+      const double sigma = sigmas[c];
+      b_fac = sigma;
+      if (KERNEL == TPH_KERNEL_TPCN) {
+        const double* __restrict__ mu = means + (size_t)c * D;
+        const double* __restrict__ P = inv + (size_t)c * D * D;
+        double df[D];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      double z0, z1;
-      gz.normal2((uint32_t)(att * NP + p), z0, z1);
-      z[2 * p] = z0;
-      if (2 * p + 1 < D) z[2 * p + 1] = z1;
+        for (int j = 0; j < D; ++j) df[j] = u[(size_t)j * ld + i] - mu[j];
+        double m_u = 0.0;
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+          double acc = 0.0;
+#pragma unroll
+          for (int j = 0; j < D; ++j) acc += P[r * D + j] * df[j];
+          m_u += df[r] * acc;
+        }
+        const double nu = dof[c];
+        tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
+        double gam = tph_gamma_mt(gg, 0.5 * ((double)D + nu)) * (2.0 / (nu + m_u));
+        b_fac = sigma * sqrt(1.0 / gam);
+        if (maha_u) maha_u[i] = m_u;
+      } else if (maha_u) {
+        maha_u[i] = 0.0;
+      }
     }
-    ok = true;
+    s_bfac[threadIdx.x] = b_fac;
+    s_list[0][threadIdx.x] = threadIdx.x;
+  }
+  __syncthreads();
+  int count = (int)((n - base) < 256 ? (n - base) : 256);
+  // ---- phase B: attempts over the shrinking work list
+  for (int att = 0; att <= PROP_MAX_ATTEMPTS && count > 0; ++att) {
+    const int cur = att & 1, nxt = cur ^ 1;
+    if (threadIdx.x < count) {
+      const int pid = s_list[cur][threadIdx.x];
+      const int64_t i = base + pid;
+      const int c = ONE_MODE ? 0 : assign[i];
+      const double* __restrict__ mu = means + (size_t)c * D;
+      const double* __restrict__ L = chol + (size_t)c * D * D;
+      const double sigma = sigmas[c];
+      const double b_fac = s_bfac[pid];
+      const double a_fac = (KERNEL == TPH_KERNEL_TPCN) ? sqrt(1.0 - sigma * sigma) : 1.0;
+      double df[D], z[D];
 #pragma unroll
-    for (int r = D - 1; r >= 0; --r) {
-      double acc = 0.0;
+      for (int j = 0; j < D; ++j) {
+        double uj = u[(size_t)j * ld + i];
+        df[j] = (KERNEL == TPH_KERNEL_TPCN) ? uj - mu[j] : uj;
+      }
+      bool ok = true;
+      if (att < PROP_MAX_ATTEMPTS) {
+        tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
 #pragma unroll
-      for (int j = 0; j <= r; ++j) acc += L[r * D + j] * z[j];
-      double v;
-      if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * df[r] + b_fac * acc;
-      else v = df[r] + b_fac * acc;
-      const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
-      if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
-      else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
-      else ok = ok && (v >= 0.0) && (v <= 1.0);
-      z[r] = v;
+        for (int p = 0; p < NP; ++p) {
+          double z0, z1;
+          gz.normal2((uint32_t)(att * NP + p), z0, z1);
+          z[2 * p] = z0;
+          if (2 * p + 1 < D) z[2 * p + 1] = z1;
+        }
+#pragma unroll
+        for (int r = D - 1; r >= 0; --r) {  // descending: slot r is free once row r is done
+          double acc = 0.0;
+#pragma unroll
+          for (int j = 0; j <= r; ++j) acc += L[r * D + j] * z[j];
+          double v;
+          if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * df[r] + b_fac * acc;
+          else v = df[r] + b_fac * acc;
+          const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
+          if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
+          else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
+          else ok = ok && (v >= 0.0) && (v <= 1.0);
+          z[r] = v;
+        }
+      } else {  // redraw cap reached (the reference would loop on): propose the current point
+#pragma unroll
+        for (int j = 0; j < D; ++j) z[j] = (KERNEL == TPH_KERNEL_TPCN) ? df[j] + mu[j] : df[j];
+      }
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) up[(size_t)j * ld + i] = z[j];
+        double m_up = 0.0;
+        if (KERNEL == TPH_KERNEL_TPCN) {
+          const double* __restrict__ P = inv + (size_t)c * D * D;
+#pragma unroll
+          for (int j = 0; j < D; ++j) z[j] -= mu[j];
+#pragma unroll
+          for (int r = 0; r < D; ++r) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) acc += P[r * D + j] * z[j];
+            m_up += z[r] * acc;
+          }
+        }
+        if (maha_up) maha_up[i] = m_up;
+      } else {
+        s_list[nxt][atomicAdd(&s_count[nxt], 1)] = pid;   // order irrelevant: particles are independent
+      }
     }
+    __syncthreads();
+    count = s_count[nxt];
+    __syncthreads();
+    if (threadIdx.x == 0) s_count[cur] = 0;   // becomes `nxt` of the following attempt (ordered by its barrier)
   }
-  if (!ok) {
-#pragma unroll
-    for (int j = 0; j < D; ++j) z[j] = (KERNEL == TPH_KERNEL_TPCN) ? df[j] + mu[j] : df[j];
-  }
-#pragma unroll
-  for (int j = 0; j < D; ++j) up[(size_t)j * ld + i] = z[j];
-  double m_up = 0.0;
-  if (KERNEL == TPH_KERNEL_TPCN) {
-#pragma unroll
-    for (int j = 0; j < D; ++j) z[j] -= mu[j];
-#pragma unroll
-    for (int r = 0; r < D; ++r) {
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < D; ++j) acc += P[r * D + j] * z[j];
-      m_up += z[r] * acc;
-    }
-  }
-  if (maha_u) maha_u[i] = m_u;
-  if (maha_up) maha_up[i] = m_up;
 }
 
 template <int KERNEL, int D>
@@ -273,8 +503,12 @@ static void launch_propose_reg(tph_ctx* ctx, const double* u, const int32_t* ass
                                const double* means, const double* chol, const double* inv, const double* dof,
                                const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick, int64_t item0,
                                double* up, double* mu_, double* mup) {
-  hipLaunchKernelGGL((k_propose_reg<KERNEL, D>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, u, assign, n, ld,
-                     means, chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup);
+  if (assign == nullptr)
+    hipLaunchKernelGGL((k_propose_reg<KERNEL, D, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, u, assign,
+                       n, ld, means, chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup);
+  else
+    hipLaunchKernelGGL((k_propose_reg<KERNEL, D, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, u, assign,
+                       n, ld, means, chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup);
 }
 
 #define TPH_PROPOSE_CASE(DD)                                                                                       \
@@ -299,7 +533,29 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const 
   if (kernel == TPH_KERNEL_TPCN)
     TPH_REQUIRE(means_dev && inv_dev && dof_dev && maha_u_dev && maha_up_dev, "tph_propose: tpCN needs means/inv/dof/maha");
   TPH_REQUIRE(K == 1 || assign_dev, "tph_propose: K>1 needs assignments");
-  if (ctx->d <= 16 && !ctx->force_generic) {
+  const int variant = ctx->force_generic;   // 0 auto | 1 one-lane LDS | 2 one-lane registers (d<=16) | 3 multi-lane
+  const bool use_reg = (variant == 2 || variant == 0) && ctx->d <= 16;
+  if (!use_reg && (variant == 3 || variant == 0) && ctx->d <= 8 * 64) {
+    // lanes per particle: enough for every normal pair (+2 Gamma lanes) in one pass and <= 8 rows per lane
+    const int want = (ctx->d + 1) / 2 + 2;
+    int lpp = 4;
+    while (lpp < want && lpp < 64) lpp *= 2;
+    while (lpp < 64 && (ctx->d + lpp - 1) / lpp > 8) lpp *= 2;
+#define TPH_ML(LL)                                                                                                      \
+  case LL:                                                                                                               \
+    if (kernel == TPH_KERNEL_TPCN)                                                                                       \
+      launch_propose_ml<TPH_KERNEL_TPCN, LL>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev,      \
+                                             sigmas_dev, bc_dev, seed, tick, item0, uprime_dev, maha_u_dev, maha_up_dev); \
+    else                                                                                                                 \
+      launch_propose_ml<TPH_KERNEL_RWM, LL>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev,       \
+                                            sigmas_dev, bc_dev, seed, tick, item0, uprime_dev, maha_u_dev, maha_up_dev);  \
+    break;
+    switch (lpp) { TPH_ML(4) TPH_ML(8) TPH_ML(16) TPH_ML(32) TPH_ML(64) }
+#undef TPH_ML
+    TPH_LAUNCH_CHECK();
+    return 0;
+  }
+  if (use_reg) {
     switch (ctx->d) {
       TPH_PROPOSE_CASE(1) TPH_PROPOSE_CASE(2) TPH_PROPOSE_CASE(3) TPH_PROPOSE_CASE(4) TPH_PROPOSE_CASE(5)
       TPH_PROPOSE_CASE(6) TPH_PROPOSE_CASE(7) TPH_PROPOSE_CASE(8) TPH_PROPOSE_CASE(9) TPH_PROPOSE_CASE(10)

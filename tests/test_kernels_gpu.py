@@ -327,10 +327,11 @@ class _Modes:
 
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
 @pytest.mark.parametrize("bc", [None, "mixed"])
-@pytest.mark.parametrize("variant", ["registers_d7", "generic_d7", "generic_d19"])
+@pytest.mark.parametrize("variant", ["multilane_d7", "registers_d7", "generic_d7", "generic_d19", "multilane_d19",
+                                     "multilane_d50", "multilane_d3"])
 def test_propose_accept_adapt_vs_oracle(dev, kernel, bc, variant):
     rs = np.random.RandomState(17)
-    d, n, K = (19 if variant.endswith("19") else 7), 5000, 3
+    d, n, K = int(variant.split("_d")[1]), 5000, 3
     means = 0.5 + 0.1 * rs.randn(K, d)
     covs = np.empty((K, d, d))
     for k in range(K):
@@ -341,12 +342,12 @@ def test_propose_accept_adapt_vs_oracle(dev, kernel, bc, variant):
     sigmas = np.array([0.9, 0.5, 0.2]) * (2.38 / np.sqrt(d) if kernel == "rwm" else 1.0)
     assign = rs.randint(K, size=n).astype(np.int32)
     u = np.clip(means[assign] + 0.2 * rs.randn(n, d), 0.01, 0.99)   # many land near the walls -> redraws
-    flags = omc.bc_flags(d, [1], [4]) if bc else omc.bc_flags(d)
+    flags = omc.bc_flags(d, [1], [min(4, d - 1)]) if bc else omc.bc_flags(d)
     seed, tick, item0 = 4242, 11, 100_000
     want_up, want_mu, want_mup = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, flags, seed, tick, item0)
     c = ctx_for(d)
-    if variant.startswith("generic"):
-        c.set_option(0, 1)          # TPH_OPT_FORCE_GENERIC: the any-n_dim LDS kernel instead of the d<=16 register one
+    # TPH_OPT_FORCE_GENERIC: 1 = one-lane LDS kernel, 2 = one-lane register kernel (d<=16), 3 = multi-lane kernel
+    c.set_option(0, {"multilane": 3, "generic": 1, "registers": 2}[variant.split("_")[0]])
     modes = _Modes(means, chol, inv, dof, dev)
     up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
     ut = soa(u, dev)
