@@ -150,12 +150,12 @@ def main():
             dist.barrier()
 
     for _ in range(a.warmup):
-        s.sample()
+        s.sample(return_state=False)
     sync()
     it0 = len(s.state._scalars["steps"])
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        s.sample()
+        s.sample(return_state=False)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -176,7 +176,7 @@ def main():
         core.n_total = n_total
         guard = 0
         while core._not_termination() and guard < 400:
-            s.sample()
+            s.sample(return_state=False)
             guard += 1
         _, logz = core._logz_at(1.0)
         extra.update({"logz": logz, "logz_abs_err_vs_analytic": abs(logz - ANALYTIC_LOGZ),

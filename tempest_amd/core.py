@@ -211,7 +211,7 @@ class SamplerCore:
         self.mutator.pbar = self.pbar if show else None
 
         while self._not_termination():
-            self.execute_iteration(save_every=save_every, t0=t0)
+            self.execute_iteration(save_every=save_every, t0=t0, return_state=False)
 
         _, logz = self._logz_at(1.0)
         self.state.set_current("logz", logz)
@@ -220,8 +220,10 @@ class SamplerCore:
             self.save_sampler_state(self.config.output_dir / f"{self.config.output_label}_final.state")
         self.pbar.close()
 
-    def execute_iteration(self, save_every: Optional[int] = None, t0: int = 0) -> dict:
-        """One PS iteration: reweight -> train -> resample -> mutate -> commit (core.py:162-185)."""
+    def execute_iteration(self, save_every: Optional[int] = None, t0: int = 0, return_state: bool = True):
+        """One PS iteration: reweight -> train -> resample -> mutate -> commit (core.py:162-185).  Returns host copies
+        of the current state like the reference unless return_state=False (the run loop does not need them: for 10^5+
+        particles that copy is megabytes over PCIe per iteration)."""
         self._ensure_callbacks()
         if self.state.get_current("iter") is None:
             self._initialize_fresh()
@@ -237,7 +239,7 @@ class SamplerCore:
         self.mutator.run(mode_stats)
         self._update_progress_bar()
         self.state.commit_current_to_history()
-        return self.state.get_current()
+        return self.state.get_current() if return_state else None
 
     def _execute_iteration_profiled(self):
         """Same pipeline with a device synchronisation after each phase; accumulates wall seconds in self.timing

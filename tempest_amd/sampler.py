@@ -84,9 +84,10 @@ class Sampler:
         return self._core.run_sampling(n_total=n_total, progress=progress, resume_state_path=resume_state_path,
                                        save_every=save_every)
 
-    def sample(self, save_every: Optional[int] = None, t0: int = 0) -> dict:
-        """One iteration (reweight, train, resample, mutate, commit); returns copies of the current state."""
-        return self._core.execute_iteration(save_every=save_every, t0=t0)
+    def sample(self, save_every: Optional[int] = None, t0: int = 0, *, return_state: bool = True) -> dict:
+        """One iteration (reweight, train, resample, mutate, commit); returns host copies of the current state
+        (the reference's contract).  return_state=False skips that device-to-host copy."""
+        return self._core.execute_iteration(save_every=save_every, t0=t0, return_state=return_state)
 
     def posterior(self, resample: bool = False, return_blobs: bool = False, trim_importance_weights: bool = True,
                   return_logw: bool = False, ess_trim: float = 0.99, bins_trim: int = 1000) -> tuple:

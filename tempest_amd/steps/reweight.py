@@ -55,7 +55,7 @@ class Reweighter:
         self.METRIC_ATOL_CV = METRIC_ATOL_CV
         self.n_evals = 0          # trial betas evaluated
         self.n_passes = 0         # passes over the history (a pass evaluates up to 16 betas)
-        self.batch_depth = 4      # bisection levels evaluated per pass (1 = one beta per pass, as the reference)
+        self.batch_depth = None   # bisection levels evaluated per pass: None = automatic, 1 = one beta per pass (reference)
         self._cache = {}
 
     # ------------------------------------------------------------------ trial betas
@@ -98,12 +98,27 @@ class Reweighter:
             level = nxt
         return out
 
+    def _depth(self) -> int:
+        """Levels per pass.  A pass costs a fixed latency (launch + sync + 24-byte copy, ~90 us) plus ~2.2 ns per
+        history row and trial beta (one FP64 exp each; measured on MI355X), and buys `depth` bisection levels for
+        2^depth - 1 betas: pick the depth with the lowest cost per level."""
+        if self.batch_depth is not None:
+            return self.batch_depth
+        rows = max(1, self.state.ctx.size)
+        best, best_cost = 1, None
+        for k in (1, 2, 3, 4):
+            cost = (90.0 + max(rows * 4e-6, rows * 2.2e-6 * (2 ** k - 1))) / k
+            if best_cost is None or cost < best_cost:
+                best, best_cost = k, cost
+        return best
+
     def _prefetch(self, lo: float, hi: float, extra=()):
         """Before the sequential logic asks for the midpoint of [lo, hi]: evaluate the coming `batch_depth`
         levels of candidates in one pass (15 betas for depth 4) unless that midpoint is already known."""
         mid = (hi + lo) * 0.5
-        if self.batch_depth > 1 and mid not in self._cache:
-            depth = self.batch_depth if not extra else min(self.batch_depth, 3)
+        bd = self._depth()
+        if bd > 1 and mid not in self._cache:
+            depth = bd if not extra else min(bd, 3)
             self._eval_many(list(extra) + self._midpoint_tree(lo, hi, depth))
 
     def _weights_dev(self, beta: float):
@@ -163,7 +178,7 @@ class Reweighter:
     def _find_ess_bracket(self, beta_current: float, ess_target: float) -> tuple:
         """reweight.py:225-297: (low, high) with ESS(low) >= target > ESS(high); equal when no crossing."""
         beta_low, beta_high = beta_current, 1.0
-        if self.batch_depth > 1:      # both ends and the first levels of the bracket search in one pass
+        if self._depth() > 1:      # both ends and the first levels of the bracket search in one pass
             self._prefetch(beta_low, beta_high, extra=(beta_current, 1.0))
         if self._eval(beta_current)[3] <= ess_target:
             return beta_current, beta_current
