@@ -1,0 +1,85 @@
+"""BASELINE.json configurations 2 and 3 end to end on one MI355X (SURVEY 8d targets with analytic evidence)."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def prior20(u):
+    return 20 * u - 10
+
+
+def c2_target(dev, d=50):
+    """50-D zero-mean correlated Gaussian, Sigma = A A^T / d + 0.5 I, A ~ N(0,1) from RandomState(1), normalised."""
+    A = np.random.RandomState(1).randn(d, d)
+    S = A @ A.T / d + 0.5 * np.eye(d)
+    P = torch.from_numpy(np.linalg.inv(S)).to(dev)
+    const = float(-0.5 * np.linalg.slogdet(S)[1] - 0.5 * d * np.log(2 * np.pi))
+
+    def loglike(x):
+        return -0.5 * ((x @ P) * x).sum(dim=1) + const
+    return loglike, S
+
+
+def test_config2_gauss50_65536_rwm():
+    """50-D correlated Gaussian, 65 536 particles, random-walk mutation: analytic logZ = -50 ln 20 = -149.79.
+    At its default settings (ess_ratio 2, n_steps 1) the ALGORITHM overestimates the evidence in 50-D: the NumPy
+    oracle sampler (the reference's algorithm restated) gives logZ = -144.482 at N=512 with seed 0 and the device run
+    with the same seed gives -144.482 as well; the excess shrinks with N (about +2.5 here).  The gate is therefore the
+    posterior moments plus an evidence window that contains that known bias."""
+    import tempest_amd as tp
+    dev = torch.device("cuda", 0)
+    loglike, S = c2_target(dev)
+    t0 = time.time()
+    s = tp.Sampler(prior20, loglike, 50, n_particles=65536, vectorize=True, clustering=False, sample="rwm",
+                   random_state=0, backend="torch", batch_prior=True)
+    s.run(n_total=4 * 65536, progress=False)
+    wall = time.time() - t0
+    logz = s.evidence()[0]
+    x, w, _ = s.posterior()
+    mean = np.average(x, weights=w, axis=0)
+    var = np.average((x - mean) ** 2, weights=w, axis=0)
+    steps = np.asarray(s.state.get_history("steps")); beta = np.asarray(s.state.get_history("beta"))
+    pms = steps[beta > 0].sum() * 65536
+    print(f"config2: logZ={logz:.3f} (analytic {-50 * np.log(20):.3f}) iters={len(beta)} wall={wall:.1f}s pms/s={pms / wall:.3g}")
+    assert -0.5 < logz + 50 * np.log(20.0) < 3.5
+    np.testing.assert_allclose(mean, 0.0, atol=0.1)
+    np.testing.assert_allclose(var, np.diag(S), rtol=0.1)
+
+
+def test_config3_mixture32_clustering():
+    """32-D four-mode Gaussian mixture (modes at (+-4, +-4, 0, ...), sigma 0.5), clustering=True; analytic
+    logZ = -32 ln 20.  65 536 particles here (BASELINE's 262 144 is run by scripts, not in the test suite)."""
+    import tempest_amd as tp
+    dev = torch.device("cuda", 0)
+    d = 32
+    mus = torch.zeros(4, d, dtype=torch.float64, device=dev)
+    for k, (a, b) in enumerate([(-4, -4), (-4, 4), (4, -4), (4, 4)]):
+        mus[k, 0], mus[k, 1] = a, b
+    const = float(-np.log(4.0) - 0.5 * d * np.log(2 * np.pi * 0.25))
+
+    def loglike(x):
+        q = ((x[:, None, :] - mus[None]) ** 2).sum(dim=2)          # (n, 4)
+        return torch.logsumexp(-0.5 * q / 0.25, dim=1) + const
+    t0 = time.time()
+    s = tp.Sampler(prior20, loglike, d, n_particles=65536, vectorize=True, clustering=True, random_state=0,
+                   backend="torch", batch_prior=True)
+    s.run(n_total=4 * 65536, progress=False)
+    wall = time.time() - t0
+    logz = s.evidence()[0]
+    x, w, _ = s.posterior()
+    occ = [float(np.sum(w[(np.sign(x[:, 0]) == a) & (np.sign(x[:, 1]) == b)])) for a in (-1, 1) for b in (-1, 1)]
+    print(f"config3: logZ={logz:.3f} (analytic {-d * np.log(20):.3f}) iters={len(s.state.get_history('beta'))} "
+          f"wall={wall:.1f}s K={s._core.trainer.clusterer.n_clusters_} mode occupancy={np.round(occ, 3)}")
+    # the algorithm's evidence excess at default settings grows with dimension (+0.2 at d=10, ~+1 at d=32, see config 2)
+    assert -0.5 < logz + d * np.log(20.0) < 2.0
+    assert min(occ) > 0.15 and max(occ) < 0.35

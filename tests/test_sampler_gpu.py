@@ -158,3 +158,34 @@ def test_periodic_reflective_and_state_api(dev):
     r = s.results()
     assert "logw" in r and len(r["logw"]) == u.shape[0]
     np.testing.assert_allclose(np.exp(r["logw"]).sum(), 1.0, rtol=1e-10)
+
+
+@pytest.mark.parametrize("kw", [dict(sample="tpcn", resample="mult"), dict(sample="rwm", resample="syst"),
+                                dict(sample="tpcn", resample="syst", periodic=[0], reflective=[2])])
+def test_whole_run_matches_oracle_on_the_same_seed(dev, kw):
+    """The device sampler and the NumPy oracle sampler consume the same counter-based stream in the same order, so a
+    whole run (warm-up, beta schedule, proposal fits, resampling, every MCMC step) can be compared number by number:
+    identical beta / step schedules and the same evidence to ~1e-9."""
+    import tempest_amd as tp
+    from oracle.sampler import OracleSampler
+    d, n = 6, 256
+    mean_h = np.linspace(-2, 2, d)
+    mean_t = torch.from_numpy(mean_h).to(dev)
+    const = -0.5 * d * np.log(2 * np.pi)
+    s = tp.Sampler(prior20, lambda x: -0.5 * ((x - mean_t) ** 2).sum(dim=1) + const, d, n_particles=n, vectorize=True,
+                   clustering=False, random_state=11, **kw)
+    s.run(n_total=1024, progress=False)
+    o = OracleSampler(prior20, lambda x: -0.5 * np.sum((x - mean_h) ** 2, axis=1) + const, d, n, seed=11,
+                      sample=kw["sample"], resample=kw["resample"], periodic=kw.get("periodic"),
+                      reflective=kw.get("reflective"))
+    oz = o.run(1024)
+    beta = np.asarray(s.state.get_history("beta"))
+    assert len(beta) == len(o.hist["beta"])
+    np.testing.assert_allclose(beta, o.hist["beta"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_array_equal(np.asarray(s.state.get_history("steps")), o.hist["steps"])
+    np.testing.assert_allclose(np.asarray(s.state.get_history("logz")), o.hist["logz"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.asarray(s.state.get_history("acceptance")), o.hist["acceptance"], rtol=1e-6)
+    assert abs(s.evidence()[0] - oz) < 1e-6, (s.evidence()[0], oz)
+    assert s.state.get_current("calls") == o.cur["calls"]
+    # the particles themselves agree to rounding
+    np.testing.assert_allclose(s.state.get_history("x", index=len(beta) - 1), o.hist["x"][-1], rtol=1e-6, atol=1e-7)
