@@ -1,0 +1,132 @@
+"""Drop-in surface on the GPU: persistence / resume, dynamic (volume-variation) mode, edge cases, host-loop likelihoods,
+posterior options -- the behaviours the reference pins in tests/test_state.py, test_sampler_features.py,
+test_volume_variation.py, test_edge_cases.py, test_posterior_evidence.py, test_sample_method.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def prior20(u):
+    return 20 * u - 10
+
+
+def tl(x):
+    return -0.5 * (x ** 2).sum(dim=1)
+
+
+def test_save_load_and_resume(tmp_path):
+    import tempest_amd as tp
+    s = tp.Sampler(prior20, tl, 3, n_particles=64, vectorize=True, clustering=False, random_state=3,
+                   output_dir=str(tmp_path), output_label="run")
+    for _ in range(6):
+        s.sample()
+    path = tmp_path / "manual.state"
+    s.save_state(path)
+    assert path.exists()
+    s2 = tp.Sampler(prior20, tl, 3, n_particles=64, vectorize=True, clustering=False, random_state=3)
+    s2.load_state(path)
+    # history AND current state come back (the reference's load drops the history, core.py:289)
+    assert s2.state.get_history_length() == 6
+    np.testing.assert_array_equal(s2.state.get_history("x", flat=True), s.state.get_history("x", flat=True))
+    assert s2.state.get_current("beta") == s.state.get_current("beta")
+    np.testing.assert_allclose(s2.state.compute_logw_and_logz(1.0)[1], s.state.compute_logw_and_logz(1.0)[1], rtol=1e-13)
+    # resume: continue to completion, same answer as the uninterrupted run (same counter-based stream)
+    s2.run(n_total=512, progress=False, resume_state_path=path)
+    s.run_continue = None
+    s3 = tp.Sampler(prior20, tl, 3, n_particles=64, vectorize=True, clustering=False, random_state=3)
+    s3.run(n_total=512, progress=False)
+    assert abs(s2.evidence()[0] - s3.evidence()[0]) < 1e-9
+    assert s2.state.get_current("iter") == s3.state.get_current("iter")
+    # save_every writes {label}_{iter}.state and {label}_final.state (core.py:154-171)
+    s4 = tp.Sampler(prior20, tl, 3, n_particles=64, vectorize=True, clustering=False, random_state=3,
+                    output_dir=str(tmp_path / "out"), output_label="ps")
+    s4.run(n_total=256, progress=False, save_every=2)
+    names = sorted(p.name for p in (tmp_path / "out").iterdir())
+    assert "ps_final.state" in names and "ps_2.state" in names and "ps_4.state" in names
+
+
+def test_dynamic_mode_reaches_beta_one():
+    """volume_variation target (reference tests/test_volume_variation.py): the run completes, beta reaches 1,
+    cv is tracked, evidence is right."""
+    import tempest_amd as tp
+    zs = []
+    for seed in range(2):
+        s = tp.Sampler(prior20, tl, 4, n_particles=128, vectorize=True, clustering=False, volume_variation=0.2,
+                       random_state=seed)
+        s.run(n_total=512, progress=False)
+        assert s.beta == pytest.approx(1.0, abs=1e-4) and s.cv is not None and np.isfinite(s.cv)
+        cv_hist = np.asarray(s.state.get_history("cv"), dtype=float)
+        beta_hist = np.asarray(s.state.get_history("beta"))
+        assert np.all(np.diff(beta_hist) >= 0) and cv_hist.shape == beta_hist.shape
+        zs.append(s.evidence()[0])
+    truth = 4 * np.log(np.sqrt(2 * np.pi) / 20)
+    assert all(abs(z - truth) < 0.5 for z in zs), (zs, truth)
+
+
+def test_edge_cases():
+    """reference tests/test_edge_cases.py: 1-D, very few particles, narrow likelihood."""
+    import tempest_amd as tp
+    s = tp.Sampler(prior20, tl, 1, n_particles=32, vectorize=True, clustering=False, random_state=0)
+    s.run(n_total=256, progress=False)
+    assert abs(s.evidence()[0] - np.log(np.sqrt(2 * np.pi) / 20)) < 0.5
+    s = tp.Sampler(prior20, tl, 2, n_particles=8, vectorize=True, clustering=False, random_state=0)
+    s.run(n_total=64, progress=False)
+    assert np.isfinite(s.evidence()[0]) and s.beta > 0.99
+    narrow = lambda x: -0.5 * ((x - 3.0) ** 2).sum(dim=1) / 1e-4            # noqa: E731
+    s = tp.Sampler(prior20, narrow, 2, n_particles=256, vectorize=True, clustering=False, random_state=0)
+    s.run(n_total=1024, progress=False)
+    x, w, _ = s.posterior()
+    np.testing.assert_allclose(np.average(x, weights=w, axis=0), 3.0, atol=0.01)
+    assert abs(s.evidence()[0] - (np.log(2 * np.pi * 1e-4) - 2 * np.log(20))) < 0.6
+
+
+def test_non_vectorised_likelihood_and_default_particles():
+    """vectorize=False: the likelihood is called per sample on the host (core.py:317-358); n_particles defaults to 2 n_dim."""
+    import tempest_amd as tp
+    calls = {"n": 0}
+
+    def single(x):
+        calls["n"] += 1
+        assert x.shape == (2,)
+        return float(-0.5 * np.sum(x ** 2))
+    s = tp.Sampler(prior20, single, 2, n_particles=32, clustering=False, random_state=1)
+    s.run(n_total=128, progress=False)
+    assert s._core.callbacks.backend == "numpy" and calls["n"] >= s.state.get_current("calls")
+    assert abs(s.evidence()[0] - 2 * np.log(np.sqrt(2 * np.pi) / 20)) < 0.7
+    assert tp.Sampler(prior20, single, 3).n_particles == 6
+
+
+def test_posterior_options_and_likelihood_args():
+    import tempest_amd as tp
+
+    def ll(x, shift, scale=1.0):
+        return -0.5 * (((x - shift) / scale) ** 2).sum(dim=1)
+    s = tp.Sampler(prior20, ll, 2, n_particles=128, vectorize=True, clustering=False, random_state=2,
+                   log_likelihood_args=[1.5], log_likelihood_kwargs={"scale": 0.5})
+    s.run(n_total=1024, progress=False)
+    x, w, logl = s.posterior()
+    xt, wt, _ = s.posterior(trim_importance_weights=False)
+    assert len(wt) == s.state.get_history("logl", flat=True).size and len(w) <= len(wt)
+    np.testing.assert_allclose([w.sum(), wt.sum()], 1.0, rtol=1e-12)
+    np.testing.assert_allclose(np.average(x, weights=w, axis=0), 1.5, atol=0.1)
+    xr, wr, lr = s.posterior(resample=True)
+    assert len(xr) == len(x) and np.allclose(wr, 1.0 / len(xr))              # resampled => uniform weights
+    np.testing.assert_allclose(xr.mean(axis=0), 1.5, atol=0.15)
+    out = s.posterior(return_logw=True)
+    assert len(out) == 4 and len(out[3]) == len(wt)                            # untrimmed log-weights (core.py:233-242)
+    np.testing.assert_allclose(np.exp(out[3]).sum(), 1.0, rtol=1e-10)
+    logz, err = s.evidence()
+    assert err is None and abs(logz - (np.log(2 * np.pi * 0.25) - 2 * np.log(20))) < 0.5
+    for name in ("n_dim", "n_particles", "ess_ratio", "volume_variation", "n_steps", "n_max_steps", "n_total", "resample",
+                 "clustering", "vectorize", "output_dir", "output_label", "random_state", "periodic", "reflective", "beta",
+                 "logz", "ess", "cv"):
+        getattr(s, name)
+    assert s.n_total == 1024 and s.beta > 0.99
