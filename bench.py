@@ -132,8 +132,12 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("TEMPEST_AMD_FORCE_COMM") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
@@ -146,7 +150,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(a.warmup):
@@ -158,7 +162,7 @@ def main():
         s.sample(return_state=False)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -196,7 +200,7 @@ def main():
             out["roofline"] = reweight_roofline(local_rank, a.roofline_rows)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -7,6 +7,8 @@ traffic exist:
   * the resample shuffle (all-to-all-v of the selected rows).
 With world_size == 1 every method is a no-op / identity.
 """
+import os
+
 import numpy as np
 
 
@@ -36,7 +38,9 @@ class Comm:
 
     @property
     def active(self):
-        return self.world_size > 1
+        # TEMPEST_AMD_FORCE_COMM=1 routes a single rank through the sharded code path and its collectives too
+        # (used to exercise the RCCL calls on a one-GPU box)
+        return self.world_size > 1 or (self._dist is not None and os.environ.get("TEMPEST_AMD_FORCE_COMM") == "1")
 
     @property
     def _stage_on_host(self):
