@@ -108,6 +108,15 @@ def cpu_baseline(budget_s=20.0):
 
 
 def main():
+    # everything except the final JSON line goes to stderr: RCCL prints a version banner on stdout at communicator
+    # creation, and the driver expects exactly one line there
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -121,7 +130,7 @@ def main():
     ap.add_argument("--roofline-only", action="store_true", help="only the reweight-kernel microbench (for rocprofv3 --pmc)")
     a = ap.parse_args()
     if a.roofline_only:
-        print(json.dumps({"roofline": reweight_roofline(int(os.environ.get("LOCAL_RANK", "0")), a.roofline_rows)}))
+        emit({"roofline": reweight_roofline(int(os.environ.get("LOCAL_RANK", "0")), a.roofline_rows)})
         return
 
     import torch
@@ -204,7 +213,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 if __name__ == "__main__":
