@@ -51,7 +51,10 @@ __global__ void __launch_bounds__(1024) k_tile_offsets(double* __restrict__ tile
     if (lane < 16) wsum[lane] = v;
   }
   __syncthreads();
-  double excl = inc - s + (wid > 0 ? wsum[wid - 1] : 0.0);
+  // exclusive prefix by shuffle, never `inclusive - own` (cancellation would wipe out a small prefix
+  // in front of a dominant weight)
+  double prev = __shfl_up(inc, 1, 64);
+  double excl = (lane > 0 ? prev : 0.0) + (wid > 0 ? wsum[wid - 1] : 0.0);
   for (int64_t i = lo; i < hi; ++i) { double t = tiles[i]; tiles[i] = excl; excl += t; }
   if (threadIdx.x == 1023 && total) *total = wsum[15];
 }
@@ -75,7 +78,10 @@ __global__ void __launch_bounds__(ST) k_scan_apply(const double* __restrict__ w,
   __syncthreads();
   double off = tiles[blockIdx.x];
   for (int k = 0; k < wid; ++k) off += wsum[k];
-  off += inc - s;
+  {
+    double prev = __shfl_up(inc, 1, 64);   // exclusive prefix inside the wave, without cancellation
+    if (lane > 0) off += prev;
+  }
 #pragma unroll
   for (int k = 0; k < SI; ++k)
     if (base + k < n) out[base + k] = off + v[k];

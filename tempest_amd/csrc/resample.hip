@@ -56,7 +56,10 @@ __global__ void __launch_bounds__(1024) k_scan_tile_offsets(double* __restrict__
     if (lane < 16) wsum[lane] = v;
   }
   __syncthreads();
-  double excl = inc - s + (wid > 0 ? wsum[wid - 1] : 0.0);
+  // exclusive prefix by shuffle, never `inclusive - own` (cancellation would wipe out a small prefix
+  // in front of a dominant weight)
+  double prev = __shfl_up(inc, 1, 64);
+  double excl = (lane > 0 ? prev : 0.0) + (wid > 0 ? wsum[wid - 1] : 0.0);
   for (int64_t i = lo; i < hi; ++i) {
     double t = tile_sums[i];
     tile_sums[i] = excl;
@@ -64,7 +67,9 @@ __global__ void __launch_bounds__(1024) k_scan_tile_offsets(double* __restrict__
   }
 }
 
-// pass 3: local inclusive scan + tile offset
+// pass 3: local inclusive scan + tile offset.  Neighbouring outputs come from different summation trees, so the
+// result is monotone only up to rounding (<= 1 ulp dips where a weight is below the running sum's ulp); the searches
+// below tolerate that (a dip can only matter for a position within 1e-16 of the running sum).
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const double* __restrict__ w, int64_t n,
                                                              const double* __restrict__ thr_dev,
                                                              const double* __restrict__ tile_offsets,
@@ -88,7 +93,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const double* __res
   __syncthreads();
   double off = tile_offsets[blockIdx.x];
   for (int k = 0; k < wid; ++k) off += wsum[k];
-  off += inc - s;
+  {
+    double prev = __shfl_up(inc, 1, 64);   // exclusive prefix inside the wave, without cancellation
+    if (lane > 0) off += prev;
+  }
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) {
     int64_t i = base + k;

@@ -186,7 +186,8 @@ class StateManager:
                 u = torch.zeros(self.n_dim, n, dtype=torch.float64, device=self.device)
             if x is None:
                 x = torch.zeros(self.n_dim, n, dtype=torch.float64, device=self.device)
-            n_glob = n if self.comm is None else self.comm.sum_int(n)
+            # shards are equal by construction (n_particles divisible by the number of ranks): no collective needed
+            n_glob = n if self.comm is None else n * self.comm.world_size
             self.ctx.use_current_stream()
             self.ctx.history_append(u.contiguous(), x.contiguous(), logl.contiguous(), float(beta),
                                     0.0 if logz is None else float(logz), n_glob)

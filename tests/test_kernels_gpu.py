@@ -163,6 +163,20 @@ def test_cdf(dev, n):
     np.testing.assert_allclose(cdfm, np.cumsum(np.where(w >= 1.0, w, 0.0)), rtol=1e-12, atol=1e-300)
 
 
+def test_cdf_wide_dynamic_range(dev):
+    """Importance weights span tens of orders of magnitude: the scan must keep the small prefix in front of a
+    dominant weight (no `inclusive - own` cancellation) and stay monotone."""
+    rs = np.random.RandomState(5)
+    n = 300_000
+    w = np.exp(rs.randn(n) * 25.0)
+    w /= w.sum()
+    c = ctx_for(1)
+    cdf = c.cdf(torch.from_numpy(w).to(dev)).cpu().numpy()
+    ref = np.cumsum(w)
+    np.testing.assert_allclose(cdf, ref, rtol=1e-12, atol=0)
+    assert np.all(np.diff(cdf) >= -1e-15 * cdf[1:])
+
+
 def test_systematic_golden(dev):
     g = load("g4_resample.npz")
     c = ctx_for(1)
