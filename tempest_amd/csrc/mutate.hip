@@ -201,7 +201,7 @@ __device__ __forceinline__ int group_and(int v) {
   return v;
 }
 
-template <int KERNEL, int LPP>
+template <int KERNEL, int LPP, int STAGE>
 __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restrict__ u, const int32_t* __restrict__ assign,
                                                            int64_t n, int64_t ld, int d, const double* __restrict__ means,
                                                            const double* __restrict__ chol, const double* __restrict__ inv,
@@ -212,17 +212,33 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
   extern __shared__ double sh[];
   constexpr int PPB = ML_THREADS / LPP;
   const int l = threadIdx.x % LPP, p = threadIdx.x / LPP;
-  double* zs = sh + (size_t)p * d;                    // z, later the proposal
-  double* df = sh + (size_t)PPB * d + (size_t)p * d;  // u - mu (tpCN) or u (RWM)
+  const int dp = d | 1;                               // odd per-particle stride: particles land on different LDS banks
+  double* zs = sh + (size_t)p * dp;                   // z, later the proposal
+  double* df = sh + (size_t)PPB * dp + (size_t)p * dp;  // u - mu (tpCN) or u (RWM)
+  // STAGE 1: Sigma^-1 and L both resident in LDS (rows padded to d+1); STAGE 2: one matrix slot, refilled per phase;
+  // STAGE 0: read from global/L2 (several modes, or matrices too large).  Staging amortises the matrix reads over the
+  // PPB particles of the block instead of re-reading d*d doubles per particle.
+  double* mat0 = sh + (size_t)2 * PPB * dp;
+  double* mat1 = mat0 + (size_t)d * (d + 1);
   const int64_t i = (int64_t)blockIdx.x * PPB + p;
   const bool live = i < n;
   const int64_t ii = live ? i : n - 1;               // dead groups shadow the last particle, never store
-  const int c = assign ? assign[ii] : 0;
+  const int c = (STAGE == 0 && assign) ? assign[ii] : 0;
   const double* __restrict__ mu = means + (size_t)c * d;
-  const double* __restrict__ L = chol + (size_t)c * d * d;
-  const double* __restrict__ P = inv + (size_t)c * d * d;
+  const double* __restrict__ Lg = chol + (size_t)c * d * d;
+  const double* __restrict__ Pg = inv + (size_t)c * d * d;
   const double sigma = sigmas[c];
   const int npairs = (d + 1) >> 1;
+  const int ms = STAGE == 0 ? d : d + 1;              // row stride of the matrices as read below
+  const double* P = STAGE == 0 ? Pg : mat0;
+  const double* L = STAGE == 0 ? Lg : (STAGE == 1 ? mat1 : mat0);
+  auto stage = [&](double* dst, const double* src) {
+    for (int e = threadIdx.x; e < d * d; e += ML_THREADS) dst[(e / d) * (d + 1) + (e % d)] = src[e];
+  };
+  if (STAGE != 0) {
+    if (KERNEL == TPH_KERNEL_TPCN) stage(mat0, Pg);
+    if (STAGE == 1 || KERNEL != TPH_KERNEL_TPCN) stage(STAGE == 1 ? mat1 : mat0, Lg);
+  }
 
   for (int j = l; j < d; j += LPP) {
     double uj = u[(size_t)j * ld + ii];
@@ -234,7 +250,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
   if (KERNEL == TPH_KERNEL_TPCN) {
     double part = 0.0;
     for (int r = l; r < d; r += LPP) {
-      const double* Pr = P + (size_t)r * d;
+      const double* Pr = P + (size_t)r * ms;
       double acc = 0.0;
       for (int j = 0; j < d; ++j) acc += Pr[j] * df[j];
       part += df[r] * acc;
@@ -289,6 +305,10 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
     b_fac = sigma * sqrt(1.0 / gam);
   }
   __syncthreads();
+  if (STAGE == 2 && KERNEL == TPH_KERNEL_TPCN) {      // Sigma^-1 is done with for now: the slot takes L
+    stage(mat0, Lg);
+    __syncthreads();
+  }
 
   int ok = 0;
   for (int att = 0; att < PROP_MAX_ATTEMPTS; ++att) {
@@ -309,7 +329,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
     if (!ok) {
       int k = 0;
       for (int r = l; r < d; r += LPP, ++k) {
-        const double* Lr = L + (size_t)r * d;
+        const double* Lr = L + (size_t)r * ms;
         double acc = 0.0;
         for (int j = 0; j <= r; ++j) acc += Lr[j] * zs[j];
         double v;
@@ -339,11 +359,12 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
   double m_up = 0.0;
   if (KERNEL == TPH_KERNEL_TPCN) {
     __syncthreads();
+    if (STAGE == 2) stage(mat0, Pg);
     for (int j = l; j < d; j += LPP) zs[j] -= mu[j];
     __syncthreads();
     double part = 0.0;
     for (int r = l; r < d; r += LPP) {
-      const double* Pr = P + (size_t)r * d;
+      const double* Pr = P + (size_t)r * ms;
       double acc = 0.0;
       for (int j = 0; j < d; ++j) acc += Pr[j] * zs[j];
       part += zs[r] * acc;
@@ -362,9 +383,26 @@ static int launch_propose_ml(tph_ctx* ctx, const double* u, const int32_t* assig
                              const uint8_t* bc, uint64_t seed, uint32_t tick, int64_t item0, double* up, double* mu_,
                              double* mup) {
   constexpr int PPB = ML_THREADS / LPP;
-  size_t lds = sizeof(double) * 2 * (size_t)PPB * ctx->d;
-  hipLaunchKernelGGL((k_propose_ml<KERNEL, LPP>), dim3((unsigned)((n + PPB - 1) / PPB)), dim3(ML_THREADS), lds, ctx->stream, u,
-                     assign, n, ld, ctx->d, means, chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup);
+  const int d = ctx->d;
+  const size_t base = sizeof(double) * 2 * (size_t)PPB * (d | 1);
+  const size_t one = sizeof(double) * (size_t)d * (d + 1);
+  const size_t budget = 150 * 1024;
+  int stage = 0;
+  if (assign == nullptr) stage = (base + 2 * one <= budget) ? 1 : ((base + one <= budget) ? 2 : 0);
+  const size_t lds = base + (stage == 1 ? 2 * one : (stage == 2 ? one : 0));
+  const dim3 grid((unsigned)((n + PPB - 1) / PPB));
+#define TPH_ML_LAUNCH(ST)                                                                                              \
+  do {                                                                                                                 \
+    if (lds > 64 * 1024)                                                                                               \
+      TPH_HIP(hipFuncSetAttribute((const void*)k_propose_ml<KERNEL, LPP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds));                                                                          \
+    hipLaunchKernelGGL((k_propose_ml<KERNEL, LPP, ST>), grid, dim3(ML_THREADS), lds, ctx->stream, u, assign, n, ld, d, means, \
+                       chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup);                                   \
+  } while (0)
+  if (stage == 1) TPH_ML_LAUNCH(1);
+  else if (stage == 2) TPH_ML_LAUNCH(2);
+  else TPH_ML_LAUNCH(0);
+#undef TPH_ML_LAUNCH
   return 0;
 }
 
@@ -536,21 +574,22 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const 
   const int variant = ctx->force_generic;   // 0 auto | 1 one-lane LDS | 2 one-lane registers (d<=16) | 3 multi-lane
   const bool use_reg = (variant == 2 || variant == 0) && ctx->d <= 16;
   if (!use_reg && (variant == 3 || variant == 0) && ctx->d <= 8 * 64) {
-    // lanes per particle: enough for every normal pair (+2 Gamma lanes) in one pass and <= 8 rows per lane
-    const int want = (ctx->d + 1) / 2 + 2;
+    // lanes per particle: the fewest with <= 8 rows per lane, so that as many particles as possible share one
+    // block's staged matrices (the draws are dealt round-robin over the lanes in as many passes as needed)
     int lpp = 4;
-    while (lpp < want && lpp < 64) lpp *= 2;
     while (lpp < 64 && (ctx->d + lpp - 1) / lpp > 8) lpp *= 2;
 #define TPH_ML(LL)                                                                                                      \
   case LL:                                                                                                               \
     if (kernel == TPH_KERNEL_TPCN)                                                                                       \
-      launch_propose_ml<TPH_KERNEL_TPCN, LL>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev,      \
+      rc_ml = launch_propose_ml<TPH_KERNEL_TPCN, LL>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, \
                                              sigmas_dev, bc_dev, seed, tick, item0, uprime_dev, maha_u_dev, maha_up_dev); \
     else                                                                                                                 \
-      launch_propose_ml<TPH_KERNEL_RWM, LL>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev,       \
+      rc_ml = launch_propose_ml<TPH_KERNEL_RWM, LL>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, \
                                             sigmas_dev, bc_dev, seed, tick, item0, uprime_dev, maha_u_dev, maha_up_dev);  \
     break;
+    int rc_ml = 0;
     switch (lpp) { TPH_ML(4) TPH_ML(8) TPH_ML(16) TPH_ML(32) TPH_ML(64) }
+    if (rc_ml) return rc_ml;
 #undef TPH_ML
     TPH_LAUNCH_CHECK();
     return 0;
