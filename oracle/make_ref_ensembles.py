@@ -44,7 +44,8 @@ _C2 = {}
 
 
 def gauss_c2(x):
-    if "P" not in _C2:
+    if _C2.get("d") != x.shape[1]:
+        _C2["d"] = x.shape[1]
         S = c2_cov(x.shape[1])
         _C2["P"] = np.linalg.inv(S)
         _C2["ld"] = np.linalg.slogdet(S)[1]
@@ -64,6 +65,9 @@ CONFIGS = {
     "e2e_gauss10_n128_rwm_syst": (gauss_e2e, 10, dict(n_particles=128, clustering=False, sample="rwm",
                                                       resample="syst"), 2048),
     "c2twin_gauss50_n512_rwm": (gauss_c2, 50, dict(n_particles=512, clustering=False, sample="rwm"), 2048),
+    # cheaper high-dimensional twins (the 50-D RWM twin spends hours in the reference's per-walker redraw loop)
+    "gauss20_n256_tpcn": (gauss_c2, 20, dict(n_particles=256, clustering=False), 1024),
+    "gauss20_n256_rwm": (gauss_c2, 20, dict(n_particles=256, clustering=False, sample="rwm"), 1024),
 }
 
 

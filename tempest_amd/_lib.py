@@ -82,6 +82,10 @@ def load(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # torch bundles its own HIP/HSA runtime; it must be in the process BEFORE our library is loaded so that both
+    # resolve to the same libamdhip64 (loading ROCm's copy first leaves the process with two HSA runtimes and
+    # "no ROCm-capable device is detected")
+    import torch  # noqa: F401
     if not os.path.exists(p):
         raise TempestHipError(
             f"{p} not found: the HIP extension is not built (run `make -C tempest_amd/csrc`). "
