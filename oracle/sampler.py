@@ -124,7 +124,8 @@ class OracleSampler:
                 sigmas, done, _, _ = omc.adapt(self.kernel, alpha, mask, assign, 1, sigmas, it, self.d, self.n_steps,
                                                self.n_max)
                 if done:
-                    break
+                    self._tick()          # the device had already launched the next proposal (speculatively) when it
+                    break                 # read the stop flag: that launch's tick is spent
             steps, acc, eff = it, float(alpha.mean()), float(sigmas.mean() / sigma_0)
             self.pms += it * self.n
             self.timing["mutate"] += time.perf_counter() - t3

@@ -5,7 +5,7 @@ acceptance, sigma adaptation and adaptive stopping rule executed by the HIP kern
 csrc/mutate.hip.  The two user callbacks are the only other work in a step.  Steps before the
 minimum step count need no host synchronisation (the rule cannot fire earlier, mcmc.py:119-131);
 afterwards one 48-byte state read per step decides whether to stop, exactly where the reference
-evaluates `_check_convergence`.
+evaluates `_check_convergence`; that read overlaps with the (speculative) proposal of the next step.
 """
 from typing import Callable, Optional
 
@@ -98,10 +98,18 @@ class DeviceMCMC:
         n_min = self.n_steps * d
         it, calls = 0, 0
         st = None
-        while True:
-            it += 1
+        state_host = torch.empty(6, dtype=torch.float64).pin_memory()
+        ev = torch.cuda.Event()
+        speculated = False
+
+        def propose():
             ctx.propose(self.kernel, u, assign, modes, sigmas, self.bc, self.rng.seed, self.rng.next(), self.item0,
                         up, maha_u, maha_up)
+        while True:
+            it += 1
+            if not speculated:
+                propose()
+            speculated = False
             xp = self.prior(up)                       # (d, n) SoA tensor
             lp = self.loglike(xp)                     # (n,) tensor
             calls += n_global
@@ -111,7 +119,14 @@ class DeviceMCMC:
                 self.comm.all_reduce_sum(sums)
             ctx.adapt(self.kernel, sums, counts, K, n_global, self.n_steps, self.n_max, sigmas, state)
             if it >= n_min:
-                st = state.cpu().numpy()              # the only host sync of the step
+                # read the 48-byte step state while the NEXT step's proposal (which only needs the adapted sigma,
+                # already ordered on the stream) is being generated; if the stopping rule fired it is discarded
+                state_host.copy_(state, non_blocking=True)
+                ev.record()
+                propose()
+                speculated = True
+                ev.synchronize()
+                st = state_host.numpy().copy()
                 if self.pbar is not None and self.verbose:
                     self.pbar.update_stats({"calls": self.pbar.info.get("calls", 0) + n_global, "acc": st[3],
                                             "steps": it, "eff": st[4]})
