@@ -129,6 +129,21 @@ class Comm:
         for q in reqs:
             q.wait()
 
+    def gather_rows(self, a):
+        """Concatenate host arrays of all ranks along axis 0 (equal or different lengths), result on every rank."""
+        import torch
+        a = np.ascontiguousarray(a)
+        if not self.active:
+            return a
+        dev = "cuda" if self._dist.get_backend(self.group) == "nccl" else "cpu"
+        n = torch.tensor([a.shape[0]], dtype=torch.int64, device=dev)
+        counts = self.all_gather(n).reshape(-1).cpu().numpy()
+        m = int(counts.max())
+        pad = np.zeros((m,) + a.shape[1:], dtype=a.dtype)
+        pad[: a.shape[0]] = a
+        allp = self.all_gather(torch.from_numpy(pad).to(dev)).cpu().numpy()
+        return np.concatenate([allp[r, : counts[r]] for r in range(self.world_size)], axis=0)
+
     def barrier(self):
         if self.active:
             self._dist.barrier(group=self.group)

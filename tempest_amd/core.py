@@ -291,6 +291,14 @@ class SamplerCore:
         x = ctx.history_read(KEY_X)
         logl = ctx.history_read(KEY_LOGL)
         weights = w_dev.cpu().numpy()
+        comm = st.comm
+        if comm is not None and comm.active:
+            # sharded run: every rank returns the posterior over the WHOLE history (rows of all shards, rank order);
+            # the weights are already normalised by the global sum
+            x, logl, weights = comm.gather_rows(x), comm.gather_rows(logl), comm.gather_rows(weights)
+            if logw is not None:
+                logw = comm.gather_rows(logw)
+            w_dev = torch.from_numpy(np.ascontiguousarray(weights)).to(ctx.device)
         blobs = st.get_history("blobs", flat=True) if (self.config.blobs_dtype is not None and st._blobs) else None
         if trim_importance_weights:
             _, out = ctx.trim_threshold(w_dev, ess_trim, bins_trim, sync=True)

@@ -125,6 +125,12 @@ def sharded_gpu_worker(rank, world, port, out_dir):
         s.run(n_total=2048, progress=False)
         logzs.append(s.evidence()[0])
         assert s.state.ctx.size == 256 * len(s.state.get_history("beta"))
+    x, w, logl = s.posterior()
+    nh_global = 512 * len(s.state.get_history("beta"))
+    assert abs(w.sum() - 1.0) < 1e-10 and x.shape[1] == 6 and len(w) <= nh_global and len(w) > nh_global // 4
+    xa, wa, _ = s.posterior(trim_importance_weights=False)
+    assert len(wa) == nh_global                                             # rows of BOTH shards on every rank
+    np.testing.assert_allclose(np.average(x, weights=w, axis=0), np.linspace(-2, 2, 6), atol=0.15)
     res["logz"] = logzs
     res["analytic"] = float(-6 * np.log(20.0))
     assert all(abs(z - res["analytic"]) < 0.35 for z in logzs), logzs
