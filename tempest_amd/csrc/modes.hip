@@ -323,6 +323,53 @@ __global__ void __launch_bounds__(256) k_wcov(const double* __restrict__ hu, int
   }
 }
 
+// Small n_dim (<= 12): one lane per row, the d(d+1)/2 accumulators live in registers, the stream over u is
+// coalesced per coordinate and nothing is staged: HBM-bound.  One block partial of npl sums per block.
+template <typename WT, int D>
+__global__ void __launch_bounds__(256) k_wcov_small(const double* __restrict__ hu, int64_t cap, const WT* __restrict__ wt,
+                                                    const int32_t* __restrict__ labels, int label, int64_t n,
+                                                    const double* __restrict__ mean, double* __restrict__ partials) {
+  constexpr int NPL = D * (D + 1) / 2;
+  double acc[NPL];
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) acc[k] = 0.0;
+  double m[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) m[j] = mean[j];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double w = (!labels || labels[i] == label) ? (double)wt[i] : 0.0;
+    double xc[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) xc[j] = hu[(size_t)j * cap + i] - m[j];
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const double wa = w * xc[a];
+#pragma unroll
+      for (int b = 0; b <= a; ++b) acc[k++] += wa * xc[b];
+    }
+  }
+  __shared__ double sh[4];
+  double* mine = partials + (size_t)blockIdx.x * NPL;
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) {
+    double t = tph_block_sum(acc[k], sh);
+    if (threadIdx.x == 0) mine[k] = t;
+  }
+}
+
+template <typename WT>
+static bool launch_wcov_small(tph_ctx* ctx, const double* src, int64_t src_ld, const WT* wt, const int32_t* labels, int label,
+                              int64_t n, const double* mean, double* partials, int nblk) {
+  switch (ctx->d) {
+#define C(DD) case DD: hipLaunchKernelGGL((k_wcov_small<WT, DD>), dim3(nblk), dim3(256), 0, ctx->stream, src, src_ld, wt, labels, label, n, mean, partials); return true;
+    C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12)
+#undef C
+    default: return false;
+  }
+}
+
 // symmetrise the lower triangle and (optionally) apply student.py:62-63:
 //   Sigma = C/n + diag(C/n)/n      (np.cov*(n-1)/n + diag(np.var)/n)
 __global__ void k_cov_finish(const double* __restrict__ csum, const double* __restrict__ sums, int d, int student,
@@ -351,6 +398,17 @@ static int moments_launch_cov(tph_ctx* ctx, const void* wt, bool wt_is_int, cons
   const int npl = d * (d + 1) / 2;
   const int S = cov_slices(npl);
   TPH_REQUIRE(npl <= COV_NPT * 256, "covariance kernel supports n_dim <= 100 (got %d)", d);
+  if (d <= 12) {
+    // register kernel: block partials [nblk][npl] (no row slices)
+    bool ok = wt_is_int ? launch_wcov_small<int32_t>(ctx, src, src_ld, (const int32_t*)wt, labels, label, n, mean_dev, partials, nblk)
+                        : launch_wcov_small<double>(ctx, src, src_ld, (const double*)wt, labels, label, n, mean_dev, partials, nblk);
+    TPH_REQUIRE(ok, "covariance: no register kernel for n_dim=%d", d);
+    double* csum1 = partials + (size_t)nblk * npl;
+    hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, partials, nblk, npl, csum1);
+    hipLaunchKernelGGL(k_cov_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum1, sums_dev, d, student, cov_dev);
+    TPH_LAUNCH_CHECK();
+    return 0;
+  }
   size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS);
   if (wt_is_int) {
     if (lds > 64 * 1024)
