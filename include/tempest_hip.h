@@ -60,10 +60,10 @@ int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void* hip_strea
 int tph_ctx_destroy(tph_ctx* ctx);
 int tph_set_stream(tph_ctx* ctx, void* hip_stream);
 int tph_synchronize(tph_ctx* ctx);
-/* option 0 (TPH_OPT_FORCE_GENERIC) selects the proposal kernel variant: 0 = automatic (registers for n_dim <= 16,
- * multi-lane above), 1 = one lane per particle with LDS columns (any n_dim), 2 = one lane per particle in registers
- * (n_dim <= 16), 3 = several lanes per particle; tests compare them */
-#define TPH_OPT_FORCE_GENERIC 0
+/* TPH_OPT_PROPOSE_VARIANT selects the proposal kernel: 0 = automatic (registers for n_dim <= 16, multi-lane above),
+ * 1 = one lane per particle with LDS columns (any n_dim), 2 = one lane per particle in registers (n_dim <= 16),
+ * 3 = several lanes per particle with the matrices staged in LDS; the parity tests run every variant */
+#define TPH_OPT_PROPOSE_VARIANT 0
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- persistent ensemble: StateManager history (state_manager.py:171-176,356-416) ------------

@@ -137,7 +137,7 @@ extern "C" int tph_set_stream(tph_ctx* ctx, void* hip_stream) {
 extern "C" int tph_set_option(tph_ctx* ctx, int option, int value) {
   TPH_REQUIRE(ctx, "tph_set_option: ctx is NULL");
   switch (option) {
-    case 0: ctx->force_generic = value; break;   // TPH_OPT_FORCE_GENERIC
+    case TPH_OPT_PROPOSE_VARIANT: ctx->propose_variant = value; break;
     default: TPH_REQUIRE(false, "tph_set_option: unknown option %d", option);
   }
   return 0;

@@ -571,7 +571,7 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const 
   if (kernel == TPH_KERNEL_TPCN)
     TPH_REQUIRE(means_dev && inv_dev && dof_dev && maha_u_dev && maha_up_dev, "tph_propose: tpCN needs means/inv/dof/maha");
   TPH_REQUIRE(K == 1 || assign_dev, "tph_propose: K>1 needs assignments");
-  const int variant = ctx->force_generic;   // 0 auto | 1 one-lane LDS | 2 one-lane registers (d<=16) | 3 multi-lane
+  const int variant = ctx->propose_variant;   // 0 auto | 1 one-lane LDS | 2 one-lane registers (d<=16) | 3 multi-lane
   const bool use_reg = (variant == 2 || variant == 0) && ctx->d <= 16;
   if (!use_reg && (variant == 3 || variant == 0) && ctx->d <= 8 * 64) {
     // lanes per particle: the fewest with <= 8 rows per lane, so that as many particles as possible share one
@@ -626,7 +626,6 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const 
 
 // ------------------------------------------------------------------------------------------ accept
 constexpr int ACC_THREADS = 256;
-constexpr int ACC_MAX_K_DET = 64;  // deterministic per-cluster block reductions up to this K
 
 // Metropolis step (mcmc.py:163-177): alpha = min(1, exp(beta (l'-l) + factor)), NaN -> 0,
 // factor (tpCN, mcmc.py:251-279) = -A + B with A,B = -0.5 (d+nu) log(1 + m/nu) at u', u.

@@ -360,7 +360,7 @@ def test_propose_accept_adapt_vs_oracle(dev, kernel, bc, variant):
     seed, tick, item0 = 4242, 11, 100_000
     want_up, want_mu, want_mup = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, flags, seed, tick, item0)
     c = ctx_for(d)
-    # TPH_OPT_FORCE_GENERIC: 1 = one-lane LDS kernel, 2 = one-lane register kernel (d<=16), 3 = multi-lane kernel
+    # TPH_OPT_PROPOSE_VARIANT: 1 = one-lane LDS kernel, 2 = one-lane register kernel (d<=16), 3 = multi-lane kernel
     c.set_option(0, {"multilane": 3, "generic": 1, "registers": 2}[variant.split("_")[0]])
     modes = _Modes(means, chol, inv, dof, dev)
     up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
