@@ -54,13 +54,15 @@ __device__ __forceinline__ trip trip_block_reduce(trip t, double* sh) {
   return t;
 }
 
-// One streaming pass for NB trial betas.  Each lane keeps a running (m, s1, s2) per beta and
-// rescales only when a 4-element chunk raises its maximum (about one exp per element).
-// Loads are 16 B/lane (double2, non-temporal) with two independent chunks in flight.
-template <int NB>
+// One streaming pass for NB trial betas.  Each block owns a CONTIGUOUS segment of the history (measured +20 % over a
+// grid-stride sweep on MI355X: fewer DRAM pages open per channel at a time) and keeps U independent 16-B
+// non-temporal loads of l and of C in flight per lane.  Each lane keeps a running (m, s1, s2) per beta and rescales
+// only when a 4-row chunk raises its maximum (about one exp per row).
+template <int NB, int U>
 __global__ void __launch_bounds__(TPH_RED_THREADS) k_reweight_reduce(const double* __restrict__ logl,
                                                                       const double* __restrict__ cmix, int64_t n,
                                                                       tph_betas betas, double* __restrict__ partials) {
+  static_assert(U % 2 == 0, "chunks are consumed in pairs (4 rows)");
   double m[NB], s1[NB], s2[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) { m[b] = -DBL_MAX; s1[b] = 0.0; s2[b] = 0.0; }
@@ -68,26 +70,37 @@ __global__ void __launch_bounds__(TPH_RED_THREADS) k_reweight_reduce(const doubl
   const int64_t n2 = n >> 1;
   const double2* __restrict__ l2 = reinterpret_cast<const double2*>(logl);
   const double2* __restrict__ c2 = reinterpret_cast<const double2*>(cmix);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += 2 * stride) {
-    // once-read stream: non-temporal 16-B loads (+6 % over default-policy loads at the 1.07 GB point)
-    double2 la = nt_load2(l2 + i), ca = nt_load2(c2 + i);
-    double2 lb = make_double2(0.0, 0.0), cb = make_double2(INFINITY, INFINITY);  // v = -inf: contributes 0
-    if (i + stride < n2) { lb = nt_load2(l2 + i + stride); cb = nt_load2(c2 + i + stride); }
+  constexpr int64_t STEP = (int64_t)TPH_RED_THREADS * U;
+  int64_t per = (n2 + gridDim.x - 1) / gridDim.x;
+  per = (per + STEP - 1) / STEP * STEP;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  const int64_t hi = lo + per < n2 ? lo + per : n2;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += STEP) {
+    double2 l[U], c[U];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const double be = betas.b[b];
-      double v0 = be * la.x - ca.x, v1 = be * la.y - ca.y, v2 = be * lb.x - cb.x, v3 = be * lb.y - cb.y;
-      double vm = fmax(fmax(v0, v1), fmax(v2, v3));
-      if (vm > m[b]) {
-        double f = exp(m[b] - vm);
-        s1[b] *= f;
-        s2[b] *= f * f;
-        m[b] = vm;
+    for (int k = 0; k < U; ++k) {
+      const int64_t j = i + (int64_t)k * TPH_RED_THREADS;
+      if (j < hi) { l[k] = nt_load2(l2 + j); c[k] = nt_load2(c2 + j); }
+      else { l[k] = make_double2(0.0, 0.0); c[k] = make_double2(INFINITY, INFINITY); }   // v = -inf: contributes 0
+    }
+#pragma unroll
+    for (int k = 0; k < U; k += 2) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const double be = betas.b[b];
+        double v0 = be * l[k].x - c[k].x, v1 = be * l[k].y - c[k].y;
+        double v2 = be * l[k + 1].x - c[k + 1].x, v3 = be * l[k + 1].y - c[k + 1].y;
+        double vm = fmax(fmax(v0, v1), fmax(v2, v3));
+        if (vm > m[b]) {
+          double f = exp(m[b] - vm);
+          s1[b] *= f;
+          s2[b] *= f * f;
+          m[b] = vm;
+        }
+        double e0 = exp(v0 - m[b]), e1 = exp(v1 - m[b]), e2 = exp(v2 - m[b]), e3 = exp(v3 - m[b]);
+        s1[b] += (e0 + e1) + (e2 + e3);
+        s2[b] += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
       }
-      double e0 = exp(v0 - m[b]), e1 = exp(v1 - m[b]), e2 = exp(v2 - m[b]), e3 = exp(v3 - m[b]);
-      s1[b] += (e0 + e1) + (e2 + e3);
-      s2[b] += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
     }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd tail
@@ -129,9 +142,14 @@ __global__ void __launch_bounds__(256) k_reweight_finalize(const double* __restr
   }
 }
 
+// contiguous segment per block; 1024 blocks (4 per CU) once there is enough work for 16 rows per lane and trip
+static int reduce_grid(int64_t n) { return tph_grid_for(n, TPH_RED_THREADS, 16, 1024); }
+
 template <int NB>
 static void launch_reduce(tph_ctx* ctx, int grid, const tph_betas& bt) {
-  hipLaunchKernelGGL(k_reweight_reduce<NB>, dim3(grid), dim3(TPH_RED_THREADS), 0, ctx->stream, ctx->logl, ctx->cmix,
+  // loads in flight per lane and array: 8 for one beta (pure streaming), fewer as the per-row exp work grows
+  constexpr int U = NB == 1 ? 8 : (NB <= 4 ? 4 : 2);
+  hipLaunchKernelGGL((k_reweight_reduce<NB, U>), dim3(grid), dim3(TPH_RED_THREADS), 0, ctx->stream, ctx->logl, ctx->cmix,
                      ctx->size, bt, ctx->partials);
 }
 
@@ -163,8 +181,7 @@ extern "C" int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int
   TPH_REQUIRE(ctx->size > 0, "tph_reweight_partials: empty history");
   tph_betas bt;
   for (int i = 0; i < TPH_MAX_NB; ++i) bt.b[i] = i < nb ? betas_host[i] : 0.0;
-  // 4 elements per lane per trip, capped at 2048 blocks (256 CUs x 8) and grid-strided beyond
-  int grid = tph_grid_for(ctx->size, TPH_RED_THREADS, 4);
+  int grid = reduce_grid(ctx->size);
   TPH_REQUIRE((size_t)grid * nb * 3 * sizeof(double) <= ctx->partials_bytes, "tph_reweight_partials: scratch too small");
   launch_reduce_nb(ctx, grid, bt, nb);
   TPH_LAUNCH_CHECK();
@@ -190,7 +207,7 @@ extern "C" int tph_reweight_time(tph_ctx* ctx, double beta, int nb, int reps, do
   TPH_REQUIRE(nb >= 1 && nb <= TPH_MAX_NB && ctx->size > 0, "tph_reweight_time: bad nb / empty history");
   tph_betas bt;
   for (int i = 0; i < TPH_MAX_NB; ++i) bt.b[i] = beta * (1.0 - 0.01 * i);
-  int grid = tph_grid_for(ctx->size, TPH_RED_THREADS, 4);
+  int grid = reduce_grid(ctx->size);
   hipEvent_t e0, e1;
   TPH_HIP(hipEventCreate(&e0));
   TPH_HIP(hipEventCreate(&e1));
