@@ -77,7 +77,7 @@ def reweight_roofline(device, n_rows):
         except Exception:
             traffic = None
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "k_reweight_reduce<1>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    return {"bound": "hbm", "kernel": "k_reweight_reduce<1, 8>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(avg_ms, 5), "history_rows": n_rows,
             "check_ess": float(s1 * s1 / s2)}
