@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
     } else {                                      // Box-Muller
       double rad = sqrt(-2.0 * log((a + 1.0) * 0x1.0p-53));
       double sn, cs;
-      sincos(6.283185307179586476925 * (b * 0x1.0p-53), &sn, &cs);
+      sincospi(2.0 * (b * 0x1.0p-53), &sn, &cs);
       if (is_norm) {
         zs[2 * q] = rad * cs;
         if (2 * q + 1 < d) zs[2 * q + 1] = rad * sn;
