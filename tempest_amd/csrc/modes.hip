@@ -4,99 +4,11 @@
 // (fit_mvstud; effective form = per-dimension median, MLE covariance + diag(var)/n, nu=inf -- SURVEY.md F5);
 // tempest/modes.py:58-119 (chol/inv with ridge), :131-288 (x4 multinomial up-sampling then fit).
 #include "common.h"
+#include "scan.h"
 
 #include <cstring>
 #include <cstdlib>
 #include <rocprim/rocprim.hpp>
-
-// ---- generic inclusive scan (same 3-pass scheme as resample.hip, with an optional square) ----------
-namespace {
-constexpr int ST = 256, SI = 8, STILE = ST * SI;
-
-__device__ __forceinline__ double wave_scan(double v) {
-  int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    double t = __shfl_up(v, o, 64);
-    if (lane >= o) v += t;
-  }
-  return v;
-}
-
-template <bool SQ>
-__global__ void __launch_bounds__(ST) k_tile_sums(const double* __restrict__ w, int64_t n, double* __restrict__ tiles) {
-  int64_t base = (int64_t)blockIdx.x * STILE + (int64_t)threadIdx.x * SI;
-  double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < SI; ++k)
-    if (base + k < n) { double v = w[base + k]; s += SQ ? v * v : v; }
-  __shared__ double sh[ST / 64];
-  s = tph_block_sum(s, sh);
-  if (threadIdx.x == 0) tiles[blockIdx.x] = s;
-}
-
-__global__ void __launch_bounds__(1024) k_tile_offsets(double* __restrict__ tiles, int64_t ntiles, double* __restrict__ total) {
-  int64_t per = (ntiles + 1023) / 1024;
-  int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
-  double s = 0.0;
-  for (int64_t i = lo; i < hi; ++i) s += tiles[i];
-  __shared__ double wsum[16];
-  double inc = wave_scan(s);
-  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (lane == 63) wsum[wid] = inc;
-  __syncthreads();
-  if (wid == 0) {
-    double v = lane < 16 ? wsum[lane] : 0.0;
-    v = wave_scan(v);
-    if (lane < 16) wsum[lane] = v;
-  }
-  __syncthreads();
-  // exclusive prefix by shuffle, never `inclusive - own` (cancellation would wipe out a small prefix
-  // in front of a dominant weight)
-  double prev = __shfl_up(inc, 1, 64);
-  double excl = (lane > 0 ? prev : 0.0) + (wid > 0 ? wsum[wid - 1] : 0.0);
-  for (int64_t i = lo; i < hi; ++i) { double t = tiles[i]; tiles[i] = excl; excl += t; }
-  if (threadIdx.x == 1023 && total) *total = wsum[15];
-}
-
-template <bool SQ>
-__global__ void __launch_bounds__(ST) k_scan_apply(const double* __restrict__ w, int64_t n, const double* __restrict__ tiles,
-                                                   double* __restrict__ out) {
-  int64_t base = (int64_t)blockIdx.x * STILE + (int64_t)threadIdx.x * SI;
-  double v[SI];
-  double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < SI; ++k) {
-    double x = base + k < n ? w[base + k] : 0.0;
-    s += SQ ? x * x : x;
-    v[k] = s;
-  }
-  __shared__ double wsum[ST / 64];
-  double inc = wave_scan(s);
-  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (lane == 63) wsum[wid] = inc;
-  __syncthreads();
-  double off = tiles[blockIdx.x];
-  for (int k = 0; k < wid; ++k) off += wsum[k];
-  {
-    double prev = __shfl_up(inc, 1, 64);   // exclusive prefix inside the wave, without cancellation
-    if (lane > 0) off += prev;
-  }
-#pragma unroll
-  for (int k = 0; k < SI; ++k)
-    if (base + k < n) out[base + k] = off + v[k];
-}
-
-template <bool SQ>
-int scan_incl(tph_ctx* ctx, const double* in, int64_t n, double* tiles, double* out, double* total_dev) {
-  int64_t ntiles = (n + STILE - 1) / STILE;
-  hipLaunchKernelGGL(k_tile_sums<SQ>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, in, n, tiles);
-  hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, ctx->stream, tiles, ntiles, total_dev);
-  hipLaunchKernelGGL(k_scan_apply<SQ>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, in, n, tiles, out);
-  TPH_LAUNCH_CHECK();
-  return 0;
-}
-}  // namespace
 
 // ------------------------------------------------------------------------------------------- trimming
 // All `bins` candidates of the reference's 99 -> 0 percentile walk at once on the sorted weights S with
@@ -156,7 +68,7 @@ extern "C" int tph_trim_threshold(tph_ctx* ctx, const double* w_dev, int64_t n, 
   size_t temp_bytes = 0;
   double* nullk = nullptr;
   TPH_HIP(rocprim::radix_sort_keys(nullptr, temp_bytes, w_dev, nullk, (size_t)n, 0, 64, ctx->stream));
-  int64_t ntiles = (n + STILE - 1) / STILE;
+  int64_t ntiles = tph_scan::num_tiles(n);
   size_t a_tiles = ((size_t)ntiles * sizeof(double) + 255) / 256 * 256;
   size_t a_n = ((size_t)n * sizeof(double) + 255) / 256 * 256;
   size_t a_tmp = (temp_bytes + 255) / 256 * 256;
@@ -168,8 +80,8 @@ extern "C" int tph_trim_threshold(tph_ctx* ctx, const double* w_dev, int64_t n, 
   double* P2 = (double*)(base + a_tiles + 2 * a_n);
   void* tmp = base + a_tiles + 3 * a_n;
   TPH_HIP(rocprim::radix_sort_keys(tmp, temp_bytes, w_dev, S, (size_t)n, 0, 64, ctx->stream));
-  if (scan_incl<false>(ctx, S, n, tiles, P1, nullptr)) return -1;
-  if (scan_incl<true>(ctx, S, n, tiles, P2, nullptr)) return -1;
+  if (tph_scan::inclusive<tph_scan::PLAIN>(ctx, S, n, nullptr, tiles, P1)) return -1;
+  if (tph_scan::inclusive<tph_scan::SQUARE>(ctx, S, n, nullptr, tiles, P2)) return -1;
   hipLaunchKernelGGL(k_trim_candidates, dim3(1), dim3(256), 0, ctx->stream, S, P1, P2, n, ess, bins, out_dev);
   TPH_LAUNCH_CHECK();
   if (out_host) {

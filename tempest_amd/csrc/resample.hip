@@ -3,117 +3,14 @@
 // (Resampler.run: np.random.choice(p=w) | systematic, then u,x,logl[idx]), tempest/modes.py:196-201
 // (x4 multinomial up-sampling before the proposal fit).
 #include "common.h"
-
-constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_ITEMS = 8;
-constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
-
-__device__ __forceinline__ double masked(double w, bool use_thr, double thr) { return (use_thr && !(w >= thr)) ? 0.0 : w; }
-
-// pass 1: sum of each 2048-element tile
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_tile_sums(const double* __restrict__ w, int64_t n,
-                                                                 const double* __restrict__ thr_dev,
-                                                                 double* __restrict__ tile_sums) {
-  const bool use_thr = thr_dev != nullptr;
-  const double thr = use_thr ? thr_dev[0] : 0.0;
-  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
-  double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    int64_t i = base + k;
-    if (i < n) s += masked(w[i], use_thr, thr);
-  }
-  __shared__ double sh[SCAN_THREADS / 64];
-  s = tph_block_sum(s, sh);
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = s;
-}
-
-// inclusive scan across the lanes of a wave
-__device__ __forceinline__ double wave_incl_scan(double v) {
-  int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    double t = __shfl_up(v, o, 64);
-    if (lane >= o) v += t;
-  }
-  return v;
-}
-
-// pass 2: exclusive scan of the tile sums, one block of 1024 threads, each owning a contiguous run
-__global__ void __launch_bounds__(1024) k_scan_tile_offsets(double* __restrict__ tile_sums, int64_t ntiles) {
-  int64_t per = (ntiles + 1023) / 1024;
-  int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
-  double s = 0.0;
-  for (int64_t i = lo; i < hi; ++i) s += tile_sums[i];
-  __shared__ double wsum[16];
-  double inc = wave_incl_scan(s);
-  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (lane == 63) wsum[wid] = inc;
-  __syncthreads();
-  if (wid == 0) {
-    double v = lane < 16 ? wsum[lane] : 0.0;
-    v = wave_incl_scan(v);
-    if (lane < 16) wsum[lane] = v;
-  }
-  __syncthreads();
-  // exclusive prefix by shuffle, never `inclusive - own` (cancellation would wipe out a small prefix
-  // in front of a dominant weight)
-  double prev = __shfl_up(inc, 1, 64);
-  double excl = (lane > 0 ? prev : 0.0) + (wid > 0 ? wsum[wid - 1] : 0.0);
-  for (int64_t i = lo; i < hi; ++i) {
-    double t = tile_sums[i];
-    tile_sums[i] = excl;
-    excl += t;
-  }
-}
-
-// pass 3: local inclusive scan + tile offset.  Neighbouring outputs come from different summation trees, so the
-// result is monotone only up to rounding (<= 1 ulp dips where a weight is below the running sum's ulp); the searches
-// below tolerate that (a dip can only matter for a position within 1e-16 of the running sum).
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const double* __restrict__ w, int64_t n,
-                                                             const double* __restrict__ thr_dev,
-                                                             const double* __restrict__ tile_offsets,
-                                                             double* __restrict__ cdf) {
-  const bool use_thr = thr_dev != nullptr;
-  const double thr = use_thr ? thr_dev[0] : 0.0;
-  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
-  double v[SCAN_ITEMS];
-  double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    int64_t i = base + k;
-    double x = i < n ? masked(w[i], use_thr, thr) : 0.0;
-    s += x;
-    v[k] = s;
-  }
-  __shared__ double wsum[SCAN_THREADS / 64];
-  double inc = wave_incl_scan(s);
-  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (lane == 63) wsum[wid] = inc;
-  __syncthreads();
-  double off = tile_offsets[blockIdx.x];
-  for (int k = 0; k < wid; ++k) off += wsum[k];
-  {
-    double prev = __shfl_up(inc, 1, 64);   // exclusive prefix inside the wave, without cancellation
-    if (lane > 0) off += prev;
-  }
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    int64_t i = base + k;
-    if (i < n) cdf[i] = off + v[k];
-  }
-}
+#include "scan.h"
 
 extern "C" int tph_cdf(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev, double* cdf_dev) {
   TPH_REQUIRE(ctx && w_dev && cdf_dev && n > 0, "tph_cdf: bad argument");
-  int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-  if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)ntiles)) return -1;
+  if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)tph_scan::num_tiles(n))) return -1;
   double* tiles = (double*)ctx->scratch;
-  hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, ctx->stream, w_dev, n, thr_dev, tiles);
-  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(1024), 0, ctx->stream, tiles, ntiles);
-  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, ctx->stream, w_dev, n, thr_dev, tiles, cdf_dev);
-  TPH_LAUNCH_CHECK();
-  return 0;
+  return thr_dev ? tph_scan::inclusive<tph_scan::MASKED>(ctx, w_dev, n, thr_dev, tiles, cdf_dev)
+                 : tph_scan::inclusive<tph_scan::PLAIN>(ctx, w_dev, n, nullptr, tiles, cdf_dev);
 }
 
 // #{k in [0,n) : pred(cdf_k)}, pred monotone (true ... true false ... false)
