@@ -141,25 +141,38 @@ int tph_prior_draw(tph_ctx* ctx, double* u_dev, int64_t n, int64_t ld, uint64_t 
 /* rows with +-inf logl replaced by uniformly chosen finite rows; stats_dev = (n_finite, n) (mutate.py:122-148) */
 int tph_inf_repair(tph_ctx* ctx, double* u_dev, double* x_dev, double* logl_dev, int64_t n, int64_t ld,
                    uint64_t seed, uint32_t tick, int64_t item0, double* stats_dev /*[2]*/);
+/* Step control (optional, ctl_dev may be NULL): tph_adapt's state_dev block, extended to TPH_STEP_STATE_LEN doubles,
+ * passed to tph_propose / tph_accept makes one MCMC step replayable as a captured hipGraph with no per-step kernel
+ * arguments: the RNG tick used is  tick + state[7] + 2 * state[0]  (state[0] = steps completed, advanced by tph_adapt;
+ * state[7] = the run's tick base, < 2^32), beta is read from state[6], and once state[1] (the stopping rule of mcmc.py:119-140) is set, tph_accept and tph_adapt of any
+ * further (speculatively launched) step leave every buffer untouched. */
+#define TPH_STEP_STATE_LEN 8
 /* proposals for all particles (mcmc.py:225-249 tpCN, :301-312 RWM) incl. boundary handling and the
  * redraw-until-in-bounds loop; maha_u/maha_up receive (u-mu)^T S^-1 (u-mu) at u and u' (tpCN). */
 int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const int32_t* assign_dev, int64_t n, int64_t ld,
                 int K, const double* means_dev, const double* chol_dev, const double* inv_dev,
                 const double* dof_dev, const double* sigmas_dev, const uint8_t* bc_dev,
                 uint64_t seed, uint32_t tick, int64_t item0,
-                double* uprime_dev, double* maha_u_dev, double* maha_up_dev);
+                double* uprime_dev, double* maha_u_dev, double* maha_up_dev, const double* ctl_dev);
 /* Metropolis step (mcmc.py:163-177 with the factor of :251-279): masked overwrite of u,x,logl and
  * per-rank sums  sums_dev = (n_accepted, sum alpha_0 .. sum alpha_{K-1}). */
 int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, double* x_dev, double* logl_dev,
                const double* uprime_dev, const double* xprime_dev, const double* loglprime_dev,
                const double* maha_u_dev, const double* maha_up_dev, const int32_t* assign_dev,
                int64_t n, int64_t ld, int K, const double* dof_dev,
-               uint64_t seed, uint32_t tick, int64_t item0, double* sums_dev /*[1+K]*/);
+               uint64_t seed, uint32_t tick, int64_t item0, double* sums_dev /*[1+K]*/, const double* ctl_dev,
+               double* partials_dev /* NULL = library scratch, or ceil(n/256)*(1+K) doubles owned by the caller: needed
+                                       when the launch is captured in a graph (the scratch may move when it grows) */);
 /* sigma adaptation + adaptive stopping rule (mcmc.py:104-140,180-194,281-288,320-323) from GLOBAL sums.
- * state_dev[6]: [0]=iteration (in/out) [1]=done flag [2]=accepted fraction [3]=mean alpha
- *            [4]=mean(sigma)/sigma_0 [5]=adaptive step target ; counts_dev = particles per cluster (global). */
+ * state_dev[6..8]: [0]=iteration (in/out) [1]=done flag [2]=accepted fraction [3]=mean alpha
+ *            [4]=mean(sigma)/sigma_0 [5]=adaptive step target ([6]=beta, [7]=tick base when used as step control);
+ * counts_dev = particles per cluster (global).  A call with the done flag already set is a no-op. */
 int tph_adapt(tph_ctx* ctx, int kernel, const double* sums_dev, const double* counts_dev, int K,
-              double n_global, int n_dim, int n_steps, int n_max, double* sigmas_dev, double* state_dev);
+              double n_global, int n_dim, int n_steps, int n_max, double* sigmas_dev, double* state_dev,
+              double* mailbox_host /* NULL, or mailbox_slots x 8 doubles of PINNED host memory (device-accessible):
+                                      the record of step s = state[0..5] goes to slot s % mailbox_slots, its field [7]
+                                      = s is stored last (system-scope release), so the host can poll for it */,
+              int mailbox_slots);
 int tph_cluster_counts(tph_ctx* ctx, const int32_t* assign_dev, int64_t n, int K, double* counts_dev);
 
 /* ---- proposal fit (student.py:6-116 effective form, modes.py:58-119,131-288) -------------------- */

@@ -57,6 +57,22 @@ def prior20(u):
     return 20 * u - 10
 
 
+def funnel(x):
+    d = x.shape[1]
+    v = x[:, 0]
+    lv = -0.5 * (v / 3.0) ** 2 - np.log(3.0) - 0.5 * np.log(2 * np.pi)
+    lr = np.sum(-0.5 * x[:, 1:] ** 2 * np.exp(-v)[:, None], axis=1) - 0.5 * (d - 1) * v - 0.5 * (d - 1) * np.log(2 * np.pi)
+    return lv + lr
+
+
+def prior_funnel(u):
+    x = 600.0 * u - 300.0
+    x[..., 0] = 30.0 * u[..., 0] - 15.0
+    return x
+
+
+PRIORS = {"c5twin_funnel100_n4096": prior_funnel}
+
 CONFIGS = {
     # name: (loglike, n_dim, kwargs, n_total)
     "c1_rosenbrock_cluster": (rosenbrock, 10, dict(n_particles=1000), 4096),
@@ -68,6 +84,8 @@ CONFIGS = {
     # cheaper high-dimensional twins (the 50-D RWM twin spends hours in the reference's per-walker redraw loop)
     "gauss20_n256_tpcn": (gauss_c2, 20, dict(n_particles=256, clustering=False), 1024),
     "gauss20_n256_rwm": (gauss_c2, 20, dict(n_particles=256, clustering=False, sample="rwm"), 1024),
+    # the parity twin of config 5 (100-D funnel) at N = 4096, reported as-is
+    "c5twin_funnel100_n4096": (funnel, 100, dict(n_particles=4096, clustering=False), 4 * 4096),
 }
 
 
@@ -77,7 +95,7 @@ def run_one(job):
     loglike, n_dim, kw, n_total = CONFIGS[name]
     np.random.seed(seed)
     t0 = time.time()
-    s = tempest.Sampler(prior20, loglike, n_dim, vectorize=True, **kw)
+    s = tempest.Sampler(PRIORS.get(name, prior20), loglike, n_dim, vectorize=True, **kw)
     s.run(n_total=n_total, progress=False)
     wall = time.time() - t0
     x, w, _ = s.posterior()
@@ -97,17 +115,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workers", type=int, default=6)
     ap.add_argument("--seeds", type=int, default=16)
+    ap.add_argument("--seed0", type=int, default=0, help="first seed; earlier results of the same configs with other seeds are kept")
     ap.add_argument("--configs", default=",".join(CONFIGS))
     ap.add_argument("--out", default="/root/repo/tests/golden/ref_ensembles.json")
     a = ap.parse_args()
     import multiprocessing as mp
     import tempest
-    jobs = [(c, k) for c in a.configs.split(",") for k in range(a.seeds)]
+    jobs = [(c, k) for c in a.configs.split(",") for k in range(a.seed0, a.seed0 + a.seeds)]
     out = {"reference": "minaskar/tempest " + tempest.__version__, "numpy": np.__version__,
            "host": "build container, 8 vCPU Xeon 2.1 GHz, 1 thread per run", "runs": []}
     if os.path.exists(a.out):
         old = json.load(open(a.out))
-        keep = [r for r in old.get("runs", []) if r["config"] not in a.configs.split(",")]
+        keep = [r for r in old.get("runs", []) if (r["config"], r["seed"]) not in set(jobs)]
         out["runs"] = keep
     with mp.Pool(a.workers) as pool:
         for r in pool.imap_unordered(run_one, jobs):

@@ -178,7 +178,8 @@ class SamplerCore:
         self.mutator = Mutator(state=state, prior_transform=config.prior_transform, log_likelihood=self._log_like,
                                pbar=None, n_particles=self.n_local, n_dim=config.n_dim, n_steps=config.n_steps,
                                n_max_steps=config.n_max_steps, sampler=config.sample, periodic=config.periodic,
-                               reflective=config.reflective, have_blobs=config.blobs_dtype is not None, rng=self.rng)
+                               reflective=config.reflective, have_blobs=config.blobs_dtype is not None, rng=self.rng,
+                               graph=config.graph)
         self.pbar = None
         self.t0 = 0
         self.timing = {"reweight": 0.0, "train": 0.0, "resample": 0.0, "mutate": 0.0, "commit": 0.0}

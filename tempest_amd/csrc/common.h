@@ -125,6 +125,19 @@ struct tph_rng {
   }
 };
 
+// RNG tick of one MCMC-step launch.  With a device-resident step-control block (tph_adapt's state_dev, see
+// tempest_hip.h) the tick is  tick + state[7] + 2 * state[0]: it advances by two per completed step ON THE DEVICE, so
+// that one captured hipGraph of a step can be replayed without new kernel arguments (and re-used by the next PS
+// iteration after rewriting the block); without one (ctl == NULL) it is the plain by-value tick.
+struct tph_stepctl {
+  uint32_t tick;
+  const double* ctl;
+  __device__ __forceinline__ operator uint32_t() const {
+    return ctl ? tick + (uint32_t)(unsigned long long)ctl[7] + 2u * (uint32_t)ctl[0] : tick;
+  }
+  __device__ __forceinline__ bool done() const { return ctl && ctl[1] != 0.0; }
+};
+
 // Gamma(shape,1), Marsaglia-Tsang; attempt a uses draws 2a (normal) and 2a+1 (uniform); shape<1 boosted.
 __device__ inline double tph_gamma_mt(const tph_rng& g, double shape, int first_attempt = 0) {
   const int max_attempts = 64;

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(PROP_THREADS) k_propose(const double* __restri
                                                           int64_t n, int64_t ld, int d, const double* __restrict__ means,
                                                           const double* __restrict__ chol, const double* __restrict__ inv,
                                                           const double* __restrict__ dof, const double* __restrict__ sigmas,
-                                                          const uint8_t* __restrict__ bc, uint64_t seed, uint32_t tick,
+                                                          const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                           int64_t item0, double* __restrict__ up,
                                                           double* __restrict__ maha_u, double* __restrict__ maha_up) {
   extern __shared__ double sh[];
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
                                                            int64_t n, int64_t ld, int d, const double* __restrict__ means,
                                                            const double* __restrict__ chol, const double* __restrict__ inv,
                                                            const double* __restrict__ dof, const double* __restrict__ sigmas,
-                                                           const uint8_t* __restrict__ bc, uint64_t seed, uint32_t tick,
+                                                           const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                            int64_t item0, double* __restrict__ up,
                                                            double* __restrict__ maha_u, double* __restrict__ maha_up) {
   extern __shared__ double sh[];
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
 template <int KERNEL, int LPP>
 static int launch_propose_ml(tph_ctx* ctx, const double* u, const int32_t* assign, int64_t n, int64_t ld, const double* means,
                              const double* chol, const double* inv, const double* dof, const double* sigmas,
-                             const uint8_t* bc, uint64_t seed, uint32_t tick, int64_t item0, double* up, double* mu_,
+                             const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0, double* up, double* mu_,
                              double* mup) {
   constexpr int PPB = ML_THREADS / LPP;
   const int d = ctx->d;
@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(256) k_propose_reg(const double* __restrict__ 
                                                      int64_t n, int64_t ld, const double* __restrict__ means,
                                                      const double* __restrict__ chol, const double* __restrict__ inv,
                                                      const double* __restrict__ dof, const double* __restrict__ sigmas,
-                                                     const uint8_t* __restrict__ bc, uint64_t seed, uint32_t tick,
+                                                     const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                      int64_t item0, double* __restrict__ up, double* __restrict__ maha_u,
                                                      double* __restrict__ maha_up) {
   __shared__ double s_bfac[256];
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(256) k_propose_reg(const double* __restrict__ 
 template <int KERNEL, int D>
 static void launch_propose_reg(tph_ctx* ctx, const double* u, const int32_t* assign, int64_t n, int64_t ld,
                                const double* means, const double* chol, const double* inv, const double* dof,
-                               const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick, int64_t item0,
+                               const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
                                double* up, double* mu_, double* mup) {
   if (assign == nullptr)
     hipLaunchKernelGGL((k_propose_reg<KERNEL, D, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, u, assign,
@@ -564,8 +564,10 @@ static void launch_propose_reg(tph_ctx* ctx, const double* u, const int32_t* ass
 extern "C" int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const int32_t* assign_dev, int64_t n, int64_t ld,
                            int K, const double* means_dev, const double* chol_dev, const double* inv_dev,
                            const double* dof_dev, const double* sigmas_dev, const uint8_t* bc_dev, uint64_t seed,
-                           uint32_t tick, int64_t item0, double* uprime_dev, double* maha_u_dev, double* maha_up_dev) {
+                           uint32_t tick0, int64_t item0, double* uprime_dev, double* maha_u_dev, double* maha_up_dev,
+                           const double* ctl_dev) {
   TPH_REQUIRE(ctx && u_dev && uprime_dev && chol_dev && sigmas_dev, "tph_propose: NULL argument");
+  const tph_stepctl tick{tick0, ctl_dev};
   TPH_REQUIRE(n > 0 && ld >= n && K >= 1, "tph_propose: bad sizes");
   TPH_REQUIRE(kernel == TPH_KERNEL_TPCN || kernel == TPH_KERNEL_RWM, "tph_propose: unknown kernel %d", kernel);
   if (kernel == TPH_KERNEL_TPCN)
@@ -636,8 +638,10 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accept(double beta, double* __r
                                                         const double* __restrict__ xp, const double* __restrict__ lp,
                                                         const double* __restrict__ maha_u, const double* __restrict__ maha_up,
                                                         const int32_t* __restrict__ assign, int64_t n, int64_t ld, int d, int K,
-                                                        const double* __restrict__ dof, uint64_t seed, uint32_t tick,
+                                                        const double* __restrict__ dof, uint64_t seed, tph_stepctl tick,
                                                         int64_t item0, double* __restrict__ partials) {
+  if (tick.done()) return;              // a step launched past the stopping rule (replayed graph) changes nothing
+  if (tick.ctl) beta = tick.ctl[6];
   int64_t i = (int64_t)blockIdx.x * ACC_THREADS + threadIdx.x;
   double alpha = 0.0, acc = 0.0;
   int c = 0;
@@ -676,9 +680,12 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accept(double beta, double* __r
   }
 }
 
-// column sums of the block partials in block order (deterministic): one thread-block per column
+// column sums of the block partials in block order (deterministic): one thread-block per column.  (Folding this
+// into k_accept behind a last-block ticket was measured SLOWER: the agent-scope release fence writes back the L2 lines
+// the accepted rows have just dirtied, +13 us, against a 5 us kernel that follows with no gap.)
 __global__ void __launch_bounds__(256) k_colsum(const double* __restrict__ partials, int nblocks, int ncol,
-                                                double* __restrict__ out) {
+                                                double* __restrict__ out, tph_stepctl tick) {
+  if (tick.done()) return;
   int cidx = blockIdx.x;
   double s = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partials[(size_t)b * ncol + cidx];
@@ -690,8 +697,9 @@ __global__ void __launch_bounds__(256) k_colsum(const double* __restrict__ parti
 extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, double* x_dev, double* logl_dev,
                           const double* uprime_dev, const double* xprime_dev, const double* loglprime_dev,
                           const double* maha_u_dev, const double* maha_up_dev, const int32_t* assign_dev, int64_t n,
-                          int64_t ld, int K, const double* dof_dev, uint64_t seed, uint32_t tick, int64_t item0,
-                          double* sums_dev) {
+                          int64_t ld, int K, const double* dof_dev, uint64_t seed, uint32_t tick0, int64_t item0,
+                          double* sums_dev, const double* ctl_dev, double* partials_dev) {
+  const tph_stepctl tick{tick0, ctl_dev};
   TPH_REQUIRE(ctx && u_dev && x_dev && logl_dev && uprime_dev && xprime_dev && loglprime_dev && sums_dev,
               "tph_accept: NULL argument");
   TPH_REQUIRE(n > 0 && ld >= n && K >= 1, "tph_accept: bad sizes");
@@ -700,9 +708,12 @@ extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, 
   TPH_REQUIRE(kernel == TPH_KERNEL_TPCN || kernel == TPH_KERNEL_RWM, "tph_accept: unknown kernel %d", kernel);
   if (kernel == TPH_KERNEL_TPCN) TPH_REQUIRE(maha_u_dev && maha_up_dev && dof_dev, "tph_accept: tpCN needs maha/dof");
   unsigned grid = (unsigned)((n + ACC_THREADS - 1) / ACC_THREADS);
-  size_t need = sizeof(double) * (size_t)grid * (1 + K);
-  if (tph_scratch_reserve(ctx, need)) return -1;
-  double* partials = (double*)ctx->scratch;
+  double* partials = partials_dev;       // caller-owned (fixed address: required when the launch is captured in a graph)
+  if (!partials) {
+    size_t need = sizeof(double) * (size_t)grid * (1 + K);
+    if (tph_scratch_reserve(ctx, need)) return -1;
+    partials = (double*)ctx->scratch;
+  }
   if (kernel == TPH_KERNEL_TPCN)
     hipLaunchKernelGGL(k_accept<TPH_KERNEL_TPCN>, dim3(grid), dim3(ACC_THREADS), 0, ctx->stream, beta, u_dev, x_dev, logl_dev,
                        uprime_dev, xprime_dev, loglprime_dev, maha_u_dev, maha_up_dev, assign_dev, n, ld, ctx->d, K, dof_dev,
@@ -711,7 +722,7 @@ extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, 
     hipLaunchKernelGGL(k_accept<TPH_KERNEL_RWM>, dim3(grid), dim3(ACC_THREADS), 0, ctx->stream, beta, u_dev, x_dev, logl_dev,
                        uprime_dev, xprime_dev, loglprime_dev, maha_u_dev, maha_up_dev, assign_dev, n, ld, ctx->d, K, dof_dev,
                        seed, tick, item0, partials);
-  hipLaunchKernelGGL(k_colsum, dim3(1 + K), dim3(256), 0, ctx->stream, partials, (int)grid, 1 + K, sums_dev);
+  hipLaunchKernelGGL(k_colsum, dim3(1 + K), dim3(256), 0, ctx->stream, partials, (int)grid, 1 + K, sums_dev, tick);
   TPH_LAUNCH_CHECK();
   return 0;
 }
@@ -720,8 +731,10 @@ extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, 
 // mcmc.py:180-186 (per-cluster mean alpha), :281-288 / :320-323 (sigma update), :104-140,192-194
 // (adaptive step count incl. the `sigmas[:n_nonempty]` weighting quirk), :196-197 (returned stats).
 __global__ void k_adapt(int kernel, const double* __restrict__ sums, const double* __restrict__ counts, int K, double n_global,
-                        int d, int n_steps, int n_max, double* __restrict__ sigmas, double* __restrict__ state) {
+                        int d, int n_steps, int n_max, double* __restrict__ sigmas, double* __restrict__ state,
+                        double* __restrict__ mailbox, int slots) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (state[1] != 0.0) return;          // stopping rule already fired: later (speculative) steps are no-ops
   const int iteration = (int)state[0] + 1;
   const double sigma_0 = 2.38 / sqrt((double)d);
   const double rate = 1.0 / (double)(iteration + 1);
@@ -755,13 +768,23 @@ __global__ void k_adapt(int kernel, const double* __restrict__ sums, const doubl
   state[3] = alpha_tot / n_global;
   state[4] = (smean / K) / sigma_0;
   state[5] = (double)n_int;
+  if (mailbox) {
+    // the step's record straight into pinned host memory: the host polls the sequence field instead of putting a
+    // device-to-host copy (and its cross-engine barrier) between two steps of the stream
+    double* rec = mailbox + (size_t)(iteration % slots) * 8;
+    for (int j = 0; j < 6; ++j) rec[j] = state[j];
+    __threadfence_system();
+    __hip_atomic_store(rec + 7, (double)iteration, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 extern "C" int tph_adapt(tph_ctx* ctx, int kernel, const double* sums_dev, const double* counts_dev, int K, double n_global,
-                         int n_dim, int n_steps, int n_max, double* sigmas_dev, double* state_dev) {
+                         int n_dim, int n_steps, int n_max, double* sigmas_dev, double* state_dev,
+                         double* mailbox_host, int mailbox_slots) {
   TPH_REQUIRE(ctx && sums_dev && counts_dev && sigmas_dev && state_dev && K >= 1, "tph_adapt: bad argument");
+  TPH_REQUIRE(!mailbox_host || mailbox_slots >= 1, "tph_adapt: mailbox needs at least one slot");
   hipLaunchKernelGGL(k_adapt, dim3(1), dim3(64), 0, ctx->stream, kernel, sums_dev, counts_dev, K, n_global, n_dim, n_steps,
-                     n_max, sigmas_dev, state_dev);
+                     n_max, sigmas_dev, state_dev, mailbox_host, mailbox_slots);
   TPH_LAUNCH_CHECK();
   return 0;
 }

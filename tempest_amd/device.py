@@ -233,25 +233,34 @@ class HipContext:
                                       item0, _ptr(stats)), "tph_inf_repair")
         return stats
 
-    def propose(self, kernel, u, assign, modes, sigmas, bc, seed, tick, item0, uprime, maha_u, maha_up):
+    def propose(self, kernel, u, assign, modes, sigmas, bc, seed, tick, item0, uprime, maha_u, maha_up, ctl=None):
         n = u.shape[1]
         check(self.lib.tph_propose(self._ctx, KERNEL_ID[kernel], _ptr(u), _ptr(assign, torch.int32) if assign is not None else None,
                                    n, n, modes.K, _ptr(modes.means_dev), _ptr(modes.chol_dev), _ptr(modes.inv_dev),
                                    _ptr(modes.dof_dev), _ptr(sigmas), _ptr(bc) if bc is not None else None, seed, tick,
-                                   item0, _ptr(uprime), _ptr(maha_u), _ptr(maha_up)), "tph_propose")
+                                   item0, _ptr(uprime), _ptr(maha_u), _ptr(maha_up),
+                                   _ptr(ctl) if ctl is not None else None), "tph_propose")
 
     def accept(self, kernel, beta, u, x, logl, uprime, xprime, loglprime, maha_u, maha_up, assign, K, dof, seed,
-               tick, item0, sums):
+               tick, item0, sums, ctl=None, partials=None):
         n = u.shape[1]
+        if partials is not None and partials.numel() < ((n + 255) // 256) * (1 + K):
+            raise _lib.TempestHipError("accept: partials buffer too small")
         check(self.lib.tph_accept(self._ctx, KERNEL_ID[kernel], float(beta), _ptr(u), _ptr(x), _ptr(logl),
                                   _ptr(uprime), _ptr(xprime, torch.float64), _ptr(loglprime, torch.float64),
                                   _ptr(maha_u), _ptr(maha_up),
                                   _ptr(assign, torch.int32) if assign is not None else None, n, n, K, _ptr(dof), seed,
-                                  tick, item0, _ptr(sums)), "tph_accept")
+                                  tick, item0, _ptr(sums), _ptr(ctl) if ctl is not None else None,
+                                  _ptr(partials) if partials is not None else None), "tph_accept")
 
-    def adapt(self, kernel, sums, counts, K, n_global, n_steps, n_max, sigmas, state):
+    def adapt(self, kernel, sums, counts, K, n_global, n_steps, n_max, sigmas, state, mailbox=None):
+        """mailbox: pinned host tensor (slots, 8) the step record is also written to (polled by the host)."""
+        if mailbox is not None and not (mailbox.is_pinned() and mailbox.dtype == torch.float64 and mailbox.is_contiguous()):
+            raise _lib.TempestHipError("adapt: mailbox must be a pinned contiguous float64 host tensor")
         check(self.lib.tph_adapt(self._ctx, KERNEL_ID[kernel], _ptr(sums), _ptr(counts), K, float(n_global),
-                                 self.n_dim, int(n_steps), int(n_max), _ptr(sigmas), _ptr(state)), "tph_adapt")
+                                 self.n_dim, int(n_steps), int(n_max), _ptr(sigmas), _ptr(state),
+                                 mailbox.data_ptr() if mailbox is not None else None,
+                                 mailbox.shape[0] if mailbox is not None else 0), "tph_adapt")
 
     def cluster_counts(self, assign, n, K):
         out = self.empty(K)

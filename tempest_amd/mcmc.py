@@ -59,13 +59,156 @@ def check_bounds(u, periodic=None, reflective=None):
     return bool(inside.all()) if u.ndim == 1 else inside.all(axis=-1)
 
 
+class StepEngine:
+    """One MCMC step -- proposal, the two user callbacks, Metropolis update, sigma adaptation -- as a replayable
+    hipGraph over persistent device buffers.
+
+    A step at BASELINE config 4's shard size (131 072 particles, d = 10) is ~15 launches of 5-50 us kernels: issued one
+    by one from Python the host cannot keep the GPU busy.  Everything that changes from step to step (RNG tick, stop
+    flag) and from one PS iteration to the next (beta, tick base, proposal modes, the active set itself) lives in device
+    memory -- the step-control block of tempest_hip.h and the buffers below -- so the graph is captured once per
+    (n, K) and replayed for every later step of the run.  Steps launched past the stopping rule are no-ops on the
+    device, so the host may run one step ahead of the 64-byte state read that tells it when to stop.
+
+    With a communicator the adaptation is not part of the graph: the host all-reduces the per-rank sums between the
+    replay and an eagerly launched tph_adapt.  The user callbacks must be pure device functions of their argument
+    (they are traced once); `graph=False` keeps the step-by-step launch path."""
+
+    SLOTS = 64          # mailbox ring: the host never runs more than a few steps ahead of the record it waits for
+
+    def __init__(self, ctx, kernel, n, K, has_assign, bc, log_likelihood, prior_transform, seed, item0, n_global,
+                 n_steps, n_max, comm_active, use_graph=True):
+        import torch
+        from types import SimpleNamespace
+        d = ctx.n_dim
+        self.ctx, self.kernel, self.n, self.K, self.bc = ctx, kernel, n, K, bc
+        self.loglike, self.prior = log_likelihood, prior_transform
+        self.seed, self.item0, self.n_global = seed, item0, n_global
+        self.n_steps, self.n_max, self.comm_active = n_steps, n_max, comm_active
+        self.u, self.x, self.logl = ctx.empty(d, n), ctx.empty(d, n), ctx.empty(n)
+        self.up, self.maha_u, self.maha_up = ctx.empty(d, n), ctx.empty(n), ctx.empty(n)
+        self.assign = torch.empty(n, dtype=torch.int32, device=ctx.device) if has_assign else None
+        self.modes = SimpleNamespace(K=K, means_dev=ctx.empty(K, d), chol_dev=ctx.empty(K, d, d),
+                                     inv_dev=ctx.empty(K, d, d), dof_dev=ctx.empty(K))
+        self.sigmas, self.counts, self.sums = ctx.empty(K), ctx.empty(K), ctx.zeros(1 + K)
+        self.partials = ctx.empty(((n + 255) // 256) * (1 + K))     # fixed address: the library's scratch may move
+        self.ctl = ctx.zeros(8)
+        self.ctl_host = torch.zeros(8, dtype=torch.float64).pin_memory()
+        self.mailbox = torch.zeros(self.SLOTS, 8, dtype=torch.float64).pin_memory()   # written by tph_adapt, polled here
+        self.mailbox_np = self.mailbox.numpy()
+        self.use_graph, self.graph, self.graph_error = bool(use_graph), None, None
+        self._keep, self.runs = None, 0
+
+    def key(self):
+        return (self.kernel, self.n, self.K, self.assign is not None, self.comm_active)
+
+    def load(self, u, x, logl, assign, modes, beta, tick_base, sigma_init, counts):
+        """Start a run: active set, proposal modes and the step-control block into the persistent buffers."""
+        self.runs += 1
+        self.u.copy_(u); self.x.copy_(x); self.logl.copy_(logl)
+        if self.assign is not None:
+            self.assign.copy_(assign)
+        m = self.modes
+        m.means_dev.copy_(modes.means_dev.reshape(m.means_dev.shape)); m.chol_dev.copy_(modes.chol_dev.reshape(m.chol_dev.shape))
+        m.inv_dev.copy_(modes.inv_dev.reshape(m.inv_dev.shape)); m.dof_dev.copy_(modes.dof_dev.reshape(m.dof_dev.shape))
+        self.sigmas.fill_(sigma_init)
+        self.counts.copy_(counts)
+        self.mailbox_np[:, 7] = -1.0          # no record yet (the device is idle or running no-op steps: see step())
+        h = self.ctl_host
+        h.zero_()
+        h[6], h[7] = float(beta), float(tick_base)
+        self.ctl.copy_(h, non_blocking=True)
+
+    def _enqueue(self):
+        """The launches of one step on the current stream (ticks are offsets: the device adds base + 2 * steps done)."""
+        ctx = self.ctx
+        ctx.propose(self.kernel, self.u, self.assign, self.modes, self.sigmas, self.bc, self.seed, 1, self.item0,
+                    self.up, self.maha_u, self.maha_up, ctl=self.ctl)
+        xp = self.prior(self.up)
+        lp = self.loglike(xp)
+        ctx.accept(self.kernel, 0.0, self.u, self.x, self.logl, self.up, xp, lp, self.maha_u, self.maha_up,
+                   self.assign, self.K, self.modes.dof_dev, self.seed, 2, self.item0, self.sums, ctl=self.ctl,
+                   partials=self.partials)
+        if not self.comm_active:
+            self._adapt()
+        return xp, lp
+
+    def _adapt(self):
+        self.ctx.adapt(self.kernel, self.sums, self.counts, self.K, self.n_global, self.n_steps, self.n_max,
+                       self.sigmas, self.ctl, mailbox=self.mailbox)
+
+    def wait_record(self, step, timeout=60.0):
+        """State record (tph_adapt's state[0..5]) of step `step`, polled from the pinned mailbox."""
+        import time
+        rec = self.mailbox_np[step % self.SLOTS]
+        spins, t0 = 0, None
+        while rec[7] != step:
+            spins += 1
+            if spins & 0x3FFF == 0:
+                t0 = t0 or time.monotonic()
+                if time.monotonic() - t0 > timeout:
+                    from ._lib import TempestHipError
+                    raise TempestHipError(f"MCMC step {step}: no record from the device after {timeout} s")
+        return rec[:6].copy()
+
+    def _capture(self):
+        """Stream capture of one step (torch.cuda.CUDAGraph without torch.cuda.graph's empty_cache(), which would hand
+        the allocator's cached blocks back to the driver in the middle of a run)."""
+        import torch
+        ctx = self.ctx
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=ctx.device)
+        side.wait_stream(torch.cuda.current_stream(ctx.device))
+        began = False
+        try:
+            with torch.cuda.stream(side):
+                ctx.use_current_stream()          # the capturing stream
+                g.capture_begin()
+                began = True
+                self._keep = self._enqueue()      # callback outputs live in the graph's private pool
+                g.capture_end()
+            self.graph = g
+        except Exception as e:                    # callbacks that synchronise or branch on data cannot be captured
+            if began:
+                try:
+                    with torch.cuda.stream(side):
+                        g.capture_end()
+                except Exception:
+                    pass
+            self.graph, self.graph_error, self.use_graph, self._keep = None, e, False, None
+            import warnings
+            warnings.warn(f"MCMC step could not be captured as a graph ({type(e).__name__}: {e}); "
+                          "launching step by step", stacklevel=2)
+        finally:
+            ctx.use_current_stream()
+            torch.cuda.current_stream(ctx.device).wait_stream(side)
+
+    def step(self, comm=None):
+        """Enqueue one full step.  An engine's first run is launched step by step (it sizes the library's scratch, warms
+        the callbacks, and a shape that never repeats -- a cluster count that changes every iteration -- never pays for a
+        capture); the graph is captured after the first step of its second run and replayed from then on."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._enqueue()
+            if self.use_graph and self.runs >= 2:
+                self._capture()
+        if self.comm_active:
+            comm.all_reduce_sum(self.sums)
+            self._adapt()
+
+
 class DeviceMCMC:
     """One mutation run over the active set held on a GPU context."""
 
     def __init__(self, ctx, kernel: str, beta: float, mode_stats, log_likelihood: Callable, prior_transform: Callable,
                  n_steps: int, n_max: int, periodic=None, reflective=None, rng: Optional[PhiloxStream] = None,
-                 comm=None, item0: int = 0, n_global: Optional[int] = None, progress_bar=None, verbose=True):
+                 comm=None, item0: int = 0, n_global: Optional[int] = None, progress_bar=None, verbose=True,
+                 engines: Optional[dict] = None, graph: Optional[bool] = None):
+        """`engines`: a dict kept by the caller across runs; given one, the steps go through a StepEngine (persistent
+        buffers + device-side step control), replayed as a hipGraph unless `graph` is False."""
         import torch
+        self.engines, self.graph = engines, graph
         self.ctx, self.kernel, self.beta, self.modes = ctx, kernel, float(beta), mode_stats
         self.loglike, self.prior = log_likelihood, prior_transform
         self.n_steps, self.n_max = int(n_steps), int(n_max)
@@ -87,8 +230,10 @@ class DeviceMCMC:
         K = modes.K
         assign = assignments if K > 1 else None
         sig0 = min(self.sigma_0, 0.99) if self.kernel == "tpcn" else self.sigma_0      # mcmc.py:222-223,298-299
-        sigmas = torch.full((K,), sig0, dtype=torch.float64, device=ctx.device)
         counts = ctx.cluster_counts(assign, n, K)
+        if self.engines is not None:
+            return self._run_engine(u, x, logl, assign, K, n, n_global, sig0, counts)
+        sigmas = torch.full((K,), sig0, dtype=torch.float64, device=ctx.device)
         state = ctx.zeros(6)
         sums = ctx.empty(1 + K)
         up, maha_u, maha_up = ctx.empty(d, n), ctx.empty(n), ctx.empty(n)
@@ -133,6 +278,42 @@ class DeviceMCMC:
                 if st[1] != 0.0:
                     break
         return float(st[4]), float(st[3]), it, calls
+
+
+    def _run_engine(self, u, x, logl, assign, K, n, n_global, sig0, counts):
+        import torch
+        ctx, d = self.ctx, self.ctx.n_dim
+        active = self.comm is not None and self.comm.active
+        if active:
+            self.comm.all_reduce_sum(counts)
+        key = (self.kernel, n, K, assign is not None, active)
+        eng = self.engines.get(key)
+        if eng is None:
+            if len(self.engines) >= 2:        # at most two engines (and graph memory pools) alive at a time
+                self.engines.pop(next(iter(self.engines)))
+            eng = StepEngine(ctx, self.kernel, n, K, assign is not None, self.bc, self.loglike, self.prior, self.rng.seed,
+                             self.item0, n_global, self.n_steps, self.n_max, active, use_graph=self.graph is not False)
+            self.engines[key] = eng
+        eng.loglike, eng.prior = self.loglike, self.prior
+        tick_base = self.rng.tick
+        eng.load(u, x, logl, assign, self.modes, self.beta, tick_base, sig0, counts)
+        n_min = self.n_steps * d
+        it, st = 0, None
+        eng.step(self.comm)
+        while True:
+            it += 1                           # step `it` is enqueued
+            eng.step(self.comm)               # one step ahead of the read; a no-op on the device if the rule has fired
+            if it >= n_min:                   # the rule cannot fire earlier (mcmc.py:119-131)
+                st = eng.wait_record(it)
+                if self.pbar is not None and self.verbose:
+                    self.pbar.update_stats({"calls": self.pbar.info.get("calls", 0) + n_global, "acc": st[3],
+                                            "steps": it, "eff": st[4]})
+                if st[1] != 0.0:
+                    break
+        u.copy_(eng.u); x.copy_(eng.x); logl.copy_(eng.logl)
+        # two ticks per step + the proposal of the step that was launched ahead (same count as the step-by-step path)
+        self.rng.tick = (tick_base + 2 * it + 1) & 0xFFFFFFFF
+        return float(st[4]), float(st[3]), it, it * n_global
 
 
 def parallel_mcmc(u, x, logl, blobs, assignments, beta, mode_stats, log_likelihood, prior_transform,

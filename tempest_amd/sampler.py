@@ -44,6 +44,7 @@ class Sampler:
         device: Optional[Union[int, str]] = None,
         backend: str = "auto",
         batch_prior: Optional[bool] = None,
+        graph: Optional[bool] = None,
         distributed: Optional[bool] = None,
     ):
         """GPU additions (keyword-only):
@@ -52,6 +53,12 @@ class Sampler:
                        SoA buffer) and return tensors; "numpy": callbacks receive NumPy arrays staged through the
                        host; "auto" (default) probes.
         batch_prior -- True if prior_transform accepts an (n, n_dim) batch (probed when None).
+        graph       -- True: with device callbacks the MCMC step (proposal, both callbacks, Metropolis update,
+                       adaptation) is captured once as a hipGraph and replayed; the callbacks must then be pure device
+                       functions of their argument (no host synchronisation, no Python side effects per call -- a
+                       callback that cannot be captured falls back with a warning).  False: launch every step's
+                       kernels one by one.  None (default): graph when the shard is small enough for the step to be
+                       launch-bound (n_particles_per_gpu * n_dim <= 2^19).
         distributed -- shard the particles over the ranks of the initialised torch.distributed group
                        (default: yes if a group is initialised); n_particles is the GLOBAL count."""
         wrapped = FunctionWrapper(log_likelihood, log_likelihood_args, log_likelihood_kwargs) \
@@ -64,7 +71,7 @@ class Sampler:
             cluster_every=cluster_every, split_threshold=split_threshold, n_max_clusters=n_max_clusters,
             sample=sample, n_steps=n_steps, n_max_steps=n_max_steps, resample=resample, output_dir=output_dir,
             output_label=output_label, random_state=random_state, device=device, backend=backend,
-            batch_prior=batch_prior)
+            batch_prior=batch_prior, graph=graph)
         comm = None
         if distributed is not False:
             from .comm import Comm

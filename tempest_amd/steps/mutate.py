@@ -10,7 +10,7 @@ from ..mcmc import DeviceMCMC
 class Mutator:
     def __init__(self, state, prior_transform, log_likelihood, pbar=None, n_particles: int = 256, n_dim: int = 1,
                  n_steps: int = 10, n_max_steps: int = 1000, sampler: str = "tpcn", periodic=None, reflective=None,
-                 have_blobs: bool = False, rng=None, device_callbacks=None):
+                 have_blobs: bool = False, rng=None, device_callbacks=None, graph=None):
         """`prior_transform(u)` / `log_likelihood(x) -> (logl, blobs)` follow the reference's conventions unless
         `device_callbacks=(prior_dev, like_dev)` is given: SoA tensor -> SoA tensor / (n,) tensor (set by SamplerCore)."""
         self.state = state
@@ -27,6 +27,8 @@ class Mutator:
         self.have_blobs = have_blobs
         self.rng = rng
         self.device_callbacks = device_callbacks
+        self.graph = graph              # None: replay the MCMC step as a hipGraph when the callbacks are device functions
+        self._engines = {}
 
     def _rng(self):
         if self.rng is None:
@@ -86,9 +88,15 @@ class Mutator:
         if self.have_blobs:
             raise NotImplementedError("blobs are not carried on the GPU path (vectorize=True forbids them)")
         u, x, logl = st.dev("u"), st.dev("x"), st.dev("logl")
+        on_device = self.device_callbacks is not None and getattr(
+            getattr(self.device_callbacks[0], "__self__", None), "backend", None) == "torch"
+        # auto: graphs pay when a step's kernels are launch-bound (small shards); at >= ~5e5 coordinates per shard the
+        # host keeps ahead of the GPU anyway and the engine's copy-in/copy-out (1-2 %) is not recovered
+        want = self.graph if self.graph is not None else n * self.n_dim <= (1 << 19)
+        engines = self._engines if (on_device and want) else None
         run = DeviceMCMC(ctx, "rwm" if self.sampler == "rwm" else "tpcn", beta, mode_stats, like_dev, prior_dev,
                          self.n_steps, self.n_max_steps, self.periodic, self.reflective, rng=rng, comm=comm,
-                         item0=item0, n_global=n_global, progress_bar=self.pbar)
+                         item0=item0, n_global=n_global, progress_bar=self.pbar, engines=engines, graph=self.graph)
         efficiency, acceptance, steps, mcmc_calls = run.run(u, x, logl, st.dev("assignments"))
         st.update_current({"efficiency": efficiency, "acceptance": acceptance, "steps": steps,
                            "calls": st.get_current("calls") + mcmc_calls})

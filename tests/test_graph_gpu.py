@@ -1,0 +1,151 @@
+"""The MCMC step as a replayable hipGraph (tempest_amd/mcmc.py: StepEngine): device-side step control
+(tick offset, beta, stop flag), the pinned-host mailbox of tph_adapt, and whole runs that must be bit-identical to the
+step-by-step launch path."""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def prior20(u):
+    return 20 * u - 10
+
+
+def rosen(x):
+    return -(10.0 * (x[:, ::2] ** 2 - x[:, 1::2]) ** 2 + (x[:, ::2] - 1.0) ** 2).sum(dim=1)
+
+
+def bimodal(x):
+    a = -0.5 * (((x - 4.0) / 0.5) ** 2).sum(dim=1)
+    b = -0.5 * (((x + 4.0) / 0.5) ** 2).sum(dim=1)
+    return torch.logaddexp(a, b)
+
+
+def _history(s):
+    st = s.state
+    return {k: np.asarray(st.get_history(k)) for k in ("beta", "logz", "steps", "acceptance", "efficiency")}
+
+
+@pytest.mark.parametrize("kernel,clustering,like,d", [("tpcn", False, rosen, 4), ("rwm", False, rosen, 4),
+                                                      ("tpcn", True, bimodal, 3)])
+def test_graph_run_is_bit_identical(kernel, clustering, like, d):
+    import tempest_amd as tp
+    runs = []
+    for graph in (False, True):
+        s = tp.Sampler(prior20, like, d, n_particles=512, vectorize=True, clustering=clustering, random_state=5,
+                       sample=kernel, graph=graph, periodic=[0] if kernel == "rwm" else None)
+        s.run(n_total=2048, progress=False)
+        runs.append((s.evidence()[0], _history(s), s.posterior()[0], s))
+    eng = runs[1][3]._core.mutator._engines
+    assert eng and any(e.graph is not None for e in eng.values()), "the step was never replayed as a graph"
+    assert not runs[0][3]._core.mutator._engines
+    assert runs[0][0] == runs[1][0]
+    for k in runs[0][1]:
+        np.testing.assert_array_equal(runs[0][1][k], runs[1][1][k], err_msg=k)
+    np.testing.assert_array_equal(runs[0][2], runs[1][2])
+
+
+def test_uncapturable_callback_falls_back():
+    """A likelihood that synchronises with the host cannot be stream-captured: the engine warns once and keeps launching
+    step by step, with the same numbers."""
+    import tempest_amd as tp
+
+    def like_sync(x):
+        ll = -0.5 * (x ** 2).sum(dim=1)
+        if float(ll.max().item()) > 1e300:       # host round trip
+            raise RuntimeError
+        return ll
+
+    def like(x):
+        return -0.5 * (x ** 2).sum(dim=1)
+    s0 = tp.Sampler(prior20, like, 3, n_particles=256, vectorize=True, clustering=False, random_state=2, graph=False)
+    s0.run(n_total=1024, progress=False)
+    s1 = tp.Sampler(prior20, like_sync, 3, n_particles=256, vectorize=True, clustering=False, random_state=2, graph=True)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        s1.run(n_total=1024, progress=False)
+    assert any("could not be captured" in str(w.message) for w in rec)
+    eng = list(s1._core.mutator._engines.values())
+    assert eng and all(e.graph is None and e.graph_error is not None for e in eng)
+    assert s0.evidence()[0] == s1.evidence()[0]
+    # the device is still usable afterwards
+    s2 = tp.Sampler(prior20, like, 3, n_particles=256, vectorize=True, clustering=False, random_state=2, graph=True)
+    s2.run(n_total=1024, progress=False)
+    assert s2.evidence()[0] == s0.evidence()[0]
+
+
+def test_step_control_block_semantics():
+    """tph_propose / tph_accept / tph_adapt with a device-resident control block: tick = tick + ctl[7] + 2 ctl[0], beta from
+    ctl[6], no-ops once ctl[1] is set; tph_adapt's record arrives in the pinned mailbox."""
+    from types import SimpleNamespace
+    from tempest_amd.device import HipContext
+    d, n, K = 5, 1000, 1
+    dev = torch.device("cuda", 0)
+    ctx = HipContext(d, device=0)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    u = (0.3 + 0.4 * torch.rand(d, n, generator=g, dtype=torch.float64)).to(dev)
+    A = torch.randn(d, d, generator=g, dtype=torch.float64)
+    cov = (A @ A.T / d + torch.eye(d, dtype=torch.float64)) * 1e-3
+    modes = SimpleNamespace(K=1, means_dev=torch.full((1, d), 0.5, dtype=torch.float64, device=dev),
+                            chol_dev=torch.linalg.cholesky(cov).reshape(1, d, d).contiguous().to(dev),
+                            inv_dev=torch.linalg.inv(cov).reshape(1, d, d).contiguous().to(dev),
+                            dof_dev=torch.full((1,), 1e6, dtype=torch.float64, device=dev))
+    sig = torch.full((1,), 0.5, dtype=torch.float64, device=dev)
+    seed, base, done_steps = 1234, 100, 3
+
+    def propose(tick, ctl):
+        up, mu, mup = ctx.empty(d, n), ctx.empty(n), ctx.empty(n)
+        ctx.propose("tpcn", u, None, modes, sig, None, seed, tick, 0, up, mu, mup, ctl=ctl)
+        return up, mu, mup
+    ctl = torch.tensor([done_steps, 0, 0, 0, 0, 0, 0.37, base], dtype=torch.float64, device=dev)
+    a = propose(1, ctl)
+    b = propose(1 + base + 2 * done_steps, None)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # accept: beta and tick from the block == by-value call
+    up, mu, mup = a
+    lp = -0.5 * ((up - 0.5) ** 2).sum(dim=0) * 50
+    logl0 = -0.5 * ((u - 0.5) ** 2).sum(dim=0) * 50
+
+    def accept(tick, beta, ctl, partials=None):
+        uu, xx, ll, sums = u.clone(), u.clone(), logl0.clone(), ctx.zeros(2)
+        ctx.accept("tpcn", beta, uu, xx, ll, up, up, lp, mu, mup, None, K, modes.dof_dev, seed, tick, 0, sums, ctl=ctl,
+                   partials=partials)
+        return uu, xx, ll, sums
+    part = ctx.empty(((n + 255) // 256) * 2)
+    r1 = accept(2, 0.0, ctl, part)
+    r2 = accept(2 + base + 2 * done_steps, 0.37, None)
+    for x, y in zip(r1, r2):
+        assert torch.equal(x, y)
+    assert 0 < r1[3][0].item() < n
+    # stop flag set: nothing moves
+    ctl_done = ctl.clone(); ctl_done[1] = 1.0
+    r3 = accept(2, 0.0, ctl_done, part)
+    assert torch.equal(r3[0], u) and torch.equal(r3[2], logl0) and float(r3[3].abs().sum()) == 0.0
+    # adapt: record in the mailbox; a second call after `done` is a no-op
+    counts = torch.full((1,), float(n), dtype=torch.float64, device=dev)
+    sums = r1[3].clone()
+    mailbox = torch.full((4, 8), -1.0, dtype=torch.float64).pin_memory()
+    state = torch.zeros(8, dtype=torch.float64, device=dev)
+    sg = sig.clone()
+    ctx.adapt("tpcn", sums, counts, K, n, 1, 1, sg, state, mailbox=mailbox)    # n_max = n_steps = 1: done after d steps
+    ctx.synchronize()
+    st = state.cpu().numpy()
+    assert st[0] == 1.0 and mailbox[1, 7] == 1.0 and np.array_equal(mailbox[1, :6].numpy(), st[:6])
+    for _ in range(d - 1):
+        ctx.adapt("tpcn", sums, counts, K, n, 1, 1, sg, state, mailbox=mailbox)
+    ctx.synchronize()
+    assert state[0].item() == d and state[1].item() == 1.0 and mailbox[d % 4, 7] == d
+    frozen, sg_frozen = state.clone(), sg.clone()
+    ctx.adapt("tpcn", sums, counts, K, n, 1, 1, sg, state, mailbox=mailbox)
+    ctx.synchronize()
+    assert torch.equal(state, frozen) and torch.equal(sg, sg_frozen)
