@@ -130,6 +130,13 @@ int tph_resample_select(tph_ctx* ctx, const double* cdf_dev, int64_t n, int64_t 
 /* u_out[j][i] = u_hist[j][idx_i] etc. (steps/resample.py:86-99) */
 int tph_gather(tph_ctx* ctx, const int64_t* idx_dev, int64_t n_out, double* u_out, double* x_out,
                double* logl_out, int64_t ld_out);
+/* posterior extraction (core.py:187-242): rows idx_i (idx_dev NULL = the first m rows) of the history's u or x
+ * (key) as ROW-MAJOR (m, d) x_out, with logl_out[i] = logl[idx_i] and, if w_out, w_out[i] = w_dev[idx_i] / wdiv:
+ * only the kept rows cross PCIe, already in the layout Sampler.posterior() returns. */
+int tph_posterior_rows(tph_ctx* ctx, int key, const int64_t* idx_dev, int64_t m, const double* w_dev, double wdiv,
+                       double* x_out /*[m][d]*/, double* logl_out /*[m]*/, double* w_out /*[m] or NULL*/);
+/* out[i] = a[b[i]]: indices of a resampling drawn over an already compacted selection */
+int tph_index_compose(tph_ctx* ctx, const int64_t* a_dev, const int64_t* b_dev, int64_t m, int64_t* out_dev);
 /* multiplicity of each history row among factor*(*kept_count_dev) multinomial draws from cdf (modes.py:196-201);
  * kept_count_dev NULL = n_draw_max draws.  The count stays on the device: no host sync. */
 int tph_multinomial_counts(tph_ctx* ctx, const double* cdf_dev, int64_t n, const double* kept_count_dev, int factor,

@@ -289,35 +289,59 @@ class SamplerCore:
         logw = None
         if return_logw:       # the untrimmed, normalised log-weights (core.py:233-242)
             logw = ctx.logw(1.0, nh).cpu().numpy() - (float(m + np.log(s1)) + np.log(nh))
-        x = ctx.history_read(KEY_X)
-        logl = ctx.history_read(KEY_LOGL)
-        weights = w_dev.cpu().numpy()
         comm = st.comm
-        if comm is not None and comm.active:
+        blobs = st.get_history("blobs", flat=True) if (self.config.blobs_dtype is not None and st._blobs) else None
+        if comm is None or not comm.active:
+            # single shard: threshold, compaction, resampling and the gather into row-major (M, d) stay on the device;
+            # only the M returned rows cross PCIe
+            sel, m_sel, wdiv = None, ctx.size, 1.0
+            if trim_importance_weights:
+                thr_dev, out = ctx.trim_threshold(w_dev, ess_trim, bins_trim, sync=True)
+                m_sel, wdiv = int(out[2]), float(out[1])
+                sel = ctx.compact_indices(w_dev, thr_dev[0:1], m_sel)
+            if resample:
+                from .tools import SQRTEPS
+                _, _, w_sel = ctx.posterior_rows(sel, m_sel, w=w_dev, wdiv=wdiv)
+                cdf = ctx.cdf(w_sel)
+                tot = float(cdf[-1].item())
+                pick = ctx.resample_systematic(cdf, m_sel, np.random.random(),
+                                               renorm=tot if abs(tot - 1.0) > SQRTEPS else 1.0)
+                sel = pick if sel is None else ctx.index_compose(sel, pick)
+                x_dev, logl_dev, _ = ctx.posterior_rows(sel, m_sel)
+                weights = np.ones(m_sel) / m_sel
+            else:
+                x_dev, logl_dev, w_sel = ctx.posterior_rows(sel, m_sel, w=w_dev, wdiv=wdiv)
+                weights = w_sel.cpu().numpy()
+            x, logl = x_dev.cpu().numpy(), logl_dev.cpu().numpy()
+            if blobs is not None and sel is not None:
+                blobs = blobs[sel.cpu().numpy()]
+        else:
             # sharded run: every rank returns the posterior over the WHOLE history (rows of all shards, rank order);
             # the weights are already normalised by the global sum
+            x = ctx.history_read(KEY_X)
+            logl = ctx.history_read(KEY_LOGL)
+            weights = w_dev.cpu().numpy()
             x, logl, weights = comm.gather_rows(x), comm.gather_rows(logl), comm.gather_rows(weights)
             if logw is not None:
                 logw = comm.gather_rows(logw)
             w_dev = torch.from_numpy(np.ascontiguousarray(weights)).to(ctx.device)
-        blobs = st.get_history("blobs", flat=True) if (self.config.blobs_dtype is not None and st._blobs) else None
-        if trim_importance_weights:
-            _, out = ctx.trim_threshold(w_dev, ess_trim, bins_trim, sync=True)
-            mask = weights >= out[0]
-            x, logl, weights = x[mask], logl[mask], weights[mask] / out[1]
-            if blobs is not None:
-                blobs = blobs[mask]
-        if resample:
-            from .tools import SQRTEPS
-            wt = torch.from_numpy(np.ascontiguousarray(weights)).to(ctx.device)
-            cdf = ctx.cdf(wt)
-            tot = float(weights.sum())
-            idx = ctx.resample_systematic(cdf, len(weights), np.random.random(),
-                                          renorm=tot if abs(tot - 1.0) > SQRTEPS else 1.0).cpu().numpy()
-            x, logl = x[idx], logl[idx]
-            if blobs is not None:
-                blobs = blobs[idx]
-            weights = np.ones(len(idx)) / len(idx)
+            if trim_importance_weights:
+                _, out = ctx.trim_threshold(w_dev, ess_trim, bins_trim, sync=True)
+                mask = weights >= out[0]
+                x, logl, weights = x[mask], logl[mask], weights[mask] / out[1]
+                if blobs is not None:
+                    blobs = blobs[mask]
+            if resample:
+                from .tools import SQRTEPS
+                wt = torch.from_numpy(np.ascontiguousarray(weights)).to(ctx.device)
+                cdf = ctx.cdf(wt)
+                tot = float(weights.sum())
+                idx = ctx.resample_systematic(cdf, len(weights), np.random.random(),
+                                              renorm=tot if abs(tot - 1.0) > SQRTEPS else 1.0).cpu().numpy()
+                x, logl = x[idx], logl[idx]
+                if blobs is not None:
+                    blobs = blobs[idx]
+                weights = np.ones(len(idx)) / len(idx)
         out = [x, weights, logl]
         if return_blobs and blobs is not None:
             out.append(blobs)

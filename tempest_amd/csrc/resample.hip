@@ -135,6 +135,70 @@ extern "C" int tph_gather(tph_ctx* ctx, const int64_t* idx_dev, int64_t n_out, d
   return 0;
 }
 
+// posterior extraction (core.py:187-242 after the trim): selected history rows as ROW-MAJOR (m, d) parameters, their
+// log-likelihoods and (rescaled) weights, so that only the kept rows cross PCIe and the host gets the layout it
+// returns.  64 rows x 32 dimensions per LDS tile: indexed reads along the rows, 256-byte row segments out.
+constexpr int POST_R = 64, POST_C = 32;
+__global__ void __launch_bounds__(256) k_posterior_rows(const double* __restrict__ hx, const double* __restrict__ hl,
+                                                        int64_t cap, int d, const int64_t* __restrict__ idx, int64_t m,
+                                                        const double* __restrict__ w, double wdiv,
+                                                        double* __restrict__ x_out, double* __restrict__ l_out,
+                                                        double* __restrict__ w_out) {
+  __shared__ double tile[POST_R][POST_C + 1];
+  __shared__ int64_t rows[POST_R];
+  const int64_t row0 = (int64_t)blockIdx.x * POST_R;
+  const int t = threadIdx.x;
+  if (t < POST_R) {
+    int64_t i = row0 + t;
+    int64_t s = i < m ? (idx ? idx[i] : i) : -1;
+    rows[t] = s;
+    if (s >= 0) {
+      l_out[i] = hl[s];
+      if (w_out) w_out[i] = w[s] / wdiv;
+    }
+  }
+  __syncthreads();
+  for (int j0 = 0; j0 < d; j0 += POST_C) {
+    for (int e = t; e < POST_R * POST_C; e += 256) {      // row fastest: neighbouring lanes read neighbouring history rows
+      int r = e % POST_R, c = e / POST_R;
+      int64_t s = rows[r];
+      if (s >= 0 && j0 + c < d) tile[r][c] = hx[(size_t)(j0 + c) * cap + s];
+    }
+    __syncthreads();
+    for (int e = t; e < POST_R * POST_C; e += 256) {      // dimension fastest: contiguous segments of the output rows
+      int c = e % POST_C, r = e / POST_C;
+      if (rows[r] >= 0 && j0 + c < d) x_out[(size_t)(row0 + r) * d + j0 + c] = tile[r][c];
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int tph_posterior_rows(tph_ctx* ctx, int key, const int64_t* idx_dev, int64_t m, const double* w_dev, double wdiv,
+                                  double* x_out, double* logl_out, double* w_out) {
+  TPH_REQUIRE(ctx && x_out && logl_out, "tph_posterior_rows: NULL argument");
+  TPH_REQUIRE(key == TPH_KEY_U || key == TPH_KEY_X, "tph_posterior_rows: key must be TPH_KEY_U or TPH_KEY_X");
+  TPH_REQUIRE(m > 0 && (idx_dev || m <= ctx->size), "tph_posterior_rows: bad sizes");
+  TPH_REQUIRE(!w_out || w_dev, "tph_posterior_rows: w_out needs w_dev");
+  hipLaunchKernelGGL(k_posterior_rows, dim3((unsigned)((m + POST_R - 1) / POST_R)), dim3(256), 0, ctx->stream,
+                     key == TPH_KEY_U ? ctx->u : ctx->x, ctx->logl, ctx->cap, ctx->d, idx_dev, m, w_dev, wdiv, x_out, logl_out,
+                     w_out);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[i] = a[b[i]]  (indices of a resampling drawn over an already compacted selection)
+__global__ void __launch_bounds__(256) k_index_compose(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t m,
+                                                       int64_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) out[i] = a[b[i]];
+}
+extern "C" int tph_index_compose(tph_ctx* ctx, const int64_t* a_dev, const int64_t* b_dev, int64_t m, int64_t* out_dev) {
+  TPH_REQUIRE(ctx && a_dev && b_dev && out_dev && m > 0, "tph_index_compose: bad argument");
+  hipLaunchKernelGGL(k_index_compose, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, a_dev, b_dev, m, out_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
 // multiplicities of `factor * kept_count` multinomial draws (kept_count lives on the device: no host sync)
 __global__ void __launch_bounds__(256) k_multinomial_counts(const double* __restrict__ cdf, int64_t n,
                                                             const double* __restrict__ kept_count_dev, int factor,

@@ -213,6 +213,21 @@ class HipContext:
         check(self.lib.tph_gather(self._ctx, _ptr(idx, torch.int64), idx.numel(), _ptr(u_out), _ptr(x_out),
                                   _ptr(logl_out), u_out.shape[1]), "tph_gather")
 
+    def posterior_rows(self, idx, m, w=None, wdiv=1.0, key=KEY_X):
+        """Rows `idx` (None: the first m) of the history as device tensors x (m, d) row-major, logl (m,), w/wdiv (m,)."""
+        x, logl = self.empty(m, self.n_dim), self.empty(m)
+        wout = self.empty(m) if w is not None else None
+        if m > 0:
+            check(self.lib.tph_posterior_rows(self._ctx, key, _ptr(idx, torch.int64), m, _ptr(w, torch.float64), float(wdiv),
+                                              _ptr(x), _ptr(logl), _ptr(wout)), "tph_posterior_rows")
+        return x, logl, wout
+
+    def index_compose(self, a, b):
+        out = self.empty(b.numel(), dtype=torch.int64)
+        check(self.lib.tph_index_compose(self._ctx, _ptr(a, torch.int64), _ptr(b, torch.int64), b.numel(), _ptr(out)),
+              "tph_index_compose")
+        return out
+
     def multinomial_counts(self, cdf, seed, tick, kept_count=None, factor=4, n_draw_max=None, tag=TAG_UPSAMPLE):
         n = cdf.numel()
         counts = self.empty(n, dtype=torch.int32)

@@ -447,3 +447,28 @@ def test_inf_repair_vs_oracle(dev):
     np.testing.assert_array_equal(aos(xt), wx)
     np.testing.assert_array_equal(lt.cpu().numpy(), wl)
     assert np.all(np.isfinite(lt.cpu().numpy()))
+
+
+@pytest.mark.parametrize("d,n,m", [(3, 1000, 1), (10, 5000, 777), (37, 3000, 3000), (100, 2000, 129)])
+def test_posterior_rows_and_index_compose(d, n, m):
+    """tph_posterior_rows: selected history rows as row-major (m, d) + logl + w / wdiv; tph_index_compose: a[b]."""
+    from tempest_amd.device import HipContext, KEY_U, KEY_X
+    rng = np.random.RandomState(d)
+    ctx = HipContext(d, device=0)
+    u, x, logl = rng.rand(n, d), rng.randn(n, d), rng.randn(n)
+    ctx.history_load(u, x, logl, [0.0], [0.0], [n])
+    w = torch.from_numpy(rng.rand(n)).cuda()
+    idx_h = np.sort(rng.choice(n, m, replace=False)) if m < n else rng.permutation(n)
+    idx = torch.from_numpy(idx_h.astype(np.int64)).cuda()
+    xo, lo, wo = ctx.posterior_rows(idx, m, w=w, wdiv=0.37)
+    np.testing.assert_array_equal(xo.cpu().numpy(), x[idx_h])
+    np.testing.assert_array_equal(lo.cpu().numpy(), logl[idx_h])
+    np.testing.assert_array_equal(wo.cpu().numpy(), w.cpu().numpy()[idx_h] / 0.37)
+    uo, lo2, none = ctx.posterior_rows(None, m, key=KEY_U)
+    assert none is None
+    np.testing.assert_array_equal(uo.cpu().numpy(), u[:m])
+    np.testing.assert_array_equal(lo2.cpu().numpy(), logl[:m])
+    b_h = rng.randint(0, m, size=2 * m + 3)
+    comp = ctx.index_compose(idx, torch.from_numpy(b_h.astype(np.int64)).cuda())
+    np.testing.assert_array_equal(comp.cpu().numpy(), idx_h[b_h])
+    _ = KEY_X
