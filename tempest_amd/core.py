@@ -218,8 +218,14 @@ class SamplerCore:
         self.state.set_current("logz", logz)
         self.logz_err = None
         if save_every is not None:
-            self.save_sampler_state(self.config.output_dir / f"{self.config.output_label}_final.state")
+            self.save_sampler_state(self._checkpoint_path("final"))
         self.pbar.close()
+
+    def _checkpoint_path(self, tag: str) -> Path:
+        """{output_dir}/{label}_{tag}.state (core.py:154-171); a sharded run writes a checkpoint directory, `.ckpt`."""
+        comm = self.state.comm
+        sharded = comm is not None and comm.active
+        return self.config.output_dir / f"{self.config.output_label}_{tag}{'.ckpt' if sharded else '.state'}"
 
     def execute_iteration(self, save_every: Optional[int] = None, t0: int = 0, return_state: bool = True):
         """One PS iteration: reweight -> train -> resample -> mutate -> commit (core.py:162-185).  Returns host copies
@@ -231,7 +237,7 @@ class SamplerCore:
         if save_every is not None:
             it = self.state.get_current("iter")
             if (it - t0) % int(save_every) == 0 and it != t0:
-                self.save_sampler_state(self.config.output_dir / f"{self.config.output_label}_{it}.state")
+                self.save_sampler_state(self._checkpoint_path(str(it)))
         if getattr(self, "profile", False):
             return self._execute_iteration_profiled()
         weights = self.reweighter.run()
@@ -353,11 +359,15 @@ class SamplerCore:
         return self.state.get_current("logz"), getattr(self, "logz_err", None)
 
     # -------------------------------------------------------------------------- persistence
-    def save_sampler_state(self, path: Union[str, Path]):
+    def save_sampler_state(self, path: Union[str, Path], format: Optional[str] = None):
         """Reference layout {_current, _history, n_dim, random_state, n_total, logz_err} (core.py:249-279);
-        the callbacks are not pickled (the reference's `sampler=dill.dumps(core)` entry is omitted)."""
+        the callbacks are not pickled (the reference's `sampler=dill.dumps(core)` entry is omitted).  `format="native"`,
+        a path ending in ".ckpt", or a sharded run write the directory format of tempest_amd/checkpoint.py instead."""
         import dill
+        from . import checkpoint
         path = Path(path)
+        if checkpoint.wants_native(path, format, self.state.comm):
+            return checkpoint.save(self, path)
         path.parent.mkdir(parents=True, exist_ok=True)
         d = self.state.to_dict()
         d["random_state"] = self.config.random_state
@@ -370,6 +380,15 @@ class SamplerCore:
     def load_sampler_state(self, path: Union[str, Path]):
         """Restore current state AND history (the reference drops the history, core.py:289)."""
         import dill
+        from . import checkpoint
+        if checkpoint.is_native(path):
+            checkpoint.load(self, path)
+            defaults = {"iter": 0, "calls": 0, "beta": 0.0, "logz": 0.0, "steps": 0, "acceptance": 0.0,
+                        "efficiency": 0.0, "cv": None}
+            for key, val in defaults.items():
+                if self.state.get_current(key) is None:
+                    self.state.set_current(key, val)
+            return
         with open(Path(path), "rb") as f:
             d = dill.load(f)
         self.state.update_from_dict(d)

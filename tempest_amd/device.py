@@ -106,12 +106,16 @@ class HipContext:
     def history_clear(self):
         check(self.lib.tph_history_clear(self._ctx), "tph_history_clear")
 
-    def history_load(self, u, x, logl, beta_t, logz_t, n_t, n_t_global=None):
-        """u, x: host arrays (N_h, d) or None; logl (N_h,)."""
+    def history_load(self, u, x, logl, beta_t, logz_t, n_t, n_t_global=None, soa=False):
+        """u, x: host arrays (N_h, d) -- or (d, N_h), the device layout, with soa=True -- or None; logl (N_h,)."""
         logl = np.ascontiguousarray(logl, dtype=np.float64)
         n = logl.size
-        ut = np.ascontiguousarray(np.asarray(u, dtype=np.float64).T) if u is not None else None
-        xt = np.ascontiguousarray(np.asarray(x, dtype=np.float64).T) if x is not None else None
+        tr = (lambda a: a) if soa else (lambda a: a.T)
+        ut = np.ascontiguousarray(tr(np.asarray(u, dtype=np.float64))) if u is not None else None
+        xt = np.ascontiguousarray(tr(np.asarray(x, dtype=np.float64))) if x is not None else None
+        for a in (ut, xt):
+            if a is not None and a.shape != (self.n_dim, n):
+                raise _lib.TempestHipError(f"history_load: array of shape {a.shape}, expected {(self.n_dim, n)}")
         bt = np.ascontiguousarray(beta_t, dtype=np.float64)
         zt = np.ascontiguousarray(logz_t, dtype=np.float64)
         nt = np.ascontiguousarray(n_t, dtype=np.int64)
@@ -120,8 +124,8 @@ class HipContext:
                                         _hptr(xt) if xt is not None else None, _hptr(logl), n, bt.size,
                                         _hptr(bt), _hptr(zt), _hptr(nt), _hptr(ng)), "tph_history_load")
 
-    def history_read(self, key, off=0, n=None):
-        """Host copy: (n, d) C-contiguous for u/x, (n,) for logl/logmix."""
+    def history_read(self, key, off=0, n=None, soa=False):
+        """Host copy: (n, d) C-contiguous for u/x -- (d, n), the device layout, with soa=True --, (n,) for logl/logmix."""
         n = self.size - off if n is None else n
         if key in (KEY_U, KEY_X):
             buf = np.empty((self.n_dim, n), dtype=np.float64)
@@ -129,7 +133,7 @@ class HipContext:
             buf = np.empty((n,), dtype=np.float64)
         if n > 0:
             check(self.lib.tph_history_read(self._ctx, key, off, n, _hptr(buf)), "tph_history_read")
-        return np.ascontiguousarray(buf.T) if buf.ndim == 2 else buf
+        return np.ascontiguousarray(buf.T) if (buf.ndim == 2 and not soa) else buf
 
     # --------------------------------------------------------------------------- reweighting
     def reweight_eval(self, betas):

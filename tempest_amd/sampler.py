@@ -110,8 +110,10 @@ class Sampler:
     def results(self):
         return self.state.compute_results()
 
-    def save_state(self, path: Union[str, Path]):
-        self._core.save_sampler_state(Path(path))
+    def save_state(self, path: Union[str, Path], *, format: Optional[str] = None):
+        """format=None: the reference's dill layout, unless `path` ends in ".ckpt" or the run is sharded over several
+        GPUs -- then (and with format="native") a checkpoint directory of raw per-shard dumps (checkpoint.py)."""
+        self._core.save_sampler_state(Path(path), format=format)
 
     def load_state(self, path: Union[str, Path]):
         self._core.load_sampler_state(Path(path))

@@ -131,6 +131,28 @@ def sharded_gpu_worker(rank, world, port, out_dir):
     xa, wa, _ = s.posterior(trim_importance_weights=False)
     assert len(wa) == nh_global                                             # rows of BOTH shards on every rank
     np.testing.assert_allclose(np.average(x, weights=w, axis=0), np.linspace(-2, 2, 6), atol=0.15)
+    # ---- sharded checkpoint: one directory, one raw shard per rank, resume continues identically on every rank
+    mk = lambda: tp.Sampler(lambda uu: 20 * uu - 10, loglike, 6, n_particles=512, vectorize=True, clustering=False,  # noqa: E731
+                            random_state=11, device=0, output_dir=os.path.join(out_dir, "ck"), output_label="ps")
+    sa = mk()
+    for _ in range(5):
+        sa.sample(return_state=False)
+    ck = os.path.join(out_dir, "mid.ckpt")
+    sa.save_state(ck)
+    comm.barrier()
+    assert sorted(os.listdir(ck)) == sorted(["meta.json"] + [f"shard{r:04d}.{n}" for r in range(world) for n in (
+        "hist_u.f64", "hist_x.f64", "hist_logl.f64", "cur_u.f64", "cur_x.f64", "cur_logl.f64", "cur_assign.i32")])
+    meta = json.load(open(os.path.join(ck, "meta.json")))
+    assert meta["world_size"] == world and meta["n_local_t"] == [256] * 5 and meta["n_global_t"] == [512] * 5
+    sb = mk()
+    sb.run(n_total=2048, progress=False, resume_state_path=ck, save_every=3)
+    sc = mk()
+    sc.run(n_total=2048, progress=False)
+    assert sb.evidence()[0] == sc.evidence()[0]
+    np.testing.assert_array_equal(sb.state.get_history("logl", flat=True), sc.state.get_history("logl", flat=True))
+    comm.barrier()
+    names = sorted(os.listdir(os.path.join(out_dir, "ck")))
+    assert "ps_final.ckpt" in names and all(n.endswith(".ckpt") for n in names), names
     res["logz"] = logzs
     res["analytic"] = float(-6 * np.log(20.0))
     assert all(abs(z - res["analytic"]) < 0.35 for z in logzs), logzs
