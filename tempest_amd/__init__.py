@@ -4,4 +4,11 @@ __version__ = "0.1.0"
 
 from .sampler import Sampler
 
-__all__ = ["Sampler"]
+__all__ = ["Sampler", "HipCallbacks"]
+
+
+def __getattr__(name):          # lazy: importing the package must not need hipcc or a GPU
+    if name == "HipCallbacks":
+        from .hipcallbacks import HipCallbacks
+        return HipCallbacks
+    raise AttributeError(name)

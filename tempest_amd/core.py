@@ -27,6 +27,8 @@ class CallbackAdapter:
         self.backend = None if config.backend == "auto" else config.backend
         self.batch_prior = config.batch_prior
         self._distribute = get_distribute_func
+        from .hipcallbacks import fused_plugin
+        self.hip_plugin = fused_plugin(config.prior_transform, config.log_likelihood)   # HipCallbacks pair -> fused step
 
     # ------------------------------------------------------------------ probing
     def _probe(self):

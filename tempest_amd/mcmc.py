@@ -77,9 +77,10 @@ class StepEngine:
     SLOTS = 64          # mailbox ring: the host never runs more than a few steps ahead of the record it waits for
 
     def __init__(self, ctx, kernel, n, K, has_assign, bc, log_likelihood, prior_transform, seed, item0, n_global,
-                 n_steps, n_max, comm_active, use_graph=True):
+                 n_steps, n_max, comm_active, use_graph=True, plugin=None):
         import torch
         from types import SimpleNamespace
+        self.plugin = plugin
         d = ctx.n_dim
         self.ctx, self.kernel, self.n, self.K, self.bc = ctx, kernel, n, K, bc
         self.loglike, self.prior = log_likelihood, prior_transform
@@ -100,7 +101,7 @@ class StepEngine:
         self._keep, self.runs = None, 0
 
     def key(self):
-        return (self.kernel, self.n, self.K, self.assign is not None, self.comm_active)
+        return (self.kernel, self.n, self.K, self.assign is not None, self.comm_active, id(self.plugin))
 
     def load(self, u, x, logl, assign, modes, beta, tick_base, sigma_init, counts):
         """Start a run: active set, proposal modes and the step-control block into the persistent buffers."""
@@ -124,11 +125,18 @@ class StepEngine:
         ctx = self.ctx
         ctx.propose(self.kernel, self.u, self.assign, self.modes, self.sigmas, self.bc, self.seed, 1, self.item0,
                     self.up, self.maha_u, self.maha_up, ctl=self.ctl)
-        xp = self.prior(self.up)
-        lp = self.loglike(xp)
-        ctx.accept(self.kernel, 0.0, self.u, self.x, self.logl, self.up, xp, lp, self.maha_u, self.maha_up,
-                   self.assign, self.K, self.modes.dof_dev, self.seed, 2, self.item0, self.sums, ctl=self.ctl,
-                   partials=self.partials)
+        if self.plugin is not None:       # callbacks compiled into the Metropolis kernel (hipcallbacks.py)
+            from .device import KERNEL_ID
+            xp = lp = None
+            self.plugin.accept(KERNEL_ID[self.kernel], 0.0, self.u, self.x, self.logl, self.up, self.maha_u, self.maha_up,
+                               self.assign, self.K, self.modes.dof_dev, self.seed, 2, self.item0, self.sums,
+                               ctl=self.ctl, partials=self.partials)
+        else:
+            xp = self.prior(self.up)
+            lp = self.loglike(xp)
+            ctx.accept(self.kernel, 0.0, self.u, self.x, self.logl, self.up, xp, lp, self.maha_u, self.maha_up,
+                       self.assign, self.K, self.modes.dof_dev, self.seed, 2, self.item0, self.sums, ctl=self.ctl,
+                       partials=self.partials)
         if not self.comm_active:
             self._adapt()
         return xp, lp
@@ -204,11 +212,11 @@ class DeviceMCMC:
     def __init__(self, ctx, kernel: str, beta: float, mode_stats, log_likelihood: Callable, prior_transform: Callable,
                  n_steps: int, n_max: int, periodic=None, reflective=None, rng: Optional[PhiloxStream] = None,
                  comm=None, item0: int = 0, n_global: Optional[int] = None, progress_bar=None, verbose=True,
-                 engines: Optional[dict] = None, graph: Optional[bool] = None):
+                 engines: Optional[dict] = None, graph: Optional[bool] = None, plugin=None):
         """`engines`: a dict kept by the caller across runs; given one, the steps go through a StepEngine (persistent
         buffers + device-side step control), replayed as a hipGraph unless `graph` is False."""
         import torch
-        self.engines, self.graph = engines, graph
+        self.engines, self.graph, self.plugin = engines, graph, plugin
         self.ctx, self.kernel, self.beta, self.modes = ctx, kernel, float(beta), mode_stats
         self.loglike, self.prior = log_likelihood, prior_transform
         self.n_steps, self.n_max = int(n_steps), int(n_max)
@@ -246,6 +254,7 @@ class DeviceMCMC:
         state_host = torch.empty(6, dtype=torch.float64).pin_memory()
         ev = torch.cuda.Event()
         speculated = False
+        partials = None
 
         def propose():
             ctx.propose(self.kernel, u, assign, modes, sigmas, self.bc, self.rng.seed, self.rng.next(), self.item0,
@@ -255,11 +264,18 @@ class DeviceMCMC:
             if not speculated:
                 propose()
             speculated = False
-            xp = self.prior(up)                       # (d, n) SoA tensor
-            lp = self.loglike(xp)                     # (n,) tensor
             calls += n_global
-            ctx.accept(self.kernel, self.beta, u, x, logl, up, xp, lp, maha_u, maha_up, assign, K, modes.dof_dev,
-                       self.rng.seed, self.rng.next(), self.item0, sums)
+            if self.plugin is not None:               # callbacks compiled into the Metropolis kernel (hipcallbacks.py)
+                from .device import KERNEL_ID
+                if partials is None:
+                    partials = ctx.empty(((n + 255) // 256) * (1 + K))
+                self.plugin.accept(KERNEL_ID[self.kernel], self.beta, u, x, logl, up, maha_u, maha_up, assign, K,
+                                   modes.dof_dev, self.rng.seed, self.rng.next(), self.item0, sums, partials=partials)
+            else:
+                xp = self.prior(up)                   # (d, n) SoA tensor
+                lp = self.loglike(xp)                 # (n,) tensor
+                ctx.accept(self.kernel, self.beta, u, x, logl, up, xp, lp, maha_u, maha_up, assign, K, modes.dof_dev,
+                           self.rng.seed, self.rng.next(), self.item0, sums)
             if active:
                 self.comm.all_reduce_sum(sums)
             ctx.adapt(self.kernel, sums, counts, K, n_global, self.n_steps, self.n_max, sigmas, state)
@@ -286,15 +302,16 @@ class DeviceMCMC:
         active = self.comm is not None and self.comm.active
         if active:
             self.comm.all_reduce_sum(counts)
-        key = (self.kernel, n, K, assign is not None, active)
+        key = (self.kernel, n, K, assign is not None, active, id(self.plugin))
         eng = self.engines.get(key)
         if eng is None:
             if len(self.engines) >= 2:        # at most two engines (and graph memory pools) alive at a time
                 self.engines.pop(next(iter(self.engines)))
             eng = StepEngine(ctx, self.kernel, n, K, assign is not None, self.bc, self.loglike, self.prior, self.rng.seed,
-                             self.item0, n_global, self.n_steps, self.n_max, active, use_graph=self.graph is not False)
+                             self.item0, n_global, self.n_steps, self.n_max, active, use_graph=self.graph is not False,
+                             plugin=self.plugin)
             self.engines[key] = eng
-        eng.loglike, eng.prior = self.loglike, self.prior
+        eng.loglike, eng.prior, eng.plugin = self.loglike, self.prior, self.plugin
         tick_base = self.rng.tick
         eng.load(u, x, logl, assign, self.modes, self.beta, tick_base, sig0, counts)
         n_min = self.n_steps * d

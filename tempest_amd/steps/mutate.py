@@ -88,15 +88,17 @@ class Mutator:
         if self.have_blobs:
             raise NotImplementedError("blobs are not carried on the GPU path (vectorize=True forbids them)")
         u, x, logl = st.dev("u"), st.dev("x"), st.dev("logl")
-        on_device = self.device_callbacks is not None and getattr(
-            getattr(self.device_callbacks[0], "__self__", None), "backend", None) == "torch"
+        adapter = getattr(self.device_callbacks[0], "__self__", None) if self.device_callbacks is not None else None
+        on_device = getattr(adapter, "backend", None) == "torch"
+        plugin = getattr(adapter, "hip_plugin", None)      # both callbacks are HIP device functions: fused step
         # auto: graphs pay when a step's kernels are launch-bound (small shards); at >= ~5e5 coordinates per shard the
         # host keeps ahead of the GPU anyway and the engine's copy-in/copy-out (1-2 %) is not recovered
         want = self.graph if self.graph is not None else n * self.n_dim <= (1 << 19)
         engines = self._engines if (on_device and want) else None
         run = DeviceMCMC(ctx, "rwm" if self.sampler == "rwm" else "tpcn", beta, mode_stats, like_dev, prior_dev,
                          self.n_steps, self.n_max_steps, self.periodic, self.reflective, rng=rng, comm=comm,
-                         item0=item0, n_global=n_global, progress_bar=self.pbar, engines=engines, graph=self.graph)
+                         item0=item0, n_global=n_global, progress_bar=self.pbar, engines=engines, graph=self.graph,
+                         plugin=plugin)
         efficiency, acceptance, steps, mcmc_calls = run.run(u, x, logl, st.dev("assignments"))
         st.update_current({"efficiency": efficiency, "acceptance": acceptance, "steps": steps,
                            "calls": st.get_current("calls") + mcmc_calls})
