@@ -40,6 +40,24 @@ def rosenbrock_numpy(x):
     return -np.sum(10.0 * (x[:, ::2] ** 2.0 - x[:, 1::2]) ** 2.0 + (x[:, ::2] - 1.0) ** 2.0, axis=1)
 
 
+# The same target as HIP device functions (tempest_amd.HipCallbacks): evaluated inside the Metropolis kernel.
+ROSENBROCK_HIP = """
+__device__ void prior_transform(const double* u, double* x) {
+#pragma unroll
+  for (int j = 0; j < N_DIM; ++j) x[j] = 20.0 * u[j] - 10.0;
+}
+__device__ double log_likelihood(const double* x) {
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < N_DIM; j += 2) {
+    double a = x[j] * x[j] - x[j + 1], b = x[j] - 1.0;
+    s += 10.0 * a * a + b * b;
+  }
+  return -s;
+}
+"""
+
+
 def prior20(u):
     return 20 * u - 10
 
@@ -126,6 +144,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-finish", action="store_true", help="skip running on to termination for logZ")
+    ap.add_argument("--no-hip-callbacks", action="store_true",
+                    help="skip the second run with the callbacks compiled into the step (tempest_amd.HipCallbacks)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--roofline-only", action="store_true", help="only the reweight-kernel microbench (for rocprofv3 --pmc)")
     a = ap.parse_args()
@@ -162,21 +182,28 @@ def main():
         if use_dist:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        s.sample(return_state=False)
-    sync()
-    it0 = len(s.state._scalars["steps"])
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        s.sample(return_state=False)
-    sync()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    steps_t = np.asarray(s.state._scalars["steps"][it0:])
-    beta_t = np.asarray(s.state._scalars["beta"][it0:])
+    def timed(s):
+        """W untimed + K timed PS iterations; (seconds [max over ranks], steps per timed iteration, betas)."""
+        import gc
+        for _ in range(a.warmup):
+            s.sample(return_state=False)
+        sync()
+        it0 = len(s.state._scalars["steps"])
+        gc.collect()
+        gc.disable()          # as timeit does: a generation-2 collection (tens of ms with torch loaded) is not the workload
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            s.sample(return_state=False)
+        sync()
+        dt = time.perf_counter() - t0
+        gc.enable()
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, np.asarray(s.state._scalars["steps"][it0:]), np.asarray(s.state._scalars["beta"][it0:])
+
+    dt, steps_t, beta_t = timed(s)
     pms = float(np.sum(steps_t[beta_t > 0])) * n_global
     value = pms / dt
 
@@ -204,6 +231,24 @@ def main():
                       "n_dim": 10, "particles_per_gpu": n_local, "particles_global": n_global, "sample": "tpcn",
                       "resample": "mult", "clustering": False, "n_total": n_total, "step": "one PS iteration"}}
     out.update(extra)
+    out["config"]["callbacks"] = "torch-ROCm tensor callbacks (the drop-in contract: prior20, rosenbrock_torch)"
+    if not a.no_hip_callbacks:
+        # same workload, same seed, same protocol, with the two callbacks written as HIP device functions and compiled
+        # into the Metropolis kernel: a step is 4 launches instead of ~16.  Reported beside `value`, never as `value`.
+        try:
+            cb = tp.HipCallbacks(ROSENBROCK_HIP, 10)
+            s2 = tp.Sampler(cb.prior_transform, cb.log_likelihood, 10, n_particles=n_global, vectorize=True,
+                            clustering=False, random_state=a.seed, backend="torch", batch_prior=True, device=local_rank)
+            dt2, st2, bt2 = timed(s2)
+            pms2 = float(np.sum(st2[bt2 > 0])) * n_global
+            out["hip_callbacks"] = {"value": pms2 / dt2, "unit": "particle-mutation-steps/s", "ms_per_step": 1e3 * dt2 / a.steps,
+                                    "timed_mcmc_steps": int(np.sum(st2[bt2 > 0])),
+                                    "same_schedule_as_value_run": bool(np.array_equal(st2, steps_t)),
+                                    "note": "tempest_amd.HipCallbacks: prior/likelihood as HIP device functions fused "
+                                            "into the Metropolis kernel (optional extension; not the headline)"}
+            del s2
+        except Exception as e:       # no hipcc on the box, ...
+            out["hip_callbacks"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         if not a.no_roofline:
             out["roofline"] = reweight_roofline(local_rank, a.roofline_rows)

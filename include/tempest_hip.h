@@ -64,6 +64,8 @@ int tph_synchronize(tph_ctx* ctx);
  * 1 = one lane per particle with LDS columns (any n_dim), 2 = one lane per particle in registers (n_dim <= 16),
  * 3 = several lanes per particle with the matrices staged in LDS; the parity tests run every variant */
 #define TPH_OPT_PROPOSE_VARIANT 0
+/* TPH_OPT_REDUCE_GRID: 0 = automatic grid of the reweight reduction, > 0 = that many blocks (experiments) */
+#define TPH_OPT_REDUCE_GRID 1
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- persistent ensemble: StateManager history (state_manager.py:171-176,356-416) ------------
@@ -167,19 +169,24 @@ int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, double* x_d
                const double* uprime_dev, const double* xprime_dev, const double* loglprime_dev,
                const double* maha_u_dev, const double* maha_up_dev, const int32_t* assign_dev,
                int64_t n, int64_t ld, int K, const double* dof_dev,
-               uint64_t seed, uint32_t tick, int64_t item0, double* sums_dev /*[1+K]*/, const double* ctl_dev,
+               uint64_t seed, uint32_t tick, int64_t item0,
+               double* sums_dev /*[1+K]; NULL = leave the block partials in partials_dev for tph_adapt to sum*/,
+               const double* ctl_dev,
                double* partials_dev /* NULL = library scratch, or ceil(n/256)*(1+K) doubles owned by the caller: needed
                                        when the launch is captured in a graph (the scratch may move when it grows) */);
 /* sigma adaptation + adaptive stopping rule (mcmc.py:104-140,180-194,281-288,320-323) from GLOBAL sums.
  * state_dev[6..8]: [0]=iteration (in/out) [1]=done flag [2]=accepted fraction [3]=mean alpha
  *            [4]=mean(sigma)/sigma_0 [5]=adaptive step target ([6]=beta, [7]=tick base when used as step control);
  * counts_dev = particles per cluster (global).  A call with the done flag already set is a no-op. */
-int tph_adapt(tph_ctx* ctx, int kernel, const double* sums_dev, const double* counts_dev, int K,
+int tph_adapt(tph_ctx* ctx, int kernel, double* sums_dev /* in; out when partials_dev is given */, const double* counts_dev, int K,
               double n_global, int n_dim, int n_steps, int n_max, double* sigmas_dev, double* state_dev,
               double* mailbox_host /* NULL, or mailbox_slots x 8 doubles of PINNED host memory (device-accessible):
                                       the record of step s = state[0..5] goes to slot s % mailbox_slots, its field [7]
                                       = s is stored last (system-scope release), so the host can poll for it */,
-              int mailbox_slots);
+              int mailbox_slots,
+              const double* partials_dev /* NULL, or tph_accept's block partials of n particles: their column sums
+                                            are formed here (into sums_dev) instead of by a kernel of their own */,
+              int64_t n);
 int tph_cluster_counts(tph_ctx* ctx, const int32_t* assign_dev, int64_t n, int K, double* counts_dev);
 
 /* ---- proposal fit (student.py:6-116 effective form, modes.py:58-119,131-288) -------------------- */

@@ -700,8 +700,8 @@ extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, 
                           int64_t ld, int K, const double* dof_dev, uint64_t seed, uint32_t tick0, int64_t item0,
                           double* sums_dev, const double* ctl_dev, double* partials_dev) {
   const tph_stepctl tick{tick0, ctl_dev};
-  TPH_REQUIRE(ctx && u_dev && x_dev && logl_dev && uprime_dev && xprime_dev && loglprime_dev && sums_dev,
-              "tph_accept: NULL argument");
+  TPH_REQUIRE(ctx && u_dev && x_dev && logl_dev && uprime_dev && xprime_dev && loglprime_dev, "tph_accept: NULL argument");
+  TPH_REQUIRE(sums_dev || partials_dev, "tph_accept: without sums_dev the block partials must go to partials_dev");
   TPH_REQUIRE(n > 0 && ld >= n && K >= 1, "tph_accept: bad sizes");
   TPH_REQUIRE(K == 1 || assign_dev, "tph_accept: K>1 needs assignments");
   TPH_REQUIRE(K <= 4096, "tph_accept: K=%d too large", K);
@@ -722,7 +722,8 @@ extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, 
     hipLaunchKernelGGL(k_accept<TPH_KERNEL_RWM>, dim3(grid), dim3(ACC_THREADS), 0, ctx->stream, beta, u_dev, x_dev, logl_dev,
                        uprime_dev, xprime_dev, loglprime_dev, maha_u_dev, maha_up_dev, assign_dev, n, ld, ctx->d, K, dof_dev,
                        seed, tick, item0, partials);
-  hipLaunchKernelGGL(k_colsum, dim3(1 + K), dim3(256), 0, ctx->stream, partials, (int)grid, 1 + K, sums_dev, tick);
+  if (sums_dev)
+    hipLaunchKernelGGL(k_colsum, dim3(1 + K), dim3(256), 0, ctx->stream, partials, (int)grid, 1 + K, sums_dev, tick);
   TPH_LAUNCH_CHECK();
   return 0;
 }
@@ -730,11 +731,23 @@ extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, 
 // ------------------------------------------------------------- sigma adaptation + stopping rule
 // mcmc.py:180-186 (per-cluster mean alpha), :281-288 / :320-323 (sigma update), :104-140,192-194
 // (adaptive step count incl. the `sigmas[:n_nonempty]` weighting quirk), :196-197 (returned stats).
-__global__ void k_adapt(int kernel, const double* __restrict__ sums, const double* __restrict__ counts, int K, double n_global,
+__global__ void __launch_bounds__(256) k_adapt(int kernel, const double* __restrict__ sums, const double* __restrict__ counts, int K, double n_global,
                         int d, int n_steps, int n_max, double* __restrict__ sigmas, double* __restrict__ state,
-                        double* __restrict__ mailbox, int slots) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+                        double* __restrict__ mailbox, int slots, const double* __restrict__ partials, int nblocks,
+                        double* __restrict__ sums_out) {
   if (state[1] != 0.0) return;          // stopping rule already fired: later (speculative) steps are no-ops
+  if (partials) {                        // single GPU: the column sums of tph_accept's block partials, folded in here
+    __shared__ double sh[4];
+    for (int col = 0; col <= K; ++col) {
+      double s = 0.0;
+      for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partials[(size_t)b * (1 + K) + col];
+      s = tph_block_sum(s, sh);
+      if (threadIdx.x == 0) sums_out[col] = s;
+    }
+    __syncthreads();
+    sums = sums_out;
+  }
+  if (threadIdx.x != 0) return;
   const int iteration = (int)state[0] + 1;
   const double sigma_0 = 2.38 / sqrt((double)d);
   const double rate = 1.0 / (double)(iteration + 1);
@@ -778,13 +791,15 @@ __global__ void k_adapt(int kernel, const double* __restrict__ sums, const doubl
   }
 }
 
-extern "C" int tph_adapt(tph_ctx* ctx, int kernel, const double* sums_dev, const double* counts_dev, int K, double n_global,
+extern "C" int tph_adapt(tph_ctx* ctx, int kernel, double* sums_dev, const double* counts_dev, int K, double n_global,
                          int n_dim, int n_steps, int n_max, double* sigmas_dev, double* state_dev,
-                         double* mailbox_host, int mailbox_slots) {
+                         double* mailbox_host, int mailbox_slots, const double* partials_dev, int64_t n) {
   TPH_REQUIRE(ctx && sums_dev && counts_dev && sigmas_dev && state_dev && K >= 1, "tph_adapt: bad argument");
+  TPH_REQUIRE(!partials_dev || n > 0, "tph_adapt: partials need the particle count");
   TPH_REQUIRE(!mailbox_host || mailbox_slots >= 1, "tph_adapt: mailbox needs at least one slot");
-  hipLaunchKernelGGL(k_adapt, dim3(1), dim3(64), 0, ctx->stream, kernel, sums_dev, counts_dev, K, n_global, n_dim, n_steps,
-                     n_max, sigmas_dev, state_dev, mailbox_host, mailbox_slots);
+  hipLaunchKernelGGL(k_adapt, dim3(1), dim3(256), 0, ctx->stream, kernel, (const double*)sums_dev, counts_dev, K, n_global, n_dim,
+                     n_steps, n_max, sigmas_dev, state_dev, mailbox_host, mailbox_slots, partials_dev,
+                     (int)((n + ACC_THREADS - 1) / ACC_THREADS), sums_dev);
   TPH_LAUNCH_CHECK();
   return 0;
 }
@@ -803,17 +818,21 @@ __global__ void k_u64_to_double(const unsigned long long* __restrict__ in, int K
   if (c < K) out[c] = (double)in[c];
 }
 
+__global__ void k_fill_count(double n, int K, double* __restrict__ out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < K) out[c] = c == 0 ? n : 0.0;
+}
+
 extern "C" int tph_cluster_counts(tph_ctx* ctx, const int32_t* assign_dev, int64_t n, int K, double* counts_dev) {
   TPH_REQUIRE(ctx && counts_dev && n > 0 && K >= 1 && K <= 4096, "tph_cluster_counts: bad argument");
   unsigned long long* cnt = (unsigned long long*)(ctx->small_dev);  // 4096 slots of 8 B
-  TPH_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * (size_t)K, ctx->stream));
-  if (assign_dev) {
-    hipLaunchKernelGGL(k_cluster_counts, dim3(tph_grid_for(n, 256, 4)), dim3(256), 0, ctx->stream, assign_dev, n, K, cnt);
-  } else {
-    unsigned long long one = (unsigned long long)n;
-    TPH_HIP(hipMemcpyAsync(cnt, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream));
-    TPH_HIP(hipStreamSynchronize(ctx->stream));
+  if (!assign_dev) {            // one mode: every particle is in cluster 0 (no copy, no host synchronisation)
+    hipLaunchKernelGGL(k_fill_count, dim3((K + 255) / 256), dim3(256), 0, ctx->stream, (double)n, K, counts_dev);
+    TPH_LAUNCH_CHECK();
+    return 0;
   }
+  TPH_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * (size_t)K, ctx->stream));
+  hipLaunchKernelGGL(k_cluster_counts, dim3(tph_grid_for(n, 256, 4)), dim3(256), 0, ctx->stream, assign_dev, n, K, cnt);
   hipLaunchKernelGGL(k_u64_to_double, dim3((K + 255) / 256), dim3(256), 0, ctx->stream, cnt, K, counts_dev);
   TPH_LAUNCH_CHECK();
   return 0;

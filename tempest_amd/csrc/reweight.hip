@@ -114,14 +114,46 @@ __global__ void __launch_bounds__(TPH_RED_THREADS) k_reweight_reduce(const doubl
       s2[b] += e * e;
     }
   }
-  __shared__ double sh[3 * (TPH_RED_THREADS / 64)];
+  // Block reduction of all NB triples with ONE exp per lane and beta: block-wide maxima first (shuffles of max only),
+  // then every lane rescales its sums to the block maximum and the sums are plain additions.  (Merging triples pairwise
+  // costs two exps per shuffle level: at 10^6-row histories that tail was as expensive as the streaming loop itself.)
+  constexpr int NW = TPH_RED_THREADS / 64;
+  __shared__ double sh_m[NW][NB];
+  __shared__ double sh_s[NW][2 * NB];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  double M[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    trip t = trip_block_reduce(trip{m[b], s1[b], s2[b]}, sh);
-    if (threadIdx.x == 0) {
-      double* p = partials + ((size_t)blockIdx.x * NB + b) * 3;
-      p[0] = t.m; p[1] = t.s1; p[2] = t.s2;
-    }
+    double v = m[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    M[b] = v;
+    if (lane == 0) sh_m[wid][b] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    double v = sh_m[0][b];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v = fmax(v, sh_m[w][b]);
+    M[b] = v;
+    const double f = exp(m[b] - v);            // lanes without rows: m = -DBL_MAX, s = 0
+    double a1 = s1[b] * f, a2 = s2[b] * (f * f);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_down(a1, o, 64); a2 += __shfl_down(a2, o, 64); }
+    if (lane == 0) { sh_s[wid][2 * b] = a1; sh_s[wid][2 * b + 1] = a2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < NB) {
+    const int b = threadIdx.x;
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { a1 += sh_s[w][2 * b]; a2 += sh_s[w][2 * b + 1]; }
+    double* p = partials + ((size_t)blockIdx.x * NB + b) * 3;
+    p[0] = sh_m[0][b];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) p[0] = fmax(p[0], sh_m[w][b]);
+    p[1] = a1; p[2] = a2;
   }
 }
 
@@ -143,7 +175,10 @@ __global__ void __launch_bounds__(256) k_reweight_finalize(const double* __restr
 }
 
 // contiguous segment per block; 1024 blocks (4 per CU) once there is enough work for 16 rows per lane and trip
-static int reduce_grid(int64_t n) { return tph_grid_for(n, TPH_RED_THREADS, 16, 1024); }
+static int reduce_grid(const tph_ctx* ctx, int64_t n) {
+  if (ctx->reduce_grid > 0) return ctx->reduce_grid < TPH_RED_BLOCKS ? ctx->reduce_grid : TPH_RED_BLOCKS;
+  return tph_grid_for(n, TPH_RED_THREADS, 16, 1024);
+}
 
 template <int NB>
 static void launch_reduce(tph_ctx* ctx, int grid, const tph_betas& bt) {
@@ -181,7 +216,7 @@ extern "C" int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int
   TPH_REQUIRE(ctx->size > 0, "tph_reweight_partials: empty history");
   tph_betas bt;
   for (int i = 0; i < TPH_MAX_NB; ++i) bt.b[i] = i < nb ? betas_host[i] : 0.0;
-  int grid = reduce_grid(ctx->size);
+  int grid = reduce_grid(ctx, ctx->size);
   TPH_REQUIRE((size_t)grid * nb * 3 * sizeof(double) <= ctx->partials_bytes, "tph_reweight_partials: scratch too small");
   launch_reduce_nb(ctx, grid, bt, nb);
   TPH_LAUNCH_CHECK();
@@ -207,7 +242,7 @@ extern "C" int tph_reweight_time(tph_ctx* ctx, double beta, int nb, int reps, do
   TPH_REQUIRE(nb >= 1 && nb <= TPH_MAX_NB && ctx->size > 0, "tph_reweight_time: bad nb / empty history");
   tph_betas bt;
   for (int i = 0; i < TPH_MAX_NB; ++i) bt.b[i] = beta * (1.0 - 0.01 * i);
-  int grid = reduce_grid(ctx->size);
+  int grid = reduce_grid(ctx, ctx->size);
   hipEvent_t e0, e1;
   TPH_HIP(hipEventCreate(&e0));
   TPH_HIP(hipEventCreate(&e1));

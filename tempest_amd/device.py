@@ -269,17 +269,20 @@ class HipContext:
                                   _ptr(uprime), _ptr(xprime, torch.float64), _ptr(loglprime, torch.float64),
                                   _ptr(maha_u), _ptr(maha_up),
                                   _ptr(assign, torch.int32) if assign is not None else None, n, n, K, _ptr(dof), seed,
-                                  tick, item0, _ptr(sums), _ptr(ctl) if ctl is not None else None,
+                                  tick, item0, _ptr(sums) if sums is not None else None,
+                                  _ptr(ctl) if ctl is not None else None,
                                   _ptr(partials) if partials is not None else None), "tph_accept")
 
-    def adapt(self, kernel, sums, counts, K, n_global, n_steps, n_max, sigmas, state, mailbox=None):
-        """mailbox: pinned host tensor (slots, 8) the step record is also written to (polled by the host)."""
+    def adapt(self, kernel, sums, counts, K, n_global, n_steps, n_max, sigmas, state, mailbox=None, partials=None, n=0):
+        """mailbox: pinned host tensor (slots, 8) the step record is also written to (polled by the host);
+        partials: accept()'s block partials of n particles, column-summed here (accept called with sums=None)."""
         if mailbox is not None and not (mailbox.is_pinned() and mailbox.dtype == torch.float64 and mailbox.is_contiguous()):
             raise _lib.TempestHipError("adapt: mailbox must be a pinned contiguous float64 host tensor")
         check(self.lib.tph_adapt(self._ctx, KERNEL_ID[kernel], _ptr(sums), _ptr(counts), K, float(n_global),
                                  self.n_dim, int(n_steps), int(n_max), _ptr(sigmas), _ptr(state),
                                  mailbox.data_ptr() if mailbox is not None else None,
-                                 mailbox.shape[0] if mailbox is not None else 0), "tph_adapt")
+                                 mailbox.shape[0] if mailbox is not None else 0,
+                                 _ptr(partials) if partials is not None else None, int(n)), "tph_adapt")
 
     def cluster_counts(self, assign, n, K):
         out = self.empty(K)

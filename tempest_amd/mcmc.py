@@ -125,25 +125,28 @@ class StepEngine:
         ctx = self.ctx
         ctx.propose(self.kernel, self.u, self.assign, self.modes, self.sigmas, self.bc, self.seed, 1, self.item0,
                     self.up, self.maha_u, self.maha_up, ctl=self.ctl)
+        # one GPU: the block partials of the Metropolis kernel are summed inside tph_adapt (one launch less per step);
+        # several: their sums are all-reduced between the two
+        sums = self.sums if self.comm_active else None
         if self.plugin is not None:       # callbacks compiled into the Metropolis kernel (hipcallbacks.py)
             from .device import KERNEL_ID
             xp = lp = None
             self.plugin.accept(KERNEL_ID[self.kernel], 0.0, self.u, self.x, self.logl, self.up, self.maha_u, self.maha_up,
-                               self.assign, self.K, self.modes.dof_dev, self.seed, 2, self.item0, self.sums,
+                               self.assign, self.K, self.modes.dof_dev, self.seed, 2, self.item0, sums,
                                ctl=self.ctl, partials=self.partials)
         else:
             xp = self.prior(self.up)
             lp = self.loglike(xp)
             ctx.accept(self.kernel, 0.0, self.u, self.x, self.logl, self.up, xp, lp, self.maha_u, self.maha_up,
-                       self.assign, self.K, self.modes.dof_dev, self.seed, 2, self.item0, self.sums, ctl=self.ctl,
+                       self.assign, self.K, self.modes.dof_dev, self.seed, 2, self.item0, sums, ctl=self.ctl,
                        partials=self.partials)
         if not self.comm_active:
-            self._adapt()
+            self._adapt(fold=True)
         return xp, lp
 
-    def _adapt(self):
+    def _adapt(self, fold=False):
         self.ctx.adapt(self.kernel, self.sums, self.counts, self.K, self.n_global, self.n_steps, self.n_max,
-                       self.sigmas, self.ctl, mailbox=self.mailbox)
+                       self.sigmas, self.ctl, mailbox=self.mailbox, partials=self.partials if fold else None, n=self.n)
 
     def wait_record(self, step, timeout=60.0):
         """State record (tph_adapt's state[0..5]) of step `step`, polled from the pinned mailbox."""
@@ -254,7 +257,7 @@ class DeviceMCMC:
         state_host = torch.empty(6, dtype=torch.float64).pin_memory()
         ev = torch.cuda.Event()
         speculated = False
-        partials = None
+        partials = ctx.empty(((n + 255) // 256) * (1 + K))
 
         def propose():
             ctx.propose(self.kernel, u, assign, modes, sigmas, self.bc, self.rng.seed, self.rng.next(), self.item0,
@@ -267,18 +270,19 @@ class DeviceMCMC:
             calls += n_global
             if self.plugin is not None:               # callbacks compiled into the Metropolis kernel (hipcallbacks.py)
                 from .device import KERNEL_ID
-                if partials is None:
-                    partials = ctx.empty(((n + 255) // 256) * (1 + K))
                 self.plugin.accept(KERNEL_ID[self.kernel], self.beta, u, x, logl, up, maha_u, maha_up, assign, K,
-                                   modes.dof_dev, self.rng.seed, self.rng.next(), self.item0, sums, partials=partials)
+                                   modes.dof_dev, self.rng.seed, self.rng.next(), self.item0, sums if active else None,
+                                   partials=partials)
             else:
                 xp = self.prior(up)                   # (d, n) SoA tensor
                 lp = self.loglike(xp)                 # (n,) tensor
                 ctx.accept(self.kernel, self.beta, u, x, logl, up, xp, lp, maha_u, maha_up, assign, K, modes.dof_dev,
-                           self.rng.seed, self.rng.next(), self.item0, sums)
+                           self.rng.seed, self.rng.next(), self.item0, sums if active else None, partials=partials)
             if active:
                 self.comm.all_reduce_sum(sums)
-            ctx.adapt(self.kernel, sums, counts, K, n_global, self.n_steps, self.n_max, sigmas, state)
+            # one GPU: tph_adapt sums the Metropolis kernel's block partials itself (one launch less per step)
+            ctx.adapt(self.kernel, sums, counts, K, n_global, self.n_steps, self.n_max, sigmas, state,
+                      partials=None if active else partials, n=n)
             if it >= n_min:
                 # read the 48-byte step state while the NEXT step's proposal (which only needs the adapted sigma,
                 # already ordered on the stream) is being generated; if the stopping rule fired it is discarded
