@@ -462,25 +462,39 @@ __global__ void __launch_bounds__(256) k_propose_reg(const double* __restrict__ 
   }
   __syncthreads();
   int count = (int)((n - base) < 256 ? (n - base) : 256);
-  // ---- phase B: attempts over the shrinking work list
-  for (int att = 0; att <= PROP_MAX_ATTEMPTS && count > 0; ++att) {
-    const int cur = att & 1, nxt = cur ^ 1;
-    if (threadIdx.x < count) {
-      const int pid = s_list[cur][threadIdx.x];
-      const int64_t i = base + pid;
-      const int c = ONE_MODE ? 0 : assign[i];
+  // ---- phase B: attempts over the shrinking work list.  A round costs the latency of one attempt whatever the number
+  // of busy lanes, and the block needs as many rounds as its unluckiest particle: so once the list is short, the spare
+  // lanes try the NEXT attempts of the same particles at the same time -- G = 256/count lanes per particle evaluate
+  // attempts a0 .. a0+G-1 (independent counter-based draws) and the first in-bounds one in attempt order wins, which
+  // is exactly the proposal the sequential loop would have returned.
+  int a0 = 0;                      // attempts [0, a0) have failed for every particle still on the list
+  for (int round = 0; a0 <= PROP_MAX_ATTEMPTS && count > 0; ++round) {
+    const int cur = round & 1, nxt = cur ^ 1;
+    int G = 1;
+    while (G < 64 && 2 * G * count <= 256) G *= 2;
+    const int slot = threadIdx.x / G, att = a0 + (threadIdx.x % G);
+    const bool busy = slot < count && att <= PROP_MAX_ATTEMPTS;
+    bool ok = false;
+    int pid = 0;
+    int64_t i = 0;
+    int c = 0;
+    double z[D];
+    if (busy) {
+      pid = s_list[cur][slot];
+      i = base + pid;
+      c = ONE_MODE ? 0 : assign[i];
       const double* __restrict__ mu = means + (size_t)c * D;
       const double* __restrict__ L = chol + (size_t)c * D * D;
       const double sigma = sigmas[c];
       const double b_fac = s_bfac[pid];
       const double a_fac = (KERNEL == TPH_KERNEL_TPCN) ? sqrt(1.0 - sigma * sigma) : 1.0;
-      double df[D], z[D];
+      double df[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) {
         double uj = u[(size_t)j * ld + i];
         df[j] = (KERNEL == TPH_KERNEL_TPCN) ? uj - mu[j] : uj;
       }
-      bool ok = true;
+      ok = true;
       if (att < PROP_MAX_ATTEMPTS) {
         tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
 #pragma unroll
@@ -508,31 +522,39 @@ __global__ void __launch_bounds__(256) k_propose_reg(const double* __restrict__ 
 #pragma unroll
         for (int j = 0; j < D; ++j) z[j] = (KERNEL == TPH_KERNEL_TPCN) ? df[j] + mu[j] : df[j];
       }
-      if (ok) {
+    }
+    // first in-bounds attempt of each particle: its G lanes are consecutive lanes of one wave (G <= 64 divides 64)
+    const unsigned long long okmask = __ballot(ok);
+    const int lane = threadIdx.x & 63, g0 = lane & ~(G - 1);
+    const unsigned long long grp = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << g0;
+    const unsigned long long mine = okmask & grp;
+    const bool winner = ok && (mine & ((1ull << lane) - 1ull)) == 0ull;
+    if (winner) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) up[(size_t)j * ld + i] = z[j];
-        double m_up = 0.0;
-        if (KERNEL == TPH_KERNEL_TPCN) {
-          const double* __restrict__ P = inv + (size_t)c * D * D;
+      for (int j = 0; j < D; ++j) up[(size_t)j * ld + i] = z[j];
+      double m_up = 0.0;
+      if (KERNEL == TPH_KERNEL_TPCN) {
+        const double* __restrict__ mu = means + (size_t)c * D;
+        const double* __restrict__ P = inv + (size_t)c * D * D;
 #pragma unroll
-          for (int j = 0; j < D; ++j) z[j] -= mu[j];
+        for (int j = 0; j < D; ++j) z[j] -= mu[j];
 #pragma unroll
-          for (int r = 0; r < D; ++r) {
-            double acc = 0.0;
+        for (int r = 0; r < D; ++r) {
+          double acc = 0.0;
 #pragma unroll
-            for (int j = 0; j < D; ++j) acc += P[r * D + j] * z[j];
-            m_up += z[r] * acc;
-          }
+          for (int j = 0; j < D; ++j) acc += P[r * D + j] * z[j];
+          m_up += z[r] * acc;
         }
-        if (maha_up) maha_up[i] = m_up;
-      } else {
-        s_list[nxt][atomicAdd(&s_count[nxt], 1)] = pid;   // order irrelevant: particles are independent
       }
+      if (maha_up) maha_up[i] = m_up;
+    } else if (busy && mine == 0ull && (lane & (G - 1)) == 0) {
+      s_list[nxt][atomicAdd(&s_count[nxt], 1)] = pid;   // all G attempts out of bounds; order irrelevant
     }
     __syncthreads();
     count = s_count[nxt];
+    a0 += G;
     __syncthreads();
-    if (threadIdx.x == 0) s_count[cur] = 0;   // becomes `nxt` of the following attempt (ordered by its barrier)
+    if (threadIdx.x == 0) s_count[cur] = 0;   // becomes `nxt` of the following round (ordered by its barrier)
   }
 }
 

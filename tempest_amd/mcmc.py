@@ -86,11 +86,14 @@ class StepEngine:
         self.loglike, self.prior = log_likelihood, prior_transform
         self.seed, self.item0, self.n_global = seed, item0, n_global
         self.n_steps, self.n_max, self.comm_active = n_steps, n_max, comm_active
-        self.u, self.x, self.logl = ctx.empty(d, n), ctx.empty(d, n), ctx.empty(n)
         self.up, self.maha_u, self.maha_up = ctx.empty(d, n), ctx.empty(n), ctx.empty(n)
-        self.assign = torch.empty(n, dtype=torch.int32, device=ctx.device) if has_assign else None
-        self.modes = SimpleNamespace(K=K, means_dev=ctx.empty(K, d), chol_dev=ctx.empty(K, d, d),
-                                     inv_dev=ctx.empty(K, d, d), dof_dev=ctx.empty(K))
+        self.u = self.x = self.logl = self.assign = self.modes = None
+        if use_graph:       # fixed-address copies of everything a captured step reads or writes
+            self.u, self.x, self.logl = ctx.empty(d, n), ctx.empty(d, n), ctx.empty(n)
+            self.assign = torch.empty(n, dtype=torch.int32, device=ctx.device) if has_assign else None
+            self.modes = SimpleNamespace(K=K, means_dev=ctx.empty(K, d), chol_dev=ctx.empty(K, d, d),
+                                         inv_dev=ctx.empty(K, d, d), dof_dev=ctx.empty(K))
+        self.has_assign = has_assign
         self.sigmas, self.counts, self.sums = ctx.empty(K), ctx.empty(K), ctx.zeros(1 + K)
         self.partials = ctx.empty(((n + 255) // 256) * (1 + K))     # fixed address: the library's scratch may move
         self.ctl = ctx.zeros(8)
@@ -98,20 +101,27 @@ class StepEngine:
         self.mailbox = torch.zeros(self.SLOTS, 8, dtype=torch.float64).pin_memory()   # written by tph_adapt, polled here
         self.mailbox_np = self.mailbox.numpy()
         self.use_graph, self.graph, self.graph_error = bool(use_graph), None, None
-        self._keep, self.runs = None, 0
+        self._keep, self.runs, self._own = None, 0, None
 
     def key(self):
-        return (self.kernel, self.n, self.K, self.assign is not None, self.comm_active, id(self.plugin))
+        return (self.kernel, self.n, self.K, self.has_assign, self.comm_active, id(self.plugin))
 
     def load(self, u, x, logl, assign, modes, beta, tick_base, sigma_init, counts):
-        """Start a run: active set, proposal modes and the step-control block into the persistent buffers."""
+        """Start a run: active set, proposal modes and the step-control block.  A graph needs fixed addresses, so
+        the data is copied into the engine's persistent buffers; without one the caller's tensors are used as they are."""
         self.runs += 1
-        self.u.copy_(u); self.x.copy_(x); self.logl.copy_(logl)
-        if self.assign is not None:
-            self.assign.copy_(assign)
-        m = self.modes
-        m.means_dev.copy_(modes.means_dev.reshape(m.means_dev.shape)); m.chol_dev.copy_(modes.chol_dev.reshape(m.chol_dev.shape))
-        m.inv_dev.copy_(modes.inv_dev.reshape(m.inv_dev.shape)); m.dof_dev.copy_(modes.dof_dev.reshape(m.dof_dev.shape))
+        if self.use_graph:
+            if self._own is None:
+                self._own = (self.u, self.x, self.logl, self.assign, self.modes)
+            self.u, self.x, self.logl, self.assign, self.modes = self._own
+            self.u.copy_(u); self.x.copy_(x); self.logl.copy_(logl)
+            if self.assign is not None:
+                self.assign.copy_(assign)
+            m = self.modes
+            m.means_dev.copy_(modes.means_dev.reshape(m.means_dev.shape)); m.chol_dev.copy_(modes.chol_dev.reshape(m.chol_dev.shape))
+            m.inv_dev.copy_(modes.inv_dev.reshape(m.inv_dev.shape)); m.dof_dev.copy_(modes.dof_dev.reshape(m.dof_dev.shape))
+        else:
+            self.u, self.x, self.logl, self.assign, self.modes = u, x, logl, assign, modes
         self.sigmas.fill_(sigma_init)
         self.counts.copy_(counts)
         self.mailbox_np[:, 7] = -1.0          # no record yet (the device is idle or running no-op steps: see step())
@@ -331,7 +341,8 @@ class DeviceMCMC:
                                             "steps": it, "eff": st[4]})
                 if st[1] != 0.0:
                     break
-        u.copy_(eng.u); x.copy_(eng.x); logl.copy_(eng.logl)
+        if eng.u is not u:                    # graph mode: the step worked on the engine's fixed-address buffers
+            u.copy_(eng.u); x.copy_(eng.x); logl.copy_(eng.logl)
         # two ticks per step + the proposal of the step that was launched ahead (same count as the step-by-step path)
         self.rng.tick = (tick_base + 2 * it + 1) & 0xFFFFFFFF
         return float(st[4]), float(st[3]), it, it * n_global

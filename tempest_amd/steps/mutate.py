@@ -94,10 +94,10 @@ class Mutator:
         # auto: graphs pay when a step's kernels are launch-bound (small shards); at >= ~5e5 coordinates per shard the
         # host keeps ahead of the GPU anyway and the engine's copy-in/copy-out (1-2 %) is not recovered
         want = self.graph if self.graph is not None else n * self.n_dim <= (1 << 19)
-        engines = self._engines if (on_device and want) else None
+        engines = self._engines if on_device else None      # device callbacks: device-side step control (mcmc.StepEngine)
         run = DeviceMCMC(ctx, "rwm" if self.sampler == "rwm" else "tpcn", beta, mode_stats, like_dev, prior_dev,
                          self.n_steps, self.n_max_steps, self.periodic, self.reflective, rng=rng, comm=comm,
-                         item0=item0, n_global=n_global, progress_bar=self.pbar, engines=engines, graph=self.graph,
+                         item0=item0, n_global=n_global, progress_bar=self.pbar, engines=engines, graph=bool(want),
                          plugin=plugin)
         efficiency, acceptance, steps, mcmc_calls = run.run(u, x, logl, st.dev("assignments"))
         st.update_current({"efficiency": efficiency, "acceptance": acceptance, "steps": steps,
