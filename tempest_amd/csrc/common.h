@@ -53,7 +53,8 @@ struct tph_ctx {
   double* partials = nullptr;       // streaming-reduction block partials
   size_t partials_bytes = 0;
   double* small_dev = nullptr;      // small device results (<= 4096 doubles)
-  double* pinned = nullptr;         // pinned host staging (<= 4096 doubles)
+  double* pinned = nullptr;         // pinned host staging (<= 4096 doubles); [4095] = tph_reweight_eval sequence word
+  uint64_t eval_seq = 0;
   void* scratch = nullptr;          // big scratch (sort buffers, scans), grown on demand
   size_t scratch_bytes = 0;
   int reduce_grid = 0;              // 0 auto | blocks of the reweight reduction (experiments)

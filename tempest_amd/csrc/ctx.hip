@@ -109,6 +109,7 @@ extern "C" int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void
     delete c;
     return -1;
   }
+  memset(c->pinned, 0, sizeof(double) * 4096);      // [4095] is the sequence word tph_reweight_eval polls
   if (capacity_hint > 0 && history_reserve(c, capacity_hint)) {
     delete c;
     return -1;

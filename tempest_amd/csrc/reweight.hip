@@ -174,6 +174,33 @@ __global__ void __launch_bounds__(256) k_reweight_finalize(const double* __restr
   }
 }
 
+// The same merge for tph_reweight_eval, results straight into PINNED HOST memory: one block, wave b merges beta b, and
+// a sequence number is stored last (system-scope release).  The host polls that word instead of queueing a device-to-
+// host copy and waiting on the stream: the ~25 adaptive-beta passes of one PS iteration are latency-bound, not
+// bandwidth-bound, and this removes a copy packet and the runtime's completion path from every one of them.
+__global__ void __launch_bounds__(1024) k_reweight_finalize_host(const double* __restrict__ partials, int nblocks, int nb,
+                                                                 double* __restrict__ out_host, double* __restrict__ seq_host,
+                                                                 double seq) {
+  const int b = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (b < nb) {
+    trip t{-DBL_MAX, 0.0, 0.0};
+    for (int i = lane; i < nblocks; i += 64) {
+      const double* p = partials + ((size_t)i * nb + b) * 3;
+      t = trip_merge(t, trip{p[0], p[1], p[2]});
+    }
+    t = trip_wave_reduce(t);
+    if (lane == 0) {
+      if (t.m == -DBL_MAX) t.m = -INFINITY;  // empty input
+      out_host[b * 3 + 0] = t.m; out_host[b * 3 + 1] = t.s1; out_host[b * 3 + 2] = t.s2;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // contiguous segment per block; 1024 blocks (4 per CU) once there is enough work for 16 rows per lane and trip
 static int reduce_grid(const tph_ctx* ctx, int64_t n) {
   if (ctx->reduce_grid > 0) return ctx->reduce_grid < TPH_RED_BLOCKS ? ctx->reduce_grid : TPH_RED_BLOCKS;
@@ -226,11 +253,33 @@ extern "C" int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int
 }
 
 extern "C" int tph_reweight_eval(tph_ctx* ctx, const double* betas_host, int nb, double* out_host) {
-  TPH_REQUIRE(out_host, "tph_reweight_eval: out is NULL");
-  int rc = tph_reweight_partials(ctx, betas_host, nb, ctx->small_dev);
-  if (rc) return rc;
-  TPH_HIP(hipMemcpyAsync(ctx->pinned, ctx->small_dev, sizeof(double) * 3 * nb, hipMemcpyDeviceToHost, ctx->stream));
-  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  TPH_REQUIRE(ctx && betas_host && out_host, "tph_reweight_eval: NULL argument");
+  TPH_REQUIRE(nb >= 1 && nb <= TPH_MAX_NB, "tph_reweight_eval: nb=%d outside [1,%d]", nb, TPH_MAX_NB);
+  TPH_REQUIRE(ctx->size > 0, "tph_reweight_eval: empty history");
+  tph_betas bt;
+  for (int i = 0; i < TPH_MAX_NB; ++i) bt.b[i] = i < nb ? betas_host[i] : 0.0;
+  int grid = reduce_grid(ctx, ctx->size);
+  TPH_REQUIRE((size_t)grid * nb * 3 * sizeof(double) <= ctx->partials_bytes, "tph_reweight_eval: scratch too small");
+  launch_reduce_nb(ctx, grid, bt, nb);
+  TPH_LAUNCH_CHECK();
+  // results + sequence word in the ctx's pinned block: [0, 48) triples, [4095] sequence
+  volatile double* seqp = ctx->pinned + 4095;
+  const double seq = (double)(++ctx->eval_seq);
+  hipLaunchKernelGGL(k_reweight_finalize_host, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials, grid, nb, ctx->pinned,
+                     ctx->pinned + 4095, seq);
+  TPH_LAUNCH_CHECK();
+  uint64_t spins = 0;
+  while (*seqp != seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xFFFFF) == 0) {               // every ~1M polls: is the stream still alive?
+      hipError_t q = hipStreamQuery(ctx->stream);
+      if (q != hipErrorNotReady) {                // idle (or failed): the record is final by now
+        TPH_HIP(hipStreamSynchronize(ctx->stream));
+        TPH_REQUIRE(*seqp == seq, "tph_reweight_eval: the device never delivered evaluation %.0f", seq);
+      }
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   for (int i = 0; i < 3 * nb; ++i) out_host[i] = ctx->pinned[i];
   return 0;
 }
