@@ -6,8 +6,10 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one full Persistent Sampling iteration (reweight -> train -> resample -> mutate -> commit) of
-`tempest_amd.Sampler` on the README Rosenbrock target (coefficient 10, prior U(-10,10)^10), 131 072 particles
-per GPU (BASELINE config 4 = 1 048 576 particles over 8 GPUs; weak scaling).  `value` = particle-mutation-steps
+`tempest_amd.Sampler` on the README Rosenbrock target (coefficient 10, prior U(-10,10)^10) with BASELINE config 4's
+1 048 576 particles.  That configuration fits one GPU (7 GB of history at termination), so at N=1 it IS the workload;
+under torchrun every GPU holds 1 048 576 particles (weak scaling; `--particles-per-gpu 131072` gives config 4's own
+8-GPU shard).  `value` = particle-mutation-steps
 (sum over the timed iterations of MCMC steps x global particles, the reference's `calls` bookkeeping,
 mcmc.py:89) / wall time, user likelihood included, inputs resident in HBM.
 
@@ -16,6 +18,7 @@ Also in the JSON line:
                 (outside the 256 MB Infinity Cache): algorithmic 16 B per historical particle /
                 HIP-event average launch duration, against 8 TB/s.
   cpu_baseline  the NumPy oracle sampler ("port") on the host cores, bounded sample, same target.
+  hip_callbacks the same run with the callbacks compiled into the Metropolis kernel (tempest_amd.HipCallbacks).
 """
 import argparse
 import json
@@ -139,7 +142,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--particles-per-gpu", type=int, default=131072)
+    ap.add_argument("--particles-per-gpu", type=int, default=1048576,
+                    help="BASELINE config 4's 1 048 576 particles, held by ONE GPU (they fit); weak scaling: the same per GPU")
     ap.add_argument("--roofline-rows", type=int, default=67_108_864)      # 1.07 GB of (logl, logmix)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -227,7 +231,8 @@ def main():
            "unit": "particle-mutation-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"rosenbrock10d_n{n_local}_per_gpu (BASELINE config 4 shard: {n_global} particles global)",
+           "config": {"workload": f"rosenbrock10d_n{n_local}_per_gpu (BASELINE config 4: 10-D Rosenbrock, 1 048 576 particles -- "
+                                  f"all of them on each GPU, weak scaling: {n_global} particles global)",
                       "n_dim": 10, "particles_per_gpu": n_local, "particles_global": n_global, "sample": "tpcn",
                       "resample": "mult", "clustering": False, "n_total": n_total, "step": "one PS iteration"}}
     out.update(extra)

@@ -4,6 +4,7 @@
 // (x4 multinomial up-sampling before the proposal fit).
 #include "common.h"
 #include "scan.h"
+#include "cdf_index.h"
 
 extern "C" int tph_cdf(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev, double* cdf_dev) {
   TPH_REQUIRE(ctx && w_dev && cdf_dev && n > 0, "tph_cdf: bad argument");
@@ -46,23 +47,26 @@ extern "C" int tph_resample_systematic(tph_ctx* ctx, const double* cdf_dev, int6
   return 0;
 }
 
-__global__ void __launch_bounds__(256) k_resample_multinomial(const double* __restrict__ cdf, int64_t n, int64_t n_out,
-                                                              uint64_t seed, uint32_t tick, uint32_t tag, int64_t item0,
-                                                              int64_t* __restrict__ idx) {
+__global__ void __launch_bounds__(256) k_resample_multinomial(tph_cdf_index ix, int64_t n_out, uint64_t seed, uint32_t tick,
+                                                              uint32_t tag, int64_t item0, int64_t* __restrict__ idx) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_out) return;
   tph_rng g(seed, tick, tag, (uint64_t)(item0 + i));
   double U, U1;
   g.uniform2(0, U, U1);
-  int64_t k = count_below<false>(cdf, n, cdf[n - 1], U);
+  const int64_t n = ix.n[0];
+  int64_t k = tph_count_below<false>(ix, ix.lvl[0][n - 1], U);
   idx[i] = k < n ? k : n - 1;
 }
 
 extern "C" int tph_resample_multinomial(tph_ctx* ctx, const double* cdf_dev, int64_t n, int64_t n_out, uint64_t seed,
                                         uint32_t tick, uint32_t tag, int64_t item0, int64_t* idx_dev) {
   TPH_REQUIRE(ctx && cdf_dev && idx_dev && n > 0 && n_out > 0, "tph_resample_multinomial: bad argument");
-  hipLaunchKernelGGL(k_resample_multinomial, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx->stream, cdf_dev, n,
-                     n_out, seed, tick, tag, item0, idx_dev);
+  if (tph_scratch_reserve(ctx, sizeof(double) * tph_cdf_index_doubles(n))) return -1;
+  tph_cdf_index ix;
+  if (tph_cdf_index_build(ctx, cdf_dev, n, (double*)ctx->scratch, &ix)) return -1;
+  hipLaunchKernelGGL(k_resample_multinomial, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx->stream, ix, n_out, seed,
+                     tick, tag, item0, idx_dev);
   TPH_LAUNCH_CHECK();
   return 0;
 }
@@ -72,8 +76,7 @@ extern "C" int tph_resample_multinomial(tph_ctx* ctx, const double* cdf_dev, int
 // its own span [w_before, w_upto) of the global cumulative weight; idx_out[i] = local row or -1.
 // scheme 0 = multinomial (position U_i * w_total, `<=` walk), 1 = systematic ((u0+i)/n_slots * w_total, `<` walk).
 // is_last: bit 0 = this rank owns the last span, bit 1 = the first.
-__global__ void __launch_bounds__(256) k_resample_select(const double* __restrict__ cdf, int64_t n, int64_t n_slots,
-                                                         int scheme, uint64_t seed, uint32_t tick, uint32_t tag, double u0,
+__global__ void __launch_bounds__(256) k_resample_select(tph_cdf_index ix, int64_t n_slots, int scheme, uint64_t seed, uint32_t tick, uint32_t tag, double u0,
                                                          double w_before, double w_upto, double w_total, int is_last,
                                                          int64_t* __restrict__ idx) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,7 +97,8 @@ __global__ void __launch_bounds__(256) k_resample_select(const double* __restric
                           : ((first || p > w_before) && (last || p <= w_upto));
   if (!mine) { idx[i] = -1; return; }
   double q = p - w_before;
-  int64_t k = scheme == 0 ? count_below<false>(cdf, n, 1.0, q) : count_below<true>(cdf, n, 1.0, q);
+  const int64_t n = ix.n[0];
+  int64_t k = scheme == 0 ? tph_count_below<false>(ix, 1.0, q) : tph_count_below<true>(ix, 1.0, q);
   idx[i] = k < n ? k : n - 1;
 }
 
@@ -103,7 +107,10 @@ extern "C" int tph_resample_select(tph_ctx* ctx, const double* cdf_dev, int64_t 
                                    double w_total, int is_last, int64_t* idx_dev) {
   TPH_REQUIRE(ctx && cdf_dev && idx_dev && n > 0 && n_slots > 0, "tph_resample_select: bad argument");
   TPH_REQUIRE(scheme == 0 || scheme == 1, "tph_resample_select: scheme must be 0 (multinomial) or 1 (systematic)");
-  hipLaunchKernelGGL(k_resample_select, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, ctx->stream, cdf_dev, n,
+  if (tph_scratch_reserve(ctx, sizeof(double) * tph_cdf_index_doubles(n))) return -1;
+  tph_cdf_index ix;
+  if (tph_cdf_index_build(ctx, cdf_dev, n, (double*)ctx->scratch, &ix)) return -1;
+  hipLaunchKernelGGL(k_resample_select, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, ctx->stream, ix,
                      n_slots, scheme, seed, tick, tag, u0, w_before, w_upto, w_total, is_last, idx_dev);
   TPH_LAUNCH_CHECK();
   return 0;
@@ -200,7 +207,7 @@ extern "C" int tph_index_compose(tph_ctx* ctx, const int64_t* a_dev, const int64
 }
 
 // multiplicities of `factor * kept_count` multinomial draws (kept_count lives on the device: no host sync)
-__global__ void __launch_bounds__(256) k_multinomial_counts(const double* __restrict__ cdf, int64_t n,
+__global__ void __launch_bounds__(256) k_multinomial_counts(tph_cdf_index ix,
                                                             const double* __restrict__ kept_count_dev, int factor,
                                                             int64_t n_draw_max, uint64_t seed, uint32_t tick, uint32_t tag,
                                                             int32_t* __restrict__ counts) {
@@ -210,7 +217,8 @@ __global__ void __launch_bounds__(256) k_multinomial_counts(const double* __rest
   tph_rng g(seed, tick, tag, (uint64_t)r);
   double U, U1;
   g.uniform2(0, U, U1);
-  int64_t k = count_below<false>(cdf, n, cdf[n - 1], U);
+  const int64_t n = ix.n[0];
+  int64_t k = tph_count_below<false>(ix, ix.lvl[0][n - 1], U);
   if (k >= n) k = n - 1;
   atomicAdd(&counts[k], 1);
 }
@@ -220,7 +228,10 @@ extern "C" int tph_multinomial_counts(tph_ctx* ctx, const double* cdf_dev, int64
                                       int32_t* counts_dev) {
   TPH_REQUIRE(ctx && cdf_dev && counts_dev && n > 0 && n_draw_max > 0, "tph_multinomial_counts: bad argument");
   TPH_HIP(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * (size_t)n, ctx->stream));
-  hipLaunchKernelGGL(k_multinomial_counts, dim3((unsigned)((n_draw_max + 255) / 256)), dim3(256), 0, ctx->stream, cdf_dev, n,
+  if (tph_scratch_reserve(ctx, sizeof(double) * tph_cdf_index_doubles(n))) return -1;
+  tph_cdf_index ix;
+  if (tph_cdf_index_build(ctx, cdf_dev, n, (double*)ctx->scratch, &ix)) return -1;
+  hipLaunchKernelGGL(k_multinomial_counts, dim3((unsigned)((n_draw_max + 255) / 256)), dim3(256), 0, ctx->stream, ix,
                      kept_count_dev, factor, n_draw_max, seed, tick, tag, counts_dev);
   TPH_LAUNCH_CHECK();
   return 0;
