@@ -66,6 +66,8 @@ int tph_synchronize(tph_ctx* ctx);
 #define TPH_OPT_PROPOSE_VARIANT 0
 /* TPH_OPT_REDUCE_GRID: 0 = automatic grid of the reweight reduction, > 0 = that many blocks (experiments) */
 #define TPH_OPT_REDUCE_GRID 1
+/* TPH_OPT_REDRAW_LANES: 0 = automatic, 64 / 256 = lanes the redraw rounds of the d <= 16 proposal kernel keep busy */
+#define TPH_OPT_REDRAW_LANES 2
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- persistent ensemble: StateManager history (state_manager.py:171-176,356-416) ------------

@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256) k_propose_reg(const double* __restrict__ 
                                                      const double* __restrict__ dof, const double* __restrict__ sigmas,
                                                      const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                      int64_t item0, double* __restrict__ up, double* __restrict__ maha_u,
-                                                     double* __restrict__ maha_up) {
+                                                     double* __restrict__ maha_up, int spare_lanes) {
   __shared__ double s_bfac[256];
   __shared__ int s_list[2][256];
   __shared__ int s_count[2];
@@ -468,10 +468,13 @@ __global__ void __launch_bounds__(256) k_propose_reg(const double* __restrict__ 
   // attempts a0 .. a0+G-1 (independent counter-based draws) and the first in-bounds one in attempt order wins, which
   // is exactly the proposal the sequential loop would have returned.
   int a0 = 0;                      // attempts [0, a0) have failed for every particle still on the list
+  const int spare = spare_lanes;   // lanes a round may keep busy: the whole block when the launch is latency-bound,
+                                   // one wave when the GPU is full anyway (a speculative attempt then costs ALU time
+                                   // another block would have used)
   for (int round = 0; a0 <= PROP_MAX_ATTEMPTS && count > 0; ++round) {
     const int cur = round & 1, nxt = cur ^ 1;
     int G = 1;
-    while (G < 64 && 2 * G * count <= 256) G *= 2;
+    while (G < 64 && 2 * G * count <= spare) G *= 2;
     const int slot = threadIdx.x / G, att = a0 + (threadIdx.x % G);
     const bool busy = slot < count && att <= PROP_MAX_ATTEMPTS;
     bool ok = false;
@@ -563,12 +566,14 @@ static void launch_propose_reg(tph_ctx* ctx, const double* u, const int32_t* ass
                                const double* means, const double* chol, const double* inv, const double* dof,
                                const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
                                double* up, double* mu_, double* mup) {
+  // redraw rounds: spare lanes of the whole block while the launch cannot fill the GPU (<= 8 waves per SIMD), else one wave
+  const int spare = ctx->redraw_lanes > 0 ? ctx->redraw_lanes : (n <= 512 * 1024 ? 256 : 64);
   if (assign == nullptr)
     hipLaunchKernelGGL((k_propose_reg<KERNEL, D, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, u, assign,
-                       n, ld, means, chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup);
+                       n, ld, means, chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, spare);
   else
     hipLaunchKernelGGL((k_propose_reg<KERNEL, D, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, u, assign,
-                       n, ld, means, chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup);
+                       n, ld, means, chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, spare);
 }
 
 #define TPH_PROPOSE_CASE(DD)                                                                                       \
