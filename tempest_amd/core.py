@@ -324,21 +324,31 @@ class SamplerCore:
             if blobs is not None and sel is not None:
                 blobs = blobs[sel.cpu().numpy()]
         else:
-            # sharded run: every rank returns the posterior over the WHOLE history (rows of all shards, rank order);
-            # the weights are already normalised by the global sum
-            x = ctx.history_read(KEY_X)
-            logl = ctx.history_read(KEY_LOGL)
-            weights = w_dev.cpu().numpy()
-            x, logl, weights = comm.gather_rows(x), comm.gather_rows(logl), comm.gather_rows(weights)
+            # sharded run: every rank returns the posterior over the WHOLE history (rows of all shards, rank order).
+            # Only the weights (8 B per row) are gathered in full -- the trim threshold is a statistic of the global
+            # weight distribution --; every shard then compacts and gathers its own kept rows on the device and only those
+            # rows travel.  The weights are already normalised by the global sum.
+            weights_all = comm.gather_rows(w_dev.cpu().numpy())
             if logw is not None:
                 logw = comm.gather_rows(logw)
-            w_dev = torch.from_numpy(np.ascontiguousarray(weights)).to(ctx.device)
+            sel, m_sel, wdiv = None, ctx.size, 1.0
             if trim_importance_weights:
-                _, out = ctx.trim_threshold(w_dev, ess_trim, bins_trim, sync=True)
-                mask = weights >= out[0]
-                x, logl, weights = x[mask], logl[mask], weights[mask] / out[1]
-                if blobs is not None:
-                    blobs = blobs[mask]
+                wg = torch.from_numpy(np.ascontiguousarray(weights_all)).to(ctx.device)
+                thr_dev, out = ctx.trim_threshold(wg, ess_trim, bins_trim, sync=True)
+                del wg
+                wdiv = float(out[1])
+                m_sel = int((w_dev >= thr_dev[0]).sum().item())      # this shard's share of the kept rows
+                sel = ctx.compact_indices(w_dev, thr_dev[0:1], m_sel) if m_sel else None
+            if m_sel:
+                x_dev, logl_dev, w_sel = ctx.posterior_rows(sel, m_sel, w=w_dev, wdiv=wdiv)
+                x, logl, weights = x_dev.cpu().numpy(), logl_dev.cpu().numpy(), w_sel.cpu().numpy()
+            else:
+                x, logl, weights = np.empty((0, st.n_dim)), np.empty(0), np.empty(0)
+            if blobs is not None and sel is not None:
+                blobs = blobs[sel.cpu().numpy()]
+            x, logl, weights = comm.gather_rows(x), comm.gather_rows(logl), comm.gather_rows(weights)
+            if blobs is not None:
+                blobs = comm.gather_rows(blobs)
             if resample:
                 from .tools import SQRTEPS
                 wt = torch.from_numpy(np.ascontiguousarray(weights)).to(ctx.device)
