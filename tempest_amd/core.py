@@ -287,7 +287,6 @@ class SamplerCore:
                           ess_trim=0.99, bins_trim=1000):
         """Weighted posterior samples from the whole history (core.py:187-242)."""
         import torch
-        from .device import KEY_LOGL, KEY_X
         st = self.state
         ctx = st.ctx
         ctx.use_current_stream()

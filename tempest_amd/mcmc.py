@@ -103,9 +103,6 @@ class StepEngine:
         self.use_graph, self.graph, self.graph_error = bool(use_graph), None, None
         self._keep, self.runs, self._own = None, 0, None
 
-    def key(self):
-        return (self.kernel, self.n, self.K, self.has_assign, self.comm_active, id(self.plugin))
-
     def load(self, u, x, logl, assign, modes, beta, tick_base, sigma_init, counts):
         """Start a run: active set, proposal modes and the step-control block.  A graph needs fixed addresses, so
         the data is copied into the engine's persistent buffers; without one the caller's tensors are used as they are."""

@@ -1,7 +1,5 @@
 """Mutation step (reference: tempest/steps/mutate.py:76-200): fresh prior draws while beta = 0
 (with the +-inf-likelihood repair and its logZ correction), MCMC on the device otherwise."""
-import math
-
 import numpy as np
 
 from ..mcmc import DeviceMCMC
@@ -102,4 +100,3 @@ class Mutator:
         efficiency, acceptance, steps, mcmc_calls = run.run(u, x, logl, st.dev("assignments"))
         st.update_current({"efficiency": efficiency, "acceptance": acceptance, "steps": steps,
                            "calls": st.get_current("calls") + mcmc_calls})
-        _ = math  # noqa: F841
