@@ -609,12 +609,102 @@ extern "C" int tph_chol_inv(tph_ctx* ctx, double* covs_dev, int K, double* chol_
 }
 
 // ------------------------------------------------------------------------------------ fit_modes
+// ---- compaction of the up-sampled set -------------------------------------------------------------------------------
+// The fit reads u five times (first moments, covariance, two histogram levels, candidate collection), but only rows with a
+// non-zero multiplicity matter, and their share falls as the history grows (4 n_particles kept rows of N_h: 60 % at iteration
+// 6, 13 % at iteration 24 of the bench run).  One order-preserving stream compaction (block counts -> offsets -> scatter)
+// gathers those rows into a dense SoA working set; the five passes then stream 8d B per KEPT row instead of per history row.
+constexpr int NZ_ROWS = 1024;   // history rows per block (4 tiles of 256)
+constexpr int64_t FIT_COMPACT_MIN = 262144;   // below this the five passes are launch-bound anyway
+__global__ void __launch_bounds__(256) k_nz_count(const int32_t* __restrict__ counts, int64_t n, int* __restrict__ blockcnt) {
+  __shared__ int s_c;
+  if (threadIdx.x == 0) s_c = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * NZ_ROWS;
+  int c = 0;
+#pragma unroll
+  for (int t = 0; t < NZ_ROWS / 256; ++t) {
+    int64_t i = base + t * 256 + threadIdx.x;
+    c += (i < n && counts[i] > 0) ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&s_c, c);     // integer: exact, order-free
+  __syncthreads();
+  if (threadIdx.x == 0) blockcnt[blockIdx.x] = s_c;
+}
+// exclusive scan of the block counts in place (one block); total[0] = number of kept rows
+__global__ void __launch_bounds__(1024) k_nz_offsets(int* __restrict__ blockcnt, int nblocks, long long* __restrict__ total) {
+  __shared__ long long s_part[1024];
+  const int per = (nblocks + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = lo + per < nblocks ? lo + per : nblocks;
+  long long sum = 0;
+  for (int b = lo; b < hi; ++b) sum += blockcnt[b];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long run = 0;
+    for (int t = 0; t < 1024; ++t) { long long v = s_part[t]; s_part[t] = run; run += v; }
+    total[0] = run;
+  }
+  __syncthreads();
+  long long run = s_part[threadIdx.x];
+  for (int b = lo; b < hi; ++b) { int v = blockcnt[b]; blockcnt[b] = (int)run; run += v; }
+}
+__global__ void __launch_bounds__(256) k_nz_scatter(const double* __restrict__ u, int64_t cap, int d,
+                                                    const int32_t* __restrict__ counts, const int32_t* __restrict__ labels,
+                                                    int64_t n, const int* __restrict__ offsets, double* __restrict__ uc,
+                                                    int64_t ldc, int32_t* __restrict__ cc, int32_t* __restrict__ lc) {
+  __shared__ int s_wave[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int64_t out = offsets[blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * NZ_ROWS;
+  for (int t = 0; t < NZ_ROWS / 256; ++t) {
+    const int64_t i = base + t * 256 + threadIdx.x;
+    const int cnt = i < n ? counts[i] : 0;
+    const bool keep = cnt > 0;
+    const unsigned long long mask = __ballot(keep);
+    const int below = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wid] = __popcll(mask);
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { if (w < wid) woff += s_wave[w]; tot += s_wave[w]; }
+    if (keep) {
+      const int64_t pos = out + woff + below;
+      cc[pos] = cnt;
+      if (lc) lc[pos] = labels[i];
+      for (int j = 0; j < d; ++j) uc[(size_t)j * ldc + pos] = u[(size_t)j * cap + i];
+    }
+    out += tot;
+    __syncthreads();
+  }
+}
+
 extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int32_t* labels_dev, int64_t n, int K,
                              double* means_dev, double* covs_dev, double* chol_dev, double* inv_dev) {
   TPH_REQUIRE(ctx && counts_dev && means_dev && covs_dev && chol_dev && inv_dev, "tph_fit_modes: NULL argument");
   TPH_REQUIRE(n > 0 && n <= ctx->size && K >= 1, "tph_fit_modes: bad sizes");
   TPH_REQUIRE(K == 1 || labels_dev, "tph_fit_modes: K>1 needs labels");
   const int d = ctx->d;
+  // ---- working set: the history itself, or (large histories) the dense copy of the rows with multiplicity > 0
+  const double* src = ctx->u;
+  int64_t src_ld = ctx->cap;
+  const int64_t n_hist = n;
+  int64_t m_keep = -1;
+  const int nzb = (int)((n_hist + NZ_ROWS - 1) / NZ_ROWS);
+  int* blockcnt = (int*)ctx->partials;
+  if (n_hist >= FIT_COMPACT_MIN && (size_t)nzb * sizeof(int) <= ctx->partials_bytes) {
+    long long* total = (long long*)ctx->small_dev;
+    hipLaunchKernelGGL(k_nz_count, dim3(nzb), dim3(256), 0, ctx->stream, counts_dev, n_hist, blockcnt);
+    hipLaunchKernelGGL(k_nz_offsets, dim3(1), dim3(1024), 0, ctx->stream, blockcnt, nzb, total);
+    TPH_LAUNCH_CHECK();
+    TPH_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    long long m = *(long long*)ctx->pinned;
+    if (m > 0 && 2 * m <= n_hist) m_keep = m;          // otherwise streaming the history is as cheap
+  }
+  if (m_keep > 0) n = m_keep;
   const int nblk = cov_blocks(n);
   const int rblk = tph_grid_for(n, 256, 4, 512);
   // scratch layout
@@ -631,8 +721,24 @@ extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int3
   size_t o_vals = take(sizeof(double) * (size_t)d * 2 * MED_CAP);
   size_t o_cnts = take(sizeof(int) * (size_t)d * 2 * MED_CAP);
   size_t o_fill = take(sizeof(int) * ((size_t)d * 2 + 1));
+  size_t o_uc = 0, o_cc = 0, o_lc = 0;
+  if (m_keep > 0) {
+    o_uc = take(sizeof(double) * (size_t)d * (size_t)m_keep);
+    o_cc = take(sizeof(int32_t) * (size_t)m_keep);
+    o_lc = take(sizeof(int32_t) * (size_t)m_keep);
+  }
   if (tph_scratch_reserve(ctx, o)) return -1;
   char* base = (char*)ctx->scratch;
+  if (m_keep > 0) {
+    double* uc = (double*)(base + o_uc);
+    int32_t* cc = (int32_t*)(base + o_cc);
+    int32_t* lc = K > 1 ? (int32_t*)(base + o_lc) : nullptr;
+    hipLaunchKernelGGL(k_nz_scatter, dim3(nzb), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, d, counts_dev, labels_dev, n_hist,
+                       blockcnt, uc, m_keep, cc, lc);
+    TPH_LAUNCH_CHECK();
+    src = uc; src_ld = m_keep; counts_dev = cc;
+    if (K > 1) labels_dev = lc;
+  }
   double* part = (double*)(base + o_part);
   double* part1 = (double*)(base + o_part1);
   double* sums = (double*)(base + o_sums);
@@ -648,22 +754,23 @@ extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int3
   for (int k = 0; k < K; ++k) {
     const int32_t* lab = K > 1 ? labels_dev : nullptr;
     // first moments -> arithmetic mean (centre of np.cov)
-    hipLaunchKernelGGL(k_wsum<int32_t>, dim3(rblk, 1 + d), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, d, counts_dev, lab, k, n,
+    hipLaunchKernelGGL(k_wsum<int32_t>, dim3(rblk, 1 + d), dim3(256), 0, ctx->stream, src, src_ld, d, counts_dev, lab, k, n,
                        part1);
     hipLaunchKernelGGL(k_wsum_final, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums, range);
     hipLaunchKernelGGL(k_mean_from_sums, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, sums, d, mean);
     // covariance (student.py:62-63)
-    if (moments_launch_cov(ctx, counts_dev, true, lab, k, n, mean, sums, 1, covs_dev + (size_t)k * d * d, part, nblk)) return -1;
+    if (moments_launch_cov(ctx, counts_dev, true, lab, k, n, mean, sums, 1, covs_dev + (size_t)k * d * d, part, nblk, src, src_ld))
+      return -1;
     // per-dimension median (student.py:61)
     TPH_HIP(hipMemsetAsync(h1, 0, sizeof(unsigned int) * (size_t)d * MED_BINS, ctx->stream));
     TPH_HIP(hipMemsetAsync(h2, 0, sizeof(unsigned int) * (size_t)d * 2 * MED_BINS, ctx->stream));
     TPH_HIP(hipMemsetAsync(fill, 0, sizeof(int) * ((size_t)d * 2 + 1), ctx->stream));
     dim3 hg(tph_grid_for(n, 256, 8, 256), d);
-    hipLaunchKernelGGL(k_med_hist1, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, range, h1);
+    hipLaunchKernelGGL(k_med_hist1, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n, range, h1);
     hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(256), 0, ctx->stream, h1, 1, sums, sel);
-    hipLaunchKernelGGL(k_med_hist2, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, range, sel, h2);
+    hipLaunchKernelGGL(k_med_hist2, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n, range, sel, h2);
     hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(256), 0, ctx->stream, h2, 2, sums, sel);
-    hipLaunchKernelGGL(k_med_collect, hg, dim3(256), 0, ctx->stream, ctx->u, ctx->cap, counts_dev, lab, k, n, range, sel, vals, cnts, fill);
+    hipLaunchKernelGGL(k_med_collect, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n, range, sel, vals, cnts, fill);
     hipLaunchKernelGGL(k_med_finish, dim3(d), dim3(256), 0, ctx->stream, sel, range, vals, cnts, fill, means_dev + (size_t)k * d, overflow);
     TPH_LAUNCH_CHECK();
   }

@@ -293,6 +293,36 @@ def test_fit_modes_large_narrow_with_duplicates(dev):
     np.testing.assert_allclose(L @ L.T, covs.cpu().numpy()[0], rtol=1e-10, atol=1e-22)
 
 
+@pytest.mark.parametrize("d,K", [(10, 1), (10, 3), (37, 1)])
+def test_fit_modes_compacts_sparse_upsampled_sets(dev, d, K):
+    """Histories >= 262 144 rows whose multiplicities are mostly zero go through the order-preserving stream compaction
+    (k_nz_count / k_nz_offsets / k_nz_scatter) before the five fit passes: same medians (exact) and covariances."""
+    rs = np.random.RandomState(100 + d + K)
+    n = 300_001
+    u = np.clip(0.5 + 0.05 * rs.randn(n, d) @ np.triu(rs.rand(d, d)) / np.sqrt(d), 0, 1)
+    counts = np.zeros(n, dtype=np.int32)
+    hot = rs.choice(n, n // 9, replace=False)                     # 11 % of the rows carry all the multiplicity
+    counts[hot] = rs.randint(1, 9, size=hot.size)
+    counts[-1] = 3; counts[0] = 2                                  # first and last row of the history kept
+    labels = rs.randint(0, K, size=n).astype(np.int32)
+    c = ctx_for(d)
+    c.history_load(u, u, np.zeros(n), [0.0], [0.0], [n])
+    ct = torch.from_numpy(counts).to(dev)
+    lt = torch.from_numpy(labels).to(dev) if K > 1 else None
+    means, covs, chol, inv = c.fit_modes(ct, lt, K=K)
+    for k in range(K):
+        ck = counts * (labels == k) if K > 1 else counts
+        mu, Sig, _ = ps.median_cov_from_counts(u, ck)
+        np.testing.assert_allclose(means.cpu().numpy()[k], mu, rtol=1e-14, atol=0)
+        np.testing.assert_allclose(covs.cpu().numpy()[k], Sig, rtol=1e-9, atol=1e-22)
+    # dense multiplicities (> half of the rows): the history is streamed as it is -- same answer as the oracle too
+    dense = rs.randint(0, 3, size=n).astype(np.int32)
+    means, covs, _, _ = c.fit_modes(torch.from_numpy(dense).to(dev))
+    mu, Sig, _ = ps.median_cov_from_counts(u, dense)
+    np.testing.assert_allclose(means.cpu().numpy()[0], mu, rtol=1e-14, atol=0)
+    np.testing.assert_allclose(covs.cpu().numpy()[0], Sig, rtol=1e-9, atol=1e-22)
+
+
 def test_chol_inv_ridge(dev):
     rs = np.random.RandomState(2)
     d = 6
