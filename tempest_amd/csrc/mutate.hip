@@ -758,13 +758,13 @@ extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, 
 // ------------------------------------------------------------- sigma adaptation + stopping rule
 // mcmc.py:180-186 (per-cluster mean alpha), :281-288 / :320-323 (sigma update), :104-140,192-194
 // (adaptive step count incl. the `sigmas[:n_nonempty]` weighting quirk), :196-197 (returned stats).
-__global__ void __launch_bounds__(256) k_adapt(int kernel, const double* __restrict__ sums, const double* __restrict__ counts, int K, double n_global,
+__global__ void __launch_bounds__(1024) k_adapt(int kernel, const double* __restrict__ sums, const double* __restrict__ counts, int K, double n_global,
                         int d, int n_steps, int n_max, double* __restrict__ sigmas, double* __restrict__ state,
                         double* __restrict__ mailbox, int slots, const double* __restrict__ partials, int nblocks,
                         double* __restrict__ sums_out) {
   if (state[1] != 0.0) return;          // stopping rule already fired: later (speculative) steps are no-ops
   if (partials) {                        // single GPU: the column sums of tph_accept's block partials, folded in here
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     for (int col = 0; col <= K; ++col) {
       double s = 0.0;
       for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partials[(size_t)b * (1 + K) + col];
@@ -824,9 +824,10 @@ extern "C" int tph_adapt(tph_ctx* ctx, int kernel, double* sums_dev, const doubl
   TPH_REQUIRE(ctx && sums_dev && counts_dev && sigmas_dev && state_dev && K >= 1, "tph_adapt: bad argument");
   TPH_REQUIRE(!partials_dev || n > 0, "tph_adapt: partials need the particle count");
   TPH_REQUIRE(!mailbox_host || mailbox_slots >= 1, "tph_adapt: mailbox needs at least one slot");
-  hipLaunchKernelGGL(k_adapt, dim3(1), dim3(256), 0, ctx->stream, kernel, (const double*)sums_dev, counts_dev, K, n_global, n_dim,
-                     n_steps, n_max, sigmas_dev, state_dev, mailbox_host, mailbox_slots, partials_dev,
-                     (int)((n + ACC_THREADS - 1) / ACC_THREADS), sums_dev);
+  const int nparts = (int)((n + ACC_THREADS - 1) / ACC_THREADS);
+  const int threads = (partials_dev && nparts > 1024) ? 1024 : 256;      // the folded column sums are the only parallel work
+  hipLaunchKernelGGL(k_adapt, dim3(1), dim3(threads), 0, ctx->stream, kernel, (const double*)sums_dev, counts_dev, K, n_global,
+                     n_dim, n_steps, n_max, sigmas_dev, state_dev, mailbox_host, mailbox_slots, partials_dev, nparts, sums_dev);
   TPH_LAUNCH_CHECK();
   return 0;
 }
