@@ -166,7 +166,9 @@ int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const int32_t* as
                 uint64_t seed, uint32_t tick, int64_t item0,
                 double* uprime_dev, double* maha_u_dev, double* maha_up_dev, const double* ctl_dev);
 /* Metropolis step (mcmc.py:163-177 with the factor of :251-279): masked overwrite of u,x,logl and
- * per-rank sums  sums_dev = (n_accepted, sum alpha_0 .. sum alpha_{K-1}). */
+ * per-rank sums  sums_dev = (n_accepted, sum alpha_0 .. sum alpha_{K-1}).  x_dev and xprime_dev may both be NULL: x is
+ * then not maintained during the run (it is a function of u: the caller re-evaluates prior_transform once at the end, which
+ * halves this kernel's masked-write traffic). */
 int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, double* x_dev, double* logl_dev,
                const double* uprime_dev, const double* xprime_dev, const double* loglprime_dev,
                const double* maha_u_dev, const double* maha_up_dev, const int32_t* assign_dev,

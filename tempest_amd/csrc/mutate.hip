@@ -690,10 +690,9 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accept(double beta, double* __r
     g.uniform2(0, U, U1);
     if (U < a) {
       acc = 1.0;
-      for (int j = 0; j < d; ++j) {
-        u[(size_t)j * ld + i] = up[(size_t)j * ld + i];
-        x[(size_t)j * ld + i] = xp[(size_t)j * ld + i];
-      }
+      for (int j = 0; j < d; ++j) u[(size_t)j * ld + i] = up[(size_t)j * ld + i];
+      if (x)
+        for (int j = 0; j < d; ++j) x[(size_t)j * ld + i] = xp[(size_t)j * ld + i];
       logl[i] = l1;
     }
   }
@@ -727,7 +726,8 @@ extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, 
                           int64_t ld, int K, const double* dof_dev, uint64_t seed, uint32_t tick0, int64_t item0,
                           double* sums_dev, const double* ctl_dev, double* partials_dev) {
   const tph_stepctl tick{tick0, ctl_dev};
-  TPH_REQUIRE(ctx && u_dev && x_dev && logl_dev && uprime_dev && xprime_dev && loglprime_dev, "tph_accept: NULL argument");
+  TPH_REQUIRE(ctx && u_dev && logl_dev && uprime_dev && loglprime_dev, "tph_accept: NULL argument");
+  TPH_REQUIRE((x_dev == nullptr) == (xprime_dev == nullptr), "tph_accept: x_dev and xprime_dev go together (both NULL = x is not maintained)");
   TPH_REQUIRE(sums_dev || partials_dev, "tph_accept: without sums_dev the block partials must go to partials_dev");
   TPH_REQUIRE(n > 0 && ld >= n && K >= 1, "tph_accept: bad sizes");
   TPH_REQUIRE(K == 1 || assign_dev, "tph_accept: K>1 needs assignments");

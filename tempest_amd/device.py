@@ -266,7 +266,8 @@ class HipContext:
         if partials is not None and partials.numel() < ((n + 255) // 256) * (1 + K):
             raise _lib.TempestHipError("accept: partials buffer too small")
         check(self.lib.tph_accept(self._ctx, KERNEL_ID[kernel], float(beta), _ptr(u), _ptr(x), _ptr(logl),
-                                  _ptr(uprime), _ptr(xprime, torch.float64), _ptr(loglprime, torch.float64),
+                                  _ptr(uprime), _ptr(xprime, torch.float64) if x is not None else None,
+                                  _ptr(loglprime, torch.float64),
                                   _ptr(maha_u), _ptr(maha_up),
                                   _ptr(assign, torch.int32) if assign is not None else None, n, n, K, _ptr(dof), seed,
                                   tick, item0, _ptr(sums) if sums is not None else None,

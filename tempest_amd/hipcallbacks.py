@@ -170,7 +170,7 @@ class HipCallbacks:
         n = u.shape[1]
         if partials is None or partials.numel() < ((n + 255) // 256) * (1 + K):
             raise TempestHipError("HipCallbacks.accept: partials buffer missing or too small")
-        for t in (u, x, logl, uprime):
+        for t in (u, logl, uprime) + ((x,) if x is not None else ()):
             if not (t.is_cuda and t.is_contiguous()):
                 raise TempestHipError("HipCallbacks.accept: expected contiguous device tensors")
         p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731

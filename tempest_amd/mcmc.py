@@ -87,9 +87,9 @@ class StepEngine:
         self.seed, self.item0, self.n_global = seed, item0, n_global
         self.n_steps, self.n_max, self.comm_active = n_steps, n_max, comm_active
         self.up, self.maha_u, self.maha_up = ctx.empty(d, n), ctx.empty(n), ctx.empty(n)
-        self.u = self.x = self.logl = self.assign = self.modes = None
+        self.u = self.logl = self.assign = self.modes = None
         if use_graph:       # fixed-address copies of everything a captured step reads or writes
-            self.u, self.x, self.logl = ctx.empty(d, n), ctx.empty(d, n), ctx.empty(n)
+            self.u, self.logl = ctx.empty(d, n), ctx.empty(n)
             self.assign = torch.empty(n, dtype=torch.int32, device=ctx.device) if has_assign else None
             self.modes = SimpleNamespace(K=K, means_dev=ctx.empty(K, d), chol_dev=ctx.empty(K, d, d),
                                          inv_dev=ctx.empty(K, d, d), dof_dev=ctx.empty(K))
@@ -109,16 +109,16 @@ class StepEngine:
         self.runs += 1
         if self.use_graph:
             if self._own is None:
-                self._own = (self.u, self.x, self.logl, self.assign, self.modes)
-            self.u, self.x, self.logl, self.assign, self.modes = self._own
-            self.u.copy_(u); self.x.copy_(x); self.logl.copy_(logl)
+                self._own = (self.u, self.logl, self.assign, self.modes)
+            self.u, self.logl, self.assign, self.modes = self._own
+            self.u.copy_(u); self.logl.copy_(logl)
             if self.assign is not None:
                 self.assign.copy_(assign)
             m = self.modes
             m.means_dev.copy_(modes.means_dev.reshape(m.means_dev.shape)); m.chol_dev.copy_(modes.chol_dev.reshape(m.chol_dev.shape))
             m.inv_dev.copy_(modes.inv_dev.reshape(m.inv_dev.shape)); m.dof_dev.copy_(modes.dof_dev.reshape(m.dof_dev.shape))
         else:
-            self.u, self.x, self.logl, self.assign, self.modes = u, x, logl, assign, modes
+            self.u, self.logl, self.assign, self.modes = u, logl, assign, modes
         self.sigmas.fill_(sigma_init)
         self.counts.copy_(counts)
         self.mailbox_np[:, 7] = -1.0          # no record yet (the device is idle or running no-op steps: see step())
@@ -138,13 +138,13 @@ class StepEngine:
         if self.plugin is not None:       # callbacks compiled into the Metropolis kernel (hipcallbacks.py)
             from .device import KERNEL_ID
             xp = lp = None
-            self.plugin.accept(KERNEL_ID[self.kernel], 0.0, self.u, self.x, self.logl, self.up, self.maha_u, self.maha_up,
+            self.plugin.accept(KERNEL_ID[self.kernel], 0.0, self.u, None, self.logl, self.up, self.maha_u, self.maha_up,
                                self.assign, self.K, self.modes.dof_dev, self.seed, 2, self.item0, sums,
                                ctl=self.ctl, partials=self.partials)
         else:
             xp = self.prior(self.up)
             lp = self.loglike(xp)
-            ctx.accept(self.kernel, 0.0, self.u, self.x, self.logl, self.up, xp, lp, self.maha_u, self.maha_up,
+            ctx.accept(self.kernel, 0.0, self.u, None, self.logl, self.up, xp, lp, self.maha_u, self.maha_up,
                        self.assign, self.K, self.modes.dof_dev, self.seed, 2, self.item0, sums, ctl=self.ctl,
                        partials=self.partials)
         if not self.comm_active:
@@ -339,7 +339,10 @@ class DeviceMCMC:
                 if st[1] != 0.0:
                     break
         if eng.u is not u:                    # graph mode: the step worked on the engine's fixed-address buffers
-            u.copy_(eng.u); x.copy_(eng.x); logl.copy_(eng.logl)
+            u.copy_(eng.u); logl.copy_(eng.logl)
+        # x = prior_transform(u) is not maintained step by step (tph_accept with x = NULL writes half the bytes): one
+        # evaluation for the final positions -- the same elementwise function of the same u, hence the same values
+        x.copy_(self.prior(u))
         # two ticks per step + the proposal of the step that was launched ahead (same count as the step-by-step path)
         self.rng.tick = (tick_base + 2 * it + 1) & 0xFFFFFFFF
         return float(st[4]), float(st[3]), it, it * n_global
