@@ -171,7 +171,8 @@ int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const int32_t* as
  * halves this kernel's masked-write traffic). */
 int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, double* x_dev, double* logl_dev,
                const double* uprime_dev, const double* xprime_dev, const double* loglprime_dev,
-               const double* maha_u_dev, const double* maha_up_dev, const int32_t* assign_dev,
+               double* maha_u_dev /* in; accepted rows take maha_up (tpCN): see ctl_dev */, const double* maha_up_dev,
+               const int32_t* assign_dev,
                int64_t n, int64_t ld, int K, const double* dof_dev,
                uint64_t seed, uint32_t tick, int64_t item0,
                double* sums_dev /*[1+K]; NULL = leave the block partials in partials_dev for tph_adapt to sum*/,

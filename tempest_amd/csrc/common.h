@@ -139,6 +139,10 @@ struct tph_stepctl {
     return ctl ? tick + (uint32_t)(unsigned long long)ctl[7] + 2u * (uint32_t)ctl[0] : tick;
   }
   __device__ __forceinline__ bool done() const { return ctl && ctl[1] != 0.0; }
+  // After the first step of a run maha_u[i] already holds (u_i - mu)^T Sigma^-1 (u_i - mu): tph_accept copies the
+  // proposal's value for accepted rows, rejected rows keep theirs.  The proposal kernels then read it instead of
+  // recomputing a d x d quadratic form per particle (same formula on the same doubles: bit-identical).
+  __device__ __forceinline__ bool carry() const { return ctl && ctl[0] > 0.0; }
 };
 
 // Gamma(shape,1), Marsaglia-Tsang; attempt a uses draws 2a (normal) and 2a+1 (uniform); shape<1 boosted.

@@ -125,10 +125,14 @@ __global__ void __launch_bounds__(PROP_THREADS) k_propose(const double* __restri
   }
   double a_fac = 1.0, b_fac = sigma, m_u = 0.0;
   if (KERNEL == TPH_KERNEL_TPCN) {
-    for (int r = 0; r < d; ++r) {
-      double acc = 0.0;
-      for (int j = 0; j < d; ++j) acc += P[r * d + j] * df[j * PROP_THREADS];
-      m_u += df[r * PROP_THREADS] * acc;
+    if (tick.carry()) {
+      m_u = maha_u[i];
+    } else {
+      for (int r = 0; r < d; ++r) {
+        double acc = 0.0;
+        for (int j = 0; j < d; ++j) acc += P[r * d + j] * df[j * PROP_THREADS];
+        m_u += df[r * PROP_THREADS] * acc;
+      }
     }
     const double nu = dof[c];
     tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
@@ -235,9 +239,10 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
   auto stage = [&](double* dst, const double* src) {
     for (int e = threadIdx.x; e < d * d; e += ML_THREADS) dst[(e / d) * (d + 1) + (e % d)] = src[e];
   };
+  const bool carry = KERNEL == TPH_KERNEL_TPCN && tick.carry();   // maha_u already holds the form at u (see tph_stepctl)
   if (STAGE != 0) {
-    if (KERNEL == TPH_KERNEL_TPCN) stage(mat0, Pg);
-    if (STAGE == 1 || KERNEL != TPH_KERNEL_TPCN) stage(STAGE == 1 ? mat1 : mat0, Lg);
+    if (KERNEL == TPH_KERNEL_TPCN && (STAGE == 1 || !carry)) stage(mat0, Pg);
+    if (STAGE == 1 || KERNEL != TPH_KERNEL_TPCN || carry) stage(STAGE == 1 ? mat1 : mat0, Lg);
   }
 
   for (int j = l; j < d; j += LPP) {
@@ -248,14 +253,18 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
   double a_fac = 1.0, b_fac = sigma, m_u = 0.0;
   double nu = 0.0, gshape = 1.0;
   if (KERNEL == TPH_KERNEL_TPCN) {
-    double part = 0.0;
-    for (int r = l; r < d; r += LPP) {
-      const double* Pr = P + (size_t)r * ms;
-      double acc = 0.0;
-      for (int j = 0; j < d; ++j) acc += Pr[j] * df[j];
-      part += df[r] * acc;
+    if (carry) {
+      m_u = maha_u[ii];
+    } else {
+      double part = 0.0;
+      for (int r = l; r < d; r += LPP) {
+        const double* Pr = P + (size_t)r * ms;
+        double acc = 0.0;
+        for (int j = 0; j < d; ++j) acc += Pr[j] * df[j];
+        part += df[r] * acc;
+      }
+      m_u = group_sum<LPP>(part);
     }
-    m_u = group_sum<LPP>(part);
     nu = dof[c];
     gshape = 0.5 * ((double)d + nu);
     a_fac = sqrt(1.0 - sigma * sigma);
@@ -305,7 +314,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
     b_fac = sigma * sqrt(1.0 / gam);
   }
   __syncthreads();
-  if (STAGE == 2 && KERNEL == TPH_KERNEL_TPCN) {      // Sigma^-1 is done with for now: the slot takes L
+  if (STAGE == 2 && KERNEL == TPH_KERNEL_TPCN && !carry) {      // Sigma^-1 is done with for now: the slot takes L
     stage(mat0, Lg);
     __syncthreads();
   }
@@ -437,16 +446,20 @@ __global__ void __launch_bounds__(256) k_propose_reg(const double* __restrict__ 
       if (KERNEL == TPH_KERNEL_TPCN) {
         const double* __restrict__ mu = means + (size_t)c * D;
         const double* __restrict__ P = inv + (size_t)c * D * D;
-        double df[D];
-#pragma unroll
-        for (int j = 0; j < D; ++j) df[j] = u[(size_t)j * ld + i] - mu[j];
         double m_u = 0.0;
+        if (tick.carry()) {
+          m_u = maha_u[i];
+        } else {
+          double df[D];
 #pragma unroll
-        for (int r = 0; r < D; ++r) {
-          double acc = 0.0;
+          for (int j = 0; j < D; ++j) df[j] = u[(size_t)j * ld + i] - mu[j];
 #pragma unroll
-          for (int j = 0; j < D; ++j) acc += P[r * D + j] * df[j];
-          m_u += df[r] * acc;
+          for (int r = 0; r < D; ++r) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) acc += P[r * D + j] * df[j];
+            m_u += df[r] * acc;
+          }
         }
         const double nu = dof[c];
         tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
@@ -663,7 +676,7 @@ template <int KERNEL>
 __global__ void __launch_bounds__(ACC_THREADS) k_accept(double beta, double* __restrict__ u, double* __restrict__ x,
                                                         double* __restrict__ logl, const double* __restrict__ up,
                                                         const double* __restrict__ xp, const double* __restrict__ lp,
-                                                        const double* __restrict__ maha_u, const double* __restrict__ maha_up,
+                                                        double* __restrict__ maha_u, const double* __restrict__ maha_up,
                                                         const int32_t* __restrict__ assign, int64_t n, int64_t ld, int d, int K,
                                                         const double* __restrict__ dof, uint64_t seed, tph_stepctl tick,
                                                         int64_t item0, double* __restrict__ partials) {
@@ -694,6 +707,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accept(double beta, double* __r
       if (x)
         for (int j = 0; j < d; ++j) x[(size_t)j * ld + i] = xp[(size_t)j * ld + i];
       logl[i] = l1;
+      if (KERNEL == TPH_KERNEL_TPCN) maha_u[i] = maha_up[i];   // the form at the new position: next step's proposal reads it
     }
   }
   __shared__ double sh[ACC_THREADS / 64];
@@ -722,7 +736,7 @@ __global__ void __launch_bounds__(256) k_colsum(const double* __restrict__ parti
 
 extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, double* x_dev, double* logl_dev,
                           const double* uprime_dev, const double* xprime_dev, const double* loglprime_dev,
-                          const double* maha_u_dev, const double* maha_up_dev, const int32_t* assign_dev, int64_t n,
+                          double* maha_u_dev, const double* maha_up_dev, const int32_t* assign_dev, int64_t n,
                           int64_t ld, int K, const double* dof_dev, uint64_t seed, uint32_t tick0, int64_t item0,
                           double* sums_dev, const double* ctl_dev, double* partials_dev) {
   const tph_stepctl tick{tick0, ctl_dev};

@@ -68,6 +68,15 @@ class HipContext:
     def empty(self, *shape, dtype=torch.float64):
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
+    def empty_rows(self, n, dtype=torch.float64):
+        """1-D scratch of `n` entries for arrays that grow with the history (weights, cdf, multiplicities): the backing
+        block is rounded up to 2^k or 1.5 * 2^k entries, so torch's caching allocator hands the same block back while the
+        history grows inside a bucket instead of calling hipMalloc for a slightly larger one every iteration."""
+        n = int(n)
+        p2 = 1 << max(10, (n - 1).bit_length())          # next power of two >= n
+        cap = p2 * 3 // 4 if p2 * 3 // 4 >= n else p2
+        return torch.empty(cap, dtype=dtype, device=self.device)[:n]
+
     def zeros(self, *shape, dtype=torch.float64):
         return torch.zeros(*shape, dtype=dtype, device=self.device)
 
@@ -159,14 +168,14 @@ class HipContext:
 
     def weights(self, beta, vmax, s1, out=None):
         if out is None:
-            out = self.empty(self.size)
+            out = self.empty_rows(self.size)
         check(self.lib.tph_weights(self._ctx, float(beta), float(vmax), float(s1), _ptr(out, torch.float64)),
               "tph_weights")
         return out
 
     def logw(self, beta, n_h_global=None, out=None):
         if out is None:
-            out = self.empty(self.size)
+            out = self.empty_rows(self.size)
         check(self.lib.tph_logw(self._ctx, float(beta), int(self.size if n_h_global is None else n_h_global),
                                 _ptr(out, torch.float64)), "tph_logw")
         return out
@@ -188,7 +197,7 @@ class HipContext:
     # ----------------------------------------------------------------------------- resampling
     def cdf(self, w, thr=None, out=None):
         if out is None:
-            out = self.empty(w.numel())
+            out = self.empty_rows(w.numel())
         check(self.lib.tph_cdf(self._ctx, _ptr(w, torch.float64), w.numel(), _ptr(thr), _ptr(out)), "tph_cdf")
         return out
 
@@ -234,7 +243,7 @@ class HipContext:
 
     def multinomial_counts(self, cdf, seed, tick, kept_count=None, factor=4, n_draw_max=None, tag=TAG_UPSAMPLE):
         n = cdf.numel()
-        counts = self.empty(n, dtype=torch.int32)
+        counts = self.empty_rows(n, dtype=torch.int32)
         if n_draw_max is None:
             n_draw_max = factor * n
         check(self.lib.tph_multinomial_counts(self._ctx, _ptr(cdf), n, _ptr(kept_count), factor, n_draw_max, seed,

@@ -47,8 +47,23 @@ class StateManager:
     def ctx(self):
         if self._ctx is None:
             from .device import HipContext
-            self._ctx = HipContext(self.n_dim, self._device_arg, self._capacity_hint)
+            self._ctx = HipContext(self.n_dim, self._device_arg, self._clamped_hint())
         return self._ctx
+
+    def _clamped_hint(self) -> int:
+        """History rows to reserve up front: the caller's hint, but never more than a quarter of the free device memory
+        (a history that outgrows it falls back to geometric growth, whose reallocations stall the stream)."""
+        rows = int(self._capacity_hint or 0)
+        if rows <= 0:
+            return 0
+        try:
+            import torch
+            dev = self._device_arg if self._device_arg is not None else torch.cuda.current_device()
+            free, _ = torch.cuda.mem_get_info(dev)
+            rows = min(rows, int(0.25 * free) // ((2 * self.n_dim + 2) * 8))
+        except Exception:
+            pass
+        return max(rows, 0)
 
     @property
     def device(self):

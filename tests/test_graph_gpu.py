@@ -102,14 +102,24 @@ def test_step_control_block_semantics():
     sig = torch.full((1,), 0.5, dtype=torch.float64, device=dev)
     seed, base, done_steps = 1234, 100, 3
 
-    def propose(tick, ctl):
-        up, mu, mup = ctx.empty(d, n), ctx.empty(n), ctx.empty(n)
+    def propose(tick, ctl, maha_u=None):
+        up, mu, mup = ctx.empty(d, n), (ctx.empty(n) if maha_u is None else maha_u.clone()), ctx.empty(n)
         ctx.propose("tpcn", u, None, modes, sig, None, seed, tick, 0, up, mu, mup, ctl=ctl)
         return up, mu, mup
     ctl = torch.tensor([done_steps, 0, 0, 0, 0, 0, 0.37, base], dtype=torch.float64, device=dev)
-    a = propose(1, ctl)
     b = propose(1 + base + 2 * done_steps, None)
+    # with steps already done the kernel READS the Mahalanobis form at u from maha_u (kept current by tph_accept)
+    a = propose(1, ctl, maha_u=b[1])
     for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # ... and a wrong carried value changes the proposal: it really is read, not recomputed
+    c = propose(1, ctl, maha_u=b[1] * 4.0 + 1.0)
+    assert not torch.equal(c[0], b[0])
+    # at step 0 of a run it is computed whatever the buffer holds
+    ctl0 = ctl.clone(); ctl0[0] = 0.0
+    e = propose(1, ctl0, maha_u=b[1] * 4.0 + 1.0)
+    f = propose(1 + base, None)
+    for x, y in zip(e, f):
         assert torch.equal(x, y)
     # accept: beta and tick from the block == by-value call
     up, mu, mup = a
@@ -122,8 +132,13 @@ def test_step_control_block_semantics():
                    partials=partials)
         return uu, xx, ll, sums
     part = ctx.empty(((n + 255) // 256) * 2)
+    mu_before = mu.clone()
     r1 = accept(2, 0.0, ctl, part)
+    moved = (r1[2] != logl0)
+    assert torch.equal(mu[moved], mup[moved]) and torch.equal(mu[~moved], mu_before[~moved])   # maha_u follows the accepted rows
+    mu.copy_(mu_before)
     r2 = accept(2 + base + 2 * done_steps, 0.37, None)
+    mu.copy_(mu_before)
     for x, y in zip(r1, r2):
         assert torch.equal(x, y)
     assert 0 < r1[3][0].item() < n

@@ -107,12 +107,14 @@ def test_fused_accept_is_bit_identical_to_library_accept(kernel, K):
     sums_a = ctx.zeros(1 + K)
     xp = cb.prior_transform(up.T).T.contiguous()
     lp = cb.log_likelihood(xp.T)
-    ctx.accept(kernel, beta, a[0], a[1], a[2], up, xp, lp, mu, mup, assign, K, dof, seed, tick, 0, sums_a)
+    mu_a, mu_b = mu.clone(), mu.clone()          # in/out: accepted rows take the proposal's Mahalanobis form
+    ctx.accept(kernel, beta, a[0], a[1], a[2], up, xp, lp, mu_a, mup, assign, K, dof, seed, tick, 0, sums_a)
     b = [t.clone() for t in (u, x, logl)]
     sums_b = ctx.zeros(1 + K)
     part = ctx.empty(((n + 255) // 256) * (1 + K))
-    cb.accept(KERNEL_ID[kernel], beta, b[0], b[1], b[2], up, mu, mup, assign, K, dof, seed, tick, 0, sums_b, partials=part)
+    cb.accept(KERNEL_ID[kernel], beta, b[0], b[1], b[2], up, mu_b, mup, assign, K, dof, seed, tick, 0, sums_b, partials=part)
     torch.cuda.synchronize()
+    assert torch.equal(mu_a, mu_b)
     for ta, tb in zip(a, b):
         assert torch.equal(ta, tb)
     assert torch.equal(sums_a, sums_b)
