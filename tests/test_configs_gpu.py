@@ -89,8 +89,9 @@ def test_config5_funnel100_small():
     """100-D Neal funnel (SURVEY 8d: v = x0 ~ N(0, 3^2), x_i | v ~ N(0, e^v)), per-dimension affine prior, tpCN;
     analytic logZ = -ln 30 - 99 ln 600 = -636.70.  4 096 particles here (BASELINE: 2 097 152 over 8 GPUs): exercises the
     d = 100 kernels (multi-lane proposal with one staged matrix slot, LDS-tiled covariance, 100 x 100 Cholesky/inverse).
-    One global Gaussian-preconditioned mode does not resolve the funnel's neck, so the gate is loose, as SURVEY notes
-    for the reference itself."""
+    One global Gaussian-preconditioned mode does not resolve the funnel's neck -- in the REFERENCE either: its own
+    run of this twin (3 seeds, 3.4 CPU-hours each, tests/golden/ref_ensembles.json) gives logZ = -639.44 +- 0.09 in 31
+    iterations with posterior mean of v = 8.55.  The GPU run must land on the reference, not on the analytic value."""
     import tempest_amd as tp
     dev = torch.device("cuda", 0)
     d = 100
@@ -113,7 +114,16 @@ def test_config5_funnel100_small():
     truth = -np.log(30.0) - 99 * np.log(600.0)
     print(f"config5 (N=4096): logZ={logz:.3f} (analytic {truth:.3f}) iters={len(s.state.get_history('beta'))} wall={time.time() - t0:.1f}s")
     assert np.isfinite(logz) and abs(logz - truth) < 8.0
+    import json
+    import os
+    ref = [r for r in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_ensembles.json")))["runs"]
+           if r["config"] == "c5twin_funnel100_n4096"]
+    assert len(ref) >= 3
+    ref_logz = np.array([r["logz"] for r in ref])
+    assert abs(logz - ref_logz.mean()) < 3 * max(ref_logz.std(ddof=1), 0.1) + 0.1, (logz, ref_logz)
+    assert abs(len(s.state.get_history("beta")) - np.mean([r["iters"] for r in ref])) <= 2
     x, w, _ = s.posterior()
+    assert abs(np.average(x[:, 0], weights=w) - np.mean([r["mean"][0] for r in ref])) < 0.5
     # x_i | v has standard deviation e^{v/2} (up to ~90 in the mouth): gate the means in units of the marginal scale
     print("config5 posterior mean of v:", np.average(x[:, 0], weights=w))
     assert np.all(np.abs(np.average(x[:, 1:], weights=w, axis=0)) < 30.0)
