@@ -71,6 +71,17 @@ def prior_funnel(u):
     return x
 
 
+def mixture32(x):
+    """config 3: four equal-weight N(mu_k, 0.25 I) modes at (+-4, +-4, 0, ...) in 32-D."""
+    d = x.shape[1]
+    mus = np.zeros((4, d))
+    for k, (a, b) in enumerate([(-4, -4), (-4, 4), (4, -4), (4, 4)]):
+        mus[k, 0], mus[k, 1] = a, b
+    q = ((x[:, None, :] - mus[None]) ** 2).sum(axis=2)
+    from scipy.special import logsumexp
+    return logsumexp(-0.5 * q / 0.25, axis=1) - np.log(4.0) - 0.5 * d * np.log(2 * np.pi * 0.25)
+
+
 PRIORS = {"c5twin_funnel100_n4096": prior_funnel}
 
 CONFIGS = {
@@ -84,6 +95,9 @@ CONFIGS = {
     # cheaper high-dimensional twins (the 50-D RWM twin spends hours in the reference's per-walker redraw loop)
     "gauss20_n256_tpcn": (gauss_c2, 20, dict(n_particles=256, clustering=False), 1024),
     "gauss20_n256_rwm": (gauss_c2, 20, dict(n_particles=256, clustering=False, sample="rwm"), 1024),
+    # config 2 with the tpCN kernel (its RWM variant spends hours in the reference's redraw loop) and config 3, small N
+    "c2twin_gauss50_n512_tpcn": (gauss_c2, 50, dict(n_particles=512, clustering=False), 2048),
+    "c3twin_mix32_n1024_cluster": (mixture32, 32, dict(n_particles=1024, clustering=True), 4096),
     # the parity twin of config 5 (100-D funnel) at N = 4096, reported as-is
     "c5twin_funnel100_n4096": (funnel, 100, dict(n_particles=4096, clustering=False), 4 * 4096),
 }
