@@ -95,6 +95,9 @@ CONFIGS = {
     # cheaper high-dimensional twins (the 50-D RWM twin spends hours in the reference's per-walker redraw loop)
     "gauss20_n256_tpcn": (gauss_c2, 20, dict(n_particles=256, clustering=False), 1024),
     "gauss20_n256_rwm": (gauss_c2, 20, dict(n_particles=256, clustering=False, sample="rwm"), 1024),
+    # dynamic (volume-variation) beta schedule and boundary conditions, end to end
+    "e2e_gauss10_n128_dynamic": (gauss_e2e, 10, dict(n_particles=128, clustering=False, volume_variation=0.5), 2048),
+    "e2e_gauss10_n128_bc": (gauss_e2e, 10, dict(n_particles=128, clustering=False, periodic=[0, 3], reflective=[1, 4]), 2048),
     # config 2 with the tpCN kernel (its RWM variant spends hours in the reference's redraw loop) and config 3, small N
     "c2twin_gauss50_n512_tpcn": (gauss_c2, 50, dict(n_particles=512, clustering=False), 2048),
     "c3twin_mix32_n1024_cluster": (mixture32, 32, dict(n_particles=1024, clustering=True), 4096),

@@ -76,7 +76,11 @@ def test_reference_end_to_end_acceptance(dev):
 
 
 @pytest.mark.parametrize("cfg,kw", [("e2e_gauss10_n128", dict(n_steps=1)),
-                                    ("e2e_gauss10_n128_rwm_syst", dict(sample="rwm", resample="syst"))])
+                                    ("e2e_gauss10_n128_rwm_syst", dict(sample="rwm", resample="syst")),
+                                    # dynamic beta schedule (volume-variation target, reweight.py:427-495) end to end
+                                    ("e2e_gauss10_n128_dynamic", dict(volume_variation=0.5)),
+                                    # boundary conditions inside the proposal (mcmc.py:326-411) end to end
+                                    ("e2e_gauss10_n128_bc", dict(periodic=[0, 3], reflective=[1, 4]))])
 def test_logz_within_3sigma_of_reference_gauss(dev, cfg, kw):
     import tempest_amd as tp
     mu, sd, runs = ref_stats(cfg)
