@@ -217,12 +217,13 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
   constexpr int PPB = ML_THREADS / LPP;
   const int l = threadIdx.x % LPP, p = threadIdx.x / LPP;
   const int dp = d | 1;                               // odd per-particle stride: particles land on different LDS banks
-  double* zs = sh + (size_t)p * dp;                   // z, later the proposal
+  double* zs = sh + (size_t)p * dp;                   // normals of the current attempt
   double* df = sh + (size_t)PPB * dp + (size_t)p * dp;  // u - mu (tpCN) or u (RWM)
+  double* vs = sh + (size_t)2 * PPB * dp + (size_t)p * dp;   // rows of the current attempt; the proposal once it is complete
   // STAGE 1: Sigma^-1 and L both resident in LDS (rows padded to d+1); STAGE 2: one matrix slot, refilled per phase;
   // STAGE 0: read from global/L2 (several modes, or matrices too large).  Staging amortises the matrix reads over the
   // PPB particles of the block instead of re-reading d*d doubles per particle.
-  double* mat0 = sh + (size_t)2 * PPB * dp;
+  double* mat0 = sh + (size_t)3 * PPB * dp;
   double* mat1 = mat0 + (size_t)d * (d + 1);
   const int64_t i = (int64_t)blockIdx.x * PPB + p;
   const bool live = i < n;
@@ -319,64 +320,76 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
     __syncthreads();
   }
 
-  int ok = 0;
-  for (int att = 0; att < PROP_MAX_ATTEMPTS; ++att) {
-    if (att > 0) {
-      if (!ok) {
-        for (int q = l; q < npairs; q += LPP) {
+  // ---- attempts (mcmc.py:239-249).  Every particle's lane group walks its OWN sequence of (attempt, row chunk) steps; nothing
+  // is block-synchronous here (a group lives inside one wave: LDS traffic between its lanes is ordered by the wave's own
+  // instruction stream).  Rows are taken in ascending order, LPP at a time: L is lower-triangular, row r needs z_0..z_r only, so
+  // the normals of a redraw attempt are generated as the rows reach them and an attempt is ABANDONED AT ITS FIRST out-of-bounds
+  // coordinate -- a violation at row r* costs ~r*^2/2 FMAs and r*/2 Box-Muller pairs instead of d^2/2 and d/2.  In the first
+  // iterations of a high-dimensional run (50-D: ~98 % of the attempts leave the unit cube) that is most of the work.  Draws,
+  // attempt order and arithmetic are those of the sequential loop: the accepted proposal is bit-identical.
+  const int nchunks = (d + LPP - 1) / LPP;
+  int att = 0, ch = 0, zgen = 2 * npairs;            // attempt 0: all normals are in zs already (generated above)
+  bool active = true;
+  while (__any(active)) {
+    if (active) {
+      const int need = (ch + 1) * LPP < d ? (ch + 1) * LPP : d;
+      if (zgen < need) {                              // 2*LPP more normals of this attempt: enough for this chunk and the next
+        const int q = zgen / 2 + l;
+        if (q < npairs) {
           double z0, z1;
           gz.normal2((uint32_t)(att * npairs + q), z0, z1);
           zs[2 * q] = z0;
           if (2 * q + 1 < d) zs[2 * q + 1] = z1;
         }
+        zgen += 2 * LPP;
       }
-      __syncthreads();
     }
-    // rows of L z for this lane; results parked in registers until every lane has read z
-    double mine[8];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int r = ch * LPP + l;
     int okl = 1;
-    if (!ok) {
-      int k = 0;
-      for (int r = l; r < d; r += LPP, ++k) {
-        const double* Lr = L + (size_t)r * ms;
-        double acc = 0.0;
-        for (int j = 0; j <= r; ++j) acc += Lr[j] * zs[j];
-        double v;
-        if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * df[r] + b_fac * acc;
-        else v = df[r] + b_fac * acc;
-        const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
-        if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
-        else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
-        else okl = okl && (v >= 0.0) && (v <= 1.0);
-        if (k < 8) mine[k] = v;
+    double v = 0.0;
+    if (active && r < d) {
+      const double* Lr = L + (size_t)r * ms;
+      double acc = 0.0;
+      for (int j = 0; j <= r; ++j) acc += Lr[j] * zs[j];
+      if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * df[r] + b_fac * acc;
+      else v = df[r] + b_fac * acc;
+      const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
+      if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
+      else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
+      else okl = (v >= 0.0) && (v <= 1.0);
+    }
+    const int okg = group_and<LPP>(okl);              // all lanes of the wave take part in the shuffles
+    if (active) {
+      if (okg) {
+        if (r < d) vs[r] = v;
+        if (++ch == nchunks) active = false;          // every row in bounds: this is the proposal
+      } else {
+        ++att; ch = 0; zgen = 0;
+        if (att >= PROP_MAX_ATTEMPTS) {               // redraw cap reached (the reference would loop on): propose the current point
+          for (int j = l; j < d; j += LPP) vs[j] = (KERNEL == TPH_KERNEL_TPCN) ? df[j] + mu[j] : df[j];
+          active = false;
+        }
       }
     }
-    __syncthreads();
-    if (!ok) {
-      int k = 0;
-      for (int r = l; r < d; r += LPP, ++k) if (k < 8) zs[r] = mine[k];
-      ok = group_and<LPP>(okl);
-    }
-    if (__syncthreads_and(ok)) break;
-  }
-  if (!ok) {  // redraw cap reached: propose the current point
-    for (int j = l; j < d; j += LPP) zs[j] = (KERNEL == TPH_KERNEL_TPCN) ? df[j] + mu[j] : df[j];
   }
   __syncthreads();
   if (live)
-    for (int j = l; j < d; j += LPP) up[(size_t)j * ld + i] = zs[j];
+    for (int j = l; j < d; j += LPP) up[(size_t)j * ld + i] = vs[j];
   double m_up = 0.0;
   if (KERNEL == TPH_KERNEL_TPCN) {
     __syncthreads();
     if (STAGE == 2) stage(mat0, Pg);
-    for (int j = l; j < d; j += LPP) zs[j] -= mu[j];
+    for (int j = l; j < d; j += LPP) vs[j] -= mu[j];
     __syncthreads();
     double part = 0.0;
     for (int r = l; r < d; r += LPP) {
       const double* Pr = P + (size_t)r * ms;
       double acc = 0.0;
-      for (int j = 0; j < d; ++j) acc += Pr[j] * zs[j];
-      part += zs[r] * acc;
+      for (int j = 0; j < d; ++j) acc += Pr[j] * vs[j];
+      part += vs[r] * acc;
     }
     m_up = group_sum<LPP>(part);
   }
@@ -393,7 +406,7 @@ static int launch_propose_ml(tph_ctx* ctx, const double* u, const int32_t* assig
                              double* mup) {
   constexpr int PPB = ML_THREADS / LPP;
   const int d = ctx->d;
-  const size_t base = sizeof(double) * 2 * (size_t)PPB * (d | 1);
+  const size_t base = sizeof(double) * 3 * (size_t)PPB * (d | 1);
   const size_t one = sizeof(double) * (size_t)d * (d + 1);
   const size_t budget = 150 * 1024;
   int stage = 0;
