@@ -174,6 +174,19 @@ __device__ inline double tph_gamma_mt(const tph_rng& g, double shape, int first_
   return out;
 }
 
+// ---- boundary conditions of the proposals (mcmc.py:326-411) and the cap of the redraw-until-in-bounds loop ----
+__device__ __forceinline__ double bc_periodic(double v) {  // numpy `v % 1.0` (npy_divmod)
+  double r = fmod(v, 1.0);
+  if (r != 0.0) { if (r < 0.0) r += 1.0; } else r = 0.0;
+  return r;
+}
+__device__ __forceinline__ double bc_reflective(double v) {  // mcmc.py:357-364
+  double nr = floor(v);
+  double rem = v - nr;
+  return fmod(nr, 2.0) == 0.0 ? rem : 1.0 - rem;
+}
+constexpr int PROP_MAX_ATTEMPTS = 256;   // then the current point is proposed (the reference loops on)
+
 // ---- wave / block reductions (wave64) ----
 __device__ __forceinline__ double tph_wave_sum(double v) {
 #pragma unroll

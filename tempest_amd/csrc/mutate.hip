@@ -80,19 +80,7 @@ extern "C" int tph_inf_repair(tph_ctx* ctx, double* u_dev, double* x_dev, double
 }
 
 // ------------------------------------------------------------------------------------------- proposals
-__device__ __forceinline__ double bc_periodic(double v) {  // numpy `v % 1.0` (npy_divmod)
-  double r = fmod(v, 1.0);
-  if (r != 0.0) { if (r < 0.0) r += 1.0; } else r = 0.0;
-  return r;
-}
-__device__ __forceinline__ double bc_reflective(double v) {  // mcmc.py:357-364
-  double nr = floor(v);
-  double rem = v - nr;
-  return fmod(nr, 2.0) == 0.0 ? rem : 1.0 - rem;
-}
-
 constexpr int PROP_THREADS = 64;
-constexpr int PROP_MAX_ATTEMPTS = 256;
 
 // One lane per particle; its z[d] and diff[d] columns live in LDS as [d][64] (conflict-free).
 // tpCN (mcmc.py:225-249): m = diff^T S^-1 diff ; s = 1/Gamma((d+nu)/2, 2/(nu+m)) (one draw, reused across

@@ -91,13 +91,14 @@ def build_plugin(source: str, n_dim: int, verbose: bool = False) -> Path:
 class HipCallbacks:
     """prior_transform + log_likelihood as HIP device functions (see the module docstring)."""
 
-    def __init__(self, source: str, n_dim: int, fused: bool = True, verbose: bool = False):
+    def __init__(self, source: str, n_dim: int, fused: bool = True, verbose: bool = False, whole_step: bool = True):
         if not isinstance(n_dim, int) or n_dim <= 0:
             raise ValueError(f"n_dim must be a positive int, got {n_dim!r}")
         for fn in ("prior_transform", "log_likelihood"):
             if fn not in source:
                 raise ValueError(f"HipCallbacks source must define __device__ {fn}(...)")
         self.n_dim, self.source, self.fused = n_dim, source, bool(fused)
+        self.whole_step = whole_step           # False: proposal and evaluate+accept as two kernels; "always": at any size
         self.path = build_plugin(source, n_dim, verbose)
         import torch  # noqa: F401  (its HIP runtime must be the one in the process, as for libtempest_hip)
         lib = C.CDLL(str(self.path))
@@ -108,7 +109,9 @@ class HipCallbacks:
         lib.tphu_like.argtypes = [ptr, ptr, i64, i64, ptr]
         lib.tphu_accept.argtypes = [ptr, C.c_int, C.c_double, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, C.c_int, ptr,
                                     C.c_uint64, C.c_uint32, i64, ptr, ptr, ptr]
-        for f in (lib.tphu_prior, lib.tphu_like, lib.tphu_accept):
+        lib.tphu_step.argtypes = [ptr, C.c_int, C.c_double, ptr, ptr, ptr, i64, i64, ptr, ptr, ptr, ptr, ptr, ptr, C.c_uint64,
+                                  C.c_uint32, C.c_uint32, i64, ptr, ptr, C.c_int]
+        for f in (lib.tphu_prior, lib.tphu_like, lib.tphu_accept, lib.tphu_step):
             f.restype = C.c_int
         if lib.tphu_n_dim() != n_dim:
             raise TempestHipError(f"plugin {self.path} was built for n_dim={lib.tphu_n_dim()}")
@@ -177,6 +180,30 @@ class HipCallbacks:
         self._check(self.lib.tphu_accept(self._stream(u), int(kernel_id), float(beta), p(u), p(x), p(logl), p(uprime),
                                          p(maha_u), p(maha_up), p(assign), n, n, int(K), p(dof), int(seed), int(tick),
                                          int(item0), p(sums), p(ctl), p(partials)), "tphu_accept")
+
+
+    def can_fuse_step(self, K, has_assign, n) -> bool:
+        """The whole step (proposal + callbacks + Metropolis update) in ONE kernel: register proposal kernel only
+        (n_dim <= 16), one proposal mode, and shards up to 512 K particles -- measured: 45 -> 41 us per step at 131 072
+        particles, where the step is latency-bound, but 157 -> 165 us at 1 048 576, where the proposal kernel is VALU-bound
+        and the longer kernel only lowers its occupancy."""
+        return (self.fused and self.whole_step and self.n_dim <= 16 and K == 1 and not has_assign
+                and (self.whole_step == "always" or n <= 512 * 1024))
+
+    def step(self, kernel_id, u, logl, maha_u, modes, sigmas, bc, seed, tick_propose, tick_accept, item0, ctl, partials,
+             redraw_lanes=0):
+        """tph_propose + tphu_accept in one launch (u: (d, n) SoA, updated in place; x is not maintained)."""
+        n = u.shape[1]
+        if partials is None or partials.numel() < ((n + 255) // 256) * 2:
+            raise TempestHipError("HipCallbacks.step: partials buffer missing or too small")
+        for t in (u, logl, maha_u):
+            if not (t.is_cuda and t.is_contiguous()):
+                raise TempestHipError("HipCallbacks.step: expected contiguous device tensors")
+        p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        self._check(self.lib.tphu_step(self._stream(u), int(kernel_id), 0.0, p(u), p(logl), p(maha_u), n, n,
+                                       p(modes.means_dev), p(modes.chol_dev), p(modes.inv_dev), p(modes.dof_dev), p(sigmas),
+                                       p(bc), int(seed), int(tick_propose), int(tick_accept), int(item0), p(ctl), p(partials),
+                                       int(redraw_lanes)), "tphu_step")
 
 
 def fused_plugin(prior_transform, log_likelihood):

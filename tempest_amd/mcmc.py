@@ -130,6 +130,15 @@ class StepEngine:
     def _enqueue(self):
         """The launches of one step on the current stream (ticks are offsets: the device adds base + 2 * steps done)."""
         ctx = self.ctx
+        if (self.plugin is not None and not self.comm_active
+                and self.plugin.can_fuse_step(self.K, self.assign is not None, self.n)):
+            # proposal, callbacks and Metropolis update in ONE kernel of the user's plugin (hipcallbacks.py); single GPU:
+            # with ranks the per-rank sums must exist before the all-reduce, so the two-kernel form is kept there
+            from .device import KERNEL_ID
+            self.plugin.step(KERNEL_ID[self.kernel], self.u, self.logl, self.maha_u, self.modes, self.sigmas, self.bc,
+                             self.seed, 1, 2, self.item0, self.ctl, self.partials)
+            self._adapt(fold=True)
+            return None, None
         ctx.propose(self.kernel, self.u, self.assign, self.modes, self.sigmas, self.bc, self.seed, 1, self.item0,
                     self.up, self.maha_u, self.maha_up, ctl=self.ctl)
         # one GPU: the block partials of the Metropolis kernel are summed inside tph_adapt (one launch less per step);

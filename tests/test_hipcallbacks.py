@@ -40,7 +40,7 @@ def test_plugin_builds_and_exports_abi():
     assert path.exists() and build_plugin(SRC, 4) == path              # cached by content hash
     assert build_plugin(SRC, 6) != path                                # n_dim is part of the key
     lib = ctypes.CDLL(str(path))
-    for sym in ("tphu_last_error", "tphu_n_dim", "tphu_abi", "tphu_prior", "tphu_like", "tphu_accept"):
+    for sym in ("tphu_last_error", "tphu_n_dim", "tphu_abi", "tphu_prior", "tphu_like", "tphu_accept", "tphu_step"):
         assert hasattr(lib, sym), sym
     assert lib.tphu_n_dim() == 4 and lib.tphu_abi() == 1
 
@@ -119,6 +119,31 @@ def test_fused_accept_is_bit_identical_to_library_accept(kernel, K):
         assert torch.equal(ta, tb)
     assert torch.equal(sums_a, sums_b)
     assert 0 < sums_a[0].item() < n
+
+
+@pytest.mark.gpu
+@needs_hipcc
+@pytest.mark.parametrize("kernel,bcs", [("tpcn", None), ("rwm", None), ("tpcn", ([0], [2]))])
+def test_whole_step_kernel_equals_two_kernel_step(kernel, bcs):
+    """tphu_step (proposal + callbacks + Metropolis update in one kernel) == tph_propose followed by tphu_accept: whole runs
+    bit-identical, with strict, periodic and reflective coordinates."""
+    import tempest_amd as tp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = 4
+    out = []
+    for whole in (True, False):
+        cb = tp.HipCallbacks(SRC, d, whole_step=whole)
+        kw = dict(periodic=bcs[0], reflective=bcs[1]) if bcs else {}
+        s = tp.Sampler(cb.prior_transform, cb.log_likelihood, d, n_particles=700, vectorize=True, clustering=False,
+                       random_state=9, sample=kernel, graph=False, **kw)
+        s.run(n_total=2800, progress=False)
+        out.append((s.evidence()[0], np.asarray(s.state.get_history("steps")), s.posterior()[0],
+                    np.asarray(s.state.get_history("acceptance"))))
+    assert out[0][0] == out[1][0]
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    np.testing.assert_array_equal(out[0][3], out[1][3])
 
 
 @pytest.mark.gpu
