@@ -68,6 +68,10 @@ int tph_synchronize(tph_ctx* ctx);
 #define TPH_OPT_REDUCE_GRID 1
 /* TPH_OPT_REDRAW_LANES: 0 = automatic, 64 / 256 = lanes the redraw rounds of the d <= 16 proposal kernel keep busy */
 #define TPH_OPT_REDRAW_LANES 2
+/* TPH_OPT_ML_UNSTAGED: 1 = the d > 16 proposal kernel reads Sigma^-1 and L from global memory instead of staging them in LDS
+ * (a quarter of the LDS footprint, four times the resident waves: the right trade while most attempts are redraws that stop
+ * after a few rows); 0 = staged (default) */
+#define TPH_OPT_ML_UNSTAGED 3
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- persistent ensemble: StateManager history (state_manager.py:171-176,356-416) ------------
@@ -156,8 +160,10 @@ int tph_inf_repair(tph_ctx* ctx, double* u_dev, double* x_dev, double* logl_dev,
  * passed to tph_propose / tph_accept makes one MCMC step replayable as a captured hipGraph with no per-step kernel
  * arguments: the RNG tick used is  tick + state[7] + 2 * state[0]  (state[0] = steps completed, advanced by tph_adapt;
  * state[7] = the run's tick base, < 2^32), beta is read from state[6], and once state[1] (the stopping rule of mcmc.py:119-140) is set, tph_accept and tph_adapt of any
- * further (speculatively launched) step leave every buffer untouched. */
-#define TPH_STEP_STATE_LEN 8
+ * further (speculatively launched) step leave every buffer untouched.  state[8] receives, from the d > 16 proposal kernel, the mean
+ * number of redraw attempts per particle of its first block (tph_adapt forwards it as field [6] of the mailbox record): the host
+ * uses it to switch TPH_OPT_ML_UNSTAGED. */
+#define TPH_STEP_STATE_LEN 10
 /* proposals for all particles (mcmc.py:225-249 tpCN, :301-312 RWM) incl. boundary handling and the
  * redraw-until-in-bounds loop; maha_u/maha_up receive (u-mu)^T S^-1 (u-mu) at u and u' (tpCN). */
 int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const int32_t* assign_dev, int64_t n, int64_t ld,

@@ -58,6 +58,7 @@ struct tph_ctx {
   void* scratch = nullptr;          // big scratch (sort buffers, scans), grown on demand
   size_t scratch_bytes = 0;
   int reduce_grid = 0;              // 0 auto | blocks of the reweight reduction (experiments)
+  int ml_unstaged = 0;              // 1: k_propose_ml reads its matrices from global memory (small LDS footprint, 4x the waves)
   int redraw_lanes = 0;             // 0 auto | lanes the redraw rounds of k_propose_reg may use (64 or 256; experiments)
   int propose_variant = 0;          // 0 auto | 1 one-lane LDS | 2 one-lane registers (d<=16) | 3 multi-lane (tests compare them)
 };

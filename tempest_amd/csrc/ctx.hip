@@ -141,6 +141,7 @@ extern "C" int tph_set_option(tph_ctx* ctx, int option, int value) {
     case TPH_OPT_PROPOSE_VARIANT: ctx->propose_variant = value; break;
     case TPH_OPT_REDUCE_GRID: ctx->reduce_grid = value; break;
     case TPH_OPT_REDRAW_LANES: ctx->redraw_lanes = value; break;
+    case TPH_OPT_ML_UNSTAGED: ctx->ml_unstaged = value; break;
     default: TPH_REQUIRE(false, "tph_set_option: unknown option %d", option);
   }
   return 0;

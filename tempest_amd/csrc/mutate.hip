@@ -364,6 +364,19 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
     }
   }
   __syncthreads();
+  if (blockIdx.x == 0 && tick.ctl) {
+    // regime probe for the host (StepEngine): mean attempts per particle in this block -> state[8].  While most attempts are
+    // redraws the kernel should run un-staged (TPH_OPT_ML_UNSTAGED: a quarter of the LDS, four times the waves).
+    double mine = (l == 0 && live) ? (double)(att + 1) : 0.0;
+    double* probe = sh;                                  // zs of particle 0 is free now
+    __syncthreads();
+    if (threadIdx.x == 0) { probe[0] = 0.0; probe[1] = 0.0; }
+    __syncthreads();
+    if (l == 0 && live) { atomicAdd(&probe[0], mine); atomicAdd(&probe[1], 1.0); }   // integer-valued: exact, order-free
+    __syncthreads();
+    if (threadIdx.x == 0) const_cast<double*>(tick.ctl)[8] = probe[0] / fmax(probe[1], 1.0);
+    __syncthreads();
+  }
   if (live)
     for (int j = l; j < d; j += LPP) up[(size_t)j * ld + i] = vs[j];
   double m_up = 0.0;
@@ -398,7 +411,7 @@ static int launch_propose_ml(tph_ctx* ctx, const double* u, const int32_t* assig
   const size_t one = sizeof(double) * (size_t)d * (d + 1);
   const size_t budget = 150 * 1024;
   int stage = 0;
-  if (assign == nullptr) stage = (base + 2 * one <= budget) ? 1 : ((base + one <= budget) ? 2 : 0);
+  if (assign == nullptr && ctx->ml_unstaged == 0) stage = (base + 2 * one <= budget) ? 1 : ((base + one <= budget) ? 2 : 0);
   const size_t lds = base + (stage == 1 ? 2 * one : (stage == 2 ? one : 0));
   const dim3 grid((unsigned)((n + PPB - 1) / PPB));
 #define TPH_ML_LAUNCH(ST)                                                                                              \
@@ -828,6 +841,7 @@ __global__ void __launch_bounds__(1024) k_adapt(int kernel, const double* __rest
     // device-to-host copy (and its cross-engine barrier) between two steps of the stream
     double* rec = mailbox + (size_t)(iteration % slots) * 8;
     for (int j = 0; j < 6; ++j) rec[j] = state[j];
+    rec[6] = state[8];                                   // mean redraw attempts seen by the d > 16 proposal kernel (0: not reported)
     __threadfence_system();
     __hip_atomic_store(rec + 7, (double)iteration, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }

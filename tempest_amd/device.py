@@ -15,6 +15,8 @@ from ._lib import check
 
 KERNEL_ID = {"tpcn": 0, "rwm": 1}
 KEY_U, KEY_X, KEY_LOGL, KEY_LOGMIX = 0, 1, 2, 3
+STEP_STATE_LEN = 10            # TPH_STEP_STATE_LEN
+OPT_ML_UNSTAGED = 3            # TPH_OPT_ML_UNSTAGED
 BC_STRICT, BC_PERIODIC, BC_REFLECTIVE = 0, 1, 2
 
 TAG_PRIOR, TAG_NORMAL, TAG_GAMMA, TAG_ACCEPT, TAG_RESAMPLE, TAG_UPSAMPLE, TAG_REPAIR, TAG_SYST = 1, 2, 3, 4, 5, 6, 7, 8
@@ -263,6 +265,8 @@ class HipContext:
 
     def propose(self, kernel, u, assign, modes, sigmas, bc, seed, tick, item0, uprime, maha_u, maha_up, ctl=None):
         n = u.shape[1]
+        if ctl is not None and ctl.numel() < STEP_STATE_LEN:
+            raise _lib.TempestHipError(f"propose: the step-control block needs {STEP_STATE_LEN} doubles")
         check(self.lib.tph_propose(self._ctx, KERNEL_ID[kernel], _ptr(u), _ptr(assign, torch.int32) if assign is not None else None,
                                    n, n, modes.K, _ptr(modes.means_dev), _ptr(modes.chol_dev), _ptr(modes.inv_dev),
                                    _ptr(modes.dof_dev), _ptr(sigmas), _ptr(bc) if bc is not None else None, seed, tick,

@@ -96,8 +96,10 @@ class StepEngine:
         self.has_assign = has_assign
         self.sigmas, self.counts, self.sums = ctx.empty(K), ctx.empty(K), ctx.zeros(1 + K)
         self.partials = ctx.empty(((n + 255) // 256) * (1 + K))     # fixed address: the library's scratch may move
-        self.ctl = ctx.zeros(8)
-        self.ctl_host = torch.zeros(8, dtype=torch.float64).pin_memory()
+        from .device import STEP_STATE_LEN
+        self.ctl = ctx.zeros(STEP_STATE_LEN)
+        self.ctl_host = torch.zeros(STEP_STATE_LEN, dtype=torch.float64).pin_memory()
+        self.unstaged = False          # d > 16 proposal kernel without LDS-staged matrices (redraw-dominated steps)
         self.mailbox = torch.zeros(self.SLOTS, 8, dtype=torch.float64).pin_memory()   # written by tph_adapt, polled here
         self.mailbox_np = self.mailbox.numpy()
         self.use_graph, self.graph, self.graph_error = bool(use_graph), None, None
@@ -176,7 +178,21 @@ class StepEngine:
                 if time.monotonic() - t0 > timeout:
                     from ._lib import TempestHipError
                     raise TempestHipError(f"MCMC step {step}: no record from the device after {timeout} s")
+        self._regime(rec[6])
         return rec[:6].copy()
+
+    def _regime(self, mean_attempts):
+        """The d > 16 proposal kernel reports the mean number of attempts per particle of the step.  While most attempts are
+        redraws that stop after a few rows, run it un-staged (matrices from global memory: a quarter of the LDS, four times
+        the resident waves -- 2x at d = 100); once a step is about one attempt, LDS-staged matrices win.  Launch geometry
+        is baked into a captured graph, so a graph keeps whatever it was captured with."""
+        if self.graph is not None or self.ctx.n_dim <= 16 or not mean_attempts > 0.0:
+            return
+        want = mean_attempts > (4.0 if self.unstaged else 8.0)      # hysteresis
+        if want != self.unstaged:
+            from .device import OPT_ML_UNSTAGED
+            self.unstaged = want
+            self.ctx.set_option(OPT_ML_UNSTAGED, 1 if want else 0)
 
     def _capture(self):
         """Stream capture of one step (torch.cuda.CUDAGraph without torch.cuda.graph's empty_cache(), which would hand
@@ -340,7 +356,10 @@ class DeviceMCMC:
         while True:
             it += 1                           # step `it` is enqueued
             eng.step(self.comm)               # one step ahead of the read; a no-op on the device if the rule has fired
-            if it >= n_min:                   # the rule cannot fire earlier (mcmc.py:119-131)
+            if it < n_min:
+                if it == 2 and d > 16 and eng.runs == 1 and eng.graph is None:
+                    eng.wait_record(2)        # first run of this engine: learn the proposal kernel's regime after two steps
+            else:                             # the rule cannot fire earlier (mcmc.py:119-131)
                 st = eng.wait_record(it)
                 if self.pbar is not None and self.verbose:
                     self.pbar.update_stats({"calls": self.pbar.info.get("calls", 0) + n_global, "acc": st[3],

@@ -106,7 +106,7 @@ def test_step_control_block_semantics():
         up, mu, mup = ctx.empty(d, n), (ctx.empty(n) if maha_u is None else maha_u.clone()), ctx.empty(n)
         ctx.propose("tpcn", u, None, modes, sig, None, seed, tick, 0, up, mu, mup, ctl=ctl)
         return up, mu, mup
-    ctl = torch.tensor([done_steps, 0, 0, 0, 0, 0, 0.37, base], dtype=torch.float64, device=dev)
+    ctl = torch.tensor([done_steps, 0, 0, 0, 0, 0, 0.37, base, 0, 0], dtype=torch.float64, device=dev)   # TPH_STEP_STATE_LEN
     b = propose(1 + base + 2 * done_steps, None)
     # with steps already done the kernel READS the Mahalanobis form at u from maha_u (kept current by tph_accept)
     a = propose(1, ctl, maha_u=b[1])
@@ -150,7 +150,7 @@ def test_step_control_block_semantics():
     counts = torch.full((1,), float(n), dtype=torch.float64, device=dev)
     sums = r1[3].clone()
     mailbox = torch.full((4, 8), -1.0, dtype=torch.float64).pin_memory()
-    state = torch.zeros(8, dtype=torch.float64, device=dev)
+    state = torch.zeros(10, dtype=torch.float64, device=dev)
     sg = sig.clone()
     ctx.adapt("tpcn", sums, counts, K, n, 1, 1, sg, state, mailbox=mailbox)    # n_max = n_steps = 1: done after d steps
     ctx.synchronize()
