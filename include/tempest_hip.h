@@ -186,14 +186,15 @@ int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, double* x_d
                double* partials_dev /* NULL = library scratch, or ceil(n/256)*(1+K) doubles owned by the caller: needed
                                        when the launch is captured in a graph (the scratch may move when it grows) */);
 /* sigma adaptation + adaptive stopping rule (mcmc.py:104-140,180-194,281-288,320-323) from GLOBAL sums.
- * state_dev[6..8]: [0]=iteration (in/out) [1]=done flag [2]=accepted fraction [3]=mean alpha
- *            [4]=mean(sigma)/sigma_0 [5]=adaptive step target ([6]=beta, [7]=tick base when used as step control);
+ * state_dev (6 doubles; TPH_STEP_STATE_LEN when it doubles as step control or a mailbox is given):
+ *            [0]=iteration (in/out) [1]=done flag [2]=accepted fraction [3]=mean alpha [4]=mean(sigma)/sigma_0
+ *            [5]=adaptive step target ([6]=beta, [7]=tick base, [8]=redraw-regime probe of the proposal kernel);
  * counts_dev = particles per cluster (global).  A call with the done flag already set is a no-op. */
 int tph_adapt(tph_ctx* ctx, int kernel, double* sums_dev /* in; out when partials_dev is given */, const double* counts_dev, int K,
               double n_global, int n_dim, int n_steps, int n_max, double* sigmas_dev, double* state_dev,
               double* mailbox_host /* NULL, or mailbox_slots x 8 doubles of PINNED host memory (device-accessible):
-                                      the record of step s = state[0..5] goes to slot s % mailbox_slots, its field [7]
-                                      = s is stored last (system-scope release), so the host can poll for it */,
+                                      the record of step s = state[0..5] (+ state[8] as field [6]) goes to slot
+                                      s % mailbox_slots, its field [7] = s is stored last (system-scope release), so the host can poll for it */,
               int mailbox_slots,
               const double* partials_dev /* NULL, or tph_accept's block partials of n particles: their column sums
                                             are formed here (into sums_dev) instead of by a kernel of their own */,

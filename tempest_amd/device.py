@@ -292,6 +292,8 @@ class HipContext:
         partials: accept()'s block partials of n particles, column-summed here (accept called with sums=None)."""
         if mailbox is not None and not (mailbox.is_pinned() and mailbox.dtype == torch.float64 and mailbox.is_contiguous()):
             raise _lib.TempestHipError("adapt: mailbox must be a pinned contiguous float64 host tensor")
+        if mailbox is not None and state.numel() < STEP_STATE_LEN:
+            raise _lib.TempestHipError(f"adapt: with a mailbox the state block needs {STEP_STATE_LEN} doubles")
         check(self.lib.tph_adapt(self._ctx, KERNEL_ID[kernel], _ptr(sums), _ptr(counts), K, float(n_global),
                                  self.n_dim, int(n_steps), int(n_max), _ptr(sigmas), _ptr(state),
                                  mailbox.data_ptr() if mailbox is not None else None,
