@@ -163,8 +163,7 @@ extern "C" int tph_history_clear(tph_ctx* ctx) {
   return 0;
 }
 
-// K1: log-mixture update.  Old rows fold in the one new term; new rows fold all T terms in
-// iteration order, i.e. the same left-to-right fold np.logaddexp.reduce performs.
+// K1: log-mixture update.  Old rows fold in the one new term (one logaddexp); new rows take all T terms in iteration order.
 // HBM: old rows 24 B (read l, C; write C); new rows 16 B + T table terms (scalar loads).
 __global__ void __launch_bounds__(256) k_logmix_append(const double* __restrict__ logl, double* __restrict__ cmix,
                                                        int64_t size_old, int64_t size_new,
@@ -179,9 +178,15 @@ __global__ void __launch_bounds__(256) k_logmix_append(const double* __restrict_
     if (s < size_old) {
       cmix[s] = tph_logaddexp(cmix[s], l * bT - zT + nT);
     } else {
-      double acc = l * beta[0] - logz[0] + logn[0];
-      for (int t = 1; t < T; ++t) acc = tph_logaddexp(acc, l * beta[t] - logz[t] + logn[t]);
-      cmix[s] = acc;
+      // streaming log-sum-exp over the T terms (running maximum m and sum of exp(a_t - m)): one exp per term and one log
+      // per row, where the pairwise fold of np.logaddexp.reduce costs an exp AND a log1p per term; same value to rounding
+      double m = l * beta[0] - logz[0] + logn[0], ssum = 1.0;
+      for (int t = 1; t < T; ++t) {
+        const double a = l * beta[t] - logz[t] + logn[t];
+        if (a > m) { ssum = ssum * exp(m - a) + 1.0; m = a; }
+        else ssum += (a == m) ? 1.0 : exp(a - m);          // a == m also covers -inf, -inf (logaddexp gives -inf)
+      }
+      cmix[s] = m + log(ssum);
     }
   }
 }
