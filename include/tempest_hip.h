@@ -219,6 +219,10 @@ int tph_weighted_sums(tph_ctx* ctx, const double* w_dev, int64_t n, double* sums
 /* cov_dev[a][b] = sum_s w_s (u_a - mean_a)(u_b - mean_b)  (raw per-rank sums, not divided by sum w) */
 int tph_weighted_cov_centered(tph_ctx* ctx, const double* w_dev, int64_t n, const double* mean_dev,
                               double* cov_dev /*[d*d]*/);
+/* one-pass variant for n_dim <= 12: moments about a centre close to the mean (cancellation-free finish);
+ * out_dev = (sum w, mean[d], cov[d][d]) with cov already divided by sum w */
+int tph_weighted_moments_shifted(tph_ctx* ctx, const double* w_dev, int64_t n, const double* centre_dev,
+                                 double* out_dev /*[1 + d + d*d]*/);
 int tph_cv_sum(tph_ctx* ctx, const double* w_dev, int64_t n, const double* mean_dev, const double* covinv_dev,
                double* out_dev /*[1]: sum w^2 dev^2*/);
 

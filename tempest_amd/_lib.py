@@ -61,6 +61,7 @@ SIGNATURES = {
     "tph_weighted_moments": (c_int, [ptr, ptr, c_i64, ptr]),
     "tph_weighted_sums": (c_int, [ptr, ptr, c_i64, ptr]),
     "tph_weighted_cov_centered": (c_int, [ptr, ptr, c_i64, ptr, ptr]),
+    "tph_weighted_moments_shifted": (c_int, [ptr, ptr, c_i64, ptr, ptr]),
     "tph_compact_indices": (c_int, [ptr, ptr, c_i64, ptr, ptr]),
     "tph_gather_u_affine": (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr, ptr, c_i64, ptr]),
     "tph_affine": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr]),

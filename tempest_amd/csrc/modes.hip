@@ -282,6 +282,60 @@ static bool launch_wcov_small(tph_ctx* ctx, const double* src, int64_t src_ld, c
   }
 }
 
+// Weighted mean AND covariance in ONE pass over u (n_dim <= 12): sums of w, w (u - c) and w (u - c)(u - c)^T about a
+// caller-supplied centre c close to the mean (the previous iteration's mean), finished as
+//     mean = c + S1/S0 ,  cov = S2/S0 - (S1/S0)(S1/S0)^T .
+// With |mean - c| a fraction of the spread the subtraction loses nothing (relative error ~eps (mean-c)^2/var), and the
+// volume-variation diagnostic of tools.py:94-99 needs two streaming passes over the history instead of three.
+template <int D>
+__global__ void __launch_bounds__(256) k_wmom_small(const double* __restrict__ hu, int64_t cap, const double* __restrict__ wt,
+                                                    int64_t n, const double* __restrict__ centre, double* __restrict__ partials) {
+  constexpr int NPL = D * (D + 1) / 2, NC = NPL + D + 1;
+  double acc[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) acc[k] = 0.0;
+  double c[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) c[j] = centre[j];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double w = wt[i];
+    double xc[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) xc[j] = hu[(size_t)j * cap + i] - c[j];
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const double wa = w * xc[a];
+      acc[NPL + 1 + a] += wa;
+#pragma unroll
+      for (int b = 0; b <= a; ++b) acc[k++] += wa * xc[b];
+    }
+    acc[NPL] += w;
+  }
+  __shared__ double sh[4];
+  double* mine = partials + (size_t)blockIdx.x * NC;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    double t = tph_block_sum(acc[k], sh);
+    if (threadIdx.x == 0) mine[k] = t;
+  }
+}
+// out = (S0, mean[d], cov[d][d]) from the column sums csum = (S2 lower triangle, S0, S1[d])
+__global__ void k_wmom_finish(const double* __restrict__ csum, const double* __restrict__ centre, int d, double* __restrict__ out) {
+  const int npl = d * (d + 1) / 2;
+  const double s0 = csum[npl];
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0) out[0] = s0;
+  if (e < d) out[1 + e] = centre[e] + csum[npl + 1 + e] / s0;
+  if (e < d * d) {
+    int a = e / d, b = e % d;
+    int hi = a >= b ? a : b, lo = a >= b ? b : a;
+    double da = csum[npl + 1 + a] / s0, db = csum[npl + 1 + b] / s0;
+    out[1 + d + e] = csum[hi * (hi + 1) / 2 + lo] / s0 - da * db;
+  }
+}
+
 // symmetrise the lower triangle and (optionally) apply student.py:62-63:
 //   Sigma = C/n + diag(C/n)/n      (np.cov*(n-1)/n + diag(np.var)/n)
 __global__ void k_cov_finish(const double* __restrict__ csum, const double* __restrict__ sums, int d, int student,
@@ -846,6 +900,27 @@ extern "C" int tph_weighted_cov_centered(tph_ctx* ctx, const double* w_dev, int6
   size_t need = sizeof(double) * cov_scratch_doubles(d, nblk);
   if (tph_scratch_reserve(ctx, need)) return -1;
   return moments_launch_cov(ctx, w_dev, false, nullptr, 0, n, mean_dev, nullptr, 0, cov_dev, (double*)ctx->scratch, nblk);
+}
+
+extern "C" int tph_weighted_moments_shifted(tph_ctx* ctx, const double* w_dev, int64_t n, const double* centre_dev,
+                                            double* out_dev) {
+  TPH_REQUIRE(ctx && w_dev && centre_dev && out_dev && n > 0 && n <= ctx->size, "tph_weighted_moments_shifted: bad argument");
+  const int d = ctx->d;
+  TPH_REQUIRE(d <= 12, "tph_weighted_moments_shifted: n_dim=%d > 12 (use tph_weighted_sums + tph_weighted_cov_centered)", d);
+  const int nc = d * (d + 1) / 2 + d + 1;
+  const int nblk = tph_grid_for(n, 256, 8, 1024);
+  if (tph_scratch_reserve(ctx, sizeof(double) * ((size_t)nblk + 1) * nc)) return -1;
+  double* part = (double*)ctx->scratch;
+  double* csum = part + (size_t)nblk * nc;
+  switch (d) {
+#define C(DD) case DD: hipLaunchKernelGGL((k_wmom_small<DD>), dim3(nblk), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, w_dev, n, centre_dev, part); break;
+    C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12)
+#undef C
+  }
+  hipLaunchKernelGGL(k_colsum2, dim3(nc), dim3(256), 0, ctx->stream, part, nblk, nc, csum);
+  hipLaunchKernelGGL(k_wmom_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum, centre_dev, d, out_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
 }
 
 // sum_s w_s^2 clip(d2_s - n_dim, +-1e6)^2 with d2 the Mahalanobis distance (tools.py:111-115).

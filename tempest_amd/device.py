@@ -115,12 +115,14 @@ class HipContext:
         return p.value, ld.value
 
     def history_clear(self):
+        self._vv_centre = None
         check(self.lib.tph_history_clear(self._ctx), "tph_history_clear")
 
     def history_load(self, u, x, logl, beta_t, logz_t, n_t, n_t_global=None, soa=False):
         """u, x: host arrays (N_h, d) -- or (d, N_h), the device layout, with soa=True -- or None; logl (N_h,)."""
         logl = np.ascontiguousarray(logl, dtype=np.float64)
         n = logl.size
+        self._vv_centre = None
         tr = (lambda a: a) if soa else (lambda a: a.T)
         ut = np.ascontiguousarray(tr(np.asarray(u, dtype=np.float64))) if u is not None else None
         xt = np.ascontiguousarray(tr(np.asarray(x, dtype=np.float64))) if x is not None else None
@@ -382,6 +384,14 @@ class HipContext:
         out = self.empty(d * d)
         check(self.lib.tph_weighted_cov_centered(self._ctx, _ptr(w), w.numel(), _ptr(mean.contiguous()), _ptr(out)),
               "tph_weighted_cov_centered")
+        return out
+
+    def weighted_moments_shifted(self, w, centre):
+        """(sum w, mean[d], cov[d*d]) of the history's u in one pass, moments taken about `centre` (n_dim <= 12)."""
+        d = self.n_dim
+        out = self.empty(1 + d + d * d)
+        check(self.lib.tph_weighted_moments_shifted(self._ctx, _ptr(w), w.numel(), _ptr(centre.contiguous()), _ptr(out)),
+              "tph_weighted_moments_shifted")
         return out
 
     def cv_sum(self, w, mean, covinv):

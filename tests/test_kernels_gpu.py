@@ -502,3 +502,24 @@ def test_posterior_rows_and_index_compose(d, n, m):
     comp = ctx.index_compose(idx, torch.from_numpy(b_h.astype(np.int64)).cuda())
     np.testing.assert_array_equal(comp.cpu().numpy(), idx_h[b_h])
     _ = KEY_X
+
+
+@pytest.mark.parametrize("d", [1, 5, 12])
+def test_weighted_moments_shifted_one_pass(dev, d):
+    """tph_weighted_moments_shifted: weighted mean and covariance in one pass about a nearby centre == NumPy's two-pass values,
+    also for a narrow cloud far from the origin of the unit cube (where raw second moments would cancel)."""
+    rs = np.random.RandomState(d)
+    n = 200_003
+    u = np.clip(0.83 + 1e-4 * rs.randn(n, d), 0, 1)                  # |mean|^2 / var ~ 7e7
+    w = np.exp(rs.randn(n)); w /= w.sum()
+    c = ctx_for(d)
+    c.history_load(u, u, np.zeros(n), [0.0], [0.0], [n])
+    wt = torch.from_numpy(w).to(dev)
+    centre = torch.from_numpy(u[0].copy()).to(dev)
+    out = c.weighted_moments_shifted(wt, centre).cpu().numpy()
+    mean = (u * w[:, None]).sum(axis=0)
+    xc = u - mean
+    cov = xc.T @ (xc * w[:, None])
+    np.testing.assert_allclose(out[0], w.sum(), rtol=1e-13)
+    np.testing.assert_allclose(out[1:1 + d], mean, rtol=1e-13)
+    np.testing.assert_allclose(out[1 + d:].reshape(d, d), cov, rtol=1e-9, atol=1e-22)
