@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one full Persistent Sampling iteration (reweight -> train -> resample -> mutate -> commit) of
+A "step" is one full Persistent Sampling iteration (reweight -> train -> resample -> mutate -> commit; the beta = 0
+prior-draw iterations that initialise a run come first and are neither warm-up nor timed steps) of
 `tempest_amd.Sampler` on the README Rosenbrock target (coefficient 10, prior U(-10,10)^10) with BASELINE config 4's
 1 048 576 particles.  That configuration fits one GPU (7 GB of history at termination), so at N=1 it IS the workload;
 under torchrun every GPU holds 1 048 576 particles (weak scaling; `--particles-per-gpu 131072` gives config 4's own
@@ -189,6 +190,14 @@ def main():
     def timed(s):
         """W untimed + K timed PS iterations; (seconds [max over ranks], steps per timed iteration, betas)."""
         import gc
+        # initialisation: the beta = 0 iterations draw the first ensembles from the prior (no MCMC steps, nothing to count);
+        # they are never part of the W warm-up or K timed steps, so that any W, K >= 1 measures mutation work
+        n_init = 0
+        while n_init == 0 or s.state.get_current("beta") == 0.0:
+            s.sample(return_state=False)
+            n_init += 1
+            if s.state.get_current("beta") > 0.0:
+                break
         for _ in range(a.warmup):
             s.sample(return_state=False)
         sync()
@@ -207,11 +216,15 @@ def main():
             dt = float(t.item())
         return dt, np.asarray(s.state._scalars["steps"][it0:]), np.asarray(s.state._scalars["beta"][it0:])
 
+    sync()
+    t_run0 = time.perf_counter()
     dt, steps_t, beta_t = timed(s)
     pms = float(np.sum(steps_t[beta_t > 0])) * n_global
     value = pms / dt
 
+    n_before = len(s.state._scalars["steps"]) - len(steps_t)
     extra = {"timed_mcmc_steps": int(np.sum(steps_t[beta_t > 0])), "timed_iterations": int(a.steps),
+             "timed_iteration_range_of_run": [n_before + 1, n_before + len(steps_t)],
              "beta_range": [float(beta_t.min()), float(beta_t.max())],
              "reweight_evals_per_iteration": round(s._core.reweighter.n_evals / max(1, len(s.state._scalars["beta"])), 1)}
     if not a.no_finish:
@@ -223,6 +236,13 @@ def main():
             s.sample(return_state=False)
             guard += 1
         _, logz = core._logz_at(1.0)
+        sync()
+        t_run = time.perf_counter() - t_run0
+        all_steps = np.asarray(s.state._scalars["steps"]); all_beta = np.asarray(s.state._scalars["beta"])
+        extra["whole_run"] = {"value": float(np.sum(all_steps[all_beta > 0])) * n_global / t_run, "unit": "particle-mutation-steps/s",
+                              "seconds": t_run, "iterations": int(len(all_beta)),
+                              "note": "first sample() to the reference's stopping rule on this rank, one-time costs (history "
+                                      "allocation, module load, callback probing) included"}
         extra.update({"logz": logz, "logz_abs_err_vs_analytic": abs(logz - ANALYTIC_LOGZ),
                       "analytic_logz": float(ANALYTIC_LOGZ), "iterations_total": len(s.state._scalars["beta"]),
                       "reference_logz_ensemble_N1000": {"mean": -29.804, "std": 0.115, "seeds": 16,
