@@ -66,13 +66,33 @@ int tph_synchronize(tph_ctx* ctx);
 #define TPH_OPT_PROPOSE_VARIANT 0
 /* TPH_OPT_REDUCE_GRID: 0 = automatic grid of the reweight reduction, > 0 = that many blocks (experiments) */
 #define TPH_OPT_REDUCE_GRID 1
-/* TPH_OPT_REDRAW_LANES: 0 = automatic, 64 / 256 = lanes the redraw rounds of the d <= 16 proposal kernel keep busy */
+/* TPH_OPT_REDRAW_LANES: 0 = automatic, t > 0 = 64-particle tiles per wave of the d <= 16 proposal kernel (its redraw work
+ * lists are per wave: more tiles = longer lists = fuller redraw passes, fewer waves) */
 #define TPH_OPT_REDRAW_LANES 2
 /* TPH_OPT_ML_UNSTAGED: 1 = the d > 16 proposal kernel reads Sigma^-1 and L from global memory instead of staging them in LDS
  * (a quarter of the LDS footprint, four times the resident waves: the right trade while most attempts are redraws that stop
  * after a few rows); 0 = staged (default) */
 #define TPH_OPT_ML_UNSTAGED 3
 int tph_set_option(tph_ctx* ctx, int option, int value);
+
+/* ---- multi-GPU: one process per GPU --------------------------------------
+ * Every iteration's particles are split evenly over the ranks: slot i of the global active set belongs to rank
+ * i / (N / world), and each rank appends its slice to its LOCAL history shard (the history never moves).  The GLOBAL
+ * history order is the reference's: iteration-major, and inside an iteration by slot -- i.e. block (t, rank 0), (t, rank 1)
+ * ... -- so that a sharded run draws, trims and fits exactly what the one-GPU run does (same counter-based draws mapped
+ * through the same cumulative weights; only floating-point summation order differs).
+ * The library does not link a communication library: the host attaches two collectives (RCCL through its framework's
+ * process group, or anything else) that operate IN PLACE on a device staging block it owns, addressed by byte offset:
+ *   allreduce(user, offset, count, dtype, op)                  dtype 0 = f64, 1 = i64, 2 = i32; op 0 = sum, 1 = max, 2 = min
+ *   allgather(user, send_offset, recv_offset, count, dtype)    recv block = world x count elements, rank order
+ * Both must be ordered with the ctx stream (enqueue on it, or synchronise) and return 0 on success.  With a communicator
+ * attached the *_global entry points below and tph_reweight_eval / tph_reweight_partials return GLOBAL results on every
+ * rank; without one they are the single-GPU functions. */
+typedef int (*tph_allreduce_fn)(void* user, int64_t offset, int64_t count, int dtype, int op);
+typedef int (*tph_allgather_fn)(void* user, int64_t send_offset, int64_t recv_offset, int64_t count, int dtype);
+int tph_comm_attach(tph_ctx* ctx, int rank, int world, void* buf_dev, int64_t buf_bytes, tph_allreduce_fn allreduce,
+                    tph_allgather_fn allgather, void* user);
+int tph_comm_detach(tph_ctx* ctx);
 
 /* ---- persistent ensemble: StateManager history (state_manager.py:171-176,356-416) ------------
  * tph_history_append = commit_current_to_history for the array keys u, x, logl, plus the cached
@@ -165,9 +185,11 @@ int tph_inf_repair(tph_ctx* ctx, double* u_dev, double* x_dev, double* logl_dev,
  * uses it to switch TPH_OPT_ML_UNSTAGED. */
 #define TPH_STEP_STATE_LEN 10
 /* proposals for all particles (mcmc.py:225-249 tpCN, :301-312 RWM) incl. boundary handling and the
- * redraw-until-in-bounds loop; maha_u/maha_up receive (u-mu)^T S^-1 (u-mu) at u and u' (tpCN). */
+ * redraw-until-in-bounds loop; maha_u/maha_up receive (u-mu)^T S^-1 (u-mu) at u and u' (tpCN), evaluated as
+ * |L^-1 (u-mu)|^2: cholinv_dev = the K inverse Cholesky factors (tph_chol_inv / tph_fit_modes produce them), or NULL --
+ * the library then inverts chol_dev itself on every call (a caller holding only ModeStatistics.chol_covariances). */
 int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const int32_t* assign_dev, int64_t n, int64_t ld,
-                int K, const double* means_dev, const double* chol_dev, const double* inv_dev,
+                int K, const double* means_dev, const double* chol_dev, const double* cholinv_dev,
                 const double* dof_dev, const double* sigmas_dev, const uint8_t* bc_dev,
                 uint64_t seed, uint32_t tick, int64_t item0,
                 double* uprime_dev, double* maha_u_dev, double* maha_up_dev, const double* ctl_dev);
@@ -204,11 +226,12 @@ int tph_cluster_counts(tph_ctx* ctx, const int32_t* assign_dev, int64_t n, int K
 /* ---- proposal fit (student.py:6-116 effective form, modes.py:58-119,131-288) -------------------- */
 /* From multiplicities counts_s over the first n history rows (labels_dev NULL = one global mode):
  * per mode k: mean = per-dimension median, cov = MLE covariance + diag(var)/n of the up-sampled set,
- * then chol/inv with the 1e-6 ridge on failure.  Outputs [K][d], [K][d][d] x3 on the device. */
+ * then chol/inv (and L^-1) with the 1e-6 ridge on failure.  Outputs [K][d], [K][d][d] x4 on the device. */
 int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int32_t* labels_dev, int64_t n, int K,
-                  double* means_dev, double* covs_dev, double* chol_dev, double* inv_dev);
-/* Cholesky + inverse of K d x d matrices with the reference's ridge rule (modes.py:105-119) */
-int tph_chol_inv(tph_ctx* ctx, double* covs_dev, int K, double* chol_dev, double* inv_dev);
+                  double* means_dev, double* covs_dev, double* chol_dev, double* inv_dev, double* cholinv_dev /*or NULL*/);
+/* Cholesky L, inverse Sigma^-1 = L^-T L^-1 and (cholinv_dev, optional) L^-1 of K d x d matrices with the reference's
+ * ridge rule (modes.py:105-119) */
+int tph_chol_inv(tph_ctx* ctx, double* covs_dev, int K, double* chol_dev, double* inv_dev, double* cholinv_dev /*or NULL*/);
 
 /* ---- volume variation (tools.py:58-117) ---------------------------------------------------------
  * stage 1: weighted mean and covariance of the history's u with weights w (device -> host, tiny);

@@ -56,8 +56,8 @@ SIGNATURES = {
     "tph_posterior_rows": (c_int, [ptr, c_int, ptr, c_i64, ptr, c_dbl, ptr, ptr, ptr]),
     "tph_index_compose": (c_int, [ptr, ptr, ptr, c_i64, ptr]),
     "tph_cluster_counts": (c_int, [ptr, ptr, c_i64, c_int, ptr]),
-    "tph_fit_modes": (c_int, [ptr, ptr, ptr, c_i64, c_int, ptr, ptr, ptr, ptr]),
-    "tph_chol_inv": (c_int, [ptr, ptr, c_int, ptr, ptr]),
+    "tph_fit_modes": (c_int, [ptr, ptr, ptr, c_i64, c_int, ptr, ptr, ptr, ptr, ptr]),
+    "tph_chol_inv": (c_int, [ptr, ptr, c_int, ptr, ptr, ptr]),
     "tph_weighted_moments": (c_int, [ptr, ptr, c_i64, ptr]),
     "tph_weighted_sums": (c_int, [ptr, ptr, c_i64, ptr]),
     "tph_weighted_cov_centered": (c_int, [ptr, ptr, c_i64, ptr, ptr]),

@@ -59,11 +59,34 @@ struct tph_ctx {
   size_t scratch_bytes = 0;
   int reduce_grid = 0;              // 0 auto | blocks of the reweight reduction (experiments)
   int ml_unstaged = 0;              // 1: k_propose_ml reads its matrices from global memory (small LDS footprint, 4x the waves)
-  int redraw_lanes = 0;             // 0 auto | lanes the redraw rounds of k_propose_reg may use (64 or 256; experiments)
+  int redraw_lanes = 0;             // 0 auto | tiles per wave of k_propose_reg (experiments)
   int propose_variant = 0;          // 0 auto | 1 one-lane LDS | 2 one-lane registers (d<=16) | 3 multi-lane (tests compare them)
+  int n_simd = 1024;                // SIMDs of the device (compute units x 4): sizes one-resident-batch launches
+  double* winv = nullptr;           // L^-1 per mode, formed by tph_propose when the caller passes cholinv_dev = NULL
+  size_t winv_bytes = 0;
+  // ---- communicator (tph_comm_attach): one process per GPU, this ctx holds one shard of every iteration's particles
+  int rank = 0, world = 1;
+  char* comm_buf = nullptr;         // caller-owned device staging block the collectives operate on (offsets into it)
+  size_t comm_bytes = 0;
+  tph_allreduce_fn comm_allreduce = nullptr;
+  tph_allgather_fn comm_allgather = nullptr;
+  void* comm_user = nullptr;
+  double* blk_table = nullptr;      // block table of the last tph_cdf_global: glo[T], ghi[T], total (device)
+  int blk_table_cap = 0, blk_T = 0;
+  int64_t blk_rows = 0;
+  bool comm_active() const { return comm_allreduce != nullptr; }
 };
 
+// collectives over the attached communicator (ctx.hip); data lives in ctx->comm_buf at byte offset `off`
+enum { TPH_DT_F64 = 0, TPH_DT_I64 = 1, TPH_DT_I32 = 2 };
+enum { TPH_OP_SUM = 0, TPH_OP_MAX = 1, TPH_OP_MIN = 2 };
+int tph_comm_require(tph_ctx* ctx, size_t bytes, const char* who);
+int tph_comm_allreduce(tph_ctx* ctx, size_t off, int64_t count, int dtype, int op);
+int tph_comm_allgather(tph_ctx* ctx, size_t send_off, size_t recv_off, int64_t count, int dtype);
+int tph_blocks(tph_ctx* ctx, int64_t n, int* T, int64_t* rows);   // equal-sized iteration blocks of the local history
+
 int tph_scratch_reserve(tph_ctx* ctx, size_t bytes);
+int tph_tri_inv(tph_ctx* ctx, const double* chol_dev, int K, double* winv_dev);   // modes.hip
 
 // --------------------------------------------------------------------------------- device helpers
 #if defined(__HIPCC__)
@@ -75,6 +98,51 @@ __device__ __forceinline__ double tph_logaddexp(double x, double y) {
   if (t > 0) return x + log1p(exp(-t));
   if (t <= 0) return y + log1p(exp(t));
   return t;  // NaN
+}
+
+// ---- lean FP64 elementary functions for the proposal kernels (gfx950) ----
+// The library log/sqrt/division are IEEE-complete (denormal scaling, special cases, < 1 ulp through double-double steps):
+// 60-70 VALU instructions for log, ~14 each for sqrt and a/b.  The proposal kernels are VALU-issue-bound and call them on
+// arguments whose range is known (uniforms in (0,1], -2 log u, Gamma candidates), so they use these forms instead:
+// hardware seed (v_rcp_f64 / v_rsq_f64) + Newton steps, and the fdlibm log kernel.  Errors stay below 1 ulp (log) /
+// 1 ulp (sqrt, division) on normal arguments; NaN/negative inputs are not handled (none occur: see the call sites).
+__device__ __forceinline__ double tph_rcp(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = fma(-b, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-b, r, 1.0);
+  return fma(r, e, r);
+}
+__device__ __forceinline__ double tph_div(double a, double b) {       // b normal, a/b in range
+  const double r = tph_rcp(b);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double tph_sqrt(double x) {                // 0 <= x, normal or zero
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  g = fma(fma(-g, g, x), h, g);
+  return x == 0.0 ? 0.0 : g;
+}
+// log of a positive normal double (fdlibm e_log.c kernel: x = 2^k (1+f), sqrt(1/2) <= 1+f < sqrt(2))
+__device__ __forceinline__ double tph_log(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);         // [0.5, 1)
+  int k = __builtin_amdgcn_frexp_exp(x);
+  const bool lowhalf = m < 0.70710678118654752440;
+  m = lowhalf ? m + m : m;
+  k = lowhalf ? k - 1 : k;
+  const double f = m - 1.0;
+  const double s = tph_div(f, 2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                            6.666666666666735130e-01);
+  const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
 }
 
 // ---- Philox4x32-10 (twin of oracle/philox.py) ----
@@ -102,8 +170,9 @@ constexpr uint32_t TPH_TAG_PRIOR = 1, TPH_TAG_NORMAL = 2, TPH_TAG_GAMMA = 3, TPH
                    TPH_TAG_RESAMPLE = 5, TPH_TAG_UPSAMPLE = 6, TPH_TAG_REPAIR = 7;
 
 __device__ __forceinline__ double tph_k53(uint32_t hi, uint32_t lo) {
-  uint64_t k = ((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6);
-  return (double)k;
+  // k = (hi >> 5) * 2^26 + (lo >> 6) < 2^53, formed exactly from two 32-bit conversions and one FMA (the generic
+  // u64 -> f64 conversion costs ~50 SIMD cycles more per value)
+  return fma((double)(hi >> 5), 67108864.0, (double)(lo >> 6));
 }
 
 struct tph_rng {
@@ -121,7 +190,7 @@ struct tph_rng {
     tph_u4 r = tph_philox(item, draw, tick, tag, k0, k1);
     double u1 = (tph_k53(r.x, r.y) + 1.0) * 0x1.0p-53;
     double u2 = tph_k53(r.z, r.w) * 0x1.0p-53;
-    double rad = sqrt(-2.0 * log(u1));
+    double rad = tph_sqrt(-2.0 * tph_log(u1));
     double s, c;
     sincospi(2.0 * u2, &s, &c);   // exact range reduction: cheaper than sincos(2 pi u2), same value to rounding
     z0 = rad * c;
@@ -152,7 +221,7 @@ __device__ inline double tph_gamma_mt(const tph_rng& g, double shape, int first_
   bool boost = shape < 1.0;
   double a = boost ? shape + 1.0 : shape;
   double d = a - 1.0 / 3.0;
-  double c = 1.0 / sqrt(9.0 * d);
+  double c = tph_rcp(tph_sqrt(9.0 * d));
   double out = d;
   for (int att = first_attempt; att < max_attempts; ++att) {
     double x, x1, uu, u1;
@@ -161,7 +230,7 @@ __device__ inline double tph_gamma_mt(const tph_rng& g, double shape, int first_
     uu += 0x1.0p-53;
     double v = 1.0 + c * x;
     v = v * v * v;
-    if (v > 0.0 && log(uu) < 0.5 * x * x + d - d * v + d * log(v)) {
+    if (v > 0.0 && tph_log(uu) < 0.5 * x * x + d - d * v + d * tph_log(v)) {
       out = d * v;
       break;
     }
@@ -187,6 +256,33 @@ __device__ __forceinline__ double bc_reflective(double v) {  // mcmc.py:357-364
   return fmod(nr, 2.0) == 0.0 ? rem : 1.0 - rem;
 }
 constexpr int PROP_MAX_ATTEMPTS = 256;   // then the current point is proposed (the reference loops on)
+
+// ---- shared pieces of the register proposal kernels (mutate.hip, user_plugin.hip.in) ----
+// tph_opaque: launders a wave-uniform pointer so that the scalar loads through it stay where they are written (see k_propose_reg)
+template <class T>
+__device__ __forceinline__ const T* tph_opaque(const T* p) {
+  // an opaque ZERO offset in an SGPR: the pointer keeps its address space and provenance (the loads stay scalar
+  // s_load's of a kernel argument), but their address now depends on a value defined here, so they cannot be hoisted
+  // above this point.  (Laundering the pointer itself turns every load behind it into a flat VECTOR load.)
+  int off = 0;
+  asm volatile("" : "+s"(off));
+  return p + off;
+}
+
+// |W (v - mu)|^2, W lower-triangular [D][D] row-major
+template <int D, bool UNIFORM>
+__device__ __forceinline__ double maha_w(const double* __restrict__ W, const double (&dv)[D]) {
+  double m = 0.0;
+#pragma unroll
+  for (int r = 0; r < D; ++r) {
+    if (UNIFORM && (r == D / 2 || r == (3 * D) / 4)) W = tph_opaque(W);
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j <= r; ++j) acc = fma(W[r * D + j], dv[j], acc);
+    m = fma(acc, acc, m);
+  }
+  return m;
+}
 
 // ---- wave / block reductions (wave64) ----
 __device__ __forceinline__ double tph_wave_sum(double v) {

@@ -101,6 +101,10 @@ extern "C" int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void
   c->device = device;
   c->d = n_dim;
   c->stream = (hipStream_t)hip_stream;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_simd = 4 * prop.multiProcessorCount;
+  }
   c->partials_bytes = sizeof(double) * (size_t)TPH_RED_BLOCKS * 64;
   if (hipMalloc((void**)&c->partials, c->partials_bytes) != hipSuccess ||
       hipMalloc((void**)&c->small_dev, sizeof(double) * 4096) != hipSuccess ||
@@ -122,10 +126,57 @@ extern "C" int tph_ctx_destroy(tph_ctx* ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  void* bufs[] = {ctx->u, ctx->x, ctx->logl, ctx->cmix, ctx->table_dev, ctx->partials, ctx->small_dev, ctx->scratch};
+  void* bufs[] = {ctx->u, ctx->x, ctx->logl, ctx->cmix, ctx->table_dev, ctx->partials, ctx->small_dev, ctx->scratch, ctx->winv,
+                  ctx->blk_table};
   for (void* b : bufs) (void)hipFree(b);
   (void)hipHostFree(ctx->pinned);
   delete ctx;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ communicator
+extern "C" int tph_comm_attach(tph_ctx* ctx, int rank, int world, void* buf_dev, int64_t buf_bytes, tph_allreduce_fn allreduce,
+                               tph_allgather_fn allgather, void* user) {
+  TPH_REQUIRE(ctx && buf_dev && allreduce && allgather, "tph_comm_attach: NULL argument");
+  TPH_REQUIRE(world >= 1 && rank >= 0 && rank < world, "tph_comm_attach: rank %d outside world %d", rank, world);
+  TPH_REQUIRE(buf_bytes >= (1 << 20), "tph_comm_attach: the staging block must hold at least 1 MiB");
+  ctx->rank = rank; ctx->world = world;
+  ctx->comm_buf = (char*)buf_dev; ctx->comm_bytes = (size_t)buf_bytes;
+  ctx->comm_allreduce = allreduce; ctx->comm_allgather = allgather; ctx->comm_user = user;
+  return 0;
+}
+extern "C" int tph_comm_detach(tph_ctx* ctx) {
+  TPH_REQUIRE(ctx, "tph_comm_detach: ctx is NULL");
+  ctx->rank = 0; ctx->world = 1;
+  ctx->comm_buf = nullptr; ctx->comm_bytes = 0;
+  ctx->comm_allreduce = nullptr; ctx->comm_allgather = nullptr; ctx->comm_user = nullptr;
+  return 0;
+}
+int tph_comm_require(tph_ctx* ctx, size_t bytes, const char* who) {
+  TPH_REQUIRE(ctx->comm_active(), "%s: no communicator attached", who);
+  TPH_REQUIRE(bytes <= ctx->comm_bytes, "%s: needs %zu B of communication staging, %zu attached (tph_comm_attach)", who, bytes,
+              ctx->comm_bytes);
+  return 0;
+}
+int tph_comm_allreduce(tph_ctx* ctx, size_t off, int64_t count, int dtype, int op) {
+  const int rc = ctx->comm_allreduce(ctx->comm_user, (int64_t)off, count, dtype, op);
+  TPH_REQUIRE(rc == 0, "all-reduce callback failed (%d)", rc);
+  return 0;
+}
+int tph_comm_allgather(tph_ctx* ctx, size_t send_off, size_t recv_off, int64_t count, int dtype) {
+  const int rc = ctx->comm_allgather(ctx->comm_user, (int64_t)send_off, (int64_t)recv_off, count, dtype);
+  TPH_REQUIRE(rc == 0, "all-gather callback failed (%d)", rc);
+  return 0;
+}
+// the local history as T equal blocks of `rows` rows (one per committed iteration): what the global order is built on
+int tph_blocks(tph_ctx* ctx, int64_t n, int* T, int64_t* rows) {
+  TPH_REQUIRE(n == ctx->size && !ctx->n_local_t.empty(), "global-order functions work on the whole local history (%lld rows given, %lld held)",
+              (long long)n, (long long)ctx->size);
+  const int64_t r = ctx->n_local_t[0];
+  for (int64_t v : ctx->n_local_t)
+    TPH_REQUIRE(v == r, "sharded runs need the same number of particles in every iteration (%lld vs %lld)", (long long)v, (long long)r);
+  *T = (int)ctx->n_local_t.size();
+  *rows = r;
   return 0;
 }
 

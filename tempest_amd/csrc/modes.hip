@@ -653,11 +653,34 @@ __global__ void __launch_bounds__(256) k_chol_inv(double* __restrict__ covs, int
   }
 }
 
-extern "C" int tph_chol_inv(tph_ctx* ctx, double* covs_dev, int K, double* chol_dev, double* inv_dev) {
+extern "C" int tph_chol_inv(tph_ctx* ctx, double* covs_dev, int K, double* chol_dev, double* inv_dev, double* cholinv_dev) {
   TPH_REQUIRE(ctx && covs_dev && chol_dev && inv_dev && K >= 1, "tph_chol_inv: bad argument");
-  size_t need = sizeof(double) * (size_t)K * ctx->d * ctx->d;
-  if (tph_scratch_reserve(ctx, need)) return -1;
-  hipLaunchKernelGGL(k_chol_inv, dim3(K), dim3(256), 0, ctx->stream, covs_dev, ctx->d, chol_dev, inv_dev, (double*)ctx->scratch);
+  double* work = cholinv_dev;            // W = L^-1: an output when asked for, scratch otherwise
+  if (!work) {
+    size_t need = sizeof(double) * (size_t)K * ctx->d * ctx->d;
+    if (tph_scratch_reserve(ctx, need)) return -1;
+    work = (double*)ctx->scratch;
+  }
+  hipLaunchKernelGGL(k_chol_inv, dim3(K), dim3(256), 0, ctx->stream, covs_dev, ctx->d, chol_dev, inv_dev, work);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+// W = L^-1 for K lower-triangular factors (column c of W solves L y = e_c): for callers of tph_propose that hold only L
+__global__ void __launch_bounds__(256) k_tri_inv(const double* __restrict__ chols, int d, double* __restrict__ winv) {
+  const double* L = chols + (size_t)blockIdx.x * d * d;
+  double* W = winv + (size_t)blockIdx.x * d * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    for (int i = 0; i < d; ++i) {
+      if (i < c) { W[i * d + c] = 0.0; continue; }
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = c; k < i; ++k) s -= L[i * d + k] * W[k * d + c];
+      W[i * d + c] = s / L[i * d + i];
+    }
+  }
+}
+int tph_tri_inv(tph_ctx* ctx, const double* chol_dev, int K, double* winv_dev) {
+  hipLaunchKernelGGL(k_tri_inv, dim3(K), dim3(256), 0, ctx->stream, chol_dev, ctx->d, winv_dev);
   TPH_LAUNCH_CHECK();
   return 0;
 }
@@ -736,7 +759,7 @@ __global__ void __launch_bounds__(256) k_nz_scatter(const double* __restrict__ u
 }
 
 extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int32_t* labels_dev, int64_t n, int K,
-                             double* means_dev, double* covs_dev, double* chol_dev, double* inv_dev) {
+                             double* means_dev, double* covs_dev, double* chol_dev, double* inv_dev, double* cholinv_dev) {
   TPH_REQUIRE(ctx && counts_dev && means_dev && covs_dev && chol_dev && inv_dev, "tph_fit_modes: NULL argument");
   TPH_REQUIRE(n > 0 && n <= ctx->size && K >= 1, "tph_fit_modes: bad sizes");
   TPH_REQUIRE(K == 1 || labels_dev, "tph_fit_modes: K>1 needs labels");
@@ -828,7 +851,7 @@ extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int3
     hipLaunchKernelGGL(k_med_finish, dim3(d), dim3(256), 0, ctx->stream, sel, range, vals, cnts, fill, means_dev + (size_t)k * d, overflow);
     TPH_LAUNCH_CHECK();
   }
-  return tph_chol_inv(ctx, covs_dev, K, chol_dev, inv_dev);
+  return tph_chol_inv(ctx, covs_dev, K, chol_dev, inv_dev, cholinv_dev);
 }
 
 // ------------------------------------------------------------------------------ volume variation

@@ -86,11 +86,12 @@ constexpr int PROP_THREADS = 64;
 // tpCN (mcmc.py:225-249): m = diff^T S^-1 diff ; s = 1/Gamma((d+nu)/2, 2/(nu+m)) (one draw, reused across
 // redraws) ; u' = mu + sqrt(1-sigma^2) diff + sigma sqrt(s) L z, redrawn until the strict dims lie in [0,1].
 // RWM (mcmc.py:301-312): u' = u + sigma L z.
-// HBM per particle: read 8d+4, write 8d+16; FLOP 2*(d^2/2) per attempt (+ 2*2*d^2 for the two Mahalanobis forms).
+// Mahalanobis forms as |W (v - mu)|^2 with W = L^-1 (lower-triangular).
+// HBM per particle: read 8d+4, write 8d+16; FLOP 2*(d^2/2) per attempt (+ 2*(d^2/2) per Mahalanobis form).
 template <int KERNEL>
 __global__ void __launch_bounds__(PROP_THREADS) k_propose(const double* __restrict__ u, const int32_t* __restrict__ assign,
                                                           int64_t n, int64_t ld, int d, const double* __restrict__ means,
-                                                          const double* __restrict__ chol, const double* __restrict__ inv,
+                                                          const double* __restrict__ chol, const double* __restrict__ winv,
                                                           const double* __restrict__ dof, const double* __restrict__ sigmas,
                                                           const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                           int64_t item0, double* __restrict__ up,
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(PROP_THREADS) k_propose(const double* __restri
   const int c = assign ? assign[i] : 0;
   const double* __restrict__ mu = means + (size_t)c * d;
   const double* __restrict__ L = chol + (size_t)c * d * d;
-  const double* __restrict__ P = inv + (size_t)c * d * d;
+  const double* __restrict__ W = winv + (size_t)c * d * d;
   const double sigma = sigmas[c];
 
   for (int j = 0; j < d; ++j) {
@@ -118,16 +119,15 @@ __global__ void __launch_bounds__(PROP_THREADS) k_propose(const double* __restri
     } else {
       for (int r = 0; r < d; ++r) {
         double acc = 0.0;
-        for (int j = 0; j < d; ++j) acc += P[r * d + j] * df[j * PROP_THREADS];
-        m_u += df[r * PROP_THREADS] * acc;
+        for (int j = 0; j <= r; ++j) acc = fma(W[r * d + j], df[j * PROP_THREADS], acc);
+        m_u = fma(acc, acc, m_u);
       }
     }
     const double nu = dof[c];
     tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
-    double gam = tph_gamma_mt(gg, 0.5 * ((double)d + nu)) * (2.0 / (nu + m_u));
-    double s = 1.0 / gam;
-    a_fac = sqrt(1.0 - sigma * sigma);
-    b_fac = sigma * sqrt(s);
+    const double gam = tph_gamma_mt(gg, 0.5 * ((double)d + nu)) * tph_div(2.0, nu + m_u);
+    a_fac = tph_sqrt(1.0 - sigma * sigma);
+    b_fac = sigma * tph_sqrt(tph_rcp(gam));
   }
   tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
   const int npairs = (d + 1) >> 1;
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(PROP_THREADS) k_propose(const double* __restri
     ok = true;
     for (int r = d - 1; r >= 0; --r) {  // descending: slot r is free once row r is done
       double acc = 0.0;
-      for (int j = 0; j <= r; ++j) acc += L[r * d + j] * zs[j * PROP_THREADS];
+      for (int j = 0; j <= r; ++j) acc = fma(L[r * d + j], zs[j * PROP_THREADS], acc);
       double v;
       if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * df[r * PROP_THREADS] + b_fac * acc;
       else v = df[r * PROP_THREADS] + b_fac * acc;
@@ -163,8 +163,8 @@ __global__ void __launch_bounds__(PROP_THREADS) k_propose(const double* __restri
     for (int j = 0; j < d; ++j) zs[j * PROP_THREADS] -= mu[j];
     for (int r = 0; r < d; ++r) {
       double acc = 0.0;
-      for (int j = 0; j < d; ++j) acc += P[r * d + j] * zs[j * PROP_THREADS];
-      m_up += zs[r * PROP_THREADS] * acc;
+      for (int j = 0; j <= r; ++j) acc = fma(W[r * d + j], zs[j * PROP_THREADS], acc);
+      m_up = fma(acc, acc, m_up);
     }
   }
   if (maha_u) maha_u[i] = m_u;
@@ -196,7 +196,7 @@ __device__ __forceinline__ int group_and(int v) {
 template <int KERNEL, int LPP, int STAGE>
 __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restrict__ u, const int32_t* __restrict__ assign,
                                                            int64_t n, int64_t ld, int d, const double* __restrict__ means,
-                                                           const double* __restrict__ chol, const double* __restrict__ inv,
+                                                           const double* __restrict__ chol, const double* __restrict__ winv,
                                                            const double* __restrict__ dof, const double* __restrict__ sigmas,
                                                            const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                            int64_t item0, double* __restrict__ up,
@@ -208,7 +208,8 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
   double* zs = sh + (size_t)p * dp;                   // normals of the current attempt
   double* df = sh + (size_t)PPB * dp + (size_t)p * dp;  // u - mu (tpCN) or u (RWM)
   double* vs = sh + (size_t)2 * PPB * dp + (size_t)p * dp;   // rows of the current attempt; the proposal once it is complete
-  // STAGE 1: Sigma^-1 and L both resident in LDS (rows padded to d+1); STAGE 2: one matrix slot, refilled per phase;
+  // (W = L^-1, lower-triangular: the Mahalanobis forms are |W (v - mu)|^2)
+  // STAGE 1: W and L both resident in LDS (rows padded to d+1); STAGE 2: one matrix slot, refilled per phase;
   // STAGE 0: read from global/L2 (several modes, or matrices too large).  Staging amortises the matrix reads over the
   // PPB particles of the block instead of re-reading d*d doubles per particle.
   double* mat0 = sh + (size_t)3 * PPB * dp;
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
   const int c = (STAGE == 0 && assign) ? assign[ii] : 0;
   const double* __restrict__ mu = means + (size_t)c * d;
   const double* __restrict__ Lg = chol + (size_t)c * d * d;
-  const double* __restrict__ Pg = inv + (size_t)c * d * d;
+  const double* __restrict__ Pg = winv + (size_t)c * d * d;
   const double sigma = sigmas[c];
   const int npairs = (d + 1) >> 1;
   const int ms = STAGE == 0 ? d : d + 1;              // row stride of the matrices as read below
@@ -249,14 +250,14 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
       for (int r = l; r < d; r += LPP) {
         const double* Pr = P + (size_t)r * ms;
         double acc = 0.0;
-        for (int j = 0; j < d; ++j) acc += Pr[j] * df[j];
-        part += df[r] * acc;
+        for (int j = 0; j <= r; ++j) acc = fma(Pr[j], df[j], acc);
+        part = fma(acc, acc, part);
       }
       m_u = group_sum<LPP>(part);
     }
     nu = dof[c];
     gshape = 0.5 * ((double)d + nu);
-    a_fac = sqrt(1.0 - sigma * sigma);
+    a_fac = tph_sqrt(1.0 - sigma * sigma);
   }
   // first attempt: normal pairs (tag NORMAL, draws 0..npairs-1) and, for tpCN, the Gamma candidate
   // (tag GAMMA: draw 0 = normal, draw 1 = uniform) are generated by different lanes at once
@@ -272,9 +273,9 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
     tph_u4 r = tph_philox(g.item, draw, g.tick, g.tag, g.k0, g.k1);
     double a = tph_k53(r.x, r.y), b = tph_k53(r.z, r.w);
     if (q == npairs + 1) {                       // Gamma uniform: (k + 1) * 2^-53 in (0, 1]
-      g_logu = log((a + 1.0) * 0x1.0p-53);
+      g_logu = tph_log((a + 1.0) * 0x1.0p-53);
     } else {                                      // Box-Muller
-      double rad = sqrt(-2.0 * log((a + 1.0) * 0x1.0p-53));
+      double rad = tph_sqrt(-2.0 * tph_log((a + 1.0) * 0x1.0p-53));
       double sn, cs;
       sincospi(2.0 * (b * 0x1.0p-53), &sn, &cs);
       if (is_norm) {
@@ -293,14 +294,14 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
     if (gshape < 1.0) {
       gam = tph_gamma_mt(gg, gshape);            // boosted small-shape path: serial (d = 1 and nu < 1 only)
     } else {
-      const double dd = gshape - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * dd);
+      const double dd = gshape - 1.0 / 3.0, cc = tph_rcp(tph_sqrt(9.0 * dd));
       double v = 1.0 + cc * g_x;
       v = v * v * v;
-      if (v > 0.0 && g_logu < 0.5 * g_x * g_x + dd - dd * v + dd * log(v)) gam = dd * v;
+      if (v > 0.0 && g_logu < 0.5 * g_x * g_x + dd - dd * v + dd * tph_log(v)) gam = dd * v;
       else gam = tph_gamma_mt(gg, gshape, 1);    // rare: continue with attempt 1, 2, ... as the one-lane kernels do
     }
-    gam *= 2.0 / (nu + m_u);
-    b_fac = sigma * sqrt(1.0 / gam);
+    gam *= tph_div(2.0, nu + m_u);
+    b_fac = sigma * tph_sqrt(tph_rcp(gam));
   }
   __syncthreads();
   if (STAGE == 2 && KERNEL == TPH_KERNEL_TPCN && !carry) {      // Sigma^-1 is done with for now: the slot takes L
@@ -341,7 +342,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
     if (active && r < d) {
       const double* Lr = L + (size_t)r * ms;
       double acc = 0.0;
-      for (int j = 0; j <= r; ++j) acc += Lr[j] * zs[j];
+      for (int j = 0; j <= r; ++j) acc = fma(Lr[j], zs[j], acc);
       if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * df[r] + b_fac * acc;
       else v = df[r] + b_fac * acc;
       const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
@@ -389,8 +390,8 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
     for (int r = l; r < d; r += LPP) {
       const double* Pr = P + (size_t)r * ms;
       double acc = 0.0;
-      for (int j = 0; j < d; ++j) acc += Pr[j] * vs[j];
-      part += vs[r] * acc;
+      for (int j = 0; j <= r; ++j) acc = fma(Pr[j], vs[j], acc);
+      part = fma(acc, acc, part);
     }
     m_up = group_sum<LPP>(part);
   }
@@ -402,7 +403,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
 
 template <int KERNEL, int LPP>
 static int launch_propose_ml(tph_ctx* ctx, const double* u, const int32_t* assign, int64_t n, int64_t ld, const double* means,
-                             const double* chol, const double* inv, const double* dof, const double* sigmas,
+                             const double* chol, const double* winv, const double* dof, const double* sigmas,
                              const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0, double* up, double* mu_,
                              double* mup) {
   constexpr int PPB = ML_THREADS / LPP;
@@ -420,7 +421,7 @@ static int launch_propose_ml(tph_ctx* ctx, const double* u, const int32_t* assig
       TPH_HIP(hipFuncSetAttribute((const void*)k_propose_ml<KERNEL, LPP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)lds));                                                                          \
     hipLaunchKernelGGL((k_propose_ml<KERNEL, LPP, ST>), grid, dim3(ML_THREADS), lds, ctx->stream, u, assign, n, ld, d, means, \
-                       chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup);                                   \
+                       chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup);                                  \
   } while (0)
   if (stage == 1) TPH_ML_LAUNCH(1);
   else if (stage == 2) TPH_ML_LAUNCH(2);
@@ -433,174 +434,224 @@ static int launch_propose_ml(tph_ctx* ctx, const double* u, const int32_t* assig
 // one lane's independent Philox / Box-Muller / matvec chains overlap.  The redraw-until-in-bounds loop
 // (mcmc.py:239-249) is run as a block-level WORK LIST: after each attempt the particles still out of bounds are
 // compacted into an LDS list and dealt to the first lanes again, so the cost follows the total number of redraws
-// instead of 64 x the worst lane of every wave (early iterations redraw ~30 % of the proposals).
-// Same draws and operation order as the generic kernel above.
-template <int KERNEL, int D, bool ONE_MODE>
-__global__ void __launch_bounds__(256) k_propose_reg(const double* __restrict__ u, const int32_t* __restrict__ assign,
-                                                     int64_t n, int64_t ld, const double* __restrict__ means,
-                                                     const double* __restrict__ chol, const double* __restrict__ inv,
-                                                     const double* __restrict__ dof, const double* __restrict__ sigmas,
-                                                     const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
-                                                     int64_t item0, double* __restrict__ up, double* __restrict__ maha_u,
-                                                     double* __restrict__ maha_up, int spare_lanes) {
-  __shared__ double s_bfac[256];
-  __shared__ int s_list[2][256];
-  __shared__ int s_count[2];
-  const int64_t base = (int64_t)blockIdx.x * 256;
+// instead of 64 x the worst lane of every wave (early iterations redraw 30-60 % of the proposals).
+// A block owns 256 * PPT particles: with PPT = 4 the straggler lists of the later rounds are four times as long and fill
+// whole waves (a round with 3 busy lanes costs the issue slots of a full wave; measured, 1 048 576 particles: PPT 1 -> 4
+// = -20 % of the kernel's VALU instructions).
+// Mahalanobis forms: (v - mu)^T Sigma^-1 (v - mu) = |W (v - mu)|^2 with W = L^-1 lower-triangular -- d(d+1)/2 FMAs and as
+// many wave-uniform operands instead of d^2 (Sigma^-1 is formed as W^T W anyway, tph_chol_inv), same value to rounding.
+// With ONE_MODE the matrices are wave-uniform and travel through scalar loads; the pointers are laundered inside the
+// round loop (tph_opaque) so that the loads stay next to their use: hoisted out of the loop their 2 x 110 SGPRs do not fit
+// the scalar file and came back as v_readlane/v_writelane spill traffic (15 % of the instructions of the first version).
+// wave-local ordering of LDS traffic between the lanes of ONE wave (no s_barrier: the workgroup is a single wave)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One WAVE per workgroup; a wave owns the 64-particle tiles  blockIdx.x + k * gridDim.x  (k < tiles <= REG_MAX_TILES).
+// The work list of the redraw rounds is wave-local (ballot + popcount compaction into LDS, deterministic order, no
+// atomics, no s_barrier).  The first version kept one list per 256-thread block: in the straggler rounds three of its
+// four waves sat at the barrier while one computed, and with three resident blocks per CU the SIMDs idled -- PMC on
+// 1 048 576 particles, half of the first attempts out of bounds: SQ_WAIT_ANY 55 % of the wave-cycles, VALU busy 38 %
+// of the launch.  Independent waves never wait for each other, several tiles per wave make the straggler lists long
+// enough to fill whole passes, and the launch is sized to ONE resident batch (WPE waves per SIMD x the chip's SIMDs)
+// so that no under-filled second batch trails behind.
+constexpr int REG_MAX_TILES = 8;
+
+template <int KERNEL, int D, bool ONE_MODE, int WPE, bool HAS_BC>
+__global__ void __launch_bounds__(64, WPE) k_propose_reg(const double* __restrict__ u, const int32_t* __restrict__ assign,
+                                                         int64_t n, int64_t ld, const double* __restrict__ means,
+                                                         const double* __restrict__ chol, const double* __restrict__ winv,
+                                                         const double* __restrict__ dof, const double* __restrict__ sigmas,
+                                                         const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
+                                                         int64_t item0, double* __restrict__ up, double* __restrict__ maha_u,
+                                                         double* __restrict__ maha_up, int tiles) {
+  constexpr int NPW = 64 * REG_MAX_TILES;
+  __shared__ double s_bfac[NPW];
+  __shared__ int s_list[2][NPW];
+  const int lane = threadIdx.x;
   constexpr int NP = (D + 1) / 2;
-  // ---- phase A: every particle of the block: Mahalanobis at u and the Gamma scale (one draw, reused by redraws)
-  {
-    const int64_t i = base + threadIdx.x;
-    if (threadIdx.x == 0) { s_count[0] = 0; s_count[1] = 0; }
+  // local particle id pid = k * 64 + lane  <->  global row (blockIdx.x + k * gridDim.x) * 64 + lane
+  auto row_of = [&](int pid) { return ((int64_t)blockIdx.x + (int64_t)(pid >> 6) * gridDim.x) * 64 + (pid & 63); };
+  // ---- phase A: every particle of the wave: Mahalanobis at u and the Gamma scale (one draw, reused by redraws)
+  int count = 0;
+#pragma unroll 1
+  for (int t = 0; t < tiles; ++t) {
+    const int pid = t * 64 + lane;
+    const int64_t i = row_of(pid);
     double b_fac = 0.0;
     if (i < n) {
       const int c = ONE_MODE ? 0 : assign[i];
       const double sigma = sigmas[c];
       b_fac = sigma;
       if (KERNEL == TPH_KERNEL_TPCN) {
-        const double* __restrict__ mu = means + (size_t)c * D;
-        const double* __restrict__ P = inv + (size_t)c * D * D;
-        double m_u = 0.0;
+        double m_u;
         if (tick.carry()) {
           m_u = maha_u[i];
         } else {
+          const double* __restrict__ mu = means + (size_t)c * D;
+          const double* __restrict__ W = winv + (size_t)c * D * D;
           double df[D];
 #pragma unroll
           for (int j = 0; j < D; ++j) df[j] = u[(size_t)j * ld + i] - mu[j];
-#pragma unroll
-          for (int r = 0; r < D; ++r) {
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j < D; ++j) acc += P[r * D + j] * df[j];
-            m_u += df[r] * acc;
-          }
+          m_u = maha_w<D, ONE_MODE>(W, df);
+          if (maha_u) maha_u[i] = m_u;
         }
         const double nu = dof[c];
         tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
-        double gam = tph_gamma_mt(gg, 0.5 * ((double)D + nu)) * (2.0 / (nu + m_u));
-        b_fac = sigma * sqrt(1.0 / gam);
-        if (maha_u) maha_u[i] = m_u;
+        const double gam = tph_gamma_mt(gg, 0.5 * ((double)D + nu)) * tph_div(2.0, nu + m_u);
+        b_fac = sigma * tph_sqrt(tph_rcp(gam));
       } else if (maha_u) {
         maha_u[i] = 0.0;
       }
     }
-    s_bfac[threadIdx.x] = b_fac;
-    s_list[0][threadIdx.x] = threadIdx.x;
+    s_bfac[pid] = b_fac;
+    if (row_of(t * 64) < n) count = (t + 1) * 64;     // slots of round 0 (rows >= n inside the last tile are skipped below)
   }
-  __syncthreads();
-  int count = (int)((n - base) < 256 ? (n - base) : 256);
-  // ---- phase B: attempts over the shrinking work list.  A round costs the latency of one attempt whatever the number
-  // of busy lanes, and the block needs as many rounds as its unluckiest particle: so once the list is short, the spare
-  // lanes try the NEXT attempts of the same particles at the same time -- G = 256/count lanes per particle evaluate
-  // attempts a0 .. a0+G-1 (independent counter-based draws) and the first in-bounds one in attempt order wins, which
-  // is exactly the proposal the sequential loop would have returned.
+  wave_sync();
+  // ---- phase B: attempts over the shrinking work list.  Round 0 takes every particle of the wave (one pass of 64
+  // lanes per tile); afterwards only the particles still out of bounds, packed into as few passes as possible.  Once
+  // the list is shorter than half a wave, the spare lanes try the NEXT attempts of the same particles at the same time
+  // -- G lanes per particle evaluate attempts a0 .. a0+G-1 (independent counter-based draws) and the first in-bounds one
+  // in attempt order wins, which is exactly the proposal the sequential loop would have returned.
   int a0 = 0;                      // attempts [0, a0) have failed for every particle still on the list
-  const int spare = spare_lanes;   // lanes a round may keep busy: the whole block when the launch is latency-bound,
-                                   // one wave when the GPU is full anyway (a speculative attempt then costs ALU time
-                                   // another block would have used)
+#pragma unroll 1
   for (int round = 0; a0 <= PROP_MAX_ATTEMPTS && count > 0; ++round) {
     const int cur = round & 1, nxt = cur ^ 1;
     int G = 1;
-    while (G < 64 && 2 * G * count <= spare) G *= 2;
-    const int slot = threadIdx.x / G, att = a0 + (threadIdx.x % G);
-    const bool busy = slot < count && att <= PROP_MAX_ATTEMPTS;
-    bool ok = false;
-    int pid = 0;
-    int64_t i = 0;
-    int c = 0;
-    double z[D];
-    if (busy) {
-      pid = s_list[cur][slot];
-      i = base + pid;
-      c = ONE_MODE ? 0 : assign[i];
-      const double* __restrict__ mu = means + (size_t)c * D;
-      const double* __restrict__ L = chol + (size_t)c * D * D;
-      const double sigma = sigmas[c];
-      const double b_fac = s_bfac[pid];
-      const double a_fac = (KERNEL == TPH_KERNEL_TPCN) ? sqrt(1.0 - sigma * sigma) : 1.0;
-      double df[D];
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        double uj = u[(size_t)j * ld + i];
-        df[j] = (KERNEL == TPH_KERNEL_TPCN) ? uj - mu[j] : uj;
+    if (round > 0)
+      while (G < 64 && 2 * G * count <= 64) G *= 2;
+    const int n_work = count * G;
+    int n_next = 0;
+#pragma unroll 1
+    for (int w0 = 0; w0 < n_work; w0 += 64) {
+      const int wl = w0 + lane;
+      const int slot = wl / G, att = a0 + (wl % G);
+      bool busy = slot < count && att <= PROP_MAX_ATTEMPTS;
+      bool ok = false;
+      int pid = 0;
+      int64_t i = 0;
+      int c = 0;
+      double z[D];
+      if (busy) {
+        pid = round == 0 ? slot : s_list[cur][slot];
+        i = row_of(pid);
+        busy = i < n;
       }
-      ok = true;
-      if (att < PROP_MAX_ATTEMPTS) {
-        tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          double z0, z1;
-          gz.normal2((uint32_t)(att * NP + p), z0, z1);
-          z[2 * p] = z0;
-          if (2 * p + 1 < D) z[2 * p + 1] = z1;
-        }
-#pragma unroll
-        for (int r = D - 1; r >= 0; --r) {  // descending: slot r is free once row r is done
-          double acc = 0.0;
-#pragma unroll
-          for (int j = 0; j <= r; ++j) acc += L[r * D + j] * z[j];
-          double v;
-          if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * df[r] + b_fac * acc;
-          else v = df[r] + b_fac * acc;
-          const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
-          if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
-          else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
-          else ok = ok && (v >= 0.0) && (v <= 1.0);
-          z[r] = v;
-        }
-      } else {  // redraw cap reached (the reference would loop on): propose the current point
-#pragma unroll
-        for (int j = 0; j < D; ++j) z[j] = (KERNEL == TPH_KERNEL_TPCN) ? df[j] + mu[j] : df[j];
-      }
-    }
-    // first in-bounds attempt of each particle: its G lanes are consecutive lanes of one wave (G <= 64 divides 64)
-    const unsigned long long okmask = __ballot(ok);
-    const int lane = threadIdx.x & 63, g0 = lane & ~(G - 1);
-    const unsigned long long grp = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << g0;
-    const unsigned long long mine = okmask & grp;
-    const bool winner = ok && (mine & ((1ull << lane) - 1ull)) == 0ull;
-    if (winner) {
-#pragma unroll
-      for (int j = 0; j < D; ++j) up[(size_t)j * ld + i] = z[j];
-      double m_up = 0.0;
-      if (KERNEL == TPH_KERNEL_TPCN) {
+      if (busy) {
+        c = ONE_MODE ? 0 : assign[i];
         const double* __restrict__ mu = means + (size_t)c * D;
-        const double* __restrict__ P = inv + (size_t)c * D * D;
+        const double* __restrict__ L = chol + (size_t)c * D * D;
+        ok = true;
+        if (att < PROP_MAX_ATTEMPTS) {
+          // the normals of this attempt: a ROLLED loop over the Box-Muller pairs writing a private array (dynamic index ->
+          // scratch memory, 8 B per value and lane, L1/L2-resident): one Philox / log / sincospi body with ~30 live
+          // registers instead of ceil(D/2) interleaved copies, so that twice as many waves fit on a SIMD -- the kernel is
+          // bound by dependent FP64 chains (PMC: issue stalls 40 % of the wave-cycles at 4 waves per SIMD), not by
+          // instruction count alone
+          double zb[2 * NP];
+          tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
+#pragma unroll 1
+          for (int p = 0; p < NP; ++p) {
+            double z0, z1;
+            gz.normal2((uint32_t)(att * NP + p), z0, z1);
+            zb[2 * p] = z0;
+            zb[2 * p + 1] = z1;
+          }
 #pragma unroll
-        for (int j = 0; j < D; ++j) z[j] -= mu[j];
+          for (int j = 0; j < D; ++j) z[j] = zb[j];
+        }
+        if (ONE_MODE) L = tph_opaque(L);
+        const double sigma = sigmas[c];
+        const double b_fac = s_bfac[pid];
+        const double a_fac = (KERNEL == TPH_KERNEL_TPCN) ? tph_sqrt(1.0 - sigma * sigma) : 1.0;
+        double df[D];
 #pragma unroll
-        for (int r = 0; r < D; ++r) {
-          double acc = 0.0;
+        for (int j = 0; j < D; ++j) {
+          double uj = u[(size_t)j * ld + i];
+          df[j] = (KERNEL == TPH_KERNEL_TPCN) ? uj - mu[j] : uj;
+        }
+        if (att < PROP_MAX_ATTEMPTS) {
 #pragma unroll
-          for (int j = 0; j < D; ++j) acc += P[r * D + j] * z[j];
-          m_up += z[r] * acc;
+          for (int r = D - 1; r >= 0; --r) {  // descending: slot r is free once row r is done
+            if (ONE_MODE && (r == (2 * D) / 3 || r == D / 3)) L = tph_opaque(L);
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j <= r; ++j) acc = fma(L[r * D + j], z[j], acc);
+            double v;
+            if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * df[r] + b_fac * acc;
+            else v = df[r] + b_fac * acc;
+            if (HAS_BC) {       // periodic / reflective dimensions (mcmc.py:326-366): a separate instantiation, so that
+                                // the usual all-strict case carries none of the fmod code in its unrolled rows
+              const uint8_t f = bc[r];
+              if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
+              else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
+              else ok = ok && (v >= 0.0) && (v <= 1.0);
+            } else {
+              ok = ok && (v >= 0.0) && (v <= 1.0);
+            }
+            z[r] = v;
+          }
+        } else {  // redraw cap reached (the reference would loop on): propose the current point
+#pragma unroll
+          for (int j = 0; j < D; ++j) z[j] = (KERNEL == TPH_KERNEL_TPCN) ? df[j] + mu[j] : df[j];
         }
       }
-      if (maha_up) maha_up[i] = m_up;
-    } else if (busy && mine == 0ull && (lane & (G - 1)) == 0) {
-      s_list[nxt][atomicAdd(&s_count[nxt], 1)] = pid;   // all G attempts out of bounds; order irrelevant
+      // first in-bounds attempt of each particle: its G lanes are consecutive lanes of the wave (G <= 64 divides 64)
+      const unsigned long long okmask = __ballot(ok);
+      const int g0 = lane & ~(G - 1);
+      const unsigned long long grp = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << g0;
+      const unsigned long long mine = okmask & grp;
+      const bool winner = ok && (mine & ((1ull << lane) - 1ull)) == 0ull;
+      if (winner) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) up[(size_t)j * ld + i] = z[j];
+        double m_up = 0.0;
+        if (KERNEL == TPH_KERNEL_TPCN) {
+          const double* __restrict__ mu = means + (size_t)c * D;
+          const double* __restrict__ W = winv + (size_t)c * D * D;
+          if (ONE_MODE) W = tph_opaque(W);
+#pragma unroll
+          for (int j = 0; j < D; ++j) z[j] -= mu[j];
+          m_up = maha_w<D, ONE_MODE>(W, z);
+        }
+        if (maha_up) maha_up[i] = m_up;
+      }
+      // particles whose G attempts all left the cube go to the next round's list, in lane order
+      const bool again = busy && mine == 0ull && (lane & (G - 1)) == 0;
+      const unsigned long long amask = __ballot(again);
+      if (again) s_list[nxt][n_next + __popcll(amask & ((1ull << lane) - 1ull))] = pid;
+      n_next += __popcll(amask);
     }
-    __syncthreads();
-    count = s_count[nxt];
+    wave_sync();
+    count = n_next;
     a0 += G;
-    __syncthreads();
-    if (threadIdx.x == 0) s_count[cur] = 0;   // becomes `nxt` of the following round (ordered by its barrier)
   }
 }
 
 template <int KERNEL, int D>
 static void launch_propose_reg(tph_ctx* ctx, const double* u, const int32_t* assign, int64_t n, int64_t ld,
-                               const double* means, const double* chol, const double* inv, const double* dof,
+                               const double* means, const double* chol, const double* winv, const double* dof,
                                const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
                                double* up, double* mu_, double* mup) {
-  // redraw rounds: spare lanes of the whole block while the launch cannot fill the GPU (<= 8 waves per SIMD), else one wave
-  const int spare = ctx->redraw_lanes > 0 ? ctx->redraw_lanes : (n <= 512 * 1024 ? 256 : 64);
-  if (assign == nullptr)
-    hipLaunchKernelGGL((k_propose_reg<KERNEL, D, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, u, assign,
-                       n, ld, means, chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, spare);
-  else
-    hipLaunchKernelGGL((k_propose_reg<KERNEL, D, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, u, assign,
-                       n, ld, means, chol, inv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, spare);
+  // one resident batch: waves = min(tiles, 4 per SIMD x SIMDs), tiles of a wave = ceil(tiles / waves) <= REG_MAX_TILES
+  // (TPH_OPT_REDRAW_LANES = t > 0 forces t tiles per wave: experiments)
+  constexpr int WPE = 4;
+  const int64_t ntiles = (n + 63) / 64;
+  int64_t waves = (int64_t)WPE * ctx->n_simd;
+  if (waves > ntiles) waves = ntiles;
+  if (ntiles > waves * REG_MAX_TILES) waves = (ntiles + REG_MAX_TILES - 1) / REG_MAX_TILES;
+  int tiles = (int)((ntiles + waves - 1) / waves);
+  if (ctx->redraw_lanes > 0) tiles = ctx->redraw_lanes < REG_MAX_TILES ? ctx->redraw_lanes : REG_MAX_TILES;
+  waves = (ntiles + tiles - 1) / tiles;
+#define TPH_REG_LAUNCH(ONE, BC)                                                                                         \
+  hipLaunchKernelGGL((k_propose_reg<KERNEL, D, ONE, WPE, BC>), dim3((unsigned)waves), dim3(64), 0, ctx->stream, u, assign, n, ld, \
+                     means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, tiles)
+  if (assign == nullptr) { if (bc) TPH_REG_LAUNCH(true, true); else TPH_REG_LAUNCH(true, false); }
+  else { if (bc) TPH_REG_LAUNCH(false, true); else TPH_REG_LAUNCH(false, false); }
+#undef TPH_REG_LAUNCH
 }
 
 #define TPH_PROPOSE_CASE(DD)                                                                                       \
@@ -616,7 +667,7 @@ static void launch_propose_reg(tph_ctx* ctx, const double* u, const int32_t* ass
     break;
 
 extern "C" int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const int32_t* assign_dev, int64_t n, int64_t ld,
-                           int K, const double* means_dev, const double* chol_dev, const double* inv_dev,
+                           int K, const double* means_dev, const double* chol_dev, const double* cholinv_dev,
                            const double* dof_dev, const double* sigmas_dev, const uint8_t* bc_dev, uint64_t seed,
                            uint32_t tick0, int64_t item0, double* uprime_dev, double* maha_u_dev, double* maha_up_dev,
                            const double* ctl_dev) {
@@ -625,8 +676,22 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const 
   TPH_REQUIRE(n > 0 && ld >= n && K >= 1, "tph_propose: bad sizes");
   TPH_REQUIRE(kernel == TPH_KERNEL_TPCN || kernel == TPH_KERNEL_RWM, "tph_propose: unknown kernel %d", kernel);
   if (kernel == TPH_KERNEL_TPCN)
-    TPH_REQUIRE(means_dev && inv_dev && dof_dev && maha_u_dev && maha_up_dev, "tph_propose: tpCN needs means/inv/dof/maha");
+    TPH_REQUIRE(means_dev && dof_dev && maha_u_dev && maha_up_dev, "tph_propose: tpCN needs means/dof/maha");
   TPH_REQUIRE(K == 1 || assign_dev, "tph_propose: K>1 needs assignments");
+  const double* inv_dev = cholinv_dev;     // W = L^-1 per mode
+  if (kernel == TPH_KERNEL_TPCN && !inv_dev) {
+    // the caller has only the Cholesky factors (the reference's ModeStatistics.chol_covariances): invert them here
+    const size_t bytes = sizeof(double) * (size_t)K * ctx->d * ctx->d;
+    if (ctx->winv_bytes < bytes) {
+      TPH_HIP(hipStreamSynchronize(ctx->stream));
+      if (ctx->winv) TPH_HIP(hipFree(ctx->winv));
+      ctx->winv = nullptr; ctx->winv_bytes = 0;
+      TPH_HIP(hipMalloc((void**)&ctx->winv, bytes));
+      ctx->winv_bytes = bytes;
+    }
+    if (tph_tri_inv(ctx, chol_dev, K, ctx->winv)) return -1;
+    inv_dev = ctx->winv;
+  }
   const int variant = ctx->propose_variant;   // 0 auto | 1 one-lane LDS | 2 one-lane registers (d<=16) | 3 multi-lane
   const bool use_reg = (variant == 2 || variant == 0) && ctx->d <= 16;
   if (!use_reg && (variant == 3 || variant == 0) && ctx->d <= 8 * 64) {

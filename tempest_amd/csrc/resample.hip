@@ -116,6 +116,259 @@ extern "C" int tph_resample_select(tph_ctx* ctx, const double* cdf_dev, int64_t 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// GLOBAL cumulative weights of a sharded history (one process per GPU, tph_comm_attach).
+// The reference resamples from ONE history ordered by iteration and, inside an iteration, by particle slot
+// (state_manager.py:267-320 flat=True; steps/resample.py:80-84; modes.py:196-201).  With the slots of every iteration split
+// evenly over the ranks that order is: block (t = 0, rank 0), (0, 1) ... (0, G-1), (1, 0) ...; a rank holds the T blocks
+// (t, rank) of `rows` rows each.  Its slice of the global cumulative sum is therefore
+//     gcdf[i] = glo[t(i)] + (inclusive scan of w inside block t(i)) ,   glo[t] = mass of all blocks before (t, rank),
+// obtained with ONE all-gather of the T block totals.  Rows are clamped into [glo[t], ghi[t]] and the last row of a block is
+// set to ghi[t] = the next block's glo exactly (every rank computes the table from the same gathered numbers with the same
+// arithmetic), so the blocks partition the global axis without gaps or overlaps whatever the rounding inside a block: each
+// draw position belongs to exactly one rank.  A draw is then mapped exactly as on one GPU: same counter-based uniform, same
+// predicate, on the same (to rounding) cumulative values -- a sharded run selects the same history rows as the one-GPU run.
+template <int MODE>
+__global__ void __launch_bounds__(tph_scan::THREADS) k_seg_tile_sums(const double* __restrict__ w, int64_t rows, int tpb,
+                                                                     const double* __restrict__ thr_dev, double* __restrict__ tiles) {
+  using namespace tph_scan;
+  const double thr = MODE == MASKED ? thr_dev[0] : 0.0;
+  const int64_t t = blockIdx.x / tpb, j = blockIdx.x % tpb;
+  const int64_t lim = (t + 1) * rows;
+  const int64_t base = t * rows + j * TILE + (int64_t)threadIdx.x * ITEMS;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k)
+    if (base + k < lim) s += load<MODE>(w, base + k, thr);
+  __shared__ double sh[THREADS / 64];
+  s = tph_block_sum(s, sh);
+  if (threadIdx.x == 0) tiles[blockIdx.x] = s;
+}
+// totals[t] = sum of the block's tile sums (one workgroup per block, fixed order)
+__global__ void __launch_bounds__(256) k_seg_totals(const double* __restrict__ tiles, int tpb, double* __restrict__ totals) {
+  double s = 0.0;
+  for (int j = threadIdx.x; j < tpb; j += 256) s += tiles[(size_t)blockIdx.x * tpb + j];
+  __shared__ double sh[4];
+  s = tph_block_sum(s, sh);
+  if (threadIdx.x == 0) totals[blockIdx.x] = s;
+}
+// table = (glo[T], ghi[T], total) of rank `rank` from the gathered totals all[G][T], accumulated in global (iteration-major)
+// order by ONE thread: identical on every rank
+__global__ void k_block_table(const double* __restrict__ all, int G, int T, int rank, double* __restrict__ table) {
+  if (blockIdx.x || threadIdx.x) return;
+  double run = 0.0;
+  for (int t = 0; t < T; ++t)
+    for (int g = 0; g < G; ++g) {
+      if (g == rank) table[t] = run;
+      run += all[(size_t)g * T + t];
+      if (g == rank) table[T + t] = run;
+    }
+  table[2 * T] = run;
+}
+// tile sums of a block -> exclusive offsets + glo[t] (one workgroup per block; sequential over chunks of 256 tiles)
+__global__ void __launch_bounds__(256) k_seg_offsets(double* __restrict__ tiles, int tpb, const double* __restrict__ table) {
+  __shared__ double wsum[4];
+  __shared__ double carry;
+  double* mine = tiles + (size_t)blockIdx.x * tpb;
+  if (threadIdx.x == 0) carry = table[blockIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int j0 = 0; j0 < tpb; j0 += 256) {
+    const int j = j0 + threadIdx.x;
+    const double v = j < tpb ? mine[j] : 0.0;
+    const double inc = tph_scan::wave_incl(v);
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    double off = carry;
+    for (int k = 0; k < wid; ++k) off += wsum[k];
+    const double prev = __shfl_up(inc, 1, 64);
+    if (lane > 0) off += prev;                      // exclusive prefix (never `inclusive - own`: see scan.h)
+    if (j < tpb) mine[j] = off;
+    __syncthreads();
+    if (threadIdx.x == 255) carry = off + v;
+    __syncthreads();
+  }
+}
+template <int MODE>
+__global__ void __launch_bounds__(tph_scan::THREADS) k_seg_apply(const double* __restrict__ w, int64_t rows, int tpb, int T,
+                                                                 const double* __restrict__ thr_dev, const double* __restrict__ tiles,
+                                                                 const double* __restrict__ table, double* __restrict__ out) {
+  using namespace tph_scan;
+  const double thr = MODE == MASKED ? thr_dev[0] : 0.0;
+  const int64_t t = blockIdx.x / tpb, j = blockIdx.x % tpb;
+  const int64_t lim = (t + 1) * rows;
+  const int64_t base = t * rows + j * TILE + (int64_t)threadIdx.x * ITEMS;
+  double v[ITEMS];
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    s += base + k < lim ? load<MODE>(w, base + k, thr) : 0.0;
+    v[k] = s;
+  }
+  __shared__ double wsum[THREADS / 64];
+  const double inc = wave_incl(s);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  double off = tiles[blockIdx.x];
+  for (int k = 0; k < wid; ++k) off += wsum[k];
+  const double prev = __shfl_up(inc, 1, 64);
+  if (lane > 0) off += prev;
+  const double lo = table[t], hi = table[T + t];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k)
+    if (base + k < lim) {
+      double c = fmin(fmax(off + v[k], lo), hi);
+      if (base + k == lim - 1) c = hi;
+      out[base + k] = c;
+    }
+}
+
+extern "C" int tph_cdf_global(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev, double* cdf_dev,
+                              double* total_host) {
+  TPH_REQUIRE(ctx && w_dev && cdf_dev && n > 0, "tph_cdf_global: bad argument");
+  if (!ctx->comm_active()) {
+    int rc = tph_cdf(ctx, w_dev, n, thr_dev, cdf_dev);
+    if (rc) return rc;
+    if (total_host) {
+      TPH_HIP(hipMemcpyAsync(ctx->pinned, cdf_dev + (n - 1), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      TPH_HIP(hipStreamSynchronize(ctx->stream));
+      *total_host = ctx->pinned[0];
+    }
+    return 0;
+  }
+  int T; int64_t rows;
+  if (tph_blocks(ctx, n, &T, &rows)) return -2;
+  const int G = ctx->world;
+  const int tpb = (int)tph_scan::num_tiles(rows);
+  if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)T * tpb)) return -1;
+  if (tph_comm_require(ctx, sizeof(double) * (size_t)T * (G + 1), "tph_cdf_global")) return -2;
+  if (ctx->blk_table_cap < 2 * T + 1) {
+    int nc = ctx->blk_table_cap ? ctx->blk_table_cap : 513;
+    while (nc < 2 * T + 1) nc = 2 * nc + 1;
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->blk_table) TPH_HIP(hipFree(ctx->blk_table));
+    ctx->blk_table = nullptr; ctx->blk_table_cap = 0;
+    TPH_HIP(hipMalloc((void**)&ctx->blk_table, sizeof(double) * (size_t)nc));
+    ctx->blk_table_cap = nc;
+  }
+  double* tiles = (double*)ctx->scratch;
+  double* mine = (double*)ctx->comm_buf;                 // [T] this rank's block totals
+  double* all = mine + T;                                // [G][T]
+  const dim3 grid((unsigned)((size_t)T * tpb)), blk(tph_scan::THREADS);
+  if (thr_dev) hipLaunchKernelGGL(k_seg_tile_sums<tph_scan::MASKED>, grid, blk, 0, ctx->stream, w_dev, rows, tpb, thr_dev, tiles);
+  else hipLaunchKernelGGL(k_seg_tile_sums<tph_scan::PLAIN>, grid, blk, 0, ctx->stream, w_dev, rows, tpb, thr_dev, tiles);
+  hipLaunchKernelGGL(k_seg_totals, dim3(T), dim3(256), 0, ctx->stream, tiles, tpb, mine);
+  TPH_LAUNCH_CHECK();
+  if (tph_comm_allgather(ctx, 0, sizeof(double) * (size_t)T, T, TPH_DT_F64)) return -2;
+  hipLaunchKernelGGL(k_block_table, dim3(1), dim3(1), 0, ctx->stream, all, G, T, ctx->rank, ctx->blk_table);
+  hipLaunchKernelGGL(k_seg_offsets, dim3(T), dim3(256), 0, ctx->stream, tiles, tpb, ctx->blk_table);
+  if (thr_dev) hipLaunchKernelGGL(k_seg_apply<tph_scan::MASKED>, grid, blk, 0, ctx->stream, w_dev, rows, tpb, T, thr_dev, tiles, ctx->blk_table, cdf_dev);
+  else hipLaunchKernelGGL(k_seg_apply<tph_scan::PLAIN>, grid, blk, 0, ctx->stream, w_dev, rows, tpb, T, thr_dev, tiles, ctx->blk_table, cdf_dev);
+  TPH_LAUNCH_CHECK();
+  ctx->blk_T = T; ctx->blk_rows = rows;
+  if (total_host) {
+    TPH_HIP(hipMemcpyAsync(ctx->pinned, ctx->blk_table + 2 * T, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    *total_host = ctx->pinned[0];
+  }
+  return 0;
+}
+
+// which of my blocks owns global position p?  -1: another rank's.  INCL: multinomial walk (#{c <= p}: block with
+// glo <= p < ghi), else systematic (#{c < p}: glo < p <= ghi).  Positions beyond either end go to the first / last block.
+template <bool INCL>
+__device__ __forceinline__ int owner_block(const double* __restrict__ table, int T, int rank, int world, double p) {
+  int lo = 0, hi = T;                      // first t with glo[t] > p (INCL) or >= p
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const bool before = INCL ? (table[mid] <= p) : (table[mid] < p);
+    if (before) lo = mid + 1; else hi = mid;
+  }
+  int t = lo - 1;
+  if (t < 0) return rank == 0 ? 0 : -1;    // p at (or below) the origin: the first block of the global order
+  const double ghi = table[T + t];
+  const bool inside = INCL ? (p < ghi) : (p <= ghi);
+  if (inside) return t;
+  return (rank == world - 1 && t == T - 1) ? t : -1;   // p at (or beyond) the total: the last block of the global order
+}
+
+__global__ void __launch_bounds__(256) k_select_global(tph_cdf_index ix, const double* __restrict__ table, int T, int64_t rows,
+                                                       int rank, int world, int64_t n_slots, int scheme, uint64_t seed,
+                                                       uint32_t tick, uint32_t tag, double u0, double pscale,
+                                                       int64_t* __restrict__ idx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots) return;
+  double p;
+  if (scheme == 0) {
+    tph_rng g(seed, tick, tag, (uint64_t)i);
+    double U, U1;
+    g.uniform2(0, U, U1);
+    p = U * table[2 * T];
+  } else {
+    p = (u0 + (double)i) / (double)n_slots * pscale;
+  }
+  const int t = scheme == 0 ? owner_block<true>(table, T, rank, world, p) : owner_block<false>(table, T, rank, world, p);
+  if (t < 0) { idx[i] = -1; return; }
+  int64_t k = scheme == 0 ? tph_count_below<false>(ix, 1.0, p) : tph_count_below<true>(ix, 1.0, p);
+  const int64_t first = (int64_t)t * rows, last = first + rows - 1;
+  idx[i] = k < first ? first : (k > last ? last : k);
+}
+
+extern "C" int tph_resample_select_global(tph_ctx* ctx, const double* cdf_dev, int64_t n, int64_t n_slots, int scheme,
+                                          uint64_t seed, uint32_t tick, uint32_t tag, double u0, double pscale, int64_t* idx_dev) {
+  TPH_REQUIRE(ctx && cdf_dev && idx_dev && n > 0 && n_slots > 0, "tph_resample_select_global: bad argument");
+  TPH_REQUIRE(scheme == 0 || scheme == 1, "tph_resample_select_global: scheme must be 0 (multinomial) or 1 (systematic)");
+  if (!ctx->comm_active()) {
+    if (scheme == 0) return tph_resample_multinomial(ctx, cdf_dev, n, n_slots, seed, tick, tag, 0, idx_dev);
+    return tph_resample_systematic(ctx, cdf_dev, n, n_slots, 0, n_slots, u0, pscale, idx_dev);
+  }
+  TPH_REQUIRE(ctx->blk_T > 0 && (int64_t)ctx->blk_T * ctx->blk_rows == n, "tph_resample_select_global: call tph_cdf_global on this history first");
+  if (tph_scratch_reserve(ctx, sizeof(double) * tph_cdf_index_doubles(n))) return -1;
+  tph_cdf_index ix;
+  if (tph_cdf_index_build(ctx, cdf_dev, n, (double*)ctx->scratch, &ix)) return -1;
+  hipLaunchKernelGGL(k_select_global, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, ctx->stream, ix, ctx->blk_table,
+                     ctx->blk_T, ctx->blk_rows, ctx->rank, ctx->world, n_slots, scheme, seed, tick, tag, u0, pscale, idx_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) k_counts_global(tph_cdf_index ix, const double* __restrict__ table, int T, int64_t rows,
+                                                       int rank, int world, const double* __restrict__ kept_count_dev, int factor,
+                                                       int64_t n_draw_max, uint64_t seed, uint32_t tick, uint32_t tag,
+                                                       int32_t* __restrict__ counts) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t n_draw = kept_count_dev ? (int64_t)(kept_count_dev[0]) * factor : n_draw_max;
+  if (r >= n_draw || r >= n_draw_max) return;
+  tph_rng g(seed, tick, tag, (uint64_t)r);
+  double U, U1;
+  g.uniform2(0, U, U1);
+  const double p = U * table[2 * T];
+  const int t = owner_block<true>(table, T, rank, world, p);
+  if (t < 0) return;
+  int64_t k = tph_count_below<false>(ix, 1.0, p);
+  const int64_t first = (int64_t)t * rows, last = first + rows - 1;
+  k = k < first ? first : (k > last ? last : k);
+  atomicAdd(&counts[k], 1);
+}
+
+extern "C" int tph_multinomial_counts_global(tph_ctx* ctx, const double* cdf_dev, int64_t n, const double* kept_count_dev,
+                                             int factor, int64_t n_draw_max, uint64_t seed, uint32_t tick, uint32_t tag,
+                                             int32_t* counts_dev) {
+  TPH_REQUIRE(ctx && cdf_dev && counts_dev && n > 0 && n_draw_max > 0, "tph_multinomial_counts_global: bad argument");
+  if (!ctx->comm_active())
+    return tph_multinomial_counts(ctx, cdf_dev, n, kept_count_dev, factor, n_draw_max, seed, tick, tag, counts_dev);
+  TPH_REQUIRE(ctx->blk_T > 0 && (int64_t)ctx->blk_T * ctx->blk_rows == n, "tph_multinomial_counts_global: call tph_cdf_global on this history first");
+  TPH_HIP(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * (size_t)n, ctx->stream));
+  if (tph_scratch_reserve(ctx, sizeof(double) * tph_cdf_index_doubles(n))) return -1;
+  tph_cdf_index ix;
+  if (tph_cdf_index_build(ctx, cdf_dev, n, (double*)ctx->scratch, &ix)) return -1;
+  hipLaunchKernelGGL(k_counts_global, dim3((unsigned)((n_draw_max + 255) / 256)), dim3(256), 0, ctx->stream, ix, ctx->blk_table,
+                     ctx->blk_T, ctx->blk_rows, ctx->rank, ctx->world, kept_count_dev, factor, n_draw_max, seed, tick, tag, counts_dev);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
 // K7: gather rows of the history; coalesced writes, indexed reads
 __global__ void __launch_bounds__(256) k_gather(const double* __restrict__ hu, const double* __restrict__ hx,
                                                 const double* __restrict__ hl, int64_t cap, int d,

@@ -270,7 +270,8 @@ class HipContext:
         if ctl is not None and ctl.numel() < STEP_STATE_LEN:
             raise _lib.TempestHipError(f"propose: the step-control block needs {STEP_STATE_LEN} doubles")
         check(self.lib.tph_propose(self._ctx, KERNEL_ID[kernel], _ptr(u), _ptr(assign, torch.int32) if assign is not None else None,
-                                   n, n, modes.K, _ptr(modes.means_dev), _ptr(modes.chol_dev), _ptr(modes.inv_dev),
+                                   n, n, modes.K, _ptr(modes.means_dev), _ptr(modes.chol_dev),
+                                   _ptr(getattr(modes, "winv_dev", None)),
                                    _ptr(modes.dof_dev), _ptr(sigmas), _ptr(bc) if bc is not None else None, seed, tick,
                                    item0, _ptr(uprime), _ptr(maha_u), _ptr(maha_up),
                                    _ptr(ctl) if ctl is not None else None), "tph_propose")
@@ -310,20 +311,22 @@ class HipContext:
 
     # --------------------------------------------------------------------------- proposal fit
     def fit_modes(self, counts, labels=None, K=1, n=None):
+        """-> (means, covs, chol, inv, winv): winv = L^-1 per mode (the form the proposal kernels consume)."""
         d = self.n_dim
         n = self.size if n is None else n
         means, covs = self.empty(K, d), self.empty(K, d, d)
-        chol, inv = self.empty(K, d, d), self.empty(K, d, d)
+        chol, inv, winv = self.empty(K, d, d), self.empty(K, d, d), self.empty(K, d, d)
         check(self.lib.tph_fit_modes(self._ctx, _ptr(counts, torch.int32),
                                      _ptr(labels, torch.int32) if labels is not None else None, n, K, _ptr(means),
-                                     _ptr(covs), _ptr(chol), _ptr(inv)), "tph_fit_modes")
-        return means, covs, chol, inv
+                                     _ptr(covs), _ptr(chol), _ptr(inv), _ptr(winv)), "tph_fit_modes")
+        return means, covs, chol, inv, winv
 
     def chol_inv(self, covs):
+        """-> (chol, inv, winv) of K covariance matrices (covs is ridged in place where the factorisation fails)."""
         K = covs.shape[0]
-        chol, inv = torch.empty_like(covs), torch.empty_like(covs)
-        check(self.lib.tph_chol_inv(self._ctx, _ptr(covs), K, _ptr(chol), _ptr(inv)), "tph_chol_inv")
-        return chol, inv
+        chol, inv, winv = torch.empty_like(covs), torch.empty_like(covs), torch.empty_like(covs)
+        check(self.lib.tph_chol_inv(self._ctx, _ptr(covs), K, _ptr(chol), _ptr(inv), _ptr(winv)), "tph_chol_inv")
+        return chol, inv, winv
 
     # ----------------------------------------------------------------------------- clustering
     def compact_indices(self, w, thr, m):

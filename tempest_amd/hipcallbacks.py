@@ -200,8 +200,12 @@ class HipCallbacks:
             if not (t.is_cuda and t.is_contiguous()):
                 raise TempestHipError("HipCallbacks.step: expected contiguous device tensors")
         p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        winv = getattr(modes, "winv_dev", None)
+        if winv is None:               # mode statistics built outside ModeStatistics: L^-1 from the factors
+            import torch
+            winv = torch.linalg.inv(modes.chol_dev)
         self._check(self.lib.tphu_step(self._stream(u), int(kernel_id), 0.0, p(u), p(logl), p(maha_u), n, n,
-                                       p(modes.means_dev), p(modes.chol_dev), p(modes.inv_dev), p(modes.dof_dev), p(sigmas),
+                                       p(modes.means_dev), p(modes.chol_dev), p(winv), p(modes.dof_dev), p(sigmas),
                                        p(bc), int(seed), int(tick_propose), int(tick_accept), int(item0), p(ctl), p(partials),
                                        int(redraw_lanes)), "tphu_step")
 

@@ -92,7 +92,7 @@ class StepEngine:
             self.u, self.logl = ctx.empty(d, n), ctx.empty(n)
             self.assign = torch.empty(n, dtype=torch.int32, device=ctx.device) if has_assign else None
             self.modes = SimpleNamespace(K=K, means_dev=ctx.empty(K, d), chol_dev=ctx.empty(K, d, d),
-                                         inv_dev=ctx.empty(K, d, d), dof_dev=ctx.empty(K))
+                                         winv_dev=ctx.empty(K, d, d), dof_dev=ctx.empty(K))
         self.has_assign = has_assign
         self.sigmas, self.counts, self.sums = ctx.empty(K), ctx.empty(K), ctx.zeros(1 + K)
         self.partials = ctx.empty(((n + 255) // 256) * (1 + K))     # fixed address: the library's scratch may move
@@ -118,7 +118,10 @@ class StepEngine:
                 self.assign.copy_(assign)
             m = self.modes
             m.means_dev.copy_(modes.means_dev.reshape(m.means_dev.shape)); m.chol_dev.copy_(modes.chol_dev.reshape(m.chol_dev.shape))
-            m.inv_dev.copy_(modes.inv_dev.reshape(m.inv_dev.shape)); m.dof_dev.copy_(modes.dof_dev.reshape(m.dof_dev.shape))
+            winv = getattr(modes, "winv_dev", None)
+            if winv is None:            # mode statistics built outside ModeStatistics: L^-1 from the factors
+                winv = torch.linalg.inv(modes.chol_dev.reshape(m.chol_dev.shape))
+            m.winv_dev.copy_(winv.reshape(m.winv_dev.shape)); m.dof_dev.copy_(modes.dof_dev.reshape(m.dof_dev.shape))
         else:
             self.u, self.logl, self.assign, self.modes = u, logl, assign, modes
         self.sigmas.fill_(sigma_init)

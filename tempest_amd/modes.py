@@ -12,8 +12,9 @@ class ModeStatistics:
         """From host arrays (modes.py:58-119): Cholesky + inverse per mode are computed by the HIP
         kernel with the reference's ridge-on-failure rule."""
         import torch
-        if _dev is not None:       # internal: already-fitted device tensors
-            self._ctx, self.means_dev, self.covs_dev, self.chol_dev, self.inv_dev, self.dof_dev = _dev
+        if _dev is not None:       # internal: already-fitted device tensors (ctx, means, covs, chol, inv, dof[, winv])
+            self._ctx, self.means_dev, self.covs_dev, self.chol_dev, self.inv_dev, self.dof_dev = _dev[:6]
+            self.winv_dev = _dev[6] if len(_dev) > 6 else None      # L^-1 per mode: what the proposal kernels consume
             self._host = {}
             return
         means = np.asarray(means, dtype=np.float64)
@@ -35,7 +36,7 @@ class ModeStatistics:
         self._ctx = ctx
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)  # noqa: E731
         self.means_dev, self.covs_dev, self.dof_dev = to(means), to(covs.copy()), to(dof)
-        self.chol_dev, self.inv_dev = ctx.chol_inv(self.covs_dev)
+        self.chol_dev, self.inv_dev, self.winv_dev = ctx.chol_inv(self.covs_dev)
         self._host = {}
 
     # ------------------------------------------------------------------ reference attributes
@@ -93,9 +94,9 @@ class ModeStatistics:
                 cdf = ctx.cdf(wk)
                 counts += ctx.multinomial_counts(cdf, seed, tick + k, kept_count=None, factor=resample_factor,
                                                  n_draw_max=resample_factor * nk)
-        means, covs, chol, inv = ctx.fit_modes(counts, labels_dev, K, n)
+        means, covs, chol, inv, winv = ctx.fit_modes(counts, labels_dev, K, n)
         dof = torch.full((K,), float(dof_fallback), dtype=torch.float64, device=ctx.device)   # nu = inf -> fallback (F5)
-        return cls(None, None, None, _dev=(ctx, means, covs, chol, inv, dof))
+        return cls(None, None, None, _dev=(ctx, means, covs, chol, inv, dof, winv))
 
     @classmethod
     def from_particles(cls, u, weights, labels, dof_fallback: float = DOF_FALLBACK, resample_factor: int = 4,

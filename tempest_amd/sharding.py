@@ -63,6 +63,6 @@ def fit_modes_sharded(state, w, trim_ess, trim_bins, dof_fallback, rng):
     thr = ctx.trim_threshold(wl, trim_ess, trim_bins)
     cdf = ctx.cdf(wl, thr[0:1])
     counts = ctx.multinomial_counts(cdf, rng.seed, tick, kept_count=thr[2:3], factor=4, n_draw_max=4 * n_h)
-    means, covs, chol, inv = ctx.fit_modes(counts, None, 1, n_h)
+    means, covs, chol, inv, winv = ctx.fit_modes(counts, None, 1, n_h)
     dof = torch.full((1,), float(dof_fallback), dtype=torch.float64, device=ctx.device)
-    return ModeStatistics(None, None, None, _dev=(ctx, means, covs, chol, inv, dof))
+    return ModeStatistics(None, None, None, _dev=(ctx, means, covs, chol, inv, dof, winv))

@@ -61,17 +61,17 @@ class Trainer:
                 cdf = ctx.cdf(w, thr[0:1])
                 counts = ctx.multinomial_counts(cdf, rng.seed, rng.next(), kept_count=thr[2:3], factor=4,
                                                 n_draw_max=4 * n_h)
-                means, covs, chol, inv = ctx.fit_modes(counts, None, 1, n_h)
+                means, covs, chol, inv, winv = ctx.fit_modes(counts, None, 1, n_h)
                 dof = torch.full((1,), float(self.DOF_FALLBACK), dtype=torch.float64, device=ctx.device)
-                ms = ModeStatistics(None, None, None, _dev=(ctx, means, covs, chol, inv, dof))
+                ms = ModeStatistics(None, None, None, _dev=(ctx, means, covs, chol, inv, dof, winv))
         else:
             thr = ctx.trim_threshold(w, self.TRIM_ESS, self.TRIM_BINS)        # (threshold, kept_sum, kept_count, ess)
             cdf = ctx.cdf(w, thr[0:1])
             counts = ctx.multinomial_counts(cdf, rng.seed, rng.next(), kept_count=thr[2:3], factor=4,
                                             n_draw_max=4 * n_h)
-            means, covs, chol, inv = ctx.fit_modes(counts, None, 1, n_h)
+            means, covs, chol, inv, winv = ctx.fit_modes(counts, None, 1, n_h)
             dof = torch.full((1,), float(self.DOF_FALLBACK), dtype=torch.float64, device=ctx.device)
-            ms = ModeStatistics(None, None, None, _dev=(ctx, means, covs, chol, inv, dof))
+            ms = ModeStatistics(None, None, None, _dev=(ctx, means, covs, chol, inv, dof, winv))
         if self.pbar is not None:
             self.pbar.update_stats(dict(K=ms.K))
         return ms

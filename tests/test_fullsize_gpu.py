@@ -92,7 +92,7 @@ def test_trim_and_fit_invariants_fullsize(big):
     cdf = c.cdf(w, thr[0:1])
     counts = c.multinomial_counts(cdf, 3, 4, kept_count=thr[2:3], factor=4, n_draw_max=4 * c.size)
     assert int(counts.sum()) == 4 * int(host[2]) and int(counts[~kept].sum()) == 0
-    means, covs, chol, inv = c.fit_modes(counts)
+    means, covs, chol, inv, _ = c.fit_modes(counts)
     L = chol[0]
     np.testing.assert_allclose((L @ L.T).cpu().numpy(), covs[0].cpu().numpy(), rtol=1e-10)
     np.testing.assert_allclose((covs[0] @ inv[0]).cpu().numpy(), np.eye(d), atol=1e-8)

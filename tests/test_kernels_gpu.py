@@ -252,7 +252,7 @@ def test_fit_modes_vs_golden_and_oracle(dev):
     c = ctx_for(d)
     c.history_load(u, u, np.zeros(n), [0.0], [0.0], [n])
     counts = np.bincount(idx, minlength=n).astype(np.int32)
-    means, covs, chol, inv = c.fit_modes(torch.from_numpy(counts).to(dev))
+    means, covs, chol, inv, _ = c.fit_modes(torch.from_numpy(counts).to(dev))
     np.testing.assert_allclose(means.cpu().numpy(), g["fg_means"], rtol=1e-14)
     np.testing.assert_allclose(covs.cpu().numpy(), g["fg_covs"], rtol=1e-10)
     np.testing.assert_allclose(chol.cpu().numpy(), g["fg_chol"], rtol=1e-9, atol=1e-15)
@@ -263,7 +263,7 @@ def test_fit_modes_vs_golden_and_oracle(dev):
     for cidx in range(3):
         sel = np.nonzero(labels == cidx)[0]
         counts += np.bincount(sel[g[f"fp_idx{cidx}"]], minlength=n).astype(np.int32)
-    means, covs, chol, inv = c.fit_modes(torch.from_numpy(counts).to(dev), torch.from_numpy(labels).to(dev), K=3)
+    means, covs, chol, inv, _ = c.fit_modes(torch.from_numpy(counts).to(dev), torch.from_numpy(labels).to(dev), K=3)
     np.testing.assert_allclose(means.cpu().numpy(), g["fp_means"], rtol=1e-14)
     np.testing.assert_allclose(covs.cpu().numpy(), g["fp_covs"], rtol=1e-10)
     np.testing.assert_allclose(inv.cpu().numpy(), g["fp_inv"], rtol=1e-8)
@@ -285,7 +285,7 @@ def test_fit_modes_large_narrow_with_duplicates(dev):
     U = px.uniform1(5, np.arange(4 * n), 1, px.TAG_UPSAMPLE)
     want_counts = np.bincount(ps.multinomial_resample(w, U), minlength=n)
     assert np.abs(cn - want_counts).sum() <= 4
-    means, covs, chol, inv = c.fit_modes(counts)
+    means, covs, chol, inv, _ = c.fit_modes(counts)
     mu, Sig, _ = ps.median_cov_from_counts(u, cn)
     np.testing.assert_allclose(means.cpu().numpy()[0], mu, rtol=1e-14, atol=0)
     np.testing.assert_allclose(covs.cpu().numpy()[0], Sig, rtol=1e-9, atol=1e-22)
@@ -309,7 +309,7 @@ def test_fit_modes_compacts_sparse_upsampled_sets(dev, d, K):
     c.history_load(u, u, np.zeros(n), [0.0], [0.0], [n])
     ct = torch.from_numpy(counts).to(dev)
     lt = torch.from_numpy(labels).to(dev) if K > 1 else None
-    means, covs, chol, inv = c.fit_modes(ct, lt, K=K)
+    means, covs, chol, inv, _ = c.fit_modes(ct, lt, K=K)
     for k in range(K):
         ck = counts * (labels == k) if K > 1 else counts
         mu, Sig, _ = ps.median_cov_from_counts(u, ck)
@@ -317,7 +317,7 @@ def test_fit_modes_compacts_sparse_upsampled_sets(dev, d, K):
         np.testing.assert_allclose(covs.cpu().numpy()[k], Sig, rtol=1e-9, atol=1e-22)
     # dense multiplicities (> half of the rows): the history is streamed as it is -- same answer as the oracle too
     dense = rs.randint(0, 3, size=n).astype(np.int32)
-    means, covs, _, _ = c.fit_modes(torch.from_numpy(dense).to(dev))
+    means, covs, _, _, _ = c.fit_modes(torch.from_numpy(dense).to(dev))
     mu, Sig, _ = ps.median_cov_from_counts(u, dense)
     np.testing.assert_allclose(means.cpu().numpy()[0], mu, rtol=1e-14, atol=0)
     np.testing.assert_allclose(covs.cpu().numpy()[0], Sig, rtol=1e-9, atol=1e-22)
@@ -332,11 +332,17 @@ def test_chol_inv_ridge(dev):
     want_cov, want_chol, want_inv = ps.mode_statistics(np.zeros((3, d)), covs)
     c = ctx_for(d)
     ct = torch.from_numpy(covs.copy()).to(dev)
-    chol, inv = c.chol_inv(ct)
+    chol, inv, winv = c.chol_inv(ct)
     np.testing.assert_allclose(ct.cpu().numpy(), want_cov, rtol=1e-14)
     np.testing.assert_allclose(chol.cpu().numpy(), want_chol, rtol=1e-7, atol=1e-12)
     np.testing.assert_allclose(inv.cpu().numpy()[0], want_inv[0], rtol=1e-9)
     np.testing.assert_allclose(inv.cpu().numpy()[2], want_inv[2], rtol=1e-9)
+    # L^-1 (what the proposal kernels consume): lower-triangular, W L = I, W^T W = Sigma^-1
+    W, L = winv.cpu().numpy(), chol.cpu().numpy()
+    for k in (0, 2):
+        assert np.allclose(np.triu(W[k], 1), 0.0)
+        np.testing.assert_allclose(W[k] @ L[k], np.eye(d), atol=1e-9)
+        np.testing.assert_allclose(W[k].T @ W[k], want_inv[k], rtol=1e-8, atol=1e-12)
 
 
 def test_volume_variation_golden(dev):
