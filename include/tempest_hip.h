@@ -117,8 +117,8 @@ int tph_history_load(tph_ctx* ctx, const double* u_host, const double* x_host, c
 /* ---- reweighting (state_manager.py:418-480, steps/reweight.py:88-118, tools.py:120-135) -------
  * For each trial beta_b:  v_s = beta_b*l_s - C_s ;  out[b] = (max_s v, sum_s e^{v-max}, sum_s e^{2(v-max)}).
  * Then ESS = s1^2/s2 (tools.py:134-135) and logZ = max + log s1 (state_manager.py:475; the two
- * log N_h cancel).  nb <= 16.  _dev leaves the triples on the device (for the cross-GPU merge),
- * _host synchronises and returns them. */
+ * log N_h cancel).  nb <= 16.  _partials leaves the triples on the device, _eval synchronises and returns them.
+ * With a communicator attached both return the GLOBAL triples (all-gather of the ranks' triples + device-side merge). */
 int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int nb, double* out_dev /*[nb][3]*/);
 int tph_reweight_eval(tph_ctx* ctx, const double* betas_host, int nb, double* out_host /*[nb][3]*/);
 /* measurement aid: average duration (ms, HIP events on the ctx stream) of `reps` back-to-back launches of the
@@ -128,6 +128,29 @@ int tph_reweight_time(tph_ctx* ctx, double beta, int nb, int reps, double* avg_m
 int tph_weights(tph_ctx* ctx, double beta, double vmax, double s1, double* w_dev);
 /* unnormalised log-weights beta*l - C + log(n_h_global)  (state_manager.py:473) */
 int tph_logw(tph_ctx* ctx, double beta, int64_t n_h_global, double* logw_dev);
+
+/* ---- the same steps over a SHARDED history (tph_comm_attach; without a communicator each is the plain function) ----------
+ * They work on the whole local history (n = tph_history_size) and return on every rank what the one-GPU run computes on
+ * the global history in the reference's order (iteration-major, then particle slot). */
+/* global trimming threshold: exact global percentiles by a radix descent over all-reduced counts (8 rounds) */
+int tph_trim_threshold_global(tph_ctx* ctx, const double* w_dev, int64_t n, double ess, int bins,
+                              double* out_dev /*[4]*/, double* out_host /*[4] or NULL*/);
+/* this rank's slice of the GLOBAL cumulative weight (one all-gather of the per-iteration block totals); records the block
+ * table the next two calls use.  total_host (optional, synchronises) = the global sum. */
+int tph_cdf_global(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev /*or NULL*/, double* cdf_dev,
+                   double* total_host /*or NULL*/);
+/* global resampling: of the n_slots GLOBAL output slots, idx = local row for those whose draw lands in one of this rank's
+ * blocks, -1 otherwise (the blocks partition the cumulative axis: exactly one rank claims each slot).
+ * scheme 0: multinomial, position U_i * total; 1: systematic, position (u0 + i) / n_slots * pscale (pscale = the renorm
+ * divisor of tph_resample_systematic: the total when tools.py:214-217 renormalises, else 1). */
+int tph_resample_select_global(tph_ctx* ctx, const double* cdf_dev, int64_t n, int64_t n_slots, int scheme, uint64_t seed,
+                               uint32_t tick, uint32_t tag, double u0, double pscale, int64_t* idx_dev);
+/* multiplicities of the LOCAL rows among factor * (*kept_count_dev) global multinomial draws (modes.py:196-201) */
+int tph_multinomial_counts_global(tph_ctx* ctx, const double* cdf_dev, int64_t n, const double* kept_count_dev, int factor,
+                                  int64_t n_draw_max, uint64_t seed, uint32_t tick, uint32_t tag, int32_t* counts_dev);
+/* tph_fit_modes of the global up-sampled set: all-reduced first/second moments and median histograms, gathered candidates */
+int tph_fit_modes_global(tph_ctx* ctx, const int32_t* counts_dev, const int32_t* labels_dev, int64_t n, int K,
+                         double* means_dev, double* covs_dev, double* chol_dev, double* inv_dev, double* cholinv_dev /*or NULL*/);
 
 /* ---- generic reductions on a device vector ---------------------------------------------------- */
 /* out_host = (sum w, sum w^2, max w) */

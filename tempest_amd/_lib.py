@@ -69,7 +69,18 @@ SIGNATURES = {
     "tph_x_weighted_cov": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr, ptr]),
     "tph_gmm_estep": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr, c_int, c_int, ptr, c_int, c_dbl, ptr, ptr, ptr, ptr, ptr]),
     "tph_cv_sum": (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr]),
+    "tph_comm_attach": (c_int, [ptr, c_int, c_int, ptr, c_i64, ptr, ptr, ptr]),
+    "tph_comm_detach": (c_int, [ptr]),
+    "tph_trim_threshold_global": (c_int, [ptr, ptr, c_i64, c_dbl, c_int, ptr, ptr]),
+    "tph_cdf_global": (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr]),
+    "tph_resample_select_global": (c_int, [ptr, ptr, c_i64, c_i64, c_int, c_u64, c_u32, c_u32, c_dbl, c_dbl, ptr]),
+    "tph_multinomial_counts_global": (c_int, [ptr, ptr, c_i64, ptr, c_int, c_i64, c_u64, c_u32, c_u32, ptr]),
+    "tph_fit_modes_global": (c_int, [ptr, ptr, ptr, c_i64, c_int, ptr, ptr, ptr, ptr, ptr]),
 }
+
+# host collectives handed to tph_comm_attach (see include/tempest_hip.h)
+ALLREDUCE_FN = C.CFUNCTYPE(c_int, ptr, c_i64, c_i64, c_int, c_int)
+ALLGATHER_FN = C.CFUNCTYPE(c_int, ptr, c_i64, c_i64, c_i64, c_int)
 
 
 class TempestHipError(RuntimeError):

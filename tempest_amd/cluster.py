@@ -394,10 +394,40 @@ class HierarchicalGaussianMixture:
         from .device import KEY_U
         ctx = state.ctx
         n_h = w.numel()
+        comm = state.comm
+        sharded = comm is not None and comm.active
         if refit or not self._gmm_ready:
             th = thr.cpu().numpy()
             n_keep = int(th[2])
-            if self.max_points is not None and n_keep > self.max_points:
+            if sharded:
+                # the working set is the GLOBAL kept set in the reference's history order, rebuilt on every rank (every rank
+                # then runs the identical split search on identical data: same kernels, same numbers, same decisions)
+                from .sharding import gather_rows_in_order
+                if self.max_points is not None and n_keep > self.max_points:
+                    cdf = ctx.cdf_global(w, thr[0:1])
+                    tick = rng.next()
+                    u0 = uniform_scalar(rng.seed, tick, TAG_CLUSTER)
+                    pick = ctx.resample_select_global(cdf, self.max_points, 1, rng.seed, tick, u0=u0, pscale=float(th[1]))
+                    slots = torch.nonzero(pick >= 0).reshape(-1)
+                    rows = pick[slots].contiguous()
+                    Xl = ctx.gather_u_affine(rows)[0] if rows.numel() else ctx.empty(ctx.n_dim, 0)
+                    X = gather_rows_in_order(comm, slots, Xl).contiguous()
+                    sw = torch.full((self.max_points,), 1.0 / self.max_points, dtype=torch.float64, device=ctx.device)
+                else:
+                    keep = w >= thr[0]
+                    m_loc = int(keep.sum().item())
+                    pos_all = ctx.cdf_global(keep.to(torch.float64))           # global 1-based rank of every kept row (exact)
+                    if m_loc:
+                        idx = ctx.compact_indices(w, thr[0:1], m_loc)
+                        Xl, swl = ctx.gather_u_affine(idx, w=w)
+                        pos = (pos_all[idx] - 1.0).long()
+                        cols = torch.cat([Xl, swl.reshape(1, -1)], dim=0)
+                    else:
+                        pos = torch.empty(0, dtype=torch.int64, device=ctx.device)
+                        cols = ctx.empty(ctx.n_dim + 1, 0)
+                    full = gather_rows_in_order(comm, pos, cols)
+                    X, sw = full[:-1].contiguous(), full[-1].contiguous()
+            elif self.max_points is not None and n_keep > self.max_points:
                 cdf = ctx.cdf(w, thr[0:1])
                 u0 = uniform_scalar(rng.seed, rng.next(), TAG_CLUSTER)
                 idx = ctx.resample_systematic(cdf, self.max_points, u0, renorm=float(th[1]))
@@ -416,7 +446,10 @@ class HierarchicalGaussianMixture:
                       shift=self._shift_dev, scale=self._scale_dev, n=n_h, ld=ld)
         # modes are built for the labels that actually occur among the kept rows (np.unique, modes.py:183)
         kept = labels[w >= thr[0]]
-        present = torch.bincount(kept.long(), minlength=self.n_clusters_) > 0
+        occ = torch.bincount(kept.long(), minlength=self.n_clusters_).to(torch.float64)
+        if sharded:
+            comm.all_reduce_sum(occ)
+        present = occ > 0
         if bool(present.all()):
             self._remap = None
             return labels, self.n_clusters_

@@ -1,11 +1,13 @@
 """Cross-GPU glue: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on the GPU
-box, "gloo" in the CPU tests).  Particles are sharded; the history never moves.  Only three kinds of
-traffic exist:
-  * scalars: the (max, s1, s2) reweight partials (all-gather + log-sum-exp merge), per-cluster alpha
-    sums / counts, moment sums (all-reduce SUM);
-  * histograms of the distributed median select (all-reduce SUM);
-  * the resample shuffle (all-to-all-v of the selected rows).
-With world_size == 1 every method is a no-op / identity.
+box, "gloo" in the CPU tests).  Particles are sharded; the history never moves.  Traffic:
+  * small reductions issued by libtempest_hip itself through the two collectives attached with `Comm.attach`
+    (tph_comm_attach): the (max, s1, s2) reweight triples (all-gather, merged on the device), the counters of the
+    global percentile select and the moment / histogram sums of the global proposal fit (all-reduce), the
+    per-iteration block totals of the global cumulative weight (all-gather);
+  * per MCMC step: all-reduce SUM of (accepted, sum alpha_c);
+  * once per iteration: the resample shuffle (all-to-all-v of the selected rows), and with clustering the gathered
+    working set of the mixture fit (all-gather-v).
+With world_size == 1 and no forced communicator every method is a no-op / identity.
 """
 import os
 
@@ -24,6 +26,31 @@ def merge_triples_host(parts):
         s1 = np.sum(parts[:, :, 1] * f, axis=0)
         s2 = np.sum(parts[:, :, 2] * f * f, axis=0)
     return np.stack([M, s1, s2], axis=1)
+
+
+def attach_loopback(ctx, nbytes: int = 64 << 20):
+    """A one-rank communicator without any process group: all-reduce = identity, all-gather = copy.  Routes a single
+    GPU through every sharded code path of the library (tests; the global entry points must then reproduce the plain
+    ones up to summation order)."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    buf = torch.empty(int(nbytes), dtype=torch.uint8, device=ctx.device)
+    sizes = {0: 8, 1: 8, 2: 4}
+
+    def allreduce(_user, off, count, dtype, op):
+        return 0
+
+    def allgather(_user, soff, roff, count, dtype):
+        nb = count * sizes[dtype]
+        buf[roff:roff + nb].copy_(buf[soff:soff + nb])
+        return 0
+
+    ar, ag = _lib.ALLREDUCE_FN(allreduce), _lib.ALLGATHER_FN(allgather)
+    _lib.check(ctx.lib.tph_comm_attach(ctx._ctx, 0, 1, C.c_void_p(buf.data_ptr()), buf.numel(), ar, ag, None),
+               "tph_comm_attach")
+    ctx._comm_keep = (buf, ar, ag)
+    return buf
 
 
 class Comm:
@@ -46,6 +73,77 @@ class Comm:
     def _stage_on_host(self):
         """gloo (the CPU-test backend) cannot move device tensors for every collective: stage through the host."""
         return self._dist is not None and self._dist.get_backend(self.group) == "gloo"
+
+    # ------------------------------------------------------------------ collectives for libtempest_hip
+    def attach(self, ctx, nbytes: int = 64 << 20):
+        """Hand the library its two collectives (tph_comm_attach): they act in place on a device staging block owned
+        here, addressed by byte offset, and are ordered with the current stream (RCCL work is enqueued behind it and the
+        stream waits for it; gloo stages through the host).  Returns the staging tensor."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        if not self.active:
+            return None
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=ctx.device)
+        dts = {0: (torch.float64, 8), 1: (torch.int64, 8), 2: (torch.int32, 4)}
+        ops = {0: self._dist.ReduceOp.SUM, 1: self._dist.ReduceOp.MAX, 2: self._dist.ReduceOp.MIN}
+        stage = self._stage_on_host
+        dist, group, world = self._dist, self.group, self.world_size
+
+        def view(off, count, dtype):
+            dt, sz = dts[dtype]
+            return buf[off:off + count * sz].view(dt)
+
+        def allreduce(_user, off, count, dtype, op):
+            try:
+                t = view(off, count, dtype)
+                if stage:
+                    h = t.cpu()
+                    dist.all_reduce(h, op=ops[op], group=group)
+                    t.copy_(h)
+                else:
+                    dist.all_reduce(t, op=ops[op], group=group)
+                return 0
+            except Exception:            # never let an exception cross the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def allgather(_user, soff, roff, count, dtype):
+            try:
+                send, recv = view(soff, count, dtype), view(roff, count * world, dtype)
+                if stage:
+                    h = send.cpu()
+                    parts = [torch.empty_like(h) for _ in range(world)]
+                    dist.all_gather(parts, h, group=group)
+                    recv.copy_(torch.cat(parts))
+                else:
+                    dist.all_gather_into_tensor(recv, send, group=group)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        ar, ag = _lib.ALLREDUCE_FN(allreduce), _lib.ALLGATHER_FN(allgather)
+        _lib.check(ctx.lib.tph_comm_attach(ctx._ctx, self.rank, world, C.c_void_p(buf.data_ptr()), buf.numel(), ar, ag,
+                                           None), "tph_comm_attach")
+        ctx._comm_keep = (buf, ar, ag)         # the library holds raw pointers to all three
+        return buf
+
+    def all_gather_v(self, t):
+        """Concatenate device tensors that differ in their FIRST dimension over the ranks (rank order); every rank gets
+        the whole.  Returns (tensor, counts)."""
+        import torch
+        if not self.active:
+            return t, [int(t.shape[0])]
+        n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+        counts = [int(c) for c in self.all_gather(n).reshape(-1).cpu().tolist()]
+        m = max(counts)
+        pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        allp = self.all_gather(pad)
+        return torch.cat([allp[r, : counts[r]] for r in range(self.world_size)], dim=0), counts
 
     def all_reduce_sum(self, t):
         """In-place SUM all-reduce of a tensor (device tensor -> RCCL; CPU tensor -> gloo)."""

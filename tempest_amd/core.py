@@ -324,17 +324,14 @@ class SamplerCore:
                 blobs = blobs[sel.cpu().numpy()]
         else:
             # sharded run: every rank returns the posterior over the WHOLE history (rows of all shards, rank order).
-            # Only the weights (8 B per row) are gathered in full -- the trim threshold is a statistic of the global
-            # weight distribution --; every shard then compacts and gathers its own kept rows on the device and only those
-            # rows travel.  The weights are already normalised by the global sum.
-            weights_all = comm.gather_rows(w_dev.cpu().numpy())
+            # The trim threshold is a statistic of the global weight distribution: the library finds it without moving
+            # the weights (tph_trim_threshold_global); every shard then compacts and gathers its own kept rows on the
+            # device and only those rows travel.  The weights are already normalised by the global sum.
             if logw is not None:
                 logw = comm.gather_rows(logw)
             sel, m_sel, wdiv = None, ctx.size, 1.0
             if trim_importance_weights:
-                wg = torch.from_numpy(np.ascontiguousarray(weights_all)).to(ctx.device)
-                thr_dev, out = ctx.trim_threshold(wg, ess_trim, bins_trim, sync=True)
-                del wg
+                thr_dev, out = ctx.trim_threshold(w_dev, ess_trim, bins_trim, sync=True, global_=True)
                 wdiv = float(out[1])
                 m_sel = int((w_dev >= thr_dev[0]).sum().item())      # this shard's share of the kept rows
                 sel = ctx.compact_indices(w_dev, thr_dev[0:1], m_sel) if m_sel else None

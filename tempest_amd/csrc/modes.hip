@@ -92,6 +92,177 @@ extern "C" int tph_trim_threshold(tph_ctx* ctx, const double* w_dev, int64_t n, 
   return 0;
 }
 
+// ---- GLOBAL trimming threshold of a sharded weight vector (tph_comm_attach) -------------------------------------------------
+// The reference's threshold is a percentile of ALL weights (np.percentile, linear interpolation between two neighbouring
+// order statistics) and its pass test needs the sums of w and w^2 above it (tools.py:42-53).  Every rank sorts its own
+// weights; the 2 x bins global order statistics are found EXACTLY by a radix descent over the 64-bit patterns of the
+// (non-negative) doubles, 8 bits per round: per target and digit, each rank counts its weights whose pattern continues the
+// target's prefix with that digit (two binary searches in its sorted array per digit boundary), the counts are all-reduced,
+// and every rank picks the digit holding the target's rank -- 8 all-reduces of [2 bins][256] counters, no weight ever moves.
+// Then the candidates' thresholds are interpolated with NumPy's arithmetic on the exact order statistics (bit-identical to
+// the one-GPU threshold), the local suffix sums above each threshold are all-reduced, and the largest passing candidate wins.
+constexpr int SEL_BITS = 8, SEL_DIGITS = 1 << SEL_BITS, SEL_ROUNDS = 64 / SEL_BITS;
+
+__device__ __forceinline__ int64_t lower_bound_key(const double* __restrict__ S, int64_t n, unsigned long long key) {
+  int64_t lo = 0, hi = n;                  // first k with bits(S[k]) >= key   (S ascending, non-negative)
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((unsigned long long)__double_as_longlong(S[mid]) < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// target ranks: candidate i -> virtual index (n-1) q_i of numpy's 'linear' method: order statistics floor(vi), floor(vi)+1
+__global__ void k_trim_targets(const long long* __restrict__ n_global_dev, int bins, long long* __restrict__ remaining,
+                               unsigned long long* __restrict__ prefix) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bins) return;
+  const long long n = n_global_dev[0];
+  const double step = bins > 1 ? 99.0 / (double)(bins - 1) : 0.0;
+  const double p = (i == bins - 1 && bins > 1) ? 99.0 : __dmul_rn((double)i, step);
+  const double vi = __dmul_rn((double)(n - 1), p / 100.0);
+  long long pi = (long long)floor(vi);
+  if (pi < 0) pi = 0;
+  if (pi > n - 1) pi = n - 1;
+  remaining[2 * i] = pi;
+  remaining[2 * i + 1] = pi + 1 < n ? pi + 1 : n - 1;
+  prefix[2 * i] = 0ull;
+  prefix[2 * i + 1] = 0ull;
+}
+// counts[q][v] = #{local weights whose pattern lies in [prefix_q + v << shift, prefix_q + (v+1) << shift)}
+__global__ void __launch_bounds__(256) k_select_count(const double* __restrict__ S, int64_t n, const unsigned long long* __restrict__ prefix,
+                                                      int round, long long* __restrict__ counts) {
+  const int q = blockIdx.x, v = threadIdx.x;
+  const int shift = 64 - SEL_BITS * (round + 1);
+  const unsigned long long base = prefix[q] + ((unsigned long long)v << shift);
+  const int64_t lo = lower_bound_key(S, n, base);
+  const unsigned long long upper = base + (1ull << shift);
+  const int64_t hi = upper < base ? n : lower_bound_key(S, n, upper);     // wrapped past 2^64: everything from `lo` on
+  counts[(size_t)q * SEL_DIGITS + v] = (long long)(hi - lo);
+}
+__global__ void __launch_bounds__(256) k_select_update(const long long* __restrict__ counts, int round, long long* __restrict__ remaining,
+                                                       unsigned long long* __restrict__ prefix) {
+  const int q = blockIdx.x;
+  __shared__ long long cum[SEL_DIGITS];
+  const long long mine = counts[(size_t)q * SEL_DIGITS + threadIdx.x];
+  cum[threadIdx.x] = mine;
+  __syncthreads();
+  for (int o = 1; o < SEL_DIGITS; o <<= 1) {
+    const long long t = threadIdx.x >= o ? cum[threadIdx.x - o] : 0;
+    __syncthreads();
+    cum[threadIdx.x] += t;
+    __syncthreads();
+  }
+  const long long before = cum[threadIdx.x] - mine, rem = remaining[q];
+  const bool owner = rem >= before && rem < cum[threadIdx.x];
+  const bool overflow = threadIdx.x == SEL_DIGITS - 1 && rem >= cum[SEL_DIGITS - 1];   // cannot happen with consistent counts
+  __syncthreads();
+  if (owner || overflow) {
+    const int shift = 64 - SEL_BITS * (round + 1);
+    prefix[q] += (unsigned long long)threadIdx.x << shift;
+    remaining[q] = overflow ? 0 : rem - before;
+  }
+}
+__device__ __forceinline__ double trim_lerp(const long long* __restrict__ n_global_dev, int bins, int i, const unsigned long long* __restrict__ keys) {
+  const long long n = n_global_dev[0];
+  const double step = bins > 1 ? 99.0 / (double)(bins - 1) : 0.0;
+  const double p = (i == bins - 1 && bins > 1) ? 99.0 : __dmul_rn((double)i, step);
+  const double vi = __dmul_rn((double)(n - 1), p / 100.0);
+  const double a = __longlong_as_double((long long)keys[2 * i]), b = __longlong_as_double((long long)keys[2 * i + 1]);
+  if (vi >= (double)(n - 1)) return b;
+  if (vi < 0.0) return a;
+  const double g = vi - floor(vi), diff = b - a;   // numpy _lerp, as trim_candidate
+  return (g >= 0.5) ? __dadd_rn(b, -__dmul_rn(diff, __dadd_rn(1.0, -g))) : __dadd_rn(a, __dmul_rn(diff, g));
+}
+// part[3 i ..] = local (count, sum w, sum w^2) of the weights >= threshold_i ; part[3 bins ..] = local (sum w, sum w^2)
+__global__ void __launch_bounds__(256) k_trim_partials(const double* __restrict__ S, const double* __restrict__ P1,
+                                                       const double* __restrict__ P2, int64_t n, const long long* __restrict__ n_global_dev,
+                                                       int bins, const unsigned long long* __restrict__ keys, double* __restrict__ part) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double tot1 = P1[n - 1], tot2 = P2[n - 1];
+  if (i == 0) { part[3 * bins] = tot1; part[3 * bins + 1] = tot2; }
+  if (i >= bins) return;
+  const double thr = trim_lerp(n_global_dev, bins, i, keys);
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (S[mid] < thr) lo = mid + 1; else hi = mid; }
+  part[3 * i] = (double)(n - lo);
+  part[3 * i + 1] = tot1 - (lo > 0 ? P1[lo - 1] : 0.0);
+  part[3 * i + 2] = tot2 - (lo > 0 ? P2[lo - 1] : 0.0);
+}
+__global__ void __launch_bounds__(256) k_trim_decide(const double* __restrict__ part, const long long* __restrict__ n_global_dev, double ess,
+                                                     int bins, const unsigned long long* __restrict__ keys, double* __restrict__ out) {
+  __shared__ int best;
+  if (threadIdx.x == 0) best = 0;
+  __syncthreads();
+  const double tot1 = part[3 * bins], tot2 = part[3 * bins + 1];
+  const double ess_total = (tot1 * tot1) / tot2;
+  for (int i = threadIdx.x; i < bins; i += blockDim.x) {
+    const double k1 = part[3 * i + 1], k2 = part[3 * i + 2];
+    if (((k1 * k1) / k2) / ess_total >= ess) atomicMax(&best, i);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = trim_lerp(n_global_dev, bins, best, keys);
+    out[1] = part[3 * best + 1];
+    out[2] = part[3 * best];
+    out[3] = ess_total;
+  }
+}
+__global__ void k_set_i64(long long* p, long long v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
+
+extern "C" int tph_trim_threshold_global(tph_ctx* ctx, const double* w_dev, int64_t n, double ess, int bins, double* out_dev,
+                                         double* out_host) {
+  TPH_REQUIRE(ctx && w_dev && out_dev && n > 0 && bins >= 1, "tph_trim_threshold_global: bad argument");
+  if (!ctx->comm_active()) return tph_trim_threshold(ctx, w_dev, n, ess, bins, out_dev, out_host);
+  const int Q = 2 * bins;
+  // staging: [0] n_global (i64, padded to 256 B) | counts [Q][256] i64  (later re-used for the [3 bins + 2] partial sums)
+  const size_t o_cnt = 256, counts_bytes = sizeof(long long) * (size_t)Q * SEL_DIGITS;
+  if (tph_comm_require(ctx, o_cnt + counts_bytes, "tph_trim_threshold_global")) return -2;
+  size_t temp_bytes = 0;
+  double* nullk = nullptr;
+  TPH_HIP(rocprim::radix_sort_keys(nullptr, temp_bytes, w_dev, nullk, (size_t)n, 0, 64, ctx->stream));
+  int64_t ntiles = tph_scan::num_tiles(n);
+  size_t a_tiles = ((size_t)ntiles * sizeof(double) + 255) / 256 * 256;
+  size_t a_n = ((size_t)n * sizeof(double) + 255) / 256 * 256;
+  size_t a_tmp = (temp_bytes + 255) / 256 * 256;
+  size_t a_q = ((size_t)Q * sizeof(long long) + 255) / 256 * 256;
+  if (tph_scratch_reserve(ctx, a_tiles + 3 * a_n + a_tmp + 2 * a_q)) return -1;
+  char* base = (char*)ctx->scratch;
+  double* tiles = (double*)base;
+  double* S = (double*)(base + a_tiles);
+  double* P1 = (double*)(base + a_tiles + a_n);
+  double* P2 = (double*)(base + a_tiles + 2 * a_n);
+  void* tmp = base + a_tiles + 3 * a_n;
+  long long* remaining = (long long*)(base + a_tiles + 3 * a_n + a_tmp);
+  unsigned long long* prefix = (unsigned long long*)(base + a_tiles + 3 * a_n + a_tmp + a_q);
+  TPH_HIP(rocprim::radix_sort_keys(tmp, temp_bytes, w_dev, S, (size_t)n, 0, 64, ctx->stream));
+  if (tph_scan::inclusive<tph_scan::PLAIN>(ctx, S, n, nullptr, tiles, P1)) return -1;
+  if (tph_scan::inclusive<tph_scan::SQUARE>(ctx, S, n, nullptr, tiles, P2)) return -1;
+  long long* n_global = (long long*)ctx->comm_buf;
+  long long* counts = (long long*)(ctx->comm_buf + o_cnt);
+  hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, ctx->stream, n_global, (long long)n);
+  TPH_LAUNCH_CHECK();
+  if (tph_comm_allreduce(ctx, 0, 1, TPH_DT_I64, TPH_OP_SUM)) return -2;
+  hipLaunchKernelGGL(k_trim_targets, dim3((bins + 255) / 256), dim3(256), 0, ctx->stream, n_global, bins, remaining, prefix);
+  for (int round = 0; round < SEL_ROUNDS; ++round) {
+    hipLaunchKernelGGL(k_select_count, dim3(Q), dim3(SEL_DIGITS), 0, ctx->stream, S, n, prefix, round, counts);
+    TPH_LAUNCH_CHECK();
+    if (tph_comm_allreduce(ctx, o_cnt, (int64_t)Q * SEL_DIGITS, TPH_DT_I64, TPH_OP_SUM)) return -2;
+    hipLaunchKernelGGL(k_select_update, dim3(Q), dim3(SEL_DIGITS), 0, ctx->stream, counts, round, remaining, prefix);
+  }
+  double* part = (double*)(ctx->comm_buf + o_cnt);
+  hipLaunchKernelGGL(k_trim_partials, dim3((bins + 255) / 256), dim3(256), 0, ctx->stream, S, P1, P2, n, n_global, bins, prefix, part);
+  TPH_LAUNCH_CHECK();
+  if (tph_comm_allreduce(ctx, o_cnt, 3 * (int64_t)bins + 2, TPH_DT_F64, TPH_OP_SUM)) return -2;
+  hipLaunchKernelGGL(k_trim_decide, dim3(1), dim3(256), 0, ctx->stream, part, n_global, ess, bins, prefix, out_dev);
+  TPH_LAUNCH_CHECK();
+  if (out_host) {
+    TPH_HIP(hipMemcpyAsync(ctx->pinned, out_dev, sizeof(double) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; ++i) out_host[i] = ctx->pinned[i];
+  }
+  return 0;
+}
+
 // -------------------------------------------------------------------------- weighted first moments
 // sums[0] = sum wt ; sums[1+j] = sum wt * u_j ; range[2j], range[2j+1] = min, max of u_j over rows with wt > 0
 // (wt = counts or real weights, optional label filter)
@@ -850,6 +1021,204 @@ extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int3
     hipLaunchKernelGGL(k_med_collect, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n, range, sel, vals, cnts, fill);
     hipLaunchKernelGGL(k_med_finish, dim3(d), dim3(256), 0, ctx->stream, sel, range, vals, cnts, fill, means_dev + (size_t)k * d, overflow);
     TPH_LAUNCH_CHECK();
+  }
+  return tph_chol_inv(ctx, covs_dev, K, chol_dev, inv_dev, cholinv_dev);
+}
+
+// ---- proposal fit over a SHARDED history (tph_comm_attach): the fit of the global up-sampled set ---------------------------
+// The reference fits ONE Gaussian per mode to the whole weighted history (train.py:91-122, modes.py:131-288).  Every
+// statistic of that fit is a sum or an order statistic over rows, so each rank runs the same kernels on its shard and the
+// small intermediate results are combined: (count, sum) and (min, max) per coordinate, the centred second moments about
+// the GLOBAL mean, the two histogram levels of the median select, and the (value, multiplicity) candidates of the final
+// median bins (gathered from all ranks; they are as few as on one GPU).  mean/covariance equal the one-GPU values to
+// rounding, the medians exactly.
+__global__ void k_pack_range(const double* __restrict__ range, int d, double* __restrict__ out) {   // (-min, max): one MAX all-reduce
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < d) { out[2 * j] = -range[2 * j]; out[2 * j + 1] = range[2 * j + 1]; }
+}
+__global__ void k_unpack_range(const double* __restrict__ in, int d, double* __restrict__ range) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < d) { range[2 * j] = -in[2 * j]; range[2 * j + 1] = in[2 * j + 1]; }
+}
+// candidates of all ranks -> exact order statistic; lists [G][d*2][cap] with fill[G][d*2]
+__global__ void __launch_bounds__(256) k_med_finish_g(const long long* __restrict__ sel, const double* __restrict__ range,
+                                                      const double* __restrict__ vals, const int* __restrict__ cnts,
+                                                      const int* __restrict__ fill, int G, int d, int cap,
+                                                      double* __restrict__ median, int* __restrict__ overflow) {
+  const int j = blockIdx.x;
+  const double lo = range[2 * j], width = range[2 * j + 1] - range[2 * j];
+  __shared__ double res[2];
+  __shared__ double sv[MED_CAP];
+  __shared__ int sc[MED_CAP];
+  __shared__ int s_m;
+  for (int t = 0; t < 2; ++t) {
+    const long long* s = sel + ((size_t)j * 2 + t) * 4;
+    const long long rank = s[2];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      res[t] = lo + width * (((double)s[0] + (double)s[1] / 4096.0) / 4096.0);  // bin edge if overflow
+      int m = 0;
+      for (int g = 0; g < G; ++g) m += fill[(size_t)g * d * 2 + j * 2 + t];
+      if (m > MED_CAP) { atomicAdd(overflow, 1); m = 0; }
+      s_m = m;
+    }
+    __syncthreads();
+    const int m = s_m;
+    if (m > 0) {
+      int base = 0;
+      for (int g = 0; g < G; ++g) {
+        const int f = fill[(size_t)g * d * 2 + j * 2 + t];
+        for (int e = threadIdx.x; e < f; e += blockDim.x) {
+          sv[base + e] = vals[((size_t)g * d * 2 + j * 2 + t) * cap + e];
+          sc[base + e] = cnts[((size_t)g * d * 2 + j * 2 + t) * cap + e];
+        }
+        base += f;
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < m; e += blockDim.x) {
+      const double v = sv[e];
+      long long below = 0, eq = 0;
+      for (int f = 0; f < m; ++f) {
+        const double o = sv[f];
+        below += o < v ? sc[f] : 0;
+        eq += o == v ? sc[f] : 0;
+      }
+      if (below <= rank && rank < below + eq) res[t] = v;  // all writers hold the same value
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) median[j] = (res[0] + res[1]) / 2.0;
+}
+// pack the first `cap` candidates of every (dimension, target) list contiguously: [d*2][cap]
+__global__ void k_med_pack(const double* __restrict__ vals, const int* __restrict__ cnts, int d, int cap, double* __restrict__ pv,
+                           int* __restrict__ pc) {
+  const int jt = blockIdx.x;
+  for (int e = threadIdx.x; e < cap; e += blockDim.x) {
+    pv[(size_t)jt * cap + e] = vals[(size_t)jt * MED_CAP + e];
+    pc[(size_t)jt * cap + e] = cnts[(size_t)jt * MED_CAP + e];
+  }
+}
+
+extern "C" int tph_fit_modes_global(tph_ctx* ctx, const int32_t* counts_dev, const int32_t* labels_dev, int64_t n, int K,
+                                    double* means_dev, double* covs_dev, double* chol_dev, double* inv_dev, double* cholinv_dev) {
+  TPH_REQUIRE(ctx && counts_dev && means_dev && covs_dev && chol_dev && inv_dev, "tph_fit_modes_global: NULL argument");
+  if (!ctx->comm_active()) return tph_fit_modes(ctx, counts_dev, labels_dev, n, K, means_dev, covs_dev, chol_dev, inv_dev, cholinv_dev);
+  TPH_REQUIRE(n > 0 && n <= ctx->size && K >= 1, "tph_fit_modes_global: bad sizes");
+  TPH_REQUIRE(K == 1 || labels_dev, "tph_fit_modes_global: K>1 needs labels");
+  const int d = ctx->d, G = ctx->world;
+  const double* src = ctx->u;
+  const int64_t src_ld = ctx->cap;
+  const int nblk = cov_blocks(n);
+  const int rblk = tph_grid_for(n, 256, 4, 512);
+  const int npl = d * (d + 1) / 2;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
+  size_t o_part = take(sizeof(double) * cov_scratch_doubles(d, nblk));
+  size_t o_part1 = take(sizeof(double) * (size_t)rblk * (1 + d) * 3);
+  size_t o_range = take(sizeof(double) * 2 * d);
+  size_t o_mean = take(sizeof(double) * d);
+  size_t o_sel = take(sizeof(long long) * (size_t)d * 2 * 4);
+  size_t o_vals = take(sizeof(double) * (size_t)d * 2 * MED_CAP);
+  size_t o_cnts = take(sizeof(int) * (size_t)d * 2 * MED_CAP);
+  size_t o_ovf = take(sizeof(int));
+  if (tph_scratch_reserve(ctx, o)) return -1;
+  char* base = (char*)ctx->scratch;
+  double* part = (double*)(base + o_part);
+  double* part1 = (double*)(base + o_part1);
+  double* range = (double*)(base + o_range);
+  double* mean = (double*)(base + o_mean);
+  long long* sel = (long long*)(base + o_sel);
+  double* vals = (double*)(base + o_vals);
+  int* cnts = (int*)(base + o_cnts);
+  int* overflow = (int*)(base + o_ovf);
+  // staging layout (fixed offsets, the largest user is the second histogram level / the gathered candidates)
+  const size_t c_sums = 0;                                                   // (1+d) f64
+  const size_t c_rng = ((sizeof(double) * (1 + d)) + 255) / 256 * 256;       // 2d f64
+  const size_t c_big = c_rng + ((sizeof(double) * 2 * d) + 255) / 256 * 256;  // histograms / covariance sums / candidate lists
+  const size_t big_need = sizeof(unsigned int) * (size_t)d * 2 * MED_BINS + sizeof(int) * (size_t)d * 2 * (G + 1) + 4096;
+  if (tph_comm_require(ctx, c_big + big_need, "tph_fit_modes_global")) return -2;
+  double* sums = (double*)(ctx->comm_buf + c_sums);
+  double* rng = (double*)(ctx->comm_buf + c_rng);
+  TPH_HIP(hipMemsetAsync(overflow, 0, sizeof(int), ctx->stream));
+  for (int k = 0; k < K; ++k) {
+    const int32_t* lab = K > 1 ? labels_dev : nullptr;
+    // first moments, data range
+    hipLaunchKernelGGL(k_wsum<int32_t>, dim3(rblk, 1 + d), dim3(256), 0, ctx->stream, src, src_ld, d, counts_dev, lab, k, n, part1);
+    hipLaunchKernelGGL(k_wsum_final, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums, range);
+    hipLaunchKernelGGL(k_pack_range, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, range, d, rng);
+    TPH_LAUNCH_CHECK();
+    if (tph_comm_allreduce(ctx, c_sums, 1 + d, TPH_DT_F64, TPH_OP_SUM)) return -2;
+    if (tph_comm_allreduce(ctx, c_rng, 2 * d, TPH_DT_F64, TPH_OP_MAX)) return -2;
+    hipLaunchKernelGGL(k_unpack_range, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, rng, d, range);
+    hipLaunchKernelGGL(k_mean_from_sums, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, sums, d, mean);
+    // centred second moments about the global mean: local lower triangle -> all-reduce -> student.py:62-63
+    {
+      double* csum = (double*)(ctx->comm_buf + c_big);
+      const int S = cov_slices(npl);
+      TPH_REQUIRE(npl <= COV_NPT * 256, "covariance kernel supports n_dim <= 100 (got %d)", d);
+      if (d <= 12) {
+        bool ok = launch_wcov_small<int32_t>(ctx, src, src_ld, counts_dev, lab, k, n, mean, part, nblk);
+        TPH_REQUIRE(ok, "covariance: no register kernel for n_dim=%d", d);
+        hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk, npl, csum);
+      } else {
+        size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS);
+        if (lds > 64 * 1024)
+          TPH_HIP(hipFuncSetAttribute((const void*)k_wcov<int32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_wcov<int32_t>, dim3(nblk), dim3(256), lds, ctx->stream, src, src_ld, d, counts_dev, lab, k, n, mean, part);
+        hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk * S, npl, csum);
+      }
+      TPH_LAUNCH_CHECK();
+      if (tph_comm_allreduce(ctx, c_big, npl, TPH_DT_F64, TPH_OP_SUM)) return -2;
+      hipLaunchKernelGGL(k_cov_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum, sums, d, 1, covs_dev + (size_t)k * d * d);
+      TPH_LAUNCH_CHECK();
+    }
+    // per-dimension median: two all-reduced histogram levels, then the gathered candidates of the final bins
+    {
+      unsigned int* h = (unsigned int*)(ctx->comm_buf + c_big);
+      dim3 hg(tph_grid_for(n, 256, 8, 256), d);
+      TPH_HIP(hipMemsetAsync(h, 0, sizeof(unsigned int) * (size_t)d * MED_BINS, ctx->stream));
+      hipLaunchKernelGGL(k_med_hist1, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n, range, h);
+      TPH_LAUNCH_CHECK();
+      if (tph_comm_allreduce(ctx, c_big, (int64_t)d * MED_BINS, TPH_DT_I32, TPH_OP_SUM)) return -2;
+      hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(256), 0, ctx->stream, h, 1, sums, sel);
+      TPH_HIP(hipMemsetAsync(h, 0, sizeof(unsigned int) * (size_t)d * 2 * MED_BINS, ctx->stream));
+      hipLaunchKernelGGL(k_med_hist2, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n, range, sel, h);
+      TPH_LAUNCH_CHECK();
+      if (tph_comm_allreduce(ctx, c_big, (int64_t)d * 2 * MED_BINS, TPH_DT_I32, TPH_OP_SUM)) return -2;
+      hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(256), 0, ctx->stream, h, 2, sums, sel);
+      // candidates: fill counts first (their maximum sizes the gather), then the packed lists
+      int* fill_mine = (int*)(ctx->comm_buf + c_big);                 // [d*2]
+      int* fill_all = fill_mine + (size_t)d * 2;                      // [G][d*2]
+      TPH_HIP(hipMemsetAsync(fill_mine, 0, sizeof(int) * (size_t)d * 2, ctx->stream));
+      hipLaunchKernelGGL(k_med_collect, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n, range, sel, vals, cnts, fill_mine);
+      TPH_LAUNCH_CHECK();
+      if (tph_comm_allgather(ctx, c_big, c_big + sizeof(int) * (size_t)d * 2, (int64_t)d * 2, TPH_DT_I32)) return -2;
+      std::vector<int> fh((size_t)G * d * 2);
+      TPH_HIP(hipMemcpyAsync(fh.data(), fill_all, sizeof(int) * fh.size(), hipMemcpyDeviceToHost, ctx->stream));
+      TPH_HIP(hipStreamSynchronize(ctx->stream));
+      int cap = 1;
+      for (int v : fh) cap = v > cap ? v : cap;
+      if (cap > MED_CAP) cap = MED_CAP;
+      cap = (cap + 7) / 8 * 8;
+      // lists: values [d*2][cap] f64 then counts [d*2][cap] i32, gathered separately behind the fill table
+      const size_t c_fill = c_big + sizeof(int) * (size_t)d * 2;                                   // fill_all stays here
+      const size_t c_pv = (c_fill + sizeof(int) * (size_t)G * d * 2 + 255) / 256 * 256;            // my values
+      const size_t pv_bytes = sizeof(double) * (size_t)d * 2 * cap, pc_bytes = sizeof(int) * (size_t)d * 2 * cap;
+      const size_t c_av = c_pv + (pv_bytes + 255) / 256 * 256;                                     // all values [G][d*2][cap]
+      const size_t c_pc = c_av + ((size_t)G * pv_bytes + 255) / 256 * 256;                         // my counts
+      const size_t c_ac = c_pc + (pc_bytes + 255) / 256 * 256;                                     // all counts
+      if (tph_comm_require(ctx, c_ac + (size_t)G * pc_bytes, "tph_fit_modes_global (median candidates)")) return -2;
+      hipLaunchKernelGGL(k_med_pack, dim3(d * 2), dim3(256), 0, ctx->stream, vals, cnts, d, cap, (double*)(ctx->comm_buf + c_pv),
+                         (int*)(ctx->comm_buf + c_pc));
+      TPH_LAUNCH_CHECK();
+      if (tph_comm_allgather(ctx, c_pv, c_av, (int64_t)d * 2 * cap, TPH_DT_F64)) return -2;
+      if (tph_comm_allgather(ctx, c_pc, c_ac, (int64_t)d * 2 * cap, TPH_DT_I32)) return -2;
+      hipLaunchKernelGGL(k_med_finish_g, dim3(d), dim3(256), 0, ctx->stream, sel, range, (const double*)(ctx->comm_buf + c_av),
+                         (const int*)(ctx->comm_buf + c_ac), (const int*)(ctx->comm_buf + c_fill), G, d, cap,
+                         means_dev + (size_t)k * d, overflow);
+      TPH_LAUNCH_CHECK();
+    }
   }
   return tph_chol_inv(ctx, covs_dev, K, chol_dev, inv_dev, cholinv_dev);
 }

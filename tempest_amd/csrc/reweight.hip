@@ -237,6 +237,18 @@ static void launch_reduce_nb(tph_ctx* ctx, int grid, const tph_betas& bt, int nb
   }
 }
 
+// with a communicator: this rank's triples -> all-gather -> the same fixed-order merge over the G rank triples
+// (a rank whose shard holds no finite row contributes (-inf, 0, 0), which the merge ignores)
+static int gather_rank_triples(tph_ctx* ctx, int grid, int nb, const double** gathered) {
+  const size_t mine = 0, all = 1024;                      // nb <= 16: 384 B per rank
+  if (tph_comm_require(ctx, all + sizeof(double) * 3 * (size_t)nb * ctx->world, "tph_reweight (sharded)")) return -2;
+  hipLaunchKernelGGL(k_reweight_finalize, dim3(nb), dim3(256), 0, ctx->stream, ctx->partials, grid, nb, (double*)(ctx->comm_buf + mine));
+  TPH_LAUNCH_CHECK();
+  if (tph_comm_allgather(ctx, mine, all, 3 * (int64_t)nb, TPH_DT_F64)) return -2;
+  *gathered = (const double*)(ctx->comm_buf + all);
+  return 0;
+}
+
 extern "C" int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int nb, double* out_dev) {
   TPH_REQUIRE(ctx && betas_host && out_dev, "tph_reweight_partials: NULL argument");
   TPH_REQUIRE(nb >= 1 && nb <= TPH_MAX_NB, "tph_reweight_partials: nb=%d outside [1,%d]", nb, TPH_MAX_NB);
@@ -247,7 +259,13 @@ extern "C" int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int
   TPH_REQUIRE((size_t)grid * nb * 3 * sizeof(double) <= ctx->partials_bytes, "tph_reweight_partials: scratch too small");
   launch_reduce_nb(ctx, grid, bt, nb);
   TPH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_reweight_finalize, dim3(nb), dim3(256), 0, ctx->stream, ctx->partials, grid, nb, out_dev);
+  const double* parts = ctx->partials;
+  int nparts = grid;
+  if (ctx->comm_active()) {
+    if (gather_rank_triples(ctx, grid, nb, &parts)) return -2;
+    nparts = ctx->world;
+  }
+  hipLaunchKernelGGL(k_reweight_finalize, dim3(nb), dim3(256), 0, ctx->stream, parts, nparts, nb, out_dev);
   TPH_LAUNCH_CHECK();
   return 0;
 }
@@ -262,10 +280,16 @@ extern "C" int tph_reweight_eval(tph_ctx* ctx, const double* betas_host, int nb,
   TPH_REQUIRE((size_t)grid * nb * 3 * sizeof(double) <= ctx->partials_bytes, "tph_reweight_eval: scratch too small");
   launch_reduce_nb(ctx, grid, bt, nb);
   TPH_LAUNCH_CHECK();
+  const double* parts = ctx->partials;
+  int nparts = grid;
+  if (ctx->comm_active()) {           // global triples: merge the ranks' results on the device, deliver through the same mailbox
+    if (gather_rank_triples(ctx, grid, nb, &parts)) return -2;
+    nparts = ctx->world;
+  }
   // results + sequence word in the ctx's pinned block: [0, 48) triples, [4095] sequence
   volatile double* seqp = ctx->pinned + 4095;
   const double seq = (double)(++ctx->eval_seq);
-  hipLaunchKernelGGL(k_reweight_finalize_host, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials, grid, nb, ctx->pinned,
+  hipLaunchKernelGGL(k_reweight_finalize_host, dim3(1), dim3(1024), 0, ctx->stream, parts, nparts, nb, ctx->pinned,
                      ctx->pinned + 4095, seq);
   TPH_LAUNCH_CHECK();
   uint64_t spins = 0;

@@ -190,13 +190,40 @@ class HipContext:
         return out
 
     # ------------------------------------------------------------------------------- trimming
-    def trim_threshold(self, w, ess=0.99, bins=1000, sync=False):
-        """Device tensor (threshold, kept_sum, kept_count, ess_total) [+ host copy if sync]."""
+    def trim_threshold(self, w, ess=0.99, bins=1000, sync=False, global_=False):
+        """Device tensor (threshold, kept_sum, kept_count, ess_total) [+ host copy if sync].  global_: the threshold of
+        the GLOBAL weight vector of a sharded history (the plain function without a communicator)."""
         out = self.empty(4)
         host = np.empty(4) if sync else None
-        check(self.lib.tph_trim_threshold(self._ctx, _ptr(w, torch.float64), w.numel(), float(ess), int(bins),
-                                          _ptr(out), _hptr(host) if sync else None), "tph_trim_threshold")
+        fn = self.lib.tph_trim_threshold_global if global_ else self.lib.tph_trim_threshold
+        check(fn(self._ctx, _ptr(w, torch.float64), w.numel(), float(ess), int(bins), _ptr(out),
+                 _hptr(host) if sync else None), "tph_trim_threshold")
         return (out, host) if sync else out
+
+    # ------------------------------------------------- global order over a sharded history (tph_comm_attach)
+    def cdf_global(self, w, thr=None, out=None, total=False):
+        """This rank's slice of the global cumulative weight (the plain cdf without a communicator) [, global total]."""
+        if out is None:
+            out = self.empty_rows(w.numel())
+        tot = C.c_double(0.0)
+        check(self.lib.tph_cdf_global(self._ctx, _ptr(w, torch.float64), w.numel(), _ptr(thr), _ptr(out),
+                                      C.byref(tot) if total else None), "tph_cdf_global")
+        return (out, tot.value) if total else out
+
+    def resample_select_global(self, cdf, n_slots, scheme, seed, tick, u0=0.0, pscale=1.0, tag=TAG_RESAMPLE):
+        idx = self.empty(n_slots, dtype=torch.int64)
+        check(self.lib.tph_resample_select_global(self._ctx, _ptr(cdf), cdf.numel(), n_slots, int(scheme), seed, tick, tag,
+                                                  float(u0), float(pscale), _ptr(idx)), "tph_resample_select_global")
+        return idx
+
+    def multinomial_counts_global(self, cdf, seed, tick, kept_count=None, factor=4, n_draw_max=None, tag=TAG_UPSAMPLE):
+        n = cdf.numel()
+        counts = self.empty_rows(n, dtype=torch.int32)
+        if n_draw_max is None:
+            n_draw_max = factor * n
+        check(self.lib.tph_multinomial_counts_global(self._ctx, _ptr(cdf), n, _ptr(kept_count), factor, n_draw_max, seed,
+                                                     tick, tag, _ptr(counts)), "tph_multinomial_counts_global")
+        return counts
 
     # ----------------------------------------------------------------------------- resampling
     def cdf(self, w, thr=None, out=None):
@@ -310,13 +337,15 @@ class HipContext:
         return out
 
     # --------------------------------------------------------------------------- proposal fit
-    def fit_modes(self, counts, labels=None, K=1, n=None):
-        """-> (means, covs, chol, inv, winv): winv = L^-1 per mode (the form the proposal kernels consume)."""
+    def fit_modes(self, counts, labels=None, K=1, n=None, global_=False):
+        """-> (means, covs, chol, inv, winv): winv = L^-1 per mode (the form the proposal kernels consume).
+        global_: the fit of the GLOBAL up-sampled set of a sharded history (the plain fit without a communicator)."""
         d = self.n_dim
         n = self.size if n is None else n
         means, covs = self.empty(K, d), self.empty(K, d, d)
         chol, inv, winv = self.empty(K, d, d), self.empty(K, d, d), self.empty(K, d, d)
-        check(self.lib.tph_fit_modes(self._ctx, _ptr(counts, torch.int32),
+        fn = self.lib.tph_fit_modes_global if global_ else self.lib.tph_fit_modes
+        check(fn(self._ctx, _ptr(counts, torch.int32),
                                      _ptr(labels, torch.int32) if labels is not None else None, n, K, _ptr(means),
                                      _ptr(covs), _ptr(chol), _ptr(inv), _ptr(winv)), "tph_fit_modes")
         return means, covs, chol, inv, winv

@@ -75,26 +75,39 @@ class ModeStatistics:
 
     # ------------------------------------------------------------------------------- fitting
     @classmethod
-    def _fit(cls, ctx, w_dev, n, labels_dev, K, seed, tick, dof_fallback, resample_factor, kept_count=None):
+    def _fit(cls, ctx, w_dev, n, labels_dev, K, seed, tick, dof_fallback, resample_factor, kept_count=None, comm=None):
         """Shared device path: multinomial x`resample_factor` up-sampling as multiplicities
-        (modes.py:196-201 / 269-274), then median + covariance + chol/inv (student.py effective form)."""
+        (modes.py:196-201 / 269-274), then median + covariance + chol/inv (student.py effective form).
+        With a communicator (`comm` active: w_dev, labels_dev cover this rank's shard of the history) the label sizes,
+        the draws and the fit are global."""
         import torch
+        sharded = comm is not None and comm.active
         if K == 1:
-            cdf = ctx.cdf(w_dev)
-            counts = ctx.multinomial_counts(cdf, seed, tick, kept_count=kept_count, factor=resample_factor,
-                                            n_draw_max=resample_factor * n)
+            cdf = ctx.cdf_global(w_dev) if sharded else ctx.cdf(w_dev)
+            draw = ctx.multinomial_counts_global if sharded else ctx.multinomial_counts
+            counts = draw(cdf, seed, tick, kept_count=kept_count, factor=resample_factor,
+                          n_draw_max=resample_factor * (n if not sharded else n * comm.world_size))
         else:
             # per label: weights renormalised inside the label, factor * n_label draws (modes.py:185-201)
             counts = torch.zeros(n, dtype=torch.int32, device=ctx.device)
+            sizes = torch.stack([((labels_dev == k) & (w_dev > 0)).sum() for k in range(K)]).to(torch.float64)
+            if sharded:
+                comm.all_reduce_sum(sizes)              # rows of each label that survived trimming, over all shards
+            sizes = [int(v) for v in sizes.cpu().tolist()]
             for k in range(K):
-                wk = torch.where(labels_dev == k, w_dev, torch.zeros_like(w_dev))      # masking: data movement only
-                nk = int(((labels_dev == k) & (w_dev > 0)).sum().item())      # rows of the label that survived trimming
+                nk = sizes[k]
                 if nk == 0:
                     continue
-                cdf = ctx.cdf(wk)
-                counts += ctx.multinomial_counts(cdf, seed, tick + k, kept_count=None, factor=resample_factor,
-                                                 n_draw_max=resample_factor * nk)
-        means, covs, chol, inv, winv = ctx.fit_modes(counts, labels_dev, K, n)
+                wk = torch.where(labels_dev == k, w_dev, torch.zeros_like(w_dev))      # masking: data movement only
+                if sharded:
+                    cdf = ctx.cdf_global(wk)
+                    counts += ctx.multinomial_counts_global(cdf, seed, tick + k, kept_count=None, factor=resample_factor,
+                                                            n_draw_max=resample_factor * nk)
+                else:
+                    cdf = ctx.cdf(wk)
+                    counts += ctx.multinomial_counts(cdf, seed, tick + k, kept_count=None, factor=resample_factor,
+                                                     n_draw_max=resample_factor * nk)
+        means, covs, chol, inv, winv = ctx.fit_modes(counts, labels_dev, K, n, global_=sharded)
         dof = torch.full((K,), float(dof_fallback), dtype=torch.float64, device=ctx.device)   # nu = inf -> fallback (F5)
         return cls(None, None, None, _dev=(ctx, means, covs, chol, inv, dof, winv))
 

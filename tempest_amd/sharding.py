@@ -1,36 +1,41 @@
 """Particle sharding across GPUs (one process per GPU).
 
 Each rank owns n_particles/G slots of every iteration's active set and appends them to its LOCAL history
-shard; the history never moves.  Cross-GPU traffic:
-  * reweight: all-gather of the (max, s1, s2) partials (comm.merge_triples), 24 B per rank per trial beta;
+shard; the history never moves.  The GLOBAL history order is the reference's (iteration-major, then slot), so a
+sharded run is the same sampler as the one-GPU run: the same counter-based draws are mapped through the same
+cumulative weights to the same history rows, and the proposal is fitted on the whole weighted history (global
+trim threshold, global up-sampling, all-reduced moments and medians: csrc/modes.hip, csrc/resample.hip).
+Cross-GPU traffic:
+  * reweight: all-gather of the (max, s1, s2) triples per pass (merged on the device);
+  * train: the small reductions of the global fit (see comm.py);
   * mutation: all-reduce of (accepted, sum alpha_c) per MCMC step;
-  * resample: the selected rows travel once per iteration by all-to-all-v (this module);
-  * proposal fit: none -- every rank fits the proposal on its own shard.  A shard is an exchangeable 1/G
-    subsample of the weighted history (slots are filled by i.i.d. / stratified draws from the global
-    weights), so the per-shard median/covariance estimate the same quantities; the Metropolis correction
-    uses the proposing rank's own statistics, which keeps every rank's kernel exactly invariant.
+  * resample: the selected rows travel once per iteration by all-to-all-v (this module).
 """
 import numpy as np
 
 
 def resample_sharded(state, w, scheme, rng, n_local):
     """Global multinomial / systematic resampling of n_local * G slots from the sharded weighted history.
-    Slot i is owned by rank i // n_local.  Every rank evaluates all global draws (counter-based RNG), keeps the
-    ones that fall in its own span of the global cumulative weight, gathers those rows and ships them to the
-    slot owners with one all-to-all-v.  Returns this rank's (u, x, logl) as (d, n_local) / (n_local,) tensors."""
+    Slot i is owned by rank i // n_local.  Every rank evaluates the position of every global draw (counter-based RNG:
+    the same numbers everywhere) and looks up only those that land in its own blocks of the global cumulative weight;
+    it gathers those rows and ships them to the slot owners with one all-to-all-v.  Returns this rank's (u, x, logl)
+    as (d, n_local) / (n_local,) tensors."""
     import torch
     from .device import TAG_RESAMPLE, TAG_SYST
     from ._philox_host import uniform_scalar
+    from .tools import SQRTEPS
     ctx, comm = state.ctx, state.comm
     G, me, d = comm.world_size, comm.rank, state.n_dim
     n_slots = n_local * G
-    cdf = ctx.cdf(w)
-    tot = comm.all_gather(cdf[-1:].clone()).cpu().numpy().reshape(-1)       # per-rank weight totals, rank order
-    bounds = np.concatenate([[0.0], np.cumsum(tot)])                          # identical on every rank
     tick = rng.next()
-    u0 = uniform_scalar(rng.seed, tick, TAG_SYST) if scheme != "mult" else 0.0
-    idx = ctx.resample_select(cdf, n_slots, 0 if scheme == "mult" else 1, rng.seed, tick, u0, bounds[me],
-                              bounds[me + 1], bounds[-1], (1 if me == G - 1 else 0) | (2 if me == 0 else 0), TAG_RESAMPLE)
+    if scheme == "mult":
+        cdf = ctx.cdf_global(w)
+        idx = ctx.resample_select_global(cdf, n_slots, 0, rng.seed, tick, tag=TAG_RESAMPLE)
+    else:
+        cdf, tot = ctx.cdf_global(w, total=True)
+        u0 = uniform_scalar(rng.seed, tick, TAG_SYST)
+        idx = ctx.resample_select_global(cdf, n_slots, 1, rng.seed, tick, u0=u0,
+                                         pscale=tot if abs(tot - 1.0) > SQRTEPS else 1.0, tag=TAG_RESAMPLE)
     slots = torch.nonzero(idx >= 0).reshape(-1)                # my outgoing slots, ascending = grouped by owner
     rows = idx[slots].contiguous()
     n_send = int(rows.numel())
@@ -43,26 +48,23 @@ def resample_sharded(state, w, scheme, rng, n_local):
     if int(recv_counts.sum()) != n_local:
         raise RuntimeError(f"resample shuffle: rank {me} would receive {int(recv_counts.sum())} rows, expected {n_local}")
     recv = comm.all_to_all_rows(send, send_counts.tolist(), recv_counts.tolist())
-    soa = recv.T.contiguous()                                   # (2d+1, n_local)
+    # a slot's row comes from exactly one rank; inside the block received from rank r the rows are in slot order, but the
+    # blocks of different senders interleave: put every row at its slot (the senders' slot lists travel with the rows)
+    slot_send = (slots % n_local).to(torch.float64).reshape(-1, 1)
+    slot_recv = comm.all_to_all_rows(slot_send.contiguous(), send_counts.tolist(), recv_counts.tolist()).reshape(-1).long()
+    soa = torch.empty(2 * d + 1, n_local, dtype=torch.float64, device=ctx.device)
+    soa[:, slot_recv] = recv.T
     return soa[:d], soa[d:2 * d], soa[2 * d]
 
 
-def fit_modes_sharded(state, w, trim_ess, trim_bins, dof_fallback, rng):
-    """Per-shard proposal fit (see module docstring): the single-GPU path on the local shard, with the
-    local weights renormalised to sum to one and a rank-specific RNG tick."""
+def gather_rows_in_order(comm, pos, cols):
+    """Rows scattered over the ranks, each with its global position `pos` (int64, a permutation of 0..M-1 over all
+    ranks) -> the whole (.., M) array in position order on every rank.  cols: (k, m_local) device tensor."""
     import torch
-    from .modes import ModeStatistics
-    ctx, comm = state.ctx, state.comm
-    n_h = w.numel()
-    base = rng.next()
-    for _ in range(comm.world_size - 1):
-        rng.next()
-    tick = (base + comm.rank) & 0xFFFFFFFF
-    s = ctx.sum_sq_max(w)
-    wl = w / float(s[0])                                         # local renormalisation (scalar scale)
-    thr = ctx.trim_threshold(wl, trim_ess, trim_bins)
-    cdf = ctx.cdf(wl, thr[0:1])
-    counts = ctx.multinomial_counts(cdf, rng.seed, tick, kept_count=thr[2:3], factor=4, n_draw_max=4 * n_h)
-    means, covs, chol, inv, winv = ctx.fit_modes(counts, None, 1, n_h)
-    dof = torch.full((1,), float(dof_fallback), dtype=torch.float64, device=ctx.device)
-    return ModeStatistics(None, None, None, _dev=(ctx, means, covs, chol, inv, dof, winv))
+    k = cols.shape[0]
+    packed = torch.cat([pos.to(torch.float64).reshape(1, -1), cols], dim=0).T.contiguous()    # (m_local, 1 + k)
+    allr, _ = comm.all_gather_v(packed)
+    M = allr.shape[0]
+    out = torch.empty(k, M, dtype=torch.float64, device=cols.device)
+    out[:, allr[:, 0].long()] = allr[:, 1:].T
+    return out

@@ -48,6 +48,9 @@ class StateManager:
         if self._ctx is None:
             from .device import HipContext
             self._ctx = HipContext(self.n_dim, self._device_arg, self._clamped_hint())
+            if self.comm is not None and self.comm.active:
+                # the library issues its own small collectives (reweight triples, global trim / fit / cumulative weights)
+                self.comm.attach(self._ctx)
         return self._ctx
 
     def _clamped_hint(self) -> int:
@@ -221,13 +224,11 @@ class StateManager:
         return int(np.sum(self._n_global)) if self._n_global else 0
 
     def reweight_eval(self, betas):
-        """Global (vmax, s1, s2) per trial beta: one device pass + (multi-GPU) an all-gather merge."""
+        """Global (vmax, s1, s2) per trial beta: one device pass; with a communicator attached the library all-gathers
+        the ranks' triples and merges them on the device, and the result arrives through the same pinned mailbox."""
         ctx = self.ctx
         ctx.use_current_stream()
-        if self.comm is None or self.comm.world_size == 1:
-            return ctx.reweight_eval(betas)
-        part = ctx.reweight_partials(betas)
-        return self.comm.merge_triples(part)
+        return ctx.reweight_eval(betas)
 
     def compute_logw_and_logz(self, beta_final: float = 1.0, normalize: bool = True):
         """Importance log-weights of every stored particle for the target at beta_final and the

@@ -42,34 +42,27 @@ class Trainer:
         rng = self._rng()
         w = _as_device_weights(weights, ctx)
         n_h = w.numel()
-        comm = st.comm
-        if comm is not None and comm.active:
-            from ..sharding import fit_modes_sharded
-            ms = fit_modes_sharded(st, w, self.TRIM_ESS, self.TRIM_BINS, self.DOF_FALLBACK, rng)
-        elif self.clustering and self.clusterer is not None:
+        # Every call below is the *_global form: on one GPU it is the plain kernel; with a communicator attached the
+        # threshold, the up-sampling draws and the fit are those of the WHOLE weighted history (train.py:91-122), so a
+        # sharded run trains the same proposal as the one-GPU run.
+        thr = ctx.trim_threshold(w, self.TRIM_ESS, self.TRIM_BINS, global_=True)   # (threshold, kept_sum, kept_count, ess)
+        n_draw_max = 4 * st.n_history_global()
+        K, labels = 1, None
+        if self.clustering and self.clusterer is not None:
             it = st.get_current("iter")
-            thr = ctx.trim_threshold(w, self.TRIM_ESS, self.TRIM_BINS)
             refit = (it % self.cluster_every == 0) or it == 0
             labels, K = self.clusterer.fit_predict_device(st, w, thr, refit, rng)
-            if K > 1:
-                wt = torch.where(w >= thr[0], w, torch.zeros_like(w))       # trimmed weights, history order
-                tick = rng.next()
-                for _ in range(K - 1):
-                    rng.next()
-                ms = ModeStatistics._fit(ctx, wt, n_h, labels, K, rng.seed, tick, self.DOF_FALLBACK, 4)
-            else:
-                cdf = ctx.cdf(w, thr[0:1])
-                counts = ctx.multinomial_counts(cdf, rng.seed, rng.next(), kept_count=thr[2:3], factor=4,
-                                                n_draw_max=4 * n_h)
-                means, covs, chol, inv, winv = ctx.fit_modes(counts, None, 1, n_h)
-                dof = torch.full((1,), float(self.DOF_FALLBACK), dtype=torch.float64, device=ctx.device)
-                ms = ModeStatistics(None, None, None, _dev=(ctx, means, covs, chol, inv, dof, winv))
+        if K > 1:
+            wt = torch.where(w >= thr[0], w, torch.zeros_like(w))       # trimmed weights, history order
+            tick = rng.next()
+            for _ in range(K - 1):
+                rng.next()
+            ms = ModeStatistics._fit(ctx, wt, n_h, labels, K, rng.seed, tick, self.DOF_FALLBACK, 4, comm=st.comm)
         else:
-            thr = ctx.trim_threshold(w, self.TRIM_ESS, self.TRIM_BINS)        # (threshold, kept_sum, kept_count, ess)
-            cdf = ctx.cdf(w, thr[0:1])
-            counts = ctx.multinomial_counts(cdf, rng.seed, rng.next(), kept_count=thr[2:3], factor=4,
-                                            n_draw_max=4 * n_h)
-            means, covs, chol, inv, winv = ctx.fit_modes(counts, None, 1, n_h)
+            cdf = ctx.cdf_global(w, thr[0:1])
+            counts = ctx.multinomial_counts_global(cdf, rng.seed, rng.next(), kept_count=thr[2:3], factor=4,
+                                                   n_draw_max=n_draw_max)
+            means, covs, chol, inv, winv = ctx.fit_modes(counts, None, 1, n_h, global_=True)
             dof = torch.full((1,), float(self.DOF_FALLBACK), dtype=torch.float64, device=ctx.device)
             ms = ModeStatistics(None, None, None, _dev=(ctx, means, covs, chol, inv, dof, winv))
         if self.pbar is not None:

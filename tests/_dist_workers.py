@@ -164,3 +164,73 @@ def sharded_gpu_worker(rank, world, port, out_dir):
     comm.barrier()
     dist.destroy_process_group()
     _ = HipContext
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# world-size parity: a sharded run is the SAME sampler as the one-GPU run (same seed -> same schedule, same evidence)
+PARITY_CASES = {
+    "tpcn_mult": dict(sample="tpcn", resample="mult", clustering=False, n_dim=6, target="gauss", n=512, n_total=2048),
+    "rwm_syst": dict(sample="rwm", resample="syst", clustering=False, n_dim=6, target="gauss", n=512, n_total=2048),
+    "tpcn_mult_bc": dict(sample="tpcn", resample="mult", clustering=False, n_dim=4, target="gauss", n=512, n_total=2048,
+                         periodic=[0], reflective=[2]),
+    "tpcn_cluster": dict(sample="tpcn", resample="mult", clustering=True, n_dim=4, target="rosen", n=1024, n_total=4096),
+    "rwm_cluster_thin": dict(sample="rwm", resample="syst", clustering=True, n_dim=4, target="bimodal", n=1024, n_total=4096,
+                             max_points=3000),
+}
+
+
+def parity_run(name, device=0):
+    """One seeded run of PARITY_CASES[name] on the current process group (or none): the quantities every world size
+    must agree on."""
+    import numpy as np
+    import torch
+    import tempest_amd as tp
+    c = PARITY_CASES[name]
+    d = c["n_dim"]
+    dev = torch.device("cuda", device)
+    mean = torch.linspace(-2, 2, d, dtype=torch.float64, device=dev)
+
+    def gauss(x):
+        return -0.5 * ((x - mean) ** 2).sum(dim=1) - 0.5 * d * float(np.log(2 * np.pi))
+
+    def rosen(x):
+        return -(10.0 * (x[:, ::2] ** 2 - x[:, 1::2]) ** 2 + (x[:, ::2] - 1.0) ** 2).sum(dim=1)
+
+    def bimodal(x):
+        a = -0.5 * (((x - 3.0) / 0.5) ** 2).sum(dim=1)
+        b = -0.5 * (((x + 3.0) / 0.5) ** 2).sum(dim=1)
+        return torch.logaddexp(a, b)
+    like = {"gauss": gauss, "rosen": rosen, "bimodal": bimodal}[c["target"]]
+    s = tp.Sampler(lambda u: 20 * u - 10, like, d, n_particles=c["n"], vectorize=True, clustering=c["clustering"],
+                   sample=c["sample"], resample=c["resample"], random_state=5, device=device,
+                   periodic=c.get("periodic"), reflective=c.get("reflective"))
+    if c.get("max_points") and s._core.trainer.clusterer is not None:
+        s._core.trainer.clusterer.max_points = c["max_points"]
+    ks = []
+    core = s._core
+    orig = core.trainer.run
+
+    def spy(weights):
+        ms = orig(weights)
+        ks.append(int(ms.K))
+        return ms
+    core.trainer.run = spy
+    s.run(n_total=c["n_total"], progress=False)
+    st = s.state
+    x, w, _ = s.posterior()
+    return {"logz": float(s.evidence()[0]), "beta": [float(v) for v in st.get_history("beta")],
+            "steps": [int(v) for v in st.get_history("steps")], "logz_t": [float(v) for v in st.get_history("logz")],
+            "ess": [float(v) for v in st.get_history("ess")], "acc": [float(v) for v in st.get_history("acceptance")],
+            "K": ks, "post_n": int(len(w)), "post_mean": [float(v) for v in np.average(x, weights=w, axis=0)],
+            "post_wsum": float(w.sum())}
+
+
+def parity_gpu_worker(rank, world, port, out_dir):
+    """`world` ranks sharing cuda:0 over gloo: every case of PARITY_CASES through the sharded path."""
+    import json
+    import torch.distributed as dist
+    _init(rank, world, port)
+    out = {name: parity_run(name) for name in PARITY_CASES}
+    json.dump(out, open(os.path.join(out_dir, f"parity{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()

@@ -59,3 +59,38 @@ def test_sharded_sampler_two_ranks_one_gpu(tmp_path):
     r1 = json.load(open(tmp_path / "res1.json"))
     assert r0["logz"] == r1["logz"]
     print(r0)
+
+
+@pytest.mark.gpu
+def test_world2_is_the_same_sampler_as_world1(tmp_path):
+    """the sharded sampler fits the proposal on the WHOLE weighted history (global trim threshold, global
+    up-sampling draws, all-reduced moments / medians, clustering on the gathered working set) and resamples in the reference's
+    global history order, so two ranks reproduce the one-GPU run on the same seed: identical beta schedule and step counts,
+    evidence equal to summation-order rounding.  tpCN/multinomial and RWM/systematic, boundary conditions, clustering on
+    (K > 1, with and without thinning of the working set)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import numpy as np
+    from tests._dist_workers import PARITY_CASES, parity_gpu_worker, parity_run
+    _spawn(parity_gpu_worker, 2, tmp_path)
+    r0 = json.load(open(tmp_path / "parity0.json"))
+    r1 = json.load(open(tmp_path / "parity1.json"))
+    assert r0 == r1                                     # both ranks hold the same global results, bit for bit
+    for name in PARITY_CASES:
+        one = parity_run(name)
+        two = r0[name]
+        assert two["steps"] == one["steps"], name
+        assert two["K"] == one["K"], name
+        assert len(two["beta"]) == len(one["beta"]), name
+        np.testing.assert_allclose(two["beta"], one["beta"], rtol=1e-9, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(two["logz_t"], one["logz_t"], rtol=0, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(two["ess"], one["ess"], rtol=1e-9, err_msg=name)
+        np.testing.assert_allclose(two["acc"], one["acc"], rtol=1e-9, atol=1e-12, err_msg=name)
+        assert abs(two["logz"] - one["logz"]) <= 1e-9, (name, two["logz"], one["logz"])
+        assert two["post_n"] == one["post_n"], name
+        np.testing.assert_allclose(two["post_mean"], one["post_mean"], rtol=1e-9, atol=1e-9, err_msg=name)
+        print(name, "iterations", len(one["beta"]), "steps", sum(one["steps"]), "K", sorted(set(one["K"])), "logz", one["logz"],
+              "world2 - world1", two["logz"] - one["logz"])
+    if "tpcn_cluster" in PARITY_CASES:
+        assert max(r0["tpcn_cluster"]["K"]) > 1         # the clustered case really exercised K > 1

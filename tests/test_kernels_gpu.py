@@ -529,3 +529,75 @@ def test_weighted_moments_shifted_one_pass(dev, d):
     np.testing.assert_allclose(out[0], w.sum(), rtol=1e-13)
     np.testing.assert_allclose(out[1:1 + d], mean, rtol=1e-13)
     np.testing.assert_allclose(out[1 + d:].reshape(d, d), cov, rtol=1e-9, atol=1e-22)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# global entry points of the sharded path through a ONE-RANK loopback communicator: all collectives become identities, the
+# blocked / staged kernels run, and the results must equal the plain one-GPU functions (up to summation order).
+def _history_ctx(d, T, rows, seed, loopback):
+    from tempest_amd.comm import attach_loopback
+    from tempest_amd.device import HipContext
+    rs = np.random.RandomState(seed)
+    n = T * rows
+    c = HipContext(d, 0)
+    u = rs.rand(n, d)
+    logl = -rs.chisquare(5, size=n) * 3.0
+    c.history_load(u, 20 * u - 10, logl, np.linspace(0, 0.5, T), -np.arange(T, dtype=float), [rows] * T)
+    if loopback:
+        attach_loopback(c)
+    return c, rs
+
+
+@pytest.mark.parametrize("T,rows", [(1, 5000), (7, 3000), (40, 700), (3, 70000)])
+def test_global_entry_points_loopback_match_plain(dev, T, rows):
+    d = 3
+    plain, rs = _history_ctx(d, T, rows, 11, False)
+    loop, _ = _history_ctx(d, T, rows, 11, True)
+    n = T * rows
+    w = np.exp(rs.randn(n) * 3.0)
+    w /= w.sum()
+    wt = torch.from_numpy(w).to(dev)
+    # reweight triples through the gathered merge
+    a, b = plain.reweight_eval([0.0, 0.4, 1.0]), loop.reweight_eval([0.0, 0.4, 1.0])
+    np.testing.assert_allclose(a[:, 0] + np.log(a[:, 1]), b[:, 0] + np.log(b[:, 1]), rtol=1e-13)
+    np.testing.assert_allclose(a[:, 1] ** 2 / a[:, 2], b[:, 1] ** 2 / b[:, 2], rtol=1e-12)
+    # trim threshold: the radix descent finds the same order statistics -> the same threshold, bit for bit
+    for ess, bins in ((0.99, 1000), (0.9, 37), (0.5, 1)):
+        tp_ = plain.trim_threshold(wt, ess, bins).cpu().numpy()
+        tl_ = loop.trim_threshold(wt, ess, bins, global_=True).cpu().numpy()
+        assert tp_[0] == tl_[0] and tp_[2] == tl_[2], (ess, bins, tp_, tl_)
+        np.testing.assert_allclose(tl_[[1, 3]], tp_[[1, 3]], rtol=1e-12)
+    thr = plain.trim_threshold(wt, 0.99, 1000)
+    # cumulative weights (plain and masked), totals
+    for t in (None, thr[0:1]):
+        cp = plain.cdf(wt, t).cpu().numpy()
+        cl, tot = loop.cdf_global(wt, t, total=True)
+        cl = cl.cpu().numpy()
+        np.testing.assert_allclose(cl, cp, rtol=1e-12, atol=1e-300)
+        assert tot == cl[-1] and np.all(np.diff(cl) >= -4e-16 * tot)      # monotone up to rounding (scan.h)
+        assert np.all(cl[rows - 1::rows][:-1] <= cl[rows::rows] + 0)       # block ends meet the next block's start
+    # draws: the same rows (a draw within one rounding error of a boundary may move to the neighbouring row)
+    cp, cl = plain.cdf(wt), loop.cdf_global(wt)
+    ip = plain.resample_multinomial(cp, 20000, 99, 3).cpu().numpy()
+    il = loop.resample_select_global(cl, 20000, 0, 99, 3).cpu().numpy()
+    assert (ip != il).sum() <= 2 and np.abs(ip - il).max() <= 1
+    tot = float(cp[-1].item())
+    ip = plain.resample_systematic(cp, 7777, 0.37, renorm=tot).cpu().numpy()
+    il = loop.resample_select_global(cl, 7777, 1, 99, 3, u0=0.37, pscale=tot).cpu().numpy()
+    assert (ip != il).sum() <= 2 and np.abs(ip - il).max() <= 1
+    cpm, clm = plain.cdf(wt, thr[0:1]), loop.cdf_global(wt, thr[0:1])
+    kp = plain.multinomial_counts(cpm, 5, 8, kept_count=thr[2:3], factor=4, n_draw_max=4 * n).cpu().numpy()
+    kl = loop.multinomial_counts_global(clm, 5, 8, kept_count=thr[2:3], factor=4, n_draw_max=4 * n).cpu().numpy()
+    assert kp.sum() == kl.sum() == 4 * int(thr[2].item()) and np.abs(kp - kl).sum() <= 4
+    # the fit on identical multiplicities: medians exactly, moments to rounding
+    counts = torch.from_numpy(kp).to(dev)
+    fp = plain.fit_modes(counts)
+    fl = loop.fit_modes(counts, global_=True)
+    assert torch.equal(fp[0], fl[0])
+    for x, y, tol in zip(fp[1:], fl[1:], (1e-11, 1e-9, 1e-8, 1e-8)):
+        np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=tol, atol=1e-14)
+    labels = torch.from_numpy((rs.rand(n) < 0.4).astype(np.int32)).to(dev)
+    fp = plain.fit_modes(counts, labels, K=2)
+    fl = loop.fit_modes(counts, labels, K=2, global_=True)
+    assert torch.equal(fp[0], fl[0])
+    np.testing.assert_allclose(fl[1].cpu().numpy(), fp[1].cpu().numpy(), rtol=1e-11, atol=1e-14)
