@@ -8,16 +8,19 @@
 A "step" is one full Persistent Sampling iteration (reweight -> train -> resample -> mutate -> commit; the beta = 0
 prior-draw iterations that initialise a run come first and are neither warm-up nor timed steps) of
 `tempest_amd.Sampler` on the README Rosenbrock target (coefficient 10, prior U(-10,10)^10) with BASELINE config 4's
-1 048 576 particles.  That configuration fits one GPU (7 GB of history at termination), so at N=1 it IS the workload;
-under torchrun every GPU holds 1 048 576 particles (weak scaling; `--particles-per-gpu 131072` gives config 4's own
-8-GPU shard).  `value` = particle-mutation-steps
-(sum over the timed iterations of MCMC steps x global particles, the reference's `calls` bookkeeping,
-mcmc.py:89) / wall time, user likelihood included, inputs resident in HBM.
+1 048 576 particles -- at every N: the configuration fits one GPU (7 GB of history at termination), so at N=1 it is the
+workload as it stands, and under torchrun the SAME 1 048 576 particles are sharded over the N ranks (131 072 per GPU at
+N=8, config 4 as BASELINE.json states it): "scaling": "strong".  `value` = particle-mutation-steps (sum over the timed
+iterations of MCMC steps x global particles, the reference's `calls` bookkeeping, mcmc.py:89) / wall time, user
+likelihood included, inputs resident in HBM.  `--particles-per-gpu P` overrides the shard size (global = P x N).
 
 Also in the JSON line:
   roofline      the reweight reduction kernel (north_star's named kernel) on a 1.07 GB synthetic history
                 (outside the 256 MB Infinity Cache): algorithmic 16 B per historical particle /
-                HIP-event average launch duration, against 8 TB/s.
+                HIP-event average launch duration, against 8 TB/s nominal AND against the streaming-read / copy ceilings
+                measured on this box in this process (`measured_peak`); the 2.6e6- and 1.05e7-row points of SURVEY 8d.
+  mutation_only pms/s inside the Mutator, from per-phase timings of the untimed tail of the run.
+  weak_scaling  (N > 1) the same protocol with 1 048 576 particles PER GPU.
   cpu_baseline  the NumPy oracle sampler ("port") on the host cores, bounded sample, same target.
   hip_callbacks the same run with the callbacks compiled into the Metropolis kernel (tempest_amd.HipCallbacks).
 """
@@ -66,43 +69,66 @@ def prior20(u):
     return 20 * u - 10
 
 
-def reweight_roofline(device, n_rows):
-    """HIP-event timing of the reduction kernel on a synthetic history of n_rows (16 B each)."""
-    import torch
-    from tempest_amd.device import HipContext
+def _synthetic_history(ctx, n_rows):
+    """logl ~ -chi2_10 * (1 + t/T), T = 64, generated in blocks to bound host memory."""
     T = 64
     rs = np.random.RandomState(0)
     n_t = np.full(T, n_rows // T, dtype=np.int64)
     n_t[-1] += n_rows - n_t.sum()
-    # logl ~ -chi2_10 * (1 + t/T) (SURVEY 8d), generated in blocks to bound host memory
     logl = np.empty(n_rows)
     off = 0
     for t in range(T):
         logl[off:off + n_t[t]] = -rs.chisquare(10, size=n_t[t]) * (1 + t / T)
         off += n_t[t]
-    ctx = HipContext(1, device)
     ctx.history_load(None, None, logl, np.linspace(0, 1, T) ** 2, -np.linspace(0, 30, T), n_t)
-    del logl
+
+
+def reweight_roofline(device, n_rows, other_rows=(2_621_440, 10_485_760)):
+    """HIP-event timing of the reduction kernel on synthetic histories of n_rows (16 B each), beside the box's own
+    streaming ceilings measured in this process."""
+    import torch
+    from tempest_amd.device import HipContext
+    ctx = HipContext(1, device)
+    _synthetic_history(ctx, n_rows)
     ms = [ctx.reweight_time(0.37, 1, 20) for _ in range(5)]
     avg_ms = float(np.median(ms))
     m, s1, s2 = ctx.reweight_eval([0.37])[0]
+    algo_bytes = 16.0 * n_rows
+    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+    # the box's own ceilings on the same number of bytes: a read-only stream (what the reduction is) and a copy
+    read_ms = float(np.median([ctx.membw_time(0, 2 * n_rows, 20) for _ in range(3)]))
+    copy_ms = float(np.median([ctx.membw_time(1, n_rows, 20) for _ in range(3)]))
+    read_gbs, copy_gbs = algo_bytes / (read_ms * 1e-3) / 1e9, algo_bytes / (copy_ms * 1e-3) / 1e9
+    fp64 = ctx.fp64_tflops()
+    points = []
+    for rows in other_rows:                      # SURVEY 8d's two smaller histories (inside / around the 256 MB Infinity Cache)
+        _synthetic_history(ctx, rows)
+        t = float(np.median([ctx.reweight_time(0.37, 1, 50) for _ in range(5)]))
+        points.append({"history_rows": rows, "bytes": 16 * rows, "avg_launch_ms": round(t, 5),
+                       "achieved": round(16.0 * rows / (t * 1e-3) / 1e9, 1), "unit": "GB/s",
+                       "note": "working set inside the 256 MB Infinity Cache: not an HBM figure" if 16 * rows < 256e6 else ""})
     ctx.close()
     torch.cuda.empty_cache()
-    algo_bytes = 16.0 * n_rows
-    traffic = None
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "r01_reweight_pmc.json")
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
             if rec.get("n_rows") == n_rows:
                 traffic = rec.get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/r01_reweight_pmc.json: rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of "
+                                  "this kernel on this history in an earlier profiled run, NOT counters of this run")
         except Exception:
             traffic = None
-    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "k_reweight_reduce<1, 8>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(avg_ms, 5), "history_rows": n_rows,
-            "check_ess": float(s1 * s1 / s2)}
+            "measured_peak": {"read_GBs": round(read_gbs, 1), "copy_GBs": round(copy_gbs, 1),
+                              "what": "16-B non-temporal streaming read / copy kernels of the library (tph_membw_time) over the "
+                                      "same 1.07 GB in this process"},
+            "frac_of_measured": round(achieved / read_gbs, 4), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+            "fp64_vector_tflops_measured": round(fp64, 2),
+            "other_points": points, "check_ess": float(s1 * s1 / s2)}
 
 
 def cpu_baseline(budget_s=20.0):
@@ -143,8 +169,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--particles-per-gpu", type=int, default=1048576,
-                    help="BASELINE config 4's 1 048 576 particles, held by ONE GPU (they fit); weak scaling: the same per GPU")
+    ap.add_argument("--particles", type=int, default=1048576, help="GLOBAL particles: BASELINE config 4's 1 048 576")
+    ap.add_argument("--particles-per-gpu", type=int, default=0,
+                    help="override: this many per rank (global = P x N); default: --particles / N (strong scaling)")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling run (1 048 576 per GPU)")
     ap.add_argument("--roofline-rows", type=int, default=67_108_864)      # 1.07 GB of (logl, logmix)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -176,11 +204,19 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import tempest_amd as tp
-    n_local = a.particles_per_gpu
+    if a.particles_per_gpu > 0:
+        n_local = a.particles_per_gpu
+    else:
+        if a.particles % world:
+            raise SystemExit(f"--particles {a.particles} is not divisible by {world} ranks")
+        n_local = a.particles // world
     n_global = n_local * world
     n_total = 4 * n_global                                                  # n_total = 4 N
-    s = tp.Sampler(prior20, rosenbrock_torch, 10, n_particles=n_global, vectorize=True, clustering=False,
-                   random_state=a.seed, backend="torch", batch_prior=True, device=local_rank)
+
+    def make(callbacks, n_glob):
+        return tp.Sampler(callbacks[0], callbacks[1], 10, n_particles=n_glob, vectorize=True, clustering=False,
+                          random_state=a.seed, backend="torch", batch_prior=True, device=local_rank)
+    s = make((prior20, rosenbrock_torch), n_global)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -189,6 +225,7 @@ def main():
 
     def timed(s):
         """W untimed + K timed PS iterations; (seconds [max over ranks], steps per timed iteration, betas)."""
+        n_global = s._core.config.n_particles
         import gc
         # initialisation: the beta = 0 iterations draw the first ensembles from the prior (no MCMC steps, nothing to count);
         # they are never part of the W warm-up or K timed steps, so that any W, K >= 1 measures mutation work
@@ -232,12 +269,29 @@ def main():
         core = s._core
         core.n_total = n_total
         guard = 0
+        # the tail is untimed by `value`: it is run with a device synchronisation after every phase, which gives the
+        # per-phase split (mutation-only throughput) at the price of a few tens of microseconds per iteration
+        core.profile = True
+        tail0 = len(s.state._scalars["steps"])
+        for k in core.timing:
+            core.timing[k] = 0.0
         while core._not_termination() and guard < 400:
             s.sample(return_state=False)
             guard += 1
+        core.profile = False
         _, logz = core._logz_at(1.0)
         sync()
         t_run = time.perf_counter() - t_run0
+        tail_steps = np.asarray(s.state._scalars["steps"][tail0:]); tail_beta = np.asarray(s.state._scalars["beta"][tail0:])
+        if len(tail_steps) and core.timing["mutate"] > 0:
+            tail_pms = float(np.sum(tail_steps[tail_beta > 0])) * n_global
+            extra["mutation_only"] = {"value": tail_pms / core.timing["mutate"], "unit": "particle-mutation-steps/s",
+                                      "iterations": [tail0 + 1, tail0 + len(tail_steps)],
+                                      "phase_seconds": {k: round(v, 4) for k, v in core.timing.items()},
+                                      "whole_iteration_value": tail_pms / sum(core.timing.values()),
+                                      "note": "untimed tail of the run (after the K timed iterations), one device "
+                                              "synchronisation after every phase; mutate = time inside Mutator.run incl. the "
+                                              "user's callbacks"}
         all_steps = np.asarray(s.state._scalars["steps"]); all_beta = np.asarray(s.state._scalars["beta"])
         extra["whole_run"] = {"value": float(np.sum(all_steps[all_beta > 0])) * n_global / t_run, "unit": "particle-mutation-steps/s",
                               "seconds": t_run, "iterations": int(len(all_beta)),
@@ -249,10 +303,11 @@ def main():
                                                         "source": "tests/golden/ref_ensembles.json"}})
     out = {"metric": "particle-mutation-steps/s (whole job), 10-D Rosenbrock", "value": value,
            "unit": "particle-mutation-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-           "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+           "scaling": "strong" if a.particles_per_gpu <= 0 else "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"rosenbrock10d_n{n_local}_per_gpu (BASELINE config 4: 10-D Rosenbrock, 1 048 576 particles -- "
-                                  f"all of them on each GPU, weak scaling: {n_global} particles global)",
+           "config": {"workload": f"rosenbrock10d_n{n_global} (BASELINE config 4: 10-D Rosenbrock, {n_global} particles "
+                                  f"sharded over {world} GPU(s), {n_local} per GPU)",
                       "n_dim": 10, "particles_per_gpu": n_local, "particles_global": n_global, "sample": "tpcn",
                       "resample": "mult", "clustering": False, "n_total": n_total, "step": "one PS iteration"}}
     out.update(extra)
@@ -262,8 +317,9 @@ def main():
         # into the Metropolis kernel: a step is 4 launches instead of ~16.  Reported beside `value`, never as `value`.
         try:
             cb = tp.HipCallbacks(ROSENBROCK_HIP, 10)
-            s2 = tp.Sampler(cb.prior_transform, cb.log_likelihood, 10, n_particles=n_global, vectorize=True,
-                            clustering=False, random_state=a.seed, backend="torch", batch_prior=True, device=local_rank)
+            del s
+            torch.cuda.empty_cache()
+            s2 = make((cb.prior_transform, cb.log_likelihood), n_global)
             dt2, st2, bt2 = timed(s2)
             pms2 = float(np.sum(st2[bt2 > 0])) * n_global
             out["hip_callbacks"] = {"value": pms2 / dt2, "unit": "particle-mutation-steps/s", "ms_per_step": 1e3 * dt2 / a.steps,
@@ -272,8 +328,24 @@ def main():
                                     "note": "tempest_amd.HipCallbacks: prior/likelihood as HIP device functions fused "
                                             "into the Metropolis kernel (optional extension; not the headline)"}
             del s2
+            torch.cuda.empty_cache()
         except Exception as e:       # no hipcc on the box, ...
             out["hip_callbacks"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+    if world > 1 and a.particles_per_gpu <= 0 and not a.no_weak:
+        # the weak-scaling figure beside the headline: 1 048 576 particles PER GPU, same protocol
+        try:
+            s = None
+            torch.cuda.empty_cache()
+            s3 = make((prior20, rosenbrock_torch), a.particles * world)
+            dt3, st3, bt3 = timed(s3)
+            out["weak_scaling"] = {"value": float(np.sum(st3[bt3 > 0])) * a.particles * world / dt3,
+                                   "unit": "particle-mutation-steps/s", "particles_per_gpu": a.particles,
+                                   "particles_global": a.particles * world, "ms_per_step": 1e3 * dt3 / a.steps,
+                                   "timed_mcmc_steps": int(np.sum(st3[bt3 > 0]))}
+            del s3
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["weak_scaling"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         if not a.no_roofline:
             out["roofline"] = reweight_roofline(local_rank, a.roofline_rows)

@@ -124,6 +124,11 @@ int tph_reweight_eval(tph_ctx* ctx, const double* betas_host, int nb, double* ou
 /* measurement aid: average duration (ms, HIP events on the ctx stream) of `reps` back-to-back launches of the
  * reduction kernel alone for nb trial betas */
 int tph_reweight_time(tph_ctx* ctx, double beta, int nb, int reps, double* avg_ms_host);
+/* measurement aids: the box's own ceilings, timed in the same process (HIP events on the ctx stream).  tph_membw_time:
+ * average duration of a streaming READ (mode 0: n_doubles * 8 bytes per launch, the reduction's access pattern) or COPY
+ * (mode 1: 2 * n_doubles * 8 bytes) over freshly allocated buffers; tph_fp64_time: sustained FP64 vector-FMA rate (TFLOP/s). */
+int tph_membw_time(tph_ctx* ctx, int mode, int64_t n_doubles, int reps, double* avg_ms_host);
+int tph_fp64_time(tph_ctx* ctx, int reps, double* tflops_host);
 /* normalised weights w_s = e^{beta l_s - C_s - vmax}/s1 for all N_h particles (reweight.py:106,328) */
 int tph_weights(tph_ctx* ctx, double beta, double vmax, double s1, double* w_dev);
 /* unnormalised log-weights beta*l - C + log(n_h_global)  (state_manager.py:473) */

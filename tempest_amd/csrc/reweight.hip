@@ -332,6 +332,107 @@ extern "C" int tph_reweight_time(tph_ctx* ctx, double beta, int nb, int reps, do
   return 0;
 }
 
+// ---- measurement aids: the box's own ceilings, timed in the same process as the kernels they are compared with --------
+// mode 0: streaming READ (16-B non-temporal loads, per-block contiguous segments, the access pattern of the reduction
+// above; every lane folds its values into one double so that the loads cannot be dropped); mode 1: streaming COPY
+// (16-B loads + 16-B non-temporal stores).  Bytes moved per launch: n * 8 (read) or 2 * n * 8 (copy).
+template <int MODE>
+__global__ void __launch_bounds__(TPH_RED_THREADS) k_membw(const double* __restrict__ src, double* __restrict__ dst, int64_t n,
+                                                          double* __restrict__ sink) {
+  constexpr int U = 8;
+  const int64_t n2 = n >> 1;
+  const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src);
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  v2d* __restrict__ d2 = reinterpret_cast<v2d*>(dst);
+  constexpr int64_t STEP = (int64_t)TPH_RED_THREADS * U;
+  int64_t per = (n2 + gridDim.x - 1) / gridDim.x;
+  per = (per + STEP - 1) / STEP * STEP;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n2 ? lo + per : n2;
+  double acc = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += STEP) {
+    double2 v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t j = i + (int64_t)k * TPH_RED_THREADS;
+      v[k] = j < hi ? nt_load2(s2 + j) : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t j = i + (int64_t)k * TPH_RED_THREADS;
+      if (MODE == 1) {
+        if (j < hi) { v2d o; o.x = v[k].x; o.y = v[k].y; __builtin_nontemporal_store(o, d2 + j); }
+      } else {
+        acc += v[k].x + v[k].y;
+      }
+    }
+  }
+  if (MODE == 0 && acc == 1.2345e300) sink[0] = acc;     // never true: keeps the loads alive
+}
+extern "C" int tph_membw_time(tph_ctx* ctx, int mode, int64_t n_doubles, int reps, double* avg_ms_host) {
+  TPH_REQUIRE(ctx && avg_ms_host && reps > 0 && n_doubles >= 1024 && (mode == 0 || mode == 1), "tph_membw_time: bad argument");
+  const size_t bytes = sizeof(double) * (size_t)n_doubles;
+  double *a = nullptr, *b = nullptr;
+  TPH_HIP(hipMalloc((void**)&a, bytes));
+  if (mode == 1 && hipMalloc((void**)&b, bytes) != hipSuccess) { (void)hipFree(a); TPH_REQUIRE(false, "tph_membw_time: out of memory"); }
+  TPH_HIP(hipMemsetAsync(a, 0, bytes, ctx->stream));
+  const int grid = tph_grid_for(n_doubles, TPH_RED_THREADS, 16, 1024);
+  hipEvent_t e0, e1;
+  TPH_HIP(hipEventCreate(&e0));
+  TPH_HIP(hipEventCreate(&e1));
+  for (int r = -2; r < reps; ++r) {
+    if (r == 0) TPH_HIP(hipEventRecord(e0, ctx->stream));
+    if (mode == 0) hipLaunchKernelGGL(k_membw<0>, dim3(grid), dim3(TPH_RED_THREADS), 0, ctx->stream, a, b, n_doubles, ctx->small_dev);
+    else hipLaunchKernelGGL(k_membw<1>, dim3(grid), dim3(TPH_RED_THREADS), 0, ctx->stream, a, b, n_doubles, ctx->small_dev);
+  }
+  TPH_HIP(hipEventRecord(e1, ctx->stream));
+  TPH_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  TPH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  TPH_HIP(hipEventDestroy(e0));
+  TPH_HIP(hipEventDestroy(e1));
+  (void)hipFree(a);
+  if (b) (void)hipFree(b);
+  *avg_ms_host = (double)ms / reps;
+  return 0;
+}
+
+// FP64 vector-FMA rate of the box under load (8 independent chains per lane, 4 waves per SIMD): the proposal kernels are
+// bound by FP64 VALU issue, and the clock a box holds for such code varies from device to device (MI355X_MICROARCH.md,
+// "DVFS give-back"), which is the first thing to look at when two boxes disagree on a VALU-bound figure.
+__global__ void __launch_bounds__(256) k_fp64_probe(double* __restrict__ out, double x0, int iters) {
+  double a0 = x0, a1 = x0 + 1, a2 = x0 + 2, a3 = x0 + 3, a4 = x0 + 4, a5 = x0 + 5, a6 = x0 + 6, a7 = x0 + 7;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      a0 = fma(a0, x0, 1.0); a1 = fma(a1, x0, 1.0); a2 = fma(a2, x0, 1.0); a3 = fma(a3, x0, 1.0);
+      a4 = fma(a4, x0, 1.0); a5 = fma(a5, x0, 1.0); a6 = fma(a6, x0, 1.0); a7 = fma(a7, x0, 1.0);
+    }
+  }
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+}
+extern "C" int tph_fp64_time(tph_ctx* ctx, int reps, double* tflops_host) {
+  TPH_REQUIRE(ctx && tflops_host && reps > 0, "tph_fp64_time: bad argument");
+  const int blocks = ctx->n_simd;                 // 4 waves per SIMD
+  const int iters = 256;
+  if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)blocks * 256)) return -1;
+  hipEvent_t e0, e1;
+  TPH_HIP(hipEventCreate(&e0));
+  TPH_HIP(hipEventCreate(&e1));
+  for (int r = -2; r < reps; ++r) {
+    if (r == 0) TPH_HIP(hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(k_fp64_probe, dim3(blocks), dim3(256), 0, ctx->stream, (double*)ctx->scratch, 0.999, iters);
+  }
+  TPH_HIP(hipEventRecord(e1, ctx->stream));
+  TPH_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  TPH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  TPH_HIP(hipEventDestroy(e0));
+  TPH_HIP(hipEventDestroy(e1));
+  const double flop = 2.0 * 128.0 * iters * 256.0 * blocks;
+  *tflops_host = flop / ((double)ms / reps * 1e-3) / 1e12;
+  return 0;
+}
+
 // K3: normalised weights, 24 B per historical particle
 __global__ void __launch_bounds__(256) k_weights(const double* __restrict__ logl, const double* __restrict__ cmix,
                                                  int64_t n, double beta, double vmax, double s1,

@@ -170,6 +170,17 @@ class HipContext:
         check(self.lib.tph_reweight_time(self._ctx, float(beta), int(nb), int(reps), C.byref(out)), "tph_reweight_time")
         return out.value
 
+    def membw_time(self, mode, n_doubles, reps=20):
+        """Average launch duration (ms) of the streaming read (mode 0) / copy (mode 1) ceiling kernel."""
+        out = C.c_double(0.0)
+        check(self.lib.tph_membw_time(self._ctx, int(mode), int(n_doubles), int(reps), C.byref(out)), "tph_membw_time")
+        return out.value
+
+    def fp64_tflops(self, reps=10):
+        out = C.c_double(0.0)
+        check(self.lib.tph_fp64_time(self._ctx, int(reps), C.byref(out)), "tph_fp64_time")
+        return out.value
+
     def weights(self, beta, vmax, s1, out=None):
         if out is None:
             out = self.empty_rows(self.size)
