@@ -216,11 +216,14 @@ int tph_inf_repair(tph_ctx* ctx, double* u_dev, double* x_dev, double* logl_dev,
  * redraw-until-in-bounds loop; maha_u/maha_up receive (u-mu)^T S^-1 (u-mu) at u and u' (tpCN), evaluated as
  * |L^-1 (u-mu)|^2: cholinv_dev = the K inverse Cholesky factors (tph_chol_inv / tph_fit_modes produce them), or NULL --
  * the library then inverts chol_dev itself on every call (a caller holding only ModeStatistics.chol_covariances). */
-int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const int32_t* assign_dev, int64_t n, int64_t ld,
+int tph_propose(tph_ctx* ctx, int kernel, double* u_dev /* in; with pending_dev also out */, const int32_t* assign_dev, int64_t n, int64_t ld,
                 int K, const double* means_dev, const double* chol_dev, const double* cholinv_dev,
                 const double* dof_dev, const double* sigmas_dev, const uint8_t* bc_dev,
                 uint64_t seed, uint32_t tick, int64_t item0,
-                double* uprime_dev, double* maha_u_dev, double* maha_up_dev, const double* ctl_dev);
+                double* uprime_dev, double* maha_u_dev, double* maha_up_dev, const double* ctl_dev,
+                uint8_t* pending_dev /* NULL, or the mask written by the previous step's deferred tph_accept: particles with
+                                        pending[i] != 0 first take uprime[i] (that step's accepted proposal) as their current
+                                        point -- u is updated in place, the flag cleared -- and then propose from it */);
 /* Metropolis step (mcmc.py:163-177 with the factor of :251-279): masked overwrite of u,x,logl and
  * per-rank sums  sums_dev = (n_accepted, sum alpha_0 .. sum alpha_{K-1}).  x_dev and xprime_dev may both be NULL: x is
  * then not maintained during the run (it is a function of u: the caller re-evaluates prior_transform once at the end, which
@@ -234,7 +237,12 @@ int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, double* x_d
                double* sums_dev /*[1+K]; NULL = leave the block partials in partials_dev for tph_adapt to sum*/,
                const double* ctl_dev,
                double* partials_dev /* NULL = library scratch, or ceil(n/256)*(1+K) doubles owned by the caller: needed
-                                       when the launch is captured in a graph (the scratch may move when it grows) */);
+                                       when the launch is captured in a graph (the scratch may move when it grows) */,
+               uint8_t* pending_dev /* NULL = update u (and x) in place; else DEFERRED mode (x_dev must be NULL): the decision
+                                       goes to pending[i] (1 = accepted), logl and maha_u take their new values, u is left
+                                       alone and the next tph_propose given this mask moves the accepted proposals into place.
+                                       The masked in-place copy is a read-modify-write of every line of u (the accepted rows
+                                       are scattered): deferred, that traffic rides under the proposal kernel's FP64 work */);
 /* sigma adaptation + adaptive stopping rule (mcmc.py:104-140,180-194,281-288,320-323) from GLOBAL sums.
  * state_dev (6 doubles; TPH_STEP_STATE_LEN when it doubles as step control or a mailbox is given):
  *            [0]=iteration (in/out) [1]=done flag [2]=accepted fraction [3]=mean alpha [4]=mean(sigma)/sigma_0

@@ -51,9 +51,9 @@ SIGNATURES = {
     "tph_prior_draw": (c_int, [ptr, ptr, c_i64, c_i64, c_u64, c_u32, c_i64]),
     "tph_inf_repair": (c_int, [ptr, ptr, ptr, ptr, c_i64, c_i64, c_u64, c_u32, c_i64, ptr]),
     "tph_propose": (c_int, [ptr, c_int, ptr, ptr, c_i64, c_i64, c_int, ptr, ptr, ptr, ptr, ptr, ptr,
-                            c_u64, c_u32, c_i64, ptr, ptr, ptr, ptr]),
+                            c_u64, c_u32, c_i64, ptr, ptr, ptr, ptr, ptr]),
     "tph_accept": (c_int, [ptr, c_int, c_dbl, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i64, c_i64,
-                           c_int, ptr, c_u64, c_u32, c_i64, ptr, ptr, ptr]),
+                           c_int, ptr, c_u64, c_u32, c_i64, ptr, ptr, ptr, ptr]),
     "tph_adapt": (c_int, [ptr, c_int, ptr, ptr, c_int, c_dbl, c_int, c_int, c_int, ptr, ptr, ptr, c_int, ptr, c_i64]),
     "tph_posterior_rows": (c_int, [ptr, c_int, ptr, c_i64, ptr, c_dbl, ptr, ptr, ptr]),
     "tph_index_compose": (c_int, [ptr, ptr, ptr, c_i64, ptr]),

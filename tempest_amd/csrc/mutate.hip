@@ -89,13 +89,14 @@ constexpr int PROP_THREADS = 64;
 // Mahalanobis forms as |W (v - mu)|^2 with W = L^-1 (lower-triangular).
 // HBM per particle: read 8d+4, write 8d+16; FLOP 2*(d^2/2) per attempt (+ 2*(d^2/2) per Mahalanobis form).
 template <int KERNEL>
-__global__ void __launch_bounds__(PROP_THREADS) k_propose(const double* __restrict__ u, const int32_t* __restrict__ assign,
+__global__ void __launch_bounds__(PROP_THREADS) k_propose(double* __restrict__ u, const int32_t* __restrict__ assign,
                                                           int64_t n, int64_t ld, int d, const double* __restrict__ means,
                                                           const double* __restrict__ chol, const double* __restrict__ winv,
                                                           const double* __restrict__ dof, const double* __restrict__ sigmas,
                                                           const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                           int64_t item0, double* __restrict__ up,
-                                                          double* __restrict__ maha_u, double* __restrict__ maha_up) {
+                                                          double* __restrict__ maha_u, double* __restrict__ maha_up,
+                                                          uint8_t* __restrict__ pend) {
   extern __shared__ double sh[];
   const int tid = threadIdx.x;
   double* zs = sh + tid;                       // zs[j*64]
@@ -108,10 +109,13 @@ __global__ void __launch_bounds__(PROP_THREADS) k_propose(const double* __restri
   const double* __restrict__ W = winv + (size_t)c * d * d;
   const double sigma = sigmas[c];
 
+  const bool pd = pend && pend[i];      // the previous step's move was accepted and is still pending (deferred tph_accept)
   for (int j = 0; j < d; ++j) {
     double uj = u[(size_t)j * ld + i];
+    if (pd) { uj = up[(size_t)j * ld + i]; u[(size_t)j * ld + i] = uj; }
     df[j * PROP_THREADS] = (KERNEL == TPH_KERNEL_TPCN) ? uj - mu[j] : uj;
   }
+  if (pd) pend[i] = 0;
   double a_fac = 1.0, b_fac = sigma, m_u = 0.0;
   if (KERNEL == TPH_KERNEL_TPCN) {
     if (tick.carry()) {
@@ -194,13 +198,14 @@ __device__ __forceinline__ int group_and(int v) {
 }
 
 template <int KERNEL, int LPP, int STAGE>
-__global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restrict__ u, const int32_t* __restrict__ assign,
+__global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ u, const int32_t* __restrict__ assign,
                                                            int64_t n, int64_t ld, int d, const double* __restrict__ means,
                                                            const double* __restrict__ chol, const double* __restrict__ winv,
                                                            const double* __restrict__ dof, const double* __restrict__ sigmas,
                                                            const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                            int64_t item0, double* __restrict__ up,
-                                                           double* __restrict__ maha_u, double* __restrict__ maha_up) {
+                                                           double* __restrict__ maha_u, double* __restrict__ maha_up,
+                                                           uint8_t* __restrict__ pend) {
   extern __shared__ double sh[];
   constexpr int PPB = ML_THREADS / LPP;
   const int l = threadIdx.x % LPP, p = threadIdx.x / LPP;
@@ -235,11 +240,14 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
     if (STAGE == 1 || KERNEL != TPH_KERNEL_TPCN || carry) stage(STAGE == 1 ? mat1 : mat0, Lg);
   }
 
+  const bool pd = pend && live && pend[i];      // pending accepted move of the previous step (deferred tph_accept)
   for (int j = l; j < d; j += LPP) {
     double uj = u[(size_t)j * ld + ii];
+    if (pd) { uj = up[(size_t)j * ld + i]; u[(size_t)j * ld + i] = uj; }
     df[j] = (KERNEL == TPH_KERNEL_TPCN) ? uj - mu[j] : uj;
   }
   __syncthreads();
+  if (pd && l == 0) pend[i] = 0;                 // every lane of the group has read the flag before the barrier
   double a_fac = 1.0, b_fac = sigma, m_u = 0.0;
   double nu = 0.0, gshape = 1.0;
   if (KERNEL == TPH_KERNEL_TPCN) {
@@ -402,10 +410,10 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(const double* __restr
 }
 
 template <int KERNEL, int LPP>
-static int launch_propose_ml(tph_ctx* ctx, const double* u, const int32_t* assign, int64_t n, int64_t ld, const double* means,
+static int launch_propose_ml(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n, int64_t ld, const double* means,
                              const double* chol, const double* winv, const double* dof, const double* sigmas,
                              const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0, double* up, double* mu_,
-                             double* mup) {
+                             double* mup, uint8_t* pend) {
   constexpr int PPB = ML_THREADS / LPP;
   const int d = ctx->d;
   const size_t base = sizeof(double) * 3 * (size_t)PPB * (d | 1);
@@ -421,7 +429,7 @@ static int launch_propose_ml(tph_ctx* ctx, const double* u, const int32_t* assig
       TPH_HIP(hipFuncSetAttribute((const void*)k_propose_ml<KERNEL, LPP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)lds));                                                                          \
     hipLaunchKernelGGL((k_propose_ml<KERNEL, LPP, ST>), grid, dim3(ML_THREADS), lds, ctx->stream, u, assign, n, ld, d, means, \
-                       chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup);                                  \
+                       chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend);                            \
   } while (0)
   if (stage == 1) TPH_ML_LAUNCH(1);
   else if (stage == 2) TPH_ML_LAUNCH(2);
@@ -461,13 +469,13 @@ __device__ __forceinline__ void wave_sync() {
 constexpr int REG_MAX_TILES = 8;
 
 template <int KERNEL, int D, bool ONE_MODE, int WPE, bool HAS_BC>
-__global__ void __launch_bounds__(64, WPE) k_propose_reg(const double* __restrict__ u, const int32_t* __restrict__ assign,
+__global__ void __launch_bounds__(64, WPE) k_propose_reg(double* __restrict__ u, const int32_t* __restrict__ assign,
                                                          int64_t n, int64_t ld, const double* __restrict__ means,
                                                          const double* __restrict__ chol, const double* __restrict__ winv,
                                                          const double* __restrict__ dof, const double* __restrict__ sigmas,
                                                          const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                          int64_t item0, double* __restrict__ up, double* __restrict__ maha_u,
-                                                         double* __restrict__ maha_up, int tiles) {
+                                                         double* __restrict__ maha_up, int tiles, uint8_t* __restrict__ pend) {
   constexpr int NPW = 64 * REG_MAX_TILES;
   __shared__ double s_bfac[NPW];
   __shared__ int s_list[2][NPW];
@@ -475,7 +483,76 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(const double* __restric
   constexpr int NP = (D + 1) / 2;
   // local particle id pid = k * 64 + lane  <->  global row (blockIdx.x + k * gridDim.x) * 64 + lane
   auto row_of = [&](int pid) { return ((int64_t)blockIdx.x + (int64_t)(pid >> 6) * gridDim.x) * 64 + (pid & 63); };
-  // ---- phase A: every particle of the wave: Mahalanobis at u and the Gamma scale (one draw, reused by redraws)
+
+  // One attempt `att` for particle i (mode c) from its current point uc: z <- the proposal; returns in-bounds?
+  // (mcmc.py:239-249 tpCN / :301-312 RWM; att == PROP_MAX_ATTEMPTS: the redraw cap, the current point is proposed.)
+  auto attempt = [&](int64_t i, int c, int att, double b_fac, const double (&uc)[D], double (&z)[D]) -> bool {
+    const double* __restrict__ mu = means + (size_t)c * D;
+    const double* __restrict__ L = chol + (size_t)c * D * D;
+    bool ok = true;
+    if (att < PROP_MAX_ATTEMPTS) {
+      // the normals of this attempt: a ROLLED loop over the Box-Muller pairs writing a private array (dynamic index ->
+      // scratch memory, 8 B per value and lane, L1/L2-resident): one Philox / log / sincospi body with ~30 live
+      // registers instead of ceil(D/2) interleaved copies
+      double zb[2 * NP];
+      tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
+#pragma unroll 1
+      for (int p = 0; p < NP; ++p) {
+        double z0, z1;
+        gz.normal2((uint32_t)(att * NP + p), z0, z1);
+        zb[2 * p] = z0;
+        zb[2 * p + 1] = z1;
+      }
+#pragma unroll
+      for (int j = 0; j < D; ++j) z[j] = zb[j];
+      if (ONE_MODE) L = tph_opaque(L);
+      const double sigma = sigmas[c];
+      const double a_fac = (KERNEL == TPH_KERNEL_TPCN) ? tph_sqrt(1.0 - sigma * sigma) : 1.0;
+#pragma unroll
+      for (int r = D - 1; r >= 0; --r) {  // descending: slot r is free once row r is done
+        if (ONE_MODE && (r == (2 * D) / 3 || r == D / 3)) L = tph_opaque(L);
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j <= r; ++j) acc = fma(L[r * D + j], z[j], acc);
+        double v;
+        if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * (uc[r] - mu[r]) + b_fac * acc;
+        else v = uc[r] + b_fac * acc;
+        if (HAS_BC) {       // periodic / reflective dimensions (mcmc.py:326-366): a separate instantiation, so that
+                            // the usual all-strict case carries none of the fmod code in its unrolled rows
+          const uint8_t f = bc[r];
+          if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
+          else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
+          else ok = ok && (v >= 0.0) && (v <= 1.0);
+        } else {
+          ok = ok && (v >= 0.0) && (v <= 1.0);
+        }
+        z[r] = v;
+      }
+    } else {  // redraw cap reached (the reference would loop on): propose the current point
+#pragma unroll
+      for (int j = 0; j < D; ++j) z[j] = (KERNEL == TPH_KERNEL_TPCN) ? (uc[j] - mu[j]) + mu[j] : uc[j];
+    }
+    return ok;
+  };
+  // the winning attempt's outputs: u' and its Mahalanobis form
+  auto commit = [&](int64_t i, int c, double (&z)[D]) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) up[(size_t)j * ld + i] = z[j];
+    double m_up = 0.0;
+    if (KERNEL == TPH_KERNEL_TPCN) {
+      const double* __restrict__ mu = means + (size_t)c * D;
+      const double* __restrict__ W = winv + (size_t)c * D * D;
+      if (ONE_MODE) W = tph_opaque(W);
+#pragma unroll
+      for (int j = 0; j < D; ++j) z[j] -= mu[j];
+      m_up = maha_w<D, ONE_MODE>(W, z);
+    }
+    if (maha_up) maha_up[i] = m_up;
+  };
+
+  // ---- phase A, tile by tile: resolve a pending accepted move; Mahalanobis at u and the Gamma scale (one draw, reused
+  // by the redraws).  (Fusing attempt 0 into this loop -- the current point stays in registers -- was measured SLOWER:
+  // the longer live ranges spill, 79.5 -> 84 us at 1 048 576 particles.)
   int count = 0;
 #pragma unroll 1
   for (int t = 0; t < tiles; ++t) {
@@ -483,6 +560,14 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(const double* __restric
     const int64_t i = row_of(pid);
     double b_fac = 0.0;
     if (i < n) {
+      // deferred Metropolis update (tph_accept with a pending mask): the previous step's accepted proposal becomes the
+      // current point HERE.  As a kernel of its own the masked in-place copy is a bandwidth-bound read-modify-write of
+      // every line of u (50 us at 1 048 576 x 10-D); here it costs ~25 us beside this kernel's FP64 work.
+      if (pend && pend[i]) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) u[(size_t)j * ld + i] = up[(size_t)j * ld + i];
+        pend[i] = 0;
+      }
       const int c = ONE_MODE ? 0 : assign[i];
       const double sigma = sigmas[c];
       b_fac = sigma;
@@ -531,9 +616,8 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(const double* __restric
       const int slot = wl / G, att = a0 + (wl % G);
       bool busy = slot < count && att <= PROP_MAX_ATTEMPTS;
       bool ok = false;
-      int pid = 0;
+      int pid = 0, c = 0;
       int64_t i = 0;
-      int c = 0;
       double z[D];
       if (busy) {
         pid = round == 0 ? slot : s_list[cur][slot];
@@ -542,62 +626,10 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(const double* __restric
       }
       if (busy) {
         c = ONE_MODE ? 0 : assign[i];
-        const double* __restrict__ mu = means + (size_t)c * D;
-        const double* __restrict__ L = chol + (size_t)c * D * D;
-        ok = true;
-        if (att < PROP_MAX_ATTEMPTS) {
-          // the normals of this attempt: a ROLLED loop over the Box-Muller pairs writing a private array (dynamic index ->
-          // scratch memory, 8 B per value and lane, L1/L2-resident): one Philox / log / sincospi body with ~30 live
-          // registers instead of ceil(D/2) interleaved copies, so that twice as many waves fit on a SIMD -- the kernel is
-          // bound by dependent FP64 chains (PMC: issue stalls 40 % of the wave-cycles at 4 waves per SIMD), not by
-          // instruction count alone
-          double zb[2 * NP];
-          tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
-#pragma unroll 1
-          for (int p = 0; p < NP; ++p) {
-            double z0, z1;
-            gz.normal2((uint32_t)(att * NP + p), z0, z1);
-            zb[2 * p] = z0;
-            zb[2 * p + 1] = z1;
-          }
+        double uc[D];
 #pragma unroll
-          for (int j = 0; j < D; ++j) z[j] = zb[j];
-        }
-        if (ONE_MODE) L = tph_opaque(L);
-        const double sigma = sigmas[c];
-        const double b_fac = s_bfac[pid];
-        const double a_fac = (KERNEL == TPH_KERNEL_TPCN) ? tph_sqrt(1.0 - sigma * sigma) : 1.0;
-        double df[D];
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          double uj = u[(size_t)j * ld + i];
-          df[j] = (KERNEL == TPH_KERNEL_TPCN) ? uj - mu[j] : uj;
-        }
-        if (att < PROP_MAX_ATTEMPTS) {
-#pragma unroll
-          for (int r = D - 1; r >= 0; --r) {  // descending: slot r is free once row r is done
-            if (ONE_MODE && (r == (2 * D) / 3 || r == D / 3)) L = tph_opaque(L);
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j <= r; ++j) acc = fma(L[r * D + j], z[j], acc);
-            double v;
-            if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * df[r] + b_fac * acc;
-            else v = df[r] + b_fac * acc;
-            if (HAS_BC) {       // periodic / reflective dimensions (mcmc.py:326-366): a separate instantiation, so that
-                                // the usual all-strict case carries none of the fmod code in its unrolled rows
-              const uint8_t f = bc[r];
-              if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
-              else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
-              else ok = ok && (v >= 0.0) && (v <= 1.0);
-            } else {
-              ok = ok && (v >= 0.0) && (v <= 1.0);
-            }
-            z[r] = v;
-          }
-        } else {  // redraw cap reached (the reference would loop on): propose the current point
-#pragma unroll
-          for (int j = 0; j < D; ++j) z[j] = (KERNEL == TPH_KERNEL_TPCN) ? df[j] + mu[j] : df[j];
-        }
+        for (int j = 0; j < D; ++j) uc[j] = u[(size_t)j * ld + i];
+        ok = attempt(i, c, att, s_bfac[pid], uc, z);
       }
       // first in-bounds attempt of each particle: its G lanes are consecutive lanes of the wave (G <= 64 divides 64)
       const unsigned long long okmask = __ballot(ok);
@@ -605,20 +637,7 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(const double* __restric
       const unsigned long long grp = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << g0;
       const unsigned long long mine = okmask & grp;
       const bool winner = ok && (mine & ((1ull << lane) - 1ull)) == 0ull;
-      if (winner) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) up[(size_t)j * ld + i] = z[j];
-        double m_up = 0.0;
-        if (KERNEL == TPH_KERNEL_TPCN) {
-          const double* __restrict__ mu = means + (size_t)c * D;
-          const double* __restrict__ W = winv + (size_t)c * D * D;
-          if (ONE_MODE) W = tph_opaque(W);
-#pragma unroll
-          for (int j = 0; j < D; ++j) z[j] -= mu[j];
-          m_up = maha_w<D, ONE_MODE>(W, z);
-        }
-        if (maha_up) maha_up[i] = m_up;
-      }
+      if (winner) commit(i, c, z);
       // particles whose G attempts all left the cube go to the next round's list, in lane order
       const bool again = busy && mine == 0ull && (lane & (G - 1)) == 0;
       const unsigned long long amask = __ballot(again);
@@ -632,10 +651,10 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(const double* __restric
 }
 
 template <int KERNEL, int D>
-static void launch_propose_reg(tph_ctx* ctx, const double* u, const int32_t* assign, int64_t n, int64_t ld,
+static void launch_propose_reg(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n, int64_t ld,
                                const double* means, const double* chol, const double* winv, const double* dof,
                                const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
-                               double* up, double* mu_, double* mup) {
+                               double* up, double* mu_, double* mup, uint8_t* pend) {
   // one resident batch: waves = min(tiles, 4 per SIMD x SIMDs), tiles of a wave = ceil(tiles / waves) <= REG_MAX_TILES
   // (TPH_OPT_REDRAW_LANES = t > 0 forces t tiles per wave: experiments)
   constexpr int WPE = 4;
@@ -648,7 +667,7 @@ static void launch_propose_reg(tph_ctx* ctx, const double* u, const int32_t* ass
   waves = (ntiles + tiles - 1) / tiles;
 #define TPH_REG_LAUNCH(ONE, BC)                                                                                         \
   hipLaunchKernelGGL((k_propose_reg<KERNEL, D, ONE, WPE, BC>), dim3((unsigned)waves), dim3(64), 0, ctx->stream, u, assign, n, ld, \
-                     means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, tiles)
+                     means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, tiles, pend)
   if (assign == nullptr) { if (bc) TPH_REG_LAUNCH(true, true); else TPH_REG_LAUNCH(true, false); }
   else { if (bc) TPH_REG_LAUNCH(false, true); else TPH_REG_LAUNCH(false, false); }
 #undef TPH_REG_LAUNCH
@@ -659,18 +678,18 @@ static void launch_propose_reg(tph_ctx* ctx, const double* u, const int32_t* ass
     if (kernel == TPH_KERNEL_TPCN)                                                                                 \
       launch_propose_reg<TPH_KERNEL_TPCN, DD>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, \
                                               sigmas_dev, bc_dev, seed, tick, item0, uprime_dev, maha_u_dev,       \
-                                              maha_up_dev);                                                        \
+                                              maha_up_dev, pending_dev);                                           \
     else                                                                                                           \
       launch_propose_reg<TPH_KERNEL_RWM, DD>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev,  \
                                              sigmas_dev, bc_dev, seed, tick, item0, uprime_dev, maha_u_dev,        \
-                                             maha_up_dev);                                                         \
+                                             maha_up_dev, pending_dev);                                            \
     break;
 
-extern "C" int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const int32_t* assign_dev, int64_t n, int64_t ld,
+extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_t* assign_dev, int64_t n, int64_t ld,
                            int K, const double* means_dev, const double* chol_dev, const double* cholinv_dev,
                            const double* dof_dev, const double* sigmas_dev, const uint8_t* bc_dev, uint64_t seed,
                            uint32_t tick0, int64_t item0, double* uprime_dev, double* maha_u_dev, double* maha_up_dev,
-                           const double* ctl_dev) {
+                           const double* ctl_dev, uint8_t* pending_dev) {
   TPH_REQUIRE(ctx && u_dev && uprime_dev && chol_dev && sigmas_dev, "tph_propose: NULL argument");
   const tph_stepctl tick{tick0, ctl_dev};
   TPH_REQUIRE(n > 0 && ld >= n && K >= 1, "tph_propose: bad sizes");
@@ -703,10 +722,10 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const 
   case LL:                                                                                                               \
     if (kernel == TPH_KERNEL_TPCN)                                                                                       \
       rc_ml = launch_propose_ml<TPH_KERNEL_TPCN, LL>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, \
-                                             sigmas_dev, bc_dev, seed, tick, item0, uprime_dev, maha_u_dev, maha_up_dev); \
+                                             sigmas_dev, bc_dev, seed, tick, item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev); \
     else                                                                                                                 \
       rc_ml = launch_propose_ml<TPH_KERNEL_RWM, LL>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, \
-                                            sigmas_dev, bc_dev, seed, tick, item0, uprime_dev, maha_u_dev, maha_up_dev);  \
+                                            sigmas_dev, bc_dev, seed, tick, item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev);  \
     break;
     int rc_ml = 0;
     switch (lpp) { TPH_ML(4) TPH_ML(8) TPH_ML(16) TPH_ML(32) TPH_ML(64) }
@@ -733,13 +752,13 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, const double* u_dev, const 
       TPH_HIP(hipFuncSetAttribute((const void*)k_propose<TPH_KERNEL_TPCN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_propose<TPH_KERNEL_TPCN>, dim3(grid), dim3(PROP_THREADS), lds, ctx->stream, u_dev, assign_dev, n, ld,
                        ctx->d, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick, item0, uprime_dev,
-                       maha_u_dev, maha_up_dev);
+                       maha_u_dev, maha_up_dev, pending_dev);
   } else {
     if (lds > 64 * 1024)
       TPH_HIP(hipFuncSetAttribute((const void*)k_propose<TPH_KERNEL_RWM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_propose<TPH_KERNEL_RWM>, dim3(grid), dim3(PROP_THREADS), lds, ctx->stream, u_dev, assign_dev, n, ld,
                        ctx->d, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick, item0, uprime_dev,
-                       maha_u_dev, maha_up_dev);
+                       maha_u_dev, maha_up_dev, pending_dev);
   }
   TPH_LAUNCH_CHECK();
   return 0;
@@ -758,7 +777,8 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accept(double beta, double* __r
                                                         double* __restrict__ maha_u, const double* __restrict__ maha_up,
                                                         const int32_t* __restrict__ assign, int64_t n, int64_t ld, int d, int K,
                                                         const double* __restrict__ dof, uint64_t seed, tph_stepctl tick,
-                                                        int64_t item0, double* __restrict__ partials) {
+                                                        int64_t item0, double* __restrict__ partials,
+                                                        uint8_t* __restrict__ pend) {
   if (tick.done()) return;              // a step launched past the stopping rule (replayed graph) changes nothing
   if (tick.ctl) beta = tick.ctl[6];
   int64_t i = (int64_t)blockIdx.x * ACC_THREADS + threadIdx.x;
@@ -780,7 +800,16 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accept(double beta, double* __r
     tph_rng g(seed, tick, TPH_TAG_ACCEPT, (uint64_t)(item0 + i));
     double U, U1;
     g.uniform2(0, U, U1);
-    if (U < a) {
+    if (pend) {
+      // deferred mode: the decision is recorded, u stays as it is -- the next tph_propose (given the same mask) moves the
+      // accepted proposals into place under its own compute.  What remains here are whole-line streams: 8 B scalars
+      // read and written for EVERY row (no partial lines), 1 B of mask.
+      const bool take = U < a;
+      acc = take ? 1.0 : 0.0;
+      pend[i] = take ? 1 : 0;
+      logl[i] = take ? l1 : l0;
+      if (KERNEL == TPH_KERNEL_TPCN) maha_u[i] = take ? maha_up[i] : maha_u[i];
+    } else if (U < a) {
       acc = 1.0;
       for (int j = 0; j < d; ++j) u[(size_t)j * ld + i] = up[(size_t)j * ld + i];
       if (x)
@@ -817,8 +846,9 @@ extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, 
                           const double* uprime_dev, const double* xprime_dev, const double* loglprime_dev,
                           double* maha_u_dev, const double* maha_up_dev, const int32_t* assign_dev, int64_t n,
                           int64_t ld, int K, const double* dof_dev, uint64_t seed, uint32_t tick0, int64_t item0,
-                          double* sums_dev, const double* ctl_dev, double* partials_dev) {
+                          double* sums_dev, const double* ctl_dev, double* partials_dev, uint8_t* pending_dev) {
   const tph_stepctl tick{tick0, ctl_dev};
+  TPH_REQUIRE(!pending_dev || !x_dev, "tph_accept: deferred mode (pending_dev) does not maintain x: pass x_dev = xprime_dev = NULL");
   TPH_REQUIRE(ctx && u_dev && logl_dev && uprime_dev && loglprime_dev, "tph_accept: NULL argument");
   TPH_REQUIRE((x_dev == nullptr) == (xprime_dev == nullptr), "tph_accept: x_dev and xprime_dev go together (both NULL = x is not maintained)");
   TPH_REQUIRE(sums_dev || partials_dev, "tph_accept: without sums_dev the block partials must go to partials_dev");
@@ -837,11 +867,11 @@ extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, 
   if (kernel == TPH_KERNEL_TPCN)
     hipLaunchKernelGGL(k_accept<TPH_KERNEL_TPCN>, dim3(grid), dim3(ACC_THREADS), 0, ctx->stream, beta, u_dev, x_dev, logl_dev,
                        uprime_dev, xprime_dev, loglprime_dev, maha_u_dev, maha_up_dev, assign_dev, n, ld, ctx->d, K, dof_dev,
-                       seed, tick, item0, partials);
+                       seed, tick, item0, partials, pending_dev);
   else
     hipLaunchKernelGGL(k_accept<TPH_KERNEL_RWM>, dim3(grid), dim3(ACC_THREADS), 0, ctx->stream, beta, u_dev, x_dev, logl_dev,
                        uprime_dev, xprime_dev, loglprime_dev, maha_u_dev, maha_up_dev, assign_dev, n, ld, ctx->d, K, dof_dev,
-                       seed, tick, item0, partials);
+                       seed, tick, item0, partials, pending_dev);
   if (sums_dev)
     hipLaunchKernelGGL(k_colsum, dim3(1 + K), dim3(256), 0, ctx->stream, partials, (int)grid, 1 + K, sums_dev, tick);
   TPH_LAUNCH_CHECK();

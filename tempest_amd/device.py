@@ -303,7 +303,8 @@ class HipContext:
                                       item0, _ptr(stats)), "tph_inf_repair")
         return stats
 
-    def propose(self, kernel, u, assign, modes, sigmas, bc, seed, tick, item0, uprime, maha_u, maha_up, ctl=None):
+    def propose(self, kernel, u, assign, modes, sigmas, bc, seed, tick, item0, uprime, maha_u, maha_up, ctl=None,
+                pending=None):
         n = u.shape[1]
         if ctl is not None and ctl.numel() < STEP_STATE_LEN:
             raise _lib.TempestHipError(f"propose: the step-control block needs {STEP_STATE_LEN} doubles")
@@ -312,10 +313,11 @@ class HipContext:
                                    _ptr(getattr(modes, "winv_dev", None)),
                                    _ptr(modes.dof_dev), _ptr(sigmas), _ptr(bc) if bc is not None else None, seed, tick,
                                    item0, _ptr(uprime), _ptr(maha_u), _ptr(maha_up),
-                                   _ptr(ctl) if ctl is not None else None), "tph_propose")
+                                   _ptr(ctl) if ctl is not None else None,
+                                   _ptr(pending, torch.uint8) if pending is not None else None), "tph_propose")
 
     def accept(self, kernel, beta, u, x, logl, uprime, xprime, loglprime, maha_u, maha_up, assign, K, dof, seed,
-               tick, item0, sums, ctl=None, partials=None):
+               tick, item0, sums, ctl=None, partials=None, pending=None):
         n = u.shape[1]
         if partials is not None and partials.numel() < ((n + 255) // 256) * (1 + K):
             raise _lib.TempestHipError("accept: partials buffer too small")
@@ -326,7 +328,8 @@ class HipContext:
                                   _ptr(assign, torch.int32) if assign is not None else None, n, n, K, _ptr(dof), seed,
                                   tick, item0, _ptr(sums) if sums is not None else None,
                                   _ptr(ctl) if ctl is not None else None,
-                                  _ptr(partials) if partials is not None else None), "tph_accept")
+                                  _ptr(partials) if partials is not None else None,
+                                  _ptr(pending, torch.uint8) if pending is not None else None), "tph_accept")
 
     def adapt(self, kernel, sums, counts, K, n_global, n_steps, n_max, sigmas, state, mailbox=None, partials=None, n=0):
         """mailbox: pinned host tensor (slots, 8) the step record is also written to (polled by the host);

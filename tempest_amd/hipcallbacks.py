@@ -108,7 +108,7 @@ class HipCallbacks:
         lib.tphu_prior.argtypes = [ptr, ptr, i64, i64, ptr, i64]
         lib.tphu_like.argtypes = [ptr, ptr, i64, i64, ptr]
         lib.tphu_accept.argtypes = [ptr, C.c_int, C.c_double, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, C.c_int, ptr,
-                                    C.c_uint64, C.c_uint32, i64, ptr, ptr, ptr]
+                                    C.c_uint64, C.c_uint32, i64, ptr, ptr, ptr, ptr]
         lib.tphu_step.argtypes = [ptr, C.c_int, C.c_double, ptr, ptr, ptr, i64, i64, ptr, ptr, ptr, ptr, ptr, ptr, C.c_uint64,
                                   C.c_uint32, C.c_uint32, i64, ptr, ptr, C.c_int]
         for f in (lib.tphu_prior, lib.tphu_like, lib.tphu_accept, lib.tphu_step):
@@ -168,7 +168,7 @@ class HipCallbacks:
 
     # ------------------------------------------------------------------------------ fused MCMC step
     def accept(self, kernel_id, beta, u, x, logl, uprime, maha_u, maha_up, assign, K, dof, seed, tick, item0, sums,
-               ctl=None, partials=None):
+               ctl=None, partials=None, pending=None):
         """tph_accept with the two callbacks evaluated inside the kernel (u, x: (d, n) SoA tensors, updated in place)."""
         n = u.shape[1]
         if partials is None or partials.numel() < ((n + 255) // 256) * (1 + K):
@@ -179,7 +179,7 @@ class HipCallbacks:
         p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         self._check(self.lib.tphu_accept(self._stream(u), int(kernel_id), float(beta), p(u), p(x), p(logl), p(uprime),
                                          p(maha_u), p(maha_up), p(assign), n, n, int(K), p(dof), int(seed), int(tick),
-                                         int(item0), p(sums), p(ctl), p(partials)), "tphu_accept")
+                                         int(item0), p(sums), p(ctl), p(partials), p(pending)), "tphu_accept")
 
 
     def can_fuse_step(self, K, has_assign, n) -> bool:

@@ -96,6 +96,9 @@ class StepEngine:
         self.has_assign = has_assign
         self.sigmas, self.counts, self.sums = ctx.empty(K), ctx.empty(K), ctx.zeros(1 + K)
         self.partials = ctx.empty(((n + 255) // 256) * (1 + K))     # fixed address: the library's scratch may move
+        # deferred Metropolis update: tph_accept records the decisions here, the NEXT tph_propose moves the accepted
+        # proposals into place (its FP64 work hides the copy; in place it was a bandwidth-bound kernel of its own)
+        self.pending = torch.zeros(n, dtype=torch.uint8, device=ctx.device)
         from .device import STEP_STATE_LEN
         self.ctl = ctx.zeros(STEP_STATE_LEN)
         self.ctl_host = torch.zeros(STEP_STATE_LEN, dtype=torch.float64).pin_memory()
@@ -125,6 +128,7 @@ class StepEngine:
         else:
             self.u, self.logl, self.assign, self.modes = u, logl, assign, modes
         self.sigmas.fill_(sigma_init)
+        self.pending.zero_()
         self.counts.copy_(counts)
         self.mailbox_np[:, 7] = -1.0          # no record yet (the device is idle or running no-op steps: see step())
         h = self.ctl_host
@@ -145,7 +149,7 @@ class StepEngine:
             self._adapt(fold=True)
             return None, None
         ctx.propose(self.kernel, self.u, self.assign, self.modes, self.sigmas, self.bc, self.seed, 1, self.item0,
-                    self.up, self.maha_u, self.maha_up, ctl=self.ctl)
+                    self.up, self.maha_u, self.maha_up, ctl=self.ctl, pending=self.pending)
         # one GPU: the block partials of the Metropolis kernel are summed inside tph_adapt (one launch less per step);
         # several: their sums are all-reduced between the two
         sums = self.sums if self.comm_active else None
@@ -154,13 +158,13 @@ class StepEngine:
             xp = lp = None
             self.plugin.accept(KERNEL_ID[self.kernel], 0.0, self.u, None, self.logl, self.up, self.maha_u, self.maha_up,
                                self.assign, self.K, self.modes.dof_dev, self.seed, 2, self.item0, sums,
-                               ctl=self.ctl, partials=self.partials)
+                               ctl=self.ctl, partials=self.partials, pending=self.pending)
         else:
             xp = self.prior(self.up)
             lp = self.loglike(xp)
             ctx.accept(self.kernel, 0.0, self.u, None, self.logl, self.up, xp, lp, self.maha_u, self.maha_up,
                        self.assign, self.K, self.modes.dof_dev, self.seed, 2, self.item0, sums, ctl=self.ctl,
-                       partials=self.partials)
+                       partials=self.partials, pending=self.pending)
         if not self.comm_active:
             self._adapt(fold=True)
         return xp, lp

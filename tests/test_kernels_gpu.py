@@ -601,3 +601,57 @@ def test_global_entry_points_loopback_match_plain(dev, T, rows):
     fl = loop.fit_modes(counts, labels, K=2, global_=True)
     assert torch.equal(fp[0], fl[0])
     np.testing.assert_allclose(fl[1].cpu().numpy(), fp[1].cpu().numpy(), rtol=1e-11, atol=1e-14)
+
+
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+@pytest.mark.parametrize("variant", ["registers_d7", "multilane_d7", "generic_d7", "multilane_d19", "registers_d10"])
+def test_deferred_metropolis_update_equals_in_place(dev, kernel, variant):
+    """tph_accept in deferred mode (decision -> pending mask, u untouched) followed by tph_propose with that mask (accepted
+    proposals moved into place, then proposed from) is the same chain, bit for bit, as the in-place update: same proposals,
+    same log-likelihoods and Mahalanobis forms after every step, and the same u once the last mask has been resolved."""
+    rs = np.random.RandomState(23)
+    d, n, K = int(variant.split("_d")[1]), 70_000 if variant == "registers_d10" else 6000, 2
+    means = 0.5 + 0.05 * rs.randn(K, d)
+    covs = np.empty((K, d, d))
+    for k in range(K):
+        A = rs.randn(d, d) * 0.07
+        covs[k] = A @ A.T + 1e-3 * np.eye(d)
+    _, chol, inv = ps.mode_statistics(means, covs)
+    dof = np.array([1e6, 6.0])
+    sigmas = np.array([0.7, 0.4]) * (2.38 / np.sqrt(d) if kernel == "rwm" else 1.0)
+    assign = rs.randint(K, size=n).astype(np.int32)
+    u0 = np.clip(means[assign] + 0.15 * rs.randn(n, d), 0.01, 0.99)
+    c = ctx_for(d)
+    c.set_option(0, {"multilane": 3, "generic": 1, "registers": 2}[variant.split("_")[0]])
+    modes = _Modes(means, chol, inv, dof, dev)
+    at, st = torch.from_numpy(assign).to(dev), torch.from_numpy(sigmas).to(dev)
+
+    def like(up):
+        x = 20 * up - 10
+        return -0.5 * (x * x).sum(dim=0) * 0.05
+
+    def chain(deferred):
+        u = soa(u0, dev)
+        logl = like(u).clone()
+        up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+        sums = c.empty(1 + K)
+        pend = torch.zeros(n, dtype=torch.uint8, device=dev) if deferred else None
+        trace = []
+        for step in range(4):
+            tick = 50 + 2 * step
+            c.propose(kernel, u, at, modes, st, None, 99, tick, 7, up, mu_, mup, pending=pend)
+            lp = like(up)
+            c.accept(kernel, 0.8, u, None, logl, up, None, lp, mu_, mup, at, K, modes.dof_dev, 99, tick + 1, 7, sums, pending=pend)
+            trace.append((up.clone(), logl.clone(), mu_.clone(), sums.clone()))
+        if deferred:
+            assert int(pend.sum().item()) > 0                 # moves are waiting
+            c.propose(kernel, u, at, modes, st, None, 99, 999, 7, up, mu_, mup, pending=pend)   # any later proposal resolves them
+            assert int(pend.sum().item()) == 0
+        return u, trace
+    ua, ta = chain(False)
+    ub, tb = chain(True)
+    for a, b in zip(ta, tb):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert torch.equal(ua, ub)
+    assert 0.05 < float(ta[-1][3][0]) / n < 0.95            # a real mix of accepted and rejected moves

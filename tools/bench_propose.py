@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--accept", action="store_true")
     ap.add_argument("--nocarry", action="store_true")
     ap.add_argument("--wpe", type=int, default=0, help="experiment knob (TPH_OPT_REDRAW_LANES)")
+    ap.add_argument("--pending", type=float, default=0.0,
+                    help="fraction of particles with a pending accepted move to resolve (deferred tph_accept), per launch")
     a = ap.parse_args()
     import torch
     from tempest_amd import _lib
@@ -74,9 +76,17 @@ def main():
         ctl = torch.zeros(10, dtype=torch.float64, device=dev)
         p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None   # noqa: E731
 
+        pend = torch.zeros(n, dtype=torch.uint8, device=dev)
+        pmask = (torch.rand(n, device=dev) < a.pending).to(torch.uint8)
+
         def propose(tick, carry):
-            rc = lib.tph_propose(ctx, kid, p(u), None, n, n, 1, p(means), p(chol), p(mat), p(dof), p(sig), None, 12345, tick, 0,
-                                 p(up), p(mu_), p(mup), p(ctl) if carry else None)
+            args = [ctx, kid, p(u), None, n, n, 1, p(means), p(chol), p(mat), p(dof), p(sig), None, 12345, tick, 0,
+                    p(up), p(mu_), p(mup), p(ctl) if carry else None]
+            if not a.legacy:
+                if a.pending > 0:
+                    pend.copy_(pmask)
+                args.append(p(pend) if a.pending > 0 else None)
+            rc = lib.tph_propose(*args)
             assert rc == 0, lib.tph_last_error()
         propose(1, False)            # fills maha_u
         torch.cuda.synchronize()
@@ -93,13 +103,16 @@ def main():
         ts = []
         for r in range(a.reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if a.pending > 0:
+                pend.copy_(pmask)
+                up.copy_(u)          # resolving copies u' over u: keep the ensemble where it is
             e0.record()
             propose(2 + 2 * r, not a.nocarry)
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
         out = {"what": "tph_propose", "lib": os.path.basename(a.lib or "libtempest_hip.so"), "kernel": a.kernel, "n": n, "d": d,
-               "scenario": scen, "variant": a.variant, "carry": not a.nocarry, "median_us": round(float(np.median(ts)), 2),
+               "scenario": scen, "variant": a.variant, "carry": not a.nocarry, "pending_fraction": a.pending, "median_us": round(float(np.median(ts)), 2),
                "min_us": round(float(np.min(ts)), 2), "first_attempt_in_bounds": inb, "fell_back_to_current": same,
                "algorithmic_bytes": (16 * d + 4 + 16) * n,
                "GBps_algorithmic": round((16 * d + 20) * n / np.median(ts) / 1e3, 1)}
