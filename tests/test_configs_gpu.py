@@ -188,3 +188,123 @@ def test_config3_twin_matches_reference_ensemble():
     assert np.all(np.abs(got - mu) <= 3 * sd + 0.15), (got, mu, sd)
     assert abs(got.mean() - mu) < 3 * sd / np.sqrt(6) + 0.1
     assert abs(np.mean(its) - np.mean([r["iters"] for r in runs])) <= 3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json's configurations at THEIR sizes on one MI355X: the sizes the kernels are tuned for.
+def test_config3_fullsize_262144_clustering():
+    """Config 3 as stated: 32-D four-mode mixture, 262 144 particles, clustering=True.  Evidence window as the 65 536 run
+    (the algorithm's own excess at d = 32 is about +1), the four modes equally occupied, cluster count as the reference's
+    twin ensemble (K = 1: the BIC on the unweighted likelihood does not split this target)."""
+    import tempest_amd as tp
+    dev = torch.device("cuda", 0)
+    d, n = 32, 262144
+    mus = torch.zeros(4, d, dtype=torch.float64, device=dev)
+    for k, (a, b) in enumerate([(-4, -4), (-4, 4), (4, -4), (4, 4)]):
+        mus[k, 0], mus[k, 1] = a, b
+    const = float(-np.log(4.0) - 0.5 * d * np.log(2 * np.pi * 0.25))
+
+    def loglike(x):
+        q = ((x[:, None, :] - mus[None]) ** 2).sum(dim=2)
+        return torch.logsumexp(-0.5 * q / 0.25, dim=1) + const
+    t0 = time.time()
+    s = tp.Sampler(prior20, loglike, d, n_particles=n, vectorize=True, clustering=True, random_state=0,
+                   backend="torch", batch_prior=True)
+    s.run(n_total=4 * n, progress=False)
+    wall = time.time() - t0
+    logz = s.evidence()[0]
+    beta = np.asarray(s.state.get_history("beta")); steps = np.asarray(s.state.get_history("steps"))
+    x, w, _ = s.posterior()
+    occ = [float(np.sum(w[(np.sign(x[:, 0]) == a) & (np.sign(x[:, 1]) == b)])) for a in (-1, 1) for b in (-1, 1)]
+    print(f"config3 full size: logZ={logz:.3f} (analytic {-d * np.log(20):.3f}) iters={len(beta)} wall={wall:.1f}s "
+          f"pms/s={steps[beta > 0].sum() * n / wall:.3g} K={s._core.trainer.clusterer.n_clusters_} occupancy={np.round(occ, 3)}")
+    assert wall < 60.0
+    assert np.all(np.diff(beta) >= 0) and beta[-1] == 1.0
+    assert -0.5 < logz + d * np.log(20.0) < 2.0
+    assert min(occ) > 0.22 and max(occ) < 0.28
+    np.testing.assert_allclose(np.average(x[:, 2:], weights=w, axis=0), 0.0, atol=0.05)
+    np.testing.assert_allclose(np.average(x[:, 2:] ** 2, weights=w, axis=0), 0.25, rtol=0.1)
+
+
+def test_config4_fullsize_1048576_rosenbrock():
+    """Config 4's ensemble on ONE GPU (it fits): 10-D README Rosenbrock, 1 048 576 particles, clustering=False.  logZ within
+    3 sigma_ref of the reference's `c1_rosenbrock_nocluster` ensemble (16 seeds at N = 1000: -29.804 +- 0.115; analytic
+    -29.990), posterior moments against the closed form (E x_even = 1, Var 0.5; E x_odd = 1.5, Var 2.55) at the accuracy the
+    reference ensemble itself reaches."""
+    import tempest_amd as tp
+    mu, sd, runs = _ref("c1_rosenbrock_nocluster")
+    n = 1048576
+
+    def like(x):
+        return -(10.0 * (x[:, ::2] ** 2.0 - x[:, 1::2]) ** 2.0 + (x[:, ::2] - 1.0) ** 2.0).sum(dim=1)
+    t0 = time.time()
+    s = tp.Sampler(prior20, like, 10, n_particles=n, vectorize=True, clustering=False, random_state=0,
+                   backend="torch", batch_prior=True)
+    s.run(n_total=4 * n, progress=False)
+    wall = time.time() - t0
+    logz = s.evidence()[0]
+    beta = np.asarray(s.state.get_history("beta")); steps = np.asarray(s.state.get_history("steps"))
+    x, w, _ = s.posterior()
+    mean = np.average(x, weights=w, axis=0)
+    var = np.average((x - mean) ** 2, weights=w, axis=0)
+    print(f"config4 full size: logZ={logz:.4f} (reference ensemble {mu:.3f} +- {sd:.3f}, analytic -29.990) iters={len(beta)} "
+          f"wall={wall:.1f}s pms/s={steps[beta > 0].sum() * n / wall:.3g} mean={np.round(mean, 3)} var={np.round(var, 3)}")
+    assert wall < 60.0
+    assert abs(logz - mu) <= 3 * sd
+    assert abs(len(beta) - np.mean([r["iters"] for r in runs])) <= 3
+    np.testing.assert_allclose(mean[::2], 1.0, atol=0.05)
+    np.testing.assert_allclose(mean[1::2], 1.5, atol=0.08)
+    np.testing.assert_allclose(var[::2], 0.5, rtol=0.08)
+    np.testing.assert_allclose(var[1::2], 2.55, rtol=0.10)
+
+
+def test_config5_shard_262144_funnel100_first_iterations():
+    """Config 5's single-GPU shard (2 097 152 / 8 = 262 144 particles, 100-D funnel, tpCN) for a fixed number of iterations:
+    the d = 100 kernels at the size they are tuned for.  The whole run is dominated by the reference's redraw-until-in-bounds
+    rule (hundreds of attempts per particle and step near the prior), so the gate is on the first annealing iterations:
+    finite evidence, a monotone schedule that has left beta = 0, sane acceptance, and the redraw probe of the proposal kernel
+    (mean attempts per particle of its first block) recorded."""
+    import tempest_amd as tp
+    dev = torch.device("cuda", 0)
+    d, n = 100, 262144
+    scale = torch.full((d,), 600.0, dtype=torch.float64, device=dev); scale[0] = 30.0
+    shift = torch.full((d,), -300.0, dtype=torch.float64, device=dev); shift[0] = -15.0
+
+    def prior(u):
+        return u * scale + shift
+
+    def loglike(x):
+        v = x[:, 0]
+        lv = -0.5 * (v / 3.0) ** 2 - np.log(3.0) - 0.5 * np.log(2 * np.pi)
+        lr = (-0.5 * (x[:, 1:] ** 2) * torch.exp(-v)[:, None]).sum(dim=1) - 0.5 * (d - 1) * v - 0.5 * (d - 1) * np.log(2 * np.pi)
+        return lv + lr
+    s = tp.Sampler(prior, loglike, d, n_particles=n, vectorize=True, clustering=False, random_state=0,
+                   backend="torch", batch_prior=True)
+    t0 = time.time()
+    attempts = []
+    while True:
+        s.sample(return_state=False)
+        beta = s.state.get_current("beta")
+        if beta > 0.0:
+            eng = next(iter(s._core.mutator._engines.values()), None)
+            if eng is not None:
+                attempts.append(float(eng.mailbox_np[:, 6].max()))
+        if beta > 0.0 and len(attempts) >= 2:
+            break
+        assert time.time() - t0 < 120.0
+    wall = time.time() - t0
+    st = s.state
+    betas = np.asarray(st.get_history("beta")); steps = np.asarray(st.get_history("steps")); acc = np.asarray(st.get_history("acceptance"))
+    logz = np.asarray(st.get_history("logz"))
+    print(f"config5 shard: iterations={len(betas)} beta={betas[-2:]} steps={steps[-2:]} acceptance={np.round(acc[-2:], 3)} "
+          f"logz={logz[-1]:.3f} attempts/particle (probe, max over the run's steps)={attempts} wall={wall:.1f}s "
+          f"pms/s={steps[betas > 0].sum() * n / wall:.3g}")
+    assert wall < 60.0
+    assert np.all(np.isfinite(logz)) and np.all(np.diff(betas) >= 0) and 0.0 < betas[-1] < 1.0
+    assert np.all(steps[betas > 0] >= d)                      # the adaptive rule's floor n_steps * n_dim (mcmc.py:119-131)
+    assert np.all((acc[betas > 0] > 0.02) & (acc[betas > 0] < 0.9))
+    assert all(a >= 1.0 for a in attempts)
+    assert st.ctx.size == n * len(betas)
+    # the ensemble is still inside the prior box and the likelihoods are finite
+    u = st.dev("u")
+    assert bool(((u >= 0) & (u <= 1)).all()) and bool(torch.isfinite(st.dev("logl")).all())
