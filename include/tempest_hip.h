@@ -284,6 +284,13 @@ int tph_weighted_moments_shifted(tph_ctx* ctx, const double* w_dev, int64_t n, c
                                  double* out_dev /*[1 + d + d*d]*/);
 int tph_cv_sum(tph_ctx* ctx, const double* w_dev, int64_t n, const double* mean_dev, const double* covinv_dev,
                double* out_dev /*[1]: sum w^2 dev^2*/);
+/* The whole statistic in one call (tools.py:58-117), d x d work on the device: weighted mean / covariance of the history's
+ * u under the (normalised) weights, the reference's rank rule (rank-deficient: cov += 1e-6 trace I; test = pivoted Cholesky
+ * with the threshold n_dim * eps * trace), Cholesky + triangular inverse, sum_s w_s^2 clip(|L^-1 (u_s - mean)|^2 - n_dim)^2
+ * and 0.5 sqrt(sum / S0^2), or 1e10 where the reference returns it (singular, non-finite).  centre_dev (n_dim doubles, in/out,
+ * optional): a point near the mean (it receives the new mean) enabling the one-pass moments for n_dim <= 12.  One host wait
+ * (pinned mailbox).  With a communicator attached: the statistic of the global weighted history. */
+int tph_volume_variation(tph_ctx* ctx, const double* w_dev, int64_t n, double* centre_dev /*or NULL*/, double* value_host);
 
 /* ---- clustering working set (cluster.py) ---------------------------------------------------------------
  * The hierarchical GMM runs on a compact, [0,1]-normalised SoA copy x[j*ld+i] of the kept (trimmed) history rows. */

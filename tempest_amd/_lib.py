@@ -71,6 +71,7 @@ SIGNATURES = {
     "tph_x_weighted_cov": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr, ptr]),
     "tph_gmm_estep": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr, c_int, c_int, ptr, c_int, c_dbl, ptr, ptr, ptr, ptr, ptr]),
     "tph_cv_sum": (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr]),
+    "tph_volume_variation": (c_int, [ptr, ptr, c_i64, ptr, ptr]),
     "tph_comm_attach": (c_int, [ptr, c_int, c_int, ptr, c_i64, ptr, ptr, ptr]),
     "tph_comm_detach": (c_int, [ptr]),
     "tph_trim_threshold_global": (c_int, [ptr, ptr, c_i64, c_dbl, c_int, ptr, ptr]),

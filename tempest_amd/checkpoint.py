@@ -127,9 +127,15 @@ def save(core, path):
             json.dump(meta, f, indent=1)
             f.flush()
             os.fsync(f.fileno())
+        # replace without a window in which no complete checkpoint exists: old -> .old, new -> path, then drop .old
+        old = path.with_name(path.name + ".old")
+        if old.exists():
+            shutil.rmtree(old)
         if path.exists():
-            shutil.rmtree(path)
+            os.rename(path, old)
         os.rename(tmp, path)
+        if old.exists():
+            shutil.rmtree(old)
     _barrier(comm)
 
 

@@ -29,6 +29,10 @@ class CallbackAdapter:
         self._distribute = get_distribute_func
         from .hipcallbacks import fused_plugin
         self.hip_plugin = fused_plugin(config.prior_transform, config.log_likelihood)   # HipCallbacks pair -> fused step
+        for cb in (config.prior_transform, config.log_likelihood):                       # host inputs land on OUR device
+            owner = getattr(cb, "__self__", None)
+            if owner is not None and hasattr(owner, "_soa"):
+                owner.device = device
 
     # ------------------------------------------------------------------ probing
     def _probe(self):

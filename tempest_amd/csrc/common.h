@@ -47,8 +47,9 @@ struct tph_ctx {
   // iteration table (host mirrors + device copy of (beta_t, -logZ_t + log n_t))
   std::vector<double> beta_t, logz_t;
   std::vector<int64_t> n_local_t, n_global_t;
-  double* table_dev = nullptr;  // [2][table_cap]: beta_t, a_t = log n_t - logZ_t ... see ctx.hip
-  int table_cap = 0;
+  double* table_dev = nullptr;  // [3][table_cap]: beta_t, logZ_t, log n_t
+  double* table_host = nullptr; // pinned mirror; rows [0, table_uploaded) are on the device
+  int table_cap = 0, table_uploaded = 0;
   // scratch
   double* partials = nullptr;       // streaming-reduction block partials
   size_t partials_bytes = 0;
@@ -64,6 +65,9 @@ struct tph_ctx {
   int n_simd = 1024;                // SIMDs of the device (compute units x 4): sizes one-resident-batch launches
   double* winv = nullptr;           // L^-1 per mode, formed by tph_propose when the caller passes cholinv_dev = NULL
   size_t winv_bytes = 0;
+  double* vv_buf = nullptr;         // small persistent buffers of tph_volume_variation (moments, factors, blocked L^-1)
+  size_t vv_bytes = 0;
+  uint64_t vv_seq = 0;
   // ---- communicator (tph_comm_attach): one process per GPU, this ctx holds one shard of every iteration's particles
   int rank = 0, world = 1;
   char* comm_buf = nullptr;         // caller-owned device staging block the collectives operate on (offsets into it)

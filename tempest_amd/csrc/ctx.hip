@@ -37,26 +37,35 @@ static int table_reserve(tph_ctx* ctx, int T) {
   while (nc < T) nc *= 2;
   TPH_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->table_dev) TPH_HIP(hipFree(ctx->table_dev));
-  ctx->table_dev = nullptr;
+  if (ctx->table_host) TPH_HIP(hipHostFree(ctx->table_host));
+  ctx->table_dev = nullptr; ctx->table_host = nullptr; ctx->table_uploaded = 0;
   TPH_HIP(hipMalloc((void**)&ctx->table_dev, sizeof(double) * 3 * (size_t)nc));
+  TPH_HIP(hipHostMalloc((void**)&ctx->table_host, sizeof(double) * 3 * (size_t)nc));
   ctx->table_cap = nc;
   return 0;
 }
 
-// upload (beta_t, logZ_t, log n_t) for t < T
+// (beta_t, logZ_t, log n_t) for t < T on the device.  The host mirror is PINNED and persistent, and only the rows not yet
+// on the device are copied (each row's three entries are written once and never again), so a commit enqueues three small
+// asynchronous copies and does not wait for the stream (the first version re-uploaded the whole table from a temporary
+// vector and synchronised on every commit).
 static int table_upload(tph_ctx* ctx) {
   int T = (int)ctx->beta_t.size();
   if (T == 0) return 0;
   if (table_reserve(ctx, T)) return -1;
-  std::vector<double> h(3 * (size_t)ctx->table_cap, 0.0);
-  for (int t = 0; t < T; ++t) {
-    h[t] = ctx->beta_t[t];
-    h[ctx->table_cap + t] = ctx->logz_t[t];
-    h[2 * (size_t)ctx->table_cap + t] = log((double)ctx->n_global_t[t]);
+  const int cap = ctx->table_cap;
+  if (ctx->table_uploaded > T) ctx->table_uploaded = 0;       // history cleared / reloaded: start over
+  const int t0 = ctx->table_uploaded;
+  for (int t = t0; t < T; ++t) {
+    ctx->table_host[t] = ctx->beta_t[t];
+    ctx->table_host[cap + t] = ctx->logz_t[t];
+    ctx->table_host[2 * (size_t)cap + t] = log((double)ctx->n_global_t[t]);
   }
-  // synchronous copy: the table is tiny and the host vector is about to go out of scope
-  TPH_HIP(hipMemcpyAsync(ctx->table_dev, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream));
-  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  const size_t nb = sizeof(double) * (size_t)(T - t0);
+  for (int k = 0; k < 3; ++k)
+    TPH_HIP(hipMemcpyAsync(ctx->table_dev + (size_t)k * cap + t0, ctx->table_host + (size_t)k * cap + t0, nb, hipMemcpyHostToDevice,
+                           ctx->stream));
+  ctx->table_uploaded = T;
   return 0;
 }
 
@@ -65,27 +74,37 @@ static int history_reserve(tph_ctx* ctx, int64_t need) {
   int64_t nc = ctx->cap ? ctx->cap : 1024;
   while (nc < need) nc *= 2;
   nc = (nc + 255) / 256 * 256;
-  double *nu = nullptr, *nx = nullptr, *nl = nullptr, *nm = nullptr;
-  size_t d = (size_t)ctx->d;
-  TPH_HIP(hipMalloc((void**)&nu, sizeof(double) * d * nc));
-  TPH_HIP(hipMalloc((void**)&nx, sizeof(double) * d * nc));
-  TPH_HIP(hipMalloc((void**)&nl, sizeof(double) * nc));
-  TPH_HIP(hipMalloc((void**)&nm, sizeof(double) * nc));
-  if (ctx->size > 0) {
-    size_t w = sizeof(double) * (size_t)ctx->size;
-    TPH_HIP(hipMemcpy2DAsync(nu, sizeof(double) * nc, ctx->u, sizeof(double) * ctx->cap, w, d,
-                             hipMemcpyDeviceToDevice, ctx->stream));
-    TPH_HIP(hipMemcpy2DAsync(nx, sizeof(double) * nc, ctx->x, sizeof(double) * ctx->cap, w, d,
-                             hipMemcpyDeviceToDevice, ctx->stream));
-    TPH_HIP(hipMemcpyAsync(nl, ctx->logl, w, hipMemcpyDeviceToDevice, ctx->stream));
-    TPH_HIP(hipMemcpyAsync(nm, ctx->cmix, w, hipMemcpyDeviceToDevice, ctx->stream));
+  // all four new arrays are allocated and filled before any old one is released: a failed allocation or copy frees what
+  // it had allocated and leaves the history exactly as it was (the four arrays share one leading dimension, so they
+  // can only be swapped together)
+  const size_t d = (size_t)ctx->d;
+  const size_t w = sizeof(double) * (size_t)ctx->size;
+  struct Arr { double** p; size_t rows; };
+  Arr arrs[4] = {{&ctx->u, d}, {&ctx->x, d}, {&ctx->logl, 1}, {&ctx->cmix, 1}};
+  double* fresh[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int a = 0; a < 4; ++a) {
+    hipError_t e = hipMalloc((void**)&fresh[a], sizeof(double) * arrs[a].rows * nc);
+    if (e != hipSuccess) {
+      for (int b = 0; b < a; ++b) (void)hipFree(fresh[b]);      // nothing has been swapped in yet: no leak, history intact
+      tph_set_error("history_reserve: cannot grow the history to %lld rows (%s)", (long long)nc, hipGetErrorString(e));
+      return -1;
+    }
+    if (ctx->size > 0) {
+      hipError_t c = hipMemcpy2DAsync(fresh[a], sizeof(double) * nc, *arrs[a].p, sizeof(double) * ctx->cap, w, arrs[a].rows,
+                                      hipMemcpyDeviceToDevice, ctx->stream);
+      if (c == hipSuccess) c = hipStreamSynchronize(ctx->stream);
+      if (c != hipSuccess) {
+        for (int b = 0; b <= a; ++b) (void)hipFree(fresh[b]);
+        tph_set_error("history_reserve: copy failed (%s)", hipGetErrorString(c));
+        return -1;
+      }
+    }
   }
   TPH_HIP(hipStreamSynchronize(ctx->stream));
-  if (ctx->u) TPH_HIP(hipFree(ctx->u));
-  if (ctx->x) TPH_HIP(hipFree(ctx->x));
-  if (ctx->logl) TPH_HIP(hipFree(ctx->logl));
-  if (ctx->cmix) TPH_HIP(hipFree(ctx->cmix));
-  ctx->u = nu; ctx->x = nx; ctx->logl = nl; ctx->cmix = nm;
+  for (int a = 0; a < 4; ++a) {
+    if (*arrs[a].p) (void)hipFree(*arrs[a].p);
+    *arrs[a].p = fresh[a];
+  }
   ctx->cap = nc;
   return 0;
 }
@@ -127,9 +146,10 @@ extern "C" int tph_ctx_destroy(tph_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   void* bufs[] = {ctx->u, ctx->x, ctx->logl, ctx->cmix, ctx->table_dev, ctx->partials, ctx->small_dev, ctx->scratch, ctx->winv,
-                  ctx->blk_table};
+                  ctx->blk_table, ctx->vv_buf};
   for (void* b : bufs) (void)hipFree(b);
   (void)hipHostFree(ctx->pinned);
+  if (ctx->table_host) (void)hipHostFree(ctx->table_host);
   delete ctx;
   return 0;
 }
@@ -211,6 +231,7 @@ extern "C" int tph_history_clear(tph_ctx* ctx) {
   TPH_REQUIRE(ctx, "tph_history_clear: ctx is NULL");
   ctx->size = 0;
   ctx->beta_t.clear(); ctx->logz_t.clear(); ctx->n_local_t.clear(); ctx->n_global_t.clear();
+  ctx->table_uploaded = 0;
   return 0;
 }
 

@@ -5,6 +5,7 @@
 // tempest/modes.py:58-119 (chol/inv with ridge), :131-288 (x4 multinomial up-sampling then fit).
 #include "common.h"
 #include "scan.h"
+#include "tri.h"
 
 #include <cstring>
 #include <cstdlib>
@@ -1357,5 +1358,274 @@ extern "C" int tph_cv_sum(tph_ctx* ctx, const double* w_dev, int64_t n, const do
   hipLaunchKernelGGL(k_cv_sum, dim3(nblk), dim3(64), lds, ctx->stream, ctx->u, ctx->cap, d, w_dev, n, mean_dev, covinv_dev, part);
   hipLaunchKernelGGL(k_colsum2, dim3(1), dim3(256), 0, ctx->stream, part, nblk, 1, out_dev);
   TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ---- volume variation in ONE call, d x d work included (tools.py:58-117) -------------------------------------
+// weighted mean / covariance of the history's u  ->  rank test, ridge, Cholesky and triangular inverse of the covariance on
+// the device (one workgroup)  ->  sum_s w_s^2 clip(|L^-1 (u_s - mean)|^2 - d, +-1e6)^2 by the blocked triangular kernel
+// ->  0.5 sqrt(sum / S0^2) delivered through the pinned mailbox.  One host wait per evaluation (the first version made two
+// or three round trips for the host's matrix_rank / inv), and |L^-1 y|^2 costs half the FMAs of y^T Sigma^-1 y with the
+// matrix operand in SGPRs (tri.h).  With a communicator attached the moments and the sum are all-reduced: the statistic of
+// the GLOBAL weighted history.
+//
+// Rank test: numpy.linalg.matrix_rank(cov) < d (tools.py:102-104) compares singular values with s_max * d * eps.  Here: a
+// diagonally pivoted Cholesky of the covariance; the rank is the number of pivots above d * eps * trace (for a positive
+// semi-definite matrix s_max <= trace, and the pivots of the pivoted factorisation bound the trailing singular values), i.e.
+// the same verdict on the degenerate ensembles the rule exists for.  Rank-deficient: cov += 1e-6 trace I as the reference.
+__global__ void __launch_bounds__(256) k_vv_prepare(double* __restrict__ cov, int d, double* __restrict__ work, double* __restrict__ L,
+                                                    double* __restrict__ W, double* __restrict__ flag) {
+  __shared__ double s_val[256];
+  __shared__ int s_idx[256];
+  __shared__ int s_rank, s_fail;
+  __shared__ double s_piv, s_tr;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < d * d; e += 256) work[e] = cov[e];
+  if (tid == 0) { s_rank = d; s_fail = 0; }
+  __syncthreads();
+  {
+    double tr = 0.0;
+    for (int j = tid; j < d; j += 256) tr += work[j * d + j];
+    s_val[tid] = tr;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_val[tid] += s_val[tid + o]; __syncthreads(); }
+    if (tid == 0) s_tr = s_val[0];
+    __syncthreads();
+  }
+  const double tol = (double)d * DBL_EPSILON * fabs(s_tr);
+  // ---- diagonally pivoted Cholesky on `work` (only its verdict is kept)
+  for (int k = 0; k < d; ++k) {
+    double best = -DBL_MAX; int bi = k;
+    for (int i = k + tid; i < d; i += 256) { const double v = work[i * d + i]; if (v > best) { best = v; bi = i; } }
+    s_val[tid] = best; s_idx[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o && (s_val[tid + o] > s_val[tid] || (s_val[tid + o] == s_val[tid] && s_idx[tid + o] < s_idx[tid]))) {
+        s_val[tid] = s_val[tid + o]; s_idx[tid] = s_idx[tid + o];
+      }
+      __syncthreads();
+    }
+    const double pv = s_val[0]; const int p = s_idx[0];
+    __syncthreads();
+    if (!(pv > tol)) { if (tid == 0) s_rank = k; break; }      // also NaN
+    if (p != k) {                                               // symmetric swap k <-> p
+      for (int j = tid; j < d; j += 256) { const double t = work[k * d + j]; work[k * d + j] = work[p * d + j]; work[p * d + j] = t; }
+      __syncthreads();
+      for (int i = tid; i < d; i += 256) { const double t = work[i * d + k]; work[i * d + k] = work[i * d + p]; work[i * d + p] = t; }
+      __syncthreads();
+    }
+    if (tid == 0) s_piv = sqrt(work[k * d + k]);
+    __syncthreads();
+    for (int i = k + 1 + tid; i < d; i += 256) work[i * d + k] /= s_piv;
+    __syncthreads();
+    const int m = d - k - 1;
+    for (int e = tid; e < m * m; e += 256) {
+      const int i = k + 1 + e / m, j = k + 1 + e % m;
+      if (j <= i) { const double v = work[i * d + j] - work[i * d + k] * work[j * d + k]; work[i * d + j] = v; work[j * d + i] = v; }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (s_rank < d) {
+    const double reg = 1e-6 * s_tr;
+    for (int j = tid; j < d; j += 256) cov[j * d + j] += reg;
+  }
+  __syncthreads();
+  // ---- plain Cholesky of the (possibly ridged) covariance, then W = L^-1
+  for (int e = tid; e < d * d; e += 256) L[e] = 0.0;
+  __syncthreads();
+  for (int j = 0; j < d; ++j) {
+    if (tid == 0) {
+      double sd = cov[j * d + j];
+      for (int k = 0; k < j; ++k) sd -= L[j * d + k] * L[j * d + k];
+      if (!(sd > 0.0)) s_fail = 1;
+      s_piv = sqrt(sd);
+      L[j * d + j] = s_piv;
+    }
+    __syncthreads();
+    if (s_fail) break;
+    for (int i = j + 1 + tid; i < d; i += 256) {
+      double sd = cov[i * d + j];
+      for (int k = 0; k < j; ++k) sd -= L[i * d + k] * L[j * d + k];
+      L[i * d + j] = sd / s_piv;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (!s_fail)
+    for (int c = tid; c < d; c += 256) {
+      for (int i = 0; i < d; ++i) {
+        if (i < c) { W[i * d + c] = 0.0; continue; }
+        double sd = (i == c) ? 1.0 : 0.0;
+        for (int k = c; k < i; ++k) sd -= L[i * d + k] * W[k * d + c];
+        W[i * d + c] = sd / L[i * d + i];
+      }
+    }
+  else
+    for (int e = tid; e < d * d; e += 256) W[e] = 0.0;
+  if (tid == 0) { flag[0] = (double)s_fail; flag[1] = (double)s_rank; }
+}
+
+// sum_s w_s^2 clip(|W (u_s - mean)|^2 - d, +-1e6)^2 : 64 rows per workgroup tile, 4 waves share the tile's LDS columns and
+// split the row chunks of W
+__global__ void __launch_bounds__(256) k_cv_sum_blk(const double* __restrict__ hu, int64_t cap, int d, const double* __restrict__ w,
+                                                    int64_t n, const double* __restrict__ mean, const double* __restrict__ Wb,
+                                                    double* __restrict__ partials) {
+  extern __shared__ double sh[];
+  double* xs = sh;                           // [d][64]
+  double* part = sh + (size_t)d * 64;        // [4][64]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  double acc = 0.0;
+  const int64_t ntiles = (n + 63) / 64;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t i = t * 64 + lane;
+    __syncthreads();
+    for (int j = wid; j < d; j += 4) xs[(size_t)j * 64 + lane] = i < n ? hu[(size_t)j * cap + i] - mean[j] : 0.0;
+    __syncthreads();
+    double d2 = 0.0;
+    tri_apply(Wb, d, xs, lane, wid, 4, [&](int, double y) { d2 = fma(y, y, d2); });
+    part[wid * 64 + lane] = d2;
+    __syncthreads();
+    if (wid == 0 && i < n) {
+      const double tot = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+      const double dev = fmin(fmax(tot - (double)d, -1e6), 1e6);
+      const double ww = w[i];
+      acc += (ww * ww) * (dev * dev);
+    }
+  }
+  if (wid == 0) {
+    acc = tph_wave_sum(acc);
+    if (lane == 0) partials[blockIdx.x] = acc;
+  }
+}
+// value = singular ? 1e10 : 0.5 sqrt(s / S0^2) -> pinned mailbox (value, then the sequence word)
+__global__ void k_vv_finish(const double* __restrict__ s, const double* __restrict__ s0, const double* __restrict__ flag,
+                            double* __restrict__ out_host, double* __restrict__ seq_host, double seq, double* __restrict__ out_dev) {
+  if (threadIdx.x || blockIdx.x) return;
+  const double S0 = s0[0];
+  double v = 1e10;
+  if (flag[0] == 0.0 && isfinite(S0) && S0 > 0.0) v = 0.5 * sqrt(s[0] / (S0 * S0));
+  if (out_dev) out_dev[0] = v;
+  out_host[0] = v;
+  out_host[1] = flag[1];
+  __threadfence_system();
+  __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_vv_split(const double* __restrict__ mom, int d, double* __restrict__ s0, double* __restrict__ mean, double* __restrict__ cov) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;        // (S0, mean[d], cov[d*d]) -> separate buffers
+  if (e == 0) s0[0] = mom[0];
+  if (e < d) mean[e] = mom[1 + e];
+  if (e < d * d) cov[e] = mom[1 + d + e];
+}
+
+extern "C" int tph_volume_variation(tph_ctx* ctx, const double* w_dev, int64_t n, double* centre_dev, double* value_host) {
+  TPH_REQUIRE(ctx && w_dev && value_host && n > 0 && n <= ctx->size, "tph_volume_variation: bad argument");
+  const int d = ctx->d;
+  TPH_REQUIRE(d <= 100, "tph_volume_variation: n_dim=%d > 100", d);
+  const bool comm = ctx->comm_active();
+  // persistent small buffers behind small_dev: s0 | mean[d] | flag[2] | s | then d x d matrices in the winv-style block
+  const size_t mat = (size_t)d * d;
+  const size_t need_small = sizeof(double) * (8 + d + 4 * mat + tri_blocked_doubles(d) + (1 + d + mat));
+  if (ctx->vv_bytes < need_small) {
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->vv_buf) TPH_HIP(hipFree(ctx->vv_buf));
+    ctx->vv_buf = nullptr; ctx->vv_bytes = 0;
+    TPH_HIP(hipMalloc((void**)&ctx->vv_buf, need_small));
+    ctx->vv_bytes = need_small;
+  }
+  double* s0 = ctx->vv_buf;
+  double* flag = s0 + 1;
+  double* ssum = s0 + 3;
+  double* mean = s0 + 8;
+  double* cov = mean + d;
+  double* work = cov + mat;
+  double* L = work + mat;
+  double* W = L + mat;
+  double* Wb = W + mat;
+  double* mom = Wb + tri_blocked_doubles(d);
+  // ---- moments
+  if (!comm && d <= 12 && centre_dev) {
+    if (tph_weighted_moments_shifted(ctx, w_dev, n, centre_dev, mom)) return -1;
+    hipLaunchKernelGGL(k_vv_split, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, mom, d, s0, mean, cov);
+    TPH_HIP(hipMemcpyAsync(centre_dev, mean, sizeof(double) * d, hipMemcpyDeviceToDevice, ctx->stream));   // next call's centre
+  } else {
+    const int nblk = cov_blocks(n);
+    const int rblk = tph_grid_for(n, 256, 4, 512);
+    const int npl = d * (d + 1) / 2;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
+    size_t o_part = take(sizeof(double) * cov_scratch_doubles(d, nblk));
+    size_t o_part1 = take(sizeof(double) * (size_t)rblk * (1 + d) * 3);
+    size_t o_sums = take(sizeof(double) * (1 + d));
+    size_t o_csum = take(sizeof(double) * npl);
+    if (tph_scratch_reserve(ctx, o)) return -1;
+    char* base = (char*)ctx->scratch;
+    double* part = (double*)(base + o_part);
+    double* part1 = (double*)(base + o_part1);
+    double* sums = comm ? (double*)ctx->comm_buf : (double*)(base + o_sums);
+    double* csum = comm ? (double*)(ctx->comm_buf + 4096) : (double*)(base + o_csum);
+    if (comm && tph_comm_require(ctx, 4096 + sizeof(double) * npl, "tph_volume_variation")) return -2;
+    hipLaunchKernelGGL(k_wsum<double>, dim3(rblk, 1 + d), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, d, w_dev,
+                       (const int32_t*)nullptr, 0, n, part1);
+    hipLaunchKernelGGL(k_wsum_final, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums, (double*)nullptr);
+    TPH_LAUNCH_CHECK();
+    if (comm && tph_comm_allreduce(ctx, 0, 1 + d, TPH_DT_F64, TPH_OP_SUM)) return -2;
+    hipLaunchKernelGGL(k_mean_from_sums, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, sums, d, mean);
+    TPH_HIP(hipMemcpyAsync(s0, sums, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    const int S = cov_slices(npl);
+    if (d <= 12) {
+      bool ok = launch_wcov_small<double>(ctx, ctx->u, ctx->cap, w_dev, nullptr, 0, n, mean, part, nblk);
+      TPH_REQUIRE(ok, "covariance: no register kernel for n_dim=%d", d);
+      hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk, npl, csum);
+    } else {
+      size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS);
+      if (lds > 64 * 1024)
+        TPH_HIP(hipFuncSetAttribute((const void*)k_wcov<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_wcov<double>, dim3(nblk), dim3(256), lds, ctx->stream, ctx->u, ctx->cap, d, w_dev, (const int32_t*)nullptr, 0,
+                         n, mean, part);
+      hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk * S, npl, csum);
+    }
+    TPH_LAUNCH_CHECK();
+    if (comm && tph_comm_allreduce(ctx, 4096, npl, TPH_DT_F64, TPH_OP_SUM)) return -2;
+    hipLaunchKernelGGL(k_cov_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum, sums, d, 2, cov);
+    TPH_LAUNCH_CHECK();
+    if (centre_dev) TPH_HIP(hipMemcpyAsync(centre_dev, mean, sizeof(double) * d, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  // ---- d x d work on the device, blocked layout of L^-1
+  hipLaunchKernelGGL(k_vv_prepare, dim3(1), dim3(256), 0, ctx->stream, cov, d, work, L, W, flag);
+  hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, W, d, Wb);
+  // ---- the statistic
+  const int64_t ntiles = (n + 63) / 64;
+  const int nb = (int)(ntiles < 2048 ? ntiles : 2048);
+  if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)nb)) return -1;
+  double* partials = (double*)ctx->scratch;
+  const size_t lds = sizeof(double) * ((size_t)d * 64 + 256);
+  if (lds > 64 * 1024)
+    TPH_HIP(hipFuncSetAttribute((const void*)k_cv_sum_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_cv_sum_blk, dim3(nb), dim3(256), lds, ctx->stream, ctx->u, ctx->cap, d, w_dev, n, mean, Wb, partials);
+  double* sdst = comm ? (double*)ctx->comm_buf : ssum;
+  hipLaunchKernelGGL(k_colsum2, dim3(1), dim3(256), 0, ctx->stream, partials, nb, 1, sdst);
+  TPH_LAUNCH_CHECK();
+  if (comm && tph_comm_allreduce(ctx, 0, 1, TPH_DT_F64, TPH_OP_SUM)) return -2;
+  // ---- result through the pinned mailbox: [64] value, [65] rank, [4094] sequence word
+  volatile double* seqp = ctx->pinned + 4094;
+  const double seq = (double)(++ctx->vv_seq);
+  hipLaunchKernelGGL(k_vv_finish, dim3(1), dim3(1), 0, ctx->stream, sdst, s0, flag, ctx->pinned + 64, ctx->pinned + 4094, seq,
+                     (double*)nullptr);
+  TPH_LAUNCH_CHECK();
+  uint64_t spins = 0;
+  while (*seqp != seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xFFFFF) == 0) {
+      hipError_t q = hipStreamQuery(ctx->stream);
+      if (q != hipErrorNotReady) {
+        TPH_HIP(hipStreamSynchronize(ctx->stream));
+        TPH_REQUIRE(*seqp == seq, "tph_volume_variation: the device never delivered evaluation %.0f", seq);
+      }
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  *value_host = ctx->pinned[64];
   return 0;
 }

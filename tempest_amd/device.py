@@ -440,6 +440,13 @@ class HipContext:
               "tph_weighted_moments_shifted")
         return out
 
+    def volume_variation(self, w, centre=None):
+        """tools.py:58-117 on the history under the normalised device weights w, d x d work included (one host wait)."""
+        out = C.c_double(0.0)
+        check(self.lib.tph_volume_variation(self._ctx, _ptr(w, torch.float64), w.numel(), _ptr(centre), C.byref(out)),
+              "tph_volume_variation")
+        return out.value
+
     def cv_sum(self, w, mean, covinv):
         out = self.empty(1)
         check(self.lib.tph_cv_sum(self._ctx, _ptr(w), w.numel(), _ptr(mean), _ptr(covinv), _ptr(out)), "tph_cv_sum")

@@ -58,11 +58,28 @@ def plugin_source(source: str) -> str:
     return _TEMPLATE.read_text().replace("@USER_SOURCE@", source)
 
 
+_TOOLCHAIN = None
+
+
+def _toolchain_id() -> str:
+    """What identifies the compiler for the cache key: `hipcc --version` (a plugin shares struct layouts and inlined device
+    code with libtempest_hip: a cached object from another toolchain must not be picked up silently)."""
+    global _TOOLCHAIN
+    if _TOOLCHAIN is None:
+        try:
+            r = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, timeout=60)
+            _TOOLCHAIN = (r.stdout + r.stderr).strip() or "unknown"
+        except Exception:
+            _TOOLCHAIN = "unknown"
+    return _TOOLCHAIN
+
+
 def build_plugin(source: str, n_dim: int, verbose: bool = False) -> Path:
     """Compile (or find in the cache) the plugin for `source`; returns the path of the shared library."""
     text = plugin_source(source)
     deps = (_CSRC / "common.h").read_bytes() + (_CSRC.parent.parent / "include" / "tempest_hip.h").read_bytes()
-    tag = hashlib.sha256(text.encode() + deps + f"|{n_dim}|{_ARCH}|{' '.join(_FLAGS)}".encode()).hexdigest()[:20]
+    key = f"|{n_dim}|{_ARCH}|{' '.join(_FLAGS)}|{_toolchain_id()}"
+    tag = hashlib.sha256(text.encode() + deps + key.encode()).hexdigest()[:20]
     name = f"tphu_{n_dim}d_{tag}.so"
     for d in _cache_dirs():
         if (d / name).exists():
@@ -128,18 +145,20 @@ class HipCallbacks:
         return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
     def _soa(self, a):
-        """(n, d) rows [or one (d,) row] -> (tensor (d, n) contiguous, was_numpy, was_1d)."""
+        """(n, d) rows [or one (d,) row] -> (tensor (d, n) contiguous, was_numpy, was_1d).  Host inputs go to `self.device`
+        (set by the sampler that owns this object; the current device otherwise)."""
         import torch
         was_np = not isinstance(a, torch.Tensor)
+        dev = getattr(self, "device", None) or torch.device("cuda", torch.cuda.current_device())
         if was_np:
-            a = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+            a = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
         one = a.dim() == 1
         if one:
             a = a.reshape(1, -1)
         if a.dim() != 2 or a.shape[1] != self.n_dim:
             raise ValueError(f"expected (..., {self.n_dim}) points, got {tuple(a.shape)}")
         if not a.is_cuda:
-            a = a.cuda()
+            a = a.to(dev)
         if a.dtype != torch.float64:
             a = a.to(torch.float64)
         t = a.T

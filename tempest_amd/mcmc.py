@@ -173,16 +173,30 @@ class StepEngine:
         self.ctx.adapt(self.kernel, self.sums, self.counts, self.K, self.n_global, self.n_steps, self.n_max,
                        self.sigmas, self.ctl, mailbox=self.mailbox, partials=self.partials if fold else None, n=self.n)
 
-    def wait_record(self, step, timeout=60.0):
-        """State record (tph_adapt's state[0..5]) of step `step`, polled from the pinned mailbox."""
+    def wait_record(self, step, timeout=None):
+        """State record (tph_adapt's state[0..5]) of step `step`, polled from the pinned mailbox.  The wait ends with an
+        error only when the stream has gone IDLE without delivering the record (like tph_reweight_eval's poll) or, if a
+        `timeout` in seconds is given (TEMPEST_AMD_STEP_TIMEOUT), after that long: a step may legitimately take minutes
+        (an expensive likelihood, a callback that compiles on first use, a shared GPU)."""
+        import os
         import time
+        import torch
+        if timeout is None:
+            env = os.environ.get("TEMPEST_AMD_STEP_TIMEOUT")
+            timeout = float(env) if env else None
         rec = self.mailbox_np[step % self.SLOTS]
         spins, t0 = 0, None
         while rec[7] != step:
             spins += 1
             if spins & 0x3FFF == 0:
-                t0 = t0 or time.monotonic()
-                if time.monotonic() - t0 > timeout:
+                now = time.monotonic()
+                t0 = t0 or now
+                if now - t0 > 0.05:
+                    time.sleep(0)                 # long wait: let other Python threads run between polls
+                if now - t0 > 2.0 and torch.cuda.current_stream(self.ctx.device).query() and rec[7] != step:
+                    from ._lib import TempestHipError
+                    raise TempestHipError(f"MCMC step {step}: the stream is idle and the device never delivered the step's record")
+                if timeout is not None and now - t0 > timeout:
                     from ._lib import TempestHipError
                     raise TempestHipError(f"MCMC step {step}: no record from the device after {timeout} s")
         self._regime(rec[6])

@@ -81,54 +81,22 @@ def volume_variation(x, w=None) -> float:
 
 
 def device_volume_variation(ctx, w_dev, n_global, comm=None) -> float:
-    """tools.py:58-117 on the device history of `ctx` with (normalised) device weights.
-    The d x d rank test / inverse stay on the host exactly as the reference writes them."""
-    import torch
+    """tools.py:58-117 on the device history of `ctx` with (normalised) device weights: one library call, the d x d rank
+    rule / Cholesky / inverse included (tph_volume_variation), one host wait for the scalar.  With a communicator attached
+    to the ctx the moments and the sum are all-reduced inside the library (`comm` is kept for the call sites' signature)."""
     d = ctx.n_dim
     if n_global < d + 1:
         return 1e10
-    if comm is None and d <= 12:
-        # one pass for mean and covariance: moments about the previous call's mean (the first stored row the first time), finished without
-        # cancellation on the device; one read of 1 + d + d^2 doubles, then the d x d work on the host as the reference has it
+    centre = None
+    if d <= 12 and not (comm is not None and comm.active):
+        # one pass for mean and covariance: moments about the previous call's mean (the first stored row the first time);
+        # the library leaves the new mean in the same buffer
         centre = getattr(ctx, "_vv_centre", None)
         if centre is None:                      # any point inside the data will do: the first stored row
             from .device import KEY_U
-            centre = ctx.posterior_rows(None, 1, key=KEY_U)[0][0].contiguous()
-        mom = ctx.weighted_moments_shifted(w_dev, centre)
-        mh = mom.cpu().numpy()
-        s0, mean_h, cov_h = mh[0], mh[1:1 + d], mh[1 + d:].reshape(d, d)
-        if not (np.isfinite(s0) and s0 > 0 and np.all(np.isfinite(mean_h))):
-            return 1e10
-        mean = mom[1:1 + d].contiguous()
-        ctx._vv_centre = mean
-        cov_h = cov_h.copy()
-        if np.linalg.matrix_rank(cov_h) < d:
-            cov_h = cov_h + np.eye(d) * (1e-6 * np.trace(cov_h))
-        try:
-            cinv = np.linalg.inv(cov_h)
-        except np.linalg.LinAlgError:
-            return 1e10
-        s = ctx.cv_sum(w_dev, mean, torch.from_numpy(np.ascontiguousarray(cinv)).to(ctx.device))
-        return float(0.5 * math.sqrt(float(s.cpu()[0]) / (s0 * s0)))
-    sums = ctx.weighted_sums(w_dev)
-    if comm is not None:
-        comm.all_reduce_sum(sums)
-    sh = sums.cpu().numpy()
-    mean = torch.from_numpy(sh[1:] / sh[0]).to(ctx.device)
-    cov = ctx.weighted_cov_centered(w_dev, mean)
-    if comm is not None:
-        comm.all_reduce_sum(cov)
-    cov_h = cov.cpu().numpy().reshape(d, d) / sh[0]
-    if np.linalg.matrix_rank(cov_h) < d:
-        cov_h = cov_h + np.eye(d) * (1e-6 * np.trace(cov_h))
-    try:
-        cinv = np.linalg.inv(cov_h)
-    except np.linalg.LinAlgError:
-        return 1e10
-    s = ctx.cv_sum(w_dev, mean, torch.from_numpy(np.ascontiguousarray(cinv)).to(ctx.device))
-    if comm is not None:
-        comm.all_reduce_sum(s)
-    return float(0.5 * math.sqrt(float(s.cpu()[0]) / (sh[0] * sh[0])))
+            centre = ctx.posterior_rows(None, 1, key=KEY_U)[0][0].contiguous().clone()
+            ctx._vv_centre = centre
+    return float(ctx.volume_variation(w_dev, centre))
 
 
 def systematic_resample(size: int, weights: np.ndarray, random_state: Optional[int] = None) -> np.ndarray:

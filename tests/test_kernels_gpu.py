@@ -655,3 +655,29 @@ def test_deferred_metropolis_update_equals_in_place(dev, kernel, variant):
             assert torch.equal(x, y)
     assert torch.equal(ua, ub)
     assert 0.05 < float(ta[-1][3][0]) / n < 0.95            # a real mix of accepted and rejected moves
+
+
+@pytest.mark.parametrize("d", [3, 10, 19, 50])
+def test_volume_variation_one_call_vs_oracle(dev, d):
+    """tph_volume_variation (moments, rank rule, Cholesky / inverse and the blocked triangular sum on the device) against the
+    oracle's tools.py:58-117 restatement: full-rank ensembles, a rank-deficient one (ridge branch), n < d + 1."""
+    from tempest_amd import tools
+    rs = np.random.RandomState(100 + d)
+    n = 20000
+    A = rs.randn(d, d) * 0.1
+    x = 0.5 + rs.randn(n, d) @ A.T
+    w = np.exp(rs.randn(n) * 1.5)
+    got = tools.volume_variation(x, w)
+    np.testing.assert_allclose(got, ps.volume_variation(x, w), rtol=1e-8)
+    # a second call on the same context re-uses the previous mean as the centre of the one-pass moments (d <= 12)
+    w2 = np.exp(rs.randn(n) * 0.5)
+    np.testing.assert_allclose(tools.volume_variation(x, w2), ps.volume_variation(x, w2), rtol=1e-8)
+    # rank-deficient: a coordinate repeated exactly -> cov += 1e-6 trace I (tools.py:102-104)
+    xd = x.copy()
+    xd[:, -1] = xd[:, 0]
+    wn = w / w.sum()
+    xc = xd - np.sum(xd * wn[:, None], axis=0)
+    assert np.linalg.matrix_rank(xc.T @ (xc * wn[:, None])) < d
+    np.testing.assert_allclose(tools.volume_variation(xd, w), ps.volume_variation(xd, w), rtol=1e-6)
+    # fewer rows than d + 1
+    assert tools.volume_variation(x[:d], w[:d]) == 1e10
