@@ -1499,6 +1499,37 @@ __global__ void __launch_bounds__(256) k_cv_sum_blk(const double* __restrict__ h
     if (lane == 0) partials[blockIdx.x] = acc;
   }
 }
+// n_dim <= 12: one lane per row, the row in registers, W wave-uniform (scalar loads): d(d+1)/2 FMAs per 8d + 8 bytes -> HBM-bound
+template <int D>
+__global__ void __launch_bounds__(256) k_cv_sum_small(const double* __restrict__ hu, int64_t cap, const double* __restrict__ w,
+                                                      int64_t n, const double* __restrict__ mean, const double* __restrict__ W,
+                                                      double* __restrict__ partials) {
+  double m[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) m[j] = mean[j];
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double xc[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) xc[j] = hu[(size_t)j * cap + i] - m[j];
+    double d2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      double y = 0.0;
+#pragma unroll
+      for (int j = 0; j <= r; ++j) y = fma(W[r * D + j], xc[j], y);
+      d2 = fma(y, y, d2);
+    }
+    const double dev = fmin(fmax(d2 - (double)D, -1e6), 1e6);
+    const double ww = w[i];
+    acc += (ww * ww) * (dev * dev);
+  }
+  __shared__ double sh[4];
+  acc = tph_block_sum(acc, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
 // value = singular ? 1e10 : 0.5 sqrt(s / S0^2) -> pinned mailbox (value, then the sequence word)
 __global__ void k_vv_finish(const double* __restrict__ s, const double* __restrict__ s0, const double* __restrict__ flag,
                             double* __restrict__ out_host, double* __restrict__ seq_host, double seq, double* __restrict__ out_dev) {
@@ -1597,13 +1628,26 @@ extern "C" int tph_volume_variation(tph_ctx* ctx, const double* w_dev, int64_t n
   hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, W, d, Wb);
   // ---- the statistic
   const int64_t ntiles = (n + 63) / 64;
-  const int nb = (int)(ntiles < 2048 ? ntiles : 2048);
-  if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)nb)) return -1;
-  double* partials = (double*)ctx->scratch;
-  const size_t lds = sizeof(double) * ((size_t)d * 64 + 256);
-  if (lds > 64 * 1024)
-    TPH_HIP(hipFuncSetAttribute((const void*)k_cv_sum_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_cv_sum_blk, dim3(nb), dim3(256), lds, ctx->stream, ctx->u, ctx->cap, d, w_dev, n, mean, Wb, partials);
+  int nb;
+  double* partials;
+  if (d <= 12) {
+    nb = tph_grid_for(n, 256, 8, 2048);
+    if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)nb)) return -1;
+    partials = (double*)ctx->scratch;
+    switch (d) {
+#define C(DD) case DD: hipLaunchKernelGGL((k_cv_sum_small<DD>), dim3(nb), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, w_dev, n, mean, W, partials); break;
+      C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12)
+#undef C
+    }
+  } else {
+    nb = (int)(ntiles < 2048 ? ntiles : 2048);
+    if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)nb)) return -1;
+    partials = (double*)ctx->scratch;
+    const size_t lds = sizeof(double) * ((size_t)d * 64 + 256);
+    if (lds > 64 * 1024)
+      TPH_HIP(hipFuncSetAttribute((const void*)k_cv_sum_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_cv_sum_blk, dim3(nb), dim3(256), lds, ctx->stream, ctx->u, ctx->cap, d, w_dev, n, mean, Wb, partials);
+  }
   double* sdst = comm ? (double*)ctx->comm_buf : ssum;
   hipLaunchKernelGGL(k_colsum2, dim3(1), dim3(256), 0, ctx->stream, partials, nb, 1, sdst);
   TPH_LAUNCH_CHECK();
