@@ -60,9 +60,10 @@ int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void* hip_strea
 int tph_ctx_destroy(tph_ctx* ctx);
 int tph_set_stream(tph_ctx* ctx, void* hip_stream);
 int tph_synchronize(tph_ctx* ctx);
-/* TPH_OPT_PROPOSE_VARIANT selects the proposal kernel: 0 = automatic (registers for n_dim <= 16, multi-lane above),
- * 1 = one lane per particle with LDS columns (any n_dim), 2 = one lane per particle in registers (n_dim <= 16),
- * 3 = several lanes per particle with the matrices staged in LDS; the parity tests run every variant */
+/* TPH_OPT_PROPOSE_VARIANT selects the proposal kernel: 0 = automatic (registers for n_dim <= 16, multi-lane above, blocked
+ * when TPH_OPT_BLOCKED is set), 1 = one lane per particle with LDS columns (any n_dim), 2 = one lane per particle in
+ * registers (n_dim <= 16), 3 = several lanes per particle with the matrices staged in LDS, 4 = blocked + straggler pass
+ * (16 < n_dim <= 100, one mode); the parity tests run every variant */
 #define TPH_OPT_PROPOSE_VARIANT 0
 /* TPH_OPT_REDUCE_GRID: 0 = automatic grid of the reweight reduction, > 0 = that many blocks (experiments) */
 #define TPH_OPT_REDUCE_GRID 1
@@ -73,6 +74,14 @@ int tph_synchronize(tph_ctx* ctx);
  * (a quarter of the LDS footprint, four times the resident waves: the right trade while most attempts are redraws that stop
  * after a few rows); 0 = staged (default) */
 #define TPH_OPT_ML_UNSTAGED 3
+/* TPH_OPT_BLOCKED: 1 = n_dim > 16, one mode: attempt 0 of every particle by the blocked kernel (lane = particle, matrix
+ * operands through the scalar cache: the fast form of a step that is one attempt), the particles it leaves out of bounds by
+ * the multi-lane kernel from attempt 1 on; 0 (default) = multi-lane kernel for everything (redraw-dominated steps).  The host
+ * switches on the redraw probe, like TPH_OPT_ML_UNSTAGED. */
+#define TPH_OPT_BLOCKED 4
+/* TPH_OPT_MODES_EPOCH: v > 0 = version of the mode statistics passed to tph_propose; the blocked copies of L and L^-1 are
+ * rebuilt only when it (or the chol pointer) changes.  0 (default) = rebuilt on every call. */
+#define TPH_OPT_MODES_EPOCH 5
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- multi-GPU: one process per GPU --------------------------------------

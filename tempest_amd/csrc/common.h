@@ -65,6 +65,12 @@ struct tph_ctx {
   int n_simd = 1024;                // SIMDs of the device (compute units x 4): sizes one-resident-batch launches
   double* winv = nullptr;           // L^-1 per mode, formed by tph_propose when the caller passes cholinv_dev = NULL
   size_t winv_bytes = 0;
+  int blocked = 0;                  // TPH_OPT_BLOCKED: d > 16 proposals through k_propose_blk + straggler pass (late iterations)
+  int modes_epoch = 0;              // TPH_OPT_MODES_EPOCH: version of the caller's mode statistics (0 = unversioned)
+  int blk_epoch = -1;
+  const void* blk_src = nullptr;
+  void* blk_buf = nullptr;          // blocked copies of L and L^-1 + the straggler flags
+  size_t blk_bytes = 0;
   double* vv_buf = nullptr;         // small persistent buffers of tph_volume_variation (moments, factors, blocked L^-1)
   size_t vv_bytes = 0;
   uint64_t vv_seq = 0;

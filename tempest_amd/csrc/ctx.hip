@@ -146,7 +146,7 @@ extern "C" int tph_ctx_destroy(tph_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   void* bufs[] = {ctx->u, ctx->x, ctx->logl, ctx->cmix, ctx->table_dev, ctx->partials, ctx->small_dev, ctx->scratch, ctx->winv,
-                  ctx->blk_table, ctx->vv_buf};
+                  ctx->blk_table, ctx->vv_buf, ctx->blk_buf};
   for (void* b : bufs) (void)hipFree(b);
   (void)hipHostFree(ctx->pinned);
   if (ctx->table_host) (void)hipHostFree(ctx->table_host);
@@ -213,6 +213,8 @@ extern "C" int tph_set_option(tph_ctx* ctx, int option, int value) {
     case TPH_OPT_REDUCE_GRID: ctx->reduce_grid = value; break;
     case TPH_OPT_REDRAW_LANES: ctx->redraw_lanes = value; break;
     case TPH_OPT_ML_UNSTAGED: ctx->ml_unstaged = value; break;
+    case TPH_OPT_BLOCKED: ctx->blocked = value; break;
+    case TPH_OPT_MODES_EPOCH: ctx->modes_epoch = value; break;
     default: TPH_REQUIRE(false, "tph_set_option: unknown option %d", option);
   }
   return 0;

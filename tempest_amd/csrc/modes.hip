@@ -1475,7 +1475,7 @@ __global__ void __launch_bounds__(256) k_cv_sum_blk(const double* __restrict__ h
   extern __shared__ double sh[];
   double* xs = sh;                           // [d][64]
   double* part = sh + (size_t)d * 64;        // [4][64]
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: see k_propose_blk
   double acc = 0.0;
   const int64_t ntiles = (n + 63) / 64;
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {

@@ -2,6 +2,7 @@
 // Reference: tempest/steps/mutate.py:76-200 (Mutator.run), tempest/mcmc.py:104-208 (runner loop,
 // adaptive step count), :211-288 (tpCN), :291-323 (RWM), :326-411 (boundary conditions).
 #include "common.h"
+#include "tri.h"
 
 // ------------------------------------------------------------------------------- prior draw (beta=0)
 // u ~ U(0,1)^d (mutate.py:102): one Philox call per coordinate pair.
@@ -205,7 +206,9 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ 
                                                            const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                            int64_t item0, double* __restrict__ up,
                                                            double* __restrict__ maha_u, double* __restrict__ maha_up,
-                                                           uint8_t* __restrict__ pend) {
+                                                           uint8_t* __restrict__ pend, const uint8_t* __restrict__ todo) {
+  // todo != NULL: straggler pass behind k_propose_blk -- only the particles it flagged (their attempt 0 left the cube),
+  // starting from attempt 1; everything else of the step (pending moves, attempt 0 of the others) is done already
   extern __shared__ double sh[];
   constexpr int PPB = ML_THREADS / LPP;
   const int l = threadIdx.x % LPP, p = threadIdx.x / LPP;
@@ -220,8 +223,16 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ 
   double* mat0 = sh + (size_t)3 * PPB * dp;
   double* mat1 = mat0 + (size_t)d * (d + 1);
   const int64_t i = (int64_t)blockIdx.x * PPB + p;
-  const bool live = i < n;
-  const int64_t ii = live ? i : n - 1;               // dead groups shadow the last particle, never store
+  const bool live = i < n && (!todo || todo[i < n ? i : n - 1] != 0);
+  const int64_t ii = i < n ? i : n - 1;              // dead groups shadow a particle, never store
+  if (todo) {                                        // a block without stragglers has nothing to do
+    __shared__ int s_any;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    if (live) s_any = 1;
+    __syncthreads();
+    if (!s_any) return;
+  }
   const int c = (STAGE == 0 && assign) ? assign[ii] : 0;
   const double* __restrict__ mu = means + (size_t)c * d;
   const double* __restrict__ Lg = chol + (size_t)c * d * d;
@@ -274,7 +285,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ 
   tph_rng gg(seed, tick, TPH_TAG_GAMMA, item);
   double g_x = 0.0, g_logu = 0.0;
   const int nq = npairs + (KERNEL == TPH_KERNEL_TPCN ? 2 : 0);
-  for (int q = l; q < nq; q += LPP) {
+  for (int q = todo ? npairs + l : l; q < nq; q += LPP) {     // straggler pass: attempt 0 is over, only the Gamma candidate
     const bool is_norm = q < npairs;
     const tph_rng& g = is_norm ? gz : gg;
     const uint32_t draw = is_norm ? (uint32_t)q : (uint32_t)(q - npairs);
@@ -325,8 +336,8 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ 
   // iterations of a high-dimensional run (50-D: ~98 % of the attempts leave the unit cube) that is most of the work.  Draws,
   // attempt order and arithmetic are those of the sequential loop: the accepted proposal is bit-identical.
   const int nchunks = (d + LPP - 1) / LPP;
-  int att = 0, ch = 0, zgen = 2 * npairs;            // attempt 0: all normals are in zs already (generated above)
-  bool active = true;
+  int att = todo ? 1 : 0, ch = 0, zgen = todo ? 0 : 2 * npairs;   // attempt 0: all normals are in zs already (generated above)
+  bool active = !todo || live;
   while (__any(active)) {
     if (active) {
       const int need = (ch + 1) * LPP < d ? (ch + 1) * LPP : d;
@@ -373,7 +384,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ 
     }
   }
   __syncthreads();
-  if (blockIdx.x == 0 && tick.ctl) {
+  if (blockIdx.x == 0 && tick.ctl && !todo) {
     // regime probe for the host (StepEngine): mean attempts per particle in this block -> state[8].  While most attempts are
     // redraws the kernel should run un-staged (TPH_OPT_ML_UNSTAGED: a quarter of the LDS, four times the waves).
     double mine = (l == 0 && live) ? (double)(att + 1) : 0.0;
@@ -413,7 +424,7 @@ template <int KERNEL, int LPP>
 static int launch_propose_ml(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n, int64_t ld, const double* means,
                              const double* chol, const double* winv, const double* dof, const double* sigmas,
                              const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0, double* up, double* mu_,
-                             double* mup, uint8_t* pend) {
+                             double* mup, uint8_t* pend, const uint8_t* todo = nullptr) {
   constexpr int PPB = ML_THREADS / LPP;
   const int d = ctx->d;
   const size_t base = sizeof(double) * 3 * (size_t)PPB * (d | 1);
@@ -429,12 +440,202 @@ static int launch_propose_ml(tph_ctx* ctx, double* u, const int32_t* assign, int
       TPH_HIP(hipFuncSetAttribute((const void*)k_propose_ml<KERNEL, LPP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)lds));                                                                          \
     hipLaunchKernelGGL((k_propose_ml<KERNEL, LPP, ST>), grid, dim3(ML_THREADS), lds, ctx->stream, u, assign, n, ld, d, means, \
-                       chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend);                            \
+                       chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend, todo);                      \
   } while (0)
   if (stage == 1) TPH_ML_LAUNCH(1);
   else if (stage == 2) TPH_ML_LAUNCH(2);
   else TPH_ML_LAUNCH(0);
 #undef TPH_ML_LAUNCH
+  return 0;
+}
+
+// ---- d > 16, one mode, a step that is (mostly) ONE attempt: the blocked kernel --------------------------------------------
+// 64 particles per workgroup, lane = particle, WV waves.  The Box-Muller pairs are dealt to the waves and land in LDS as
+// columns zs[j][lane]; L z and, for tpCN, |L^-1 (u' - mu)|^2 are the blocked triangular products of tri.h (matrix
+// element wave-uniform through the scalar cache, 8 rows per x_j read), the row chunks dealt to the waves.  Every particle
+// gets attempt 0 only -- in lockstep, which is what makes the matrix operand uniform; the particles whose attempt 0 leaves
+// the cube are flagged in `todo` and finished by k_propose_ml in straggler mode (attempt 1, 2, ... with early exit, as
+// before).  The host uses this path while the redraw probe says that most first attempts succeed (late iterations); the
+// redraw-dominated early iterations stay on k_propose_ml.  Same draws, same formulas: the proposal equals the other
+// kernels' to rounding (different summation order in the products).
+template <int KERNEL, int WV>
+__global__ void __launch_bounds__(64 * WV) k_propose_blk(double* __restrict__ u, int64_t n, int64_t ld, int d,
+                                                         const double* __restrict__ means, const double* __restrict__ Lb,
+                                                         const double* __restrict__ Wb, const double* __restrict__ dof,
+                                                         const double* __restrict__ sigmas, const uint8_t* __restrict__ bc,
+                                                         uint64_t seed, tph_stepctl tick, int64_t item0, double* __restrict__ up,
+                                                         double* __restrict__ maha_u, double* __restrict__ maha_up,
+                                                         uint8_t* __restrict__ pend, uint8_t* __restrict__ todo) {
+  extern __shared__ double sh[];
+  double* zs = sh;                               // [d][64] normals, later u' - mu
+  double* vs = sh + (size_t)d * 64;              // [d][64] u - mu (first step of a run), then the proposal
+  double* sc = sh + (size_t)2 * d * 64;          // [WV][64] per-wave partials; [WV*64 ..] b_fac[64]
+  double* bf = sc + (size_t)WV * 64;
+  __shared__ int s_ok[WV][64];
+  // the wave index as a SCALAR (readfirstlane): the row chunks a wave takes, hence the matrix addresses, are then provably
+  // wave-uniform and the matrix comes through scalar loads (with threadIdx.x >> 6 the compiler emits vector loads)
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = i < n;
+  const int64_t ii = live ? i : n - 1;
+  const int npairs = (d + 1) >> 1;
+  const double sigma = sigmas[0];
+  const bool carry = KERNEL == TPH_KERNEL_TPCN && tick.carry();
+  // ---- current point: resolve a pending accepted move (deferred tph_accept), rows dealt to the waves
+  const bool pd = pend && live && pend[i];
+  for (int j = wid; j < d; j += WV) {
+    double uj = u[(size_t)j * ld + ii];
+    if (pd) { uj = up[(size_t)j * ld + i]; u[(size_t)j * ld + i] = uj; }
+    if (KERNEL == TPH_KERNEL_TPCN && !carry) vs[(size_t)j * 64 + lane] = uj - means[j];
+  }
+  // ---- the normals of attempt 0, pairs dealt to the waves
+  {
+    tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + ii));
+    for (int p = wid; p < npairs; p += WV) {
+      double z0, z1;
+      gz.normal2((uint32_t)p, z0, z1);
+      zs[(size_t)(2 * p) * 64 + lane] = z0;
+      if (2 * p + 1 < d) zs[(size_t)(2 * p + 1) * 64 + lane] = z1;
+    }
+  }
+  __syncthreads();
+  if (pd && wid == 0) pend[i] = 0;               // every wave has read the flag
+  // ---- tpCN: Mahalanobis form at u (first step of a run; afterwards carried) and the Gamma scale
+  double a_fac = 1.0;
+  if (KERNEL == TPH_KERNEL_TPCN) {
+    if (!carry) {
+      double part = 0.0;
+      tri_apply(Wb, d, vs, lane, wid, WV, [&](int, double y) { part = fma(y, y, part); });
+      sc[(size_t)wid * 64 + lane] = part;
+      __syncthreads();
+    }
+    if (wid == 0) {
+      double m_u;
+      if (carry) {
+        m_u = maha_u[ii];
+      } else {
+        m_u = 0.0;
+        for (int w = 0; w < WV; ++w) m_u += sc[(size_t)w * 64 + lane];
+        if (live && maha_u) maha_u[i] = m_u;
+      }
+      const double nu = dof[0];
+      tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + ii));
+      const double gam = tph_gamma_mt(gg, 0.5 * ((double)d + nu)) * tph_div(2.0, nu + m_u);
+      bf[lane] = sigma * tph_sqrt(tph_rcp(gam));
+    }
+    a_fac = tph_sqrt(1.0 - sigma * sigma);
+    __syncthreads();
+  } else if (wid == 0) {
+    bf[lane] = sigma;
+    if (live && maha_u) maha_u[i] = 0.0;
+  }
+  if (KERNEL != TPH_KERNEL_TPCN) __syncthreads();
+  const double b_fac = bf[lane];
+  // ---- rows of attempt 0: v = mu + a (u - mu) + b (L z)_r, bounds
+  int ok = 1;
+  tri_apply(Lb, d, zs, lane, wid, WV, [&](int r, double acc) {
+    const double ur = u[(size_t)r * ld + ii];
+    double v;
+    if (KERNEL == TPH_KERNEL_TPCN) v = means[r] + a_fac * (ur - means[r]) + b_fac * acc;
+    else v = ur + b_fac * acc;
+    const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
+    if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
+    else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
+    else ok &= (v >= 0.0) && (v <= 1.0);
+    vs[(size_t)r * 64 + lane] = v;
+  });
+  s_ok[wid][lane] = ok;
+  __syncthreads();
+  int all_ok = 1;
+#pragma unroll
+  for (int w = 0; w < WV; ++w) all_ok &= s_ok[w][lane];
+  // ---- outputs of the particles whose attempt 0 is in bounds; the others are left to the straggler pass
+  for (int j = wid; j < d; j += WV) {
+    const double v = vs[(size_t)j * 64 + lane];
+    if (live && all_ok) up[(size_t)j * ld + i] = v;
+    if (KERNEL == TPH_KERNEL_TPCN) zs[(size_t)j * 64 + lane] = v - means[j];      // the normals are done with
+  }
+  if (wid == 0 && live) todo[i] = all_ok ? 0 : 1;
+  if (blockIdx.x == 0 && tick.ctl) {             // regime probe: mean attempts implied by this block's failures, 1 / (1 - f)
+    __syncthreads();
+    if (wid == 0) {
+      const unsigned long long fm = __ballot(live && !all_ok), lm = __ballot(live);
+      if (lane == 0) {
+        const double f = (double)__popcll(fm) / fmax(1.0, (double)__popcll(lm));
+        const_cast<double*>(tick.ctl)[8] = f < 0.99 ? 1.0 / (1.0 - f) : 100.0;
+      }
+    }
+  }
+  if (KERNEL == TPH_KERNEL_TPCN) {
+    __syncthreads();
+    double part = 0.0;
+    tri_apply(Wb, d, zs, lane, wid, WV, [&](int, double y) { part = fma(y, y, part); });
+    sc[(size_t)wid * 64 + lane] = part;
+    __syncthreads();
+    if (wid == 0 && live && all_ok) {
+      double m_up = 0.0;
+      for (int w = 0; w < WV; ++w) m_up += sc[(size_t)w * 64 + lane];
+      maha_up[i] = m_up;
+    }
+  } else if (wid == 0 && live && all_ok && maha_up) {
+    maha_up[i] = 0.0;
+  }
+}
+
+template <int KERNEL>
+static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
+                              const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed,
+                              tph_stepctl tick, int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend) {
+  const int d = ctx->d;
+  // blocked copies of L and L^-1 (tri.h) and the straggler flags, owned by the ctx.  The copies are rebuilt on every call
+  // unless the caller versions its mode statistics (TPH_OPT_MODES_EPOCH > 0 and unchanged since the last call)
+  const size_t tb = tri_blocked_doubles(d);
+  const size_t need = sizeof(double) * 2 * tb + (size_t)n;
+  if (ctx->blk_bytes < need) {
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->blk_buf) TPH_HIP(hipFree(ctx->blk_buf));
+    ctx->blk_buf = nullptr; ctx->blk_bytes = 0; ctx->blk_epoch = -1;
+    TPH_HIP(hipMalloc((void**)&ctx->blk_buf, need));
+    ctx->blk_bytes = need;
+  }
+  double* Lb = (double*)ctx->blk_buf;
+  double* Wb = Lb + tb;
+  uint8_t* todo = (uint8_t*)(Wb + tb);
+  if (ctx->modes_epoch <= 0 || ctx->blk_epoch != ctx->modes_epoch || ctx->blk_src != (const void*)chol) {
+    hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, chol, d, Lb);
+    if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, winv, d, Wb);
+    ctx->blk_epoch = ctx->modes_epoch; ctx->blk_src = (const void*)chol;
+  }
+  const int wv = d <= 64 ? 4 : 8;
+  const size_t lds = sizeof(double) * ((size_t)2 * d * 64 + (size_t)(wv + 1) * 64);
+  const dim3 grid((unsigned)((n + 63) / 64));
+#define TPH_BLK_LAUNCH(WV)                                                                                              \
+  do {                                                                                                                  \
+    if (lds > 64 * 1024)                                                                                                \
+      TPH_HIP(hipFuncSetAttribute((const void*)k_propose_blk<KERNEL, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_propose_blk<KERNEL, WV>), grid, dim3(64 * WV), lds, ctx->stream, u, n, ld, d, means, Lb, Wb, dof,   \
+                       sigmas, bc, seed, tick, item0, up, mu_, mup, pend, todo);                                        \
+  } while (0)
+  if (wv == 4) TPH_BLK_LAUNCH(4); else TPH_BLK_LAUNCH(8);
+#undef TPH_BLK_LAUNCH
+  TPH_LAUNCH_CHECK();
+  // straggler pass: the flagged particles continue with attempt 1, 2, ... in the multi-lane kernel (un-staged: few blocks
+  // have work, and those that do are redraw-bound)
+  // as many lanes per straggler as it has Box-Muller pairs: a straggler's chain of attempts is latency-bound (few blocks
+  // have any work), so the pairs of an attempt are generated in ONE round and the rows spread over more lanes
+  int lpp = 4;
+  while (lpp < 64 && lpp < (d + 1) / 2) lpp *= 2;
+  const int keep = ctx->ml_unstaged;
+  ctx->ml_unstaged = 1;
+  int rc = 0;
+  switch (lpp) {
+#define TPH_ML_S(LL) case LL: rc = launch_propose_ml<KERNEL, LL>(ctx, u, nullptr, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, nullptr, todo); break;
+    TPH_ML_S(4) TPH_ML_S(8) TPH_ML_S(16) TPH_ML_S(32) TPH_ML_S(64)
+#undef TPH_ML_S
+  }
+  ctx->ml_unstaged = keep;
+  if (rc) return rc;
+  TPH_LAUNCH_CHECK();
   return 0;
 }
 
@@ -711,8 +912,15 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
     if (tph_tri_inv(ctx, chol_dev, K, ctx->winv)) return -1;
     inv_dev = ctx->winv;
   }
-  const int variant = ctx->propose_variant;   // 0 auto | 1 one-lane LDS | 2 one-lane registers (d<=16) | 3 multi-lane
+  const int variant = ctx->propose_variant;   // 0 auto | 1 one-lane LDS | 2 one-lane registers (d<=16) | 3 multi-lane | 4 blocked
   const bool use_reg = (variant == 2 || variant == 0) && ctx->d <= 16;
+  if (!use_reg && ctx->d > 16 && ctx->d <= 100 && !assign_dev && K == 1 && (variant == 4 || (variant == 0 && ctx->blocked))) {
+    if (kernel == TPH_KERNEL_TPCN)
+      return launch_propose_blk<TPH_KERNEL_TPCN>(ctx, u_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed,
+                                                 tick, item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev);
+    return launch_propose_blk<TPH_KERNEL_RWM>(ctx, u_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed,
+                                              tick, item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev);
+  }
   if (!use_reg && (variant == 3 || variant == 0) && ctx->d <= 8 * 64) {
     // lanes per particle: the fewest with <= 8 rows per lane, so that as many particles as possible share one
     // block's staged matrices (the draws are dealt round-robin over the lanes in as many passes as needed)

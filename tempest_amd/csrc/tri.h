@@ -18,7 +18,7 @@ __host__ __device__ static inline size_t tri_blocked_doubles(int d) { return (si
 
 #if defined(__HIPCC__)
 // Tb[k][c][j][q] = T[k][8c+q][j] (0 beyond the matrix); one workgroup per matrix
-__global__ void __launch_bounds__(256) k_tri_block(const double* __restrict__ T, int d, double* __restrict__ Tb) {
+static __global__ void __launch_bounds__(256) k_tri_block(const double* __restrict__ T, int d, double* __restrict__ Tb) {
   const int nch = (d + TRI_RB - 1) / TRI_RB;
   const double* A = T + (size_t)blockIdx.x * d * d;
   double* B = Tb + (size_t)blockIdx.x * tri_blocked_doubles(d);
@@ -29,11 +29,14 @@ __global__ void __launch_bounds__(256) k_tri_block(const double* __restrict__ T,
   }
 }
 
-// chunks c = c0, c0 + cstep, ... of  y = T x ; f(r, y_r) is called for every row r < d of those chunks
+// chunks c = c0, c0 + cstep, ... of  y = T x ; f(r, y_r) is called for every row r < d of those chunks.
+// Four columns per trip: their 4 x 64 B of matrix come as back-to-back scalar loads behind ONE wait (a scalar load that
+// is waited for alone costs its full ~200-cycle latency per 8 FMAs), then 32 FMAs.
 template <class F>
 __device__ __forceinline__ void tri_apply(const double* __restrict__ Tb, int d, const double* __restrict__ xs, int lane, int c0,
                                           int cstep, F&& f) {
   const int nch = (d + TRI_RB - 1) / TRI_RB;
+  constexpr int JU = 4;
   for (int c = c0; c < nch; c += cstep) {
     const double* __restrict__ Tc = Tb + (size_t)c * d * TRI_RB;
     const int jmax = (c + 1) * TRI_RB < d ? (c + 1) * TRI_RB : d;
@@ -41,14 +44,20 @@ __device__ __forceinline__ void tri_apply(const double* __restrict__ Tb, int d, 
 #pragma unroll
     for (int q = 0; q < TRI_RB; ++q) acc[q] = 0.0;
     int j = 0;
-    for (; j + 2 <= jmax; j += 2) {
-      const double x0 = xs[(size_t)j * 64 + lane], x1 = xs[(size_t)(j + 1) * 64 + lane];
+    for (; j + JU <= jmax; j += JU) {
+      double t[JU][TRI_RB], x[JU];
 #pragma unroll
-      for (int q = 0; q < TRI_RB; ++q) acc[q] = fma(Tc[(size_t)j * TRI_RB + q], x0, acc[q]);
+      for (int a = 0; a < JU; ++a) {
 #pragma unroll
-      for (int q = 0; q < TRI_RB; ++q) acc[q] = fma(Tc[(size_t)(j + 1) * TRI_RB + q], x1, acc[q]);
+        for (int q = 0; q < TRI_RB; ++q) t[a][q] = Tc[(size_t)(j + a) * TRI_RB + q];
+        x[a] = xs[(size_t)(j + a) * 64 + lane];
+      }
+#pragma unroll
+      for (int a = 0; a < JU; ++a)
+#pragma unroll
+        for (int q = 0; q < TRI_RB; ++q) acc[q] = fma(t[a][q], x[a], acc[q]);
     }
-    if (j < jmax) {
+    for (; j < jmax; ++j) {
       const double x0 = xs[(size_t)j * 64 + lane];
 #pragma unroll
       for (int q = 0; q < TRI_RB; ++q) acc[q] = fma(Tc[(size_t)j * TRI_RB + q], x0, acc[q]);

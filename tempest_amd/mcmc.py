@@ -75,6 +75,7 @@ class StepEngine:
     (they are traced once); `graph=False` keeps the step-by-step launch path."""
 
     SLOTS = 64          # mailbox ring: the host never runs more than a few steps ahead of the record it waits for
+    _epoch = 0          # version counter of the mode statistics handed to the library (TPH_OPT_MODES_EPOCH)
 
     def __init__(self, ctx, kernel, n, K, has_assign, bc, log_likelihood, prior_transform, seed, item0, n_global,
                  n_steps, n_max, comm_active, use_graph=True, plugin=None):
@@ -103,6 +104,7 @@ class StepEngine:
         self.ctl = ctx.zeros(STEP_STATE_LEN)
         self.ctl_host = torch.zeros(STEP_STATE_LEN, dtype=torch.float64).pin_memory()
         self.unstaged = False          # d > 16 proposal kernel without LDS-staged matrices (redraw-dominated steps)
+        self.blocked = False           # d > 16: blocked kernel for attempt 0 + straggler pass (steps that are ~one attempt)
         self.mailbox = torch.zeros(self.SLOTS, 8, dtype=torch.float64).pin_memory()   # written by tph_adapt, polled here
         self.mailbox_np = self.mailbox.numpy()
         self.use_graph, self.graph, self.graph_error = bool(use_graph), None, None
@@ -127,6 +129,10 @@ class StepEngine:
             m.winv_dev.copy_(winv.reshape(m.winv_dev.shape)); m.dof_dev.copy_(modes.dof_dev.reshape(m.dof_dev.shape))
         else:
             self.u, self.logl, self.assign, self.modes = u, logl, assign, modes
+        if self.ctx.n_dim > 16:        # new mode statistics: the library rebuilds its blocked copies of L and L^-1 once
+            from .device import OPT_MODES_EPOCH
+            StepEngine._epoch += 1
+            self.ctx.set_option(OPT_MODES_EPOCH, StepEngine._epoch)
         self.sigmas.fill_(sigma_init)
         self.pending.zero_()
         self.counts.copy_(counts)
@@ -209,9 +215,15 @@ class StepEngine:
         is baked into a captured graph, so a graph keeps whatever it was captured with."""
         if self.graph is not None or self.ctx.n_dim <= 16 or not mean_attempts > 0.0:
             return
+        from .device import OPT_BLOCKED, OPT_ML_UNSTAGED
+        # one mode and (nearly) every first attempt in bounds: attempt 0 of all particles in the blocked kernel (matrix
+        # operands through the scalar cache), the few others finished by the multi-lane kernel (hysteresis 1.3 / 2.0)
+        want_blk = self.K == 1 and mean_attempts < (2.0 if self.blocked else 1.3)
+        if want_blk != self.blocked:
+            self.blocked = want_blk
+            self.ctx.set_option(OPT_BLOCKED, 1 if want_blk else 0)
         want = mean_attempts > (4.0 if self.unstaged else 8.0)      # hysteresis
         if want != self.unstaged:
-            from .device import OPT_ML_UNSTAGED
             self.unstaged = want
             self.ctx.set_option(OPT_ML_UNSTAGED, 1 if want else 0)
 

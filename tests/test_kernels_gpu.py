@@ -681,3 +681,94 @@ def test_volume_variation_one_call_vs_oracle(dev, d):
     np.testing.assert_allclose(tools.volume_variation(xd, w), ps.volume_variation(xd, w), rtol=1e-6)
     # fewer rows than d + 1
     assert tools.volume_variation(x[:d], w[:d]) == 1e10
+
+
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+@pytest.mark.parametrize("bc", [None, "mixed"])
+@pytest.mark.parametrize("d", [19, 50, 100])
+def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d):
+    """TPH_OPT_PROPOSE_VARIANT 4: attempt 0 of every particle in the blocked kernel (lane = particle, L and L^-1 through the
+    scalar cache), the particles it leaves out of bounds finished by the multi-lane kernel from attempt 1 on.  Same draws and
+    formulas as the other kernels: the proposals and both Mahalanobis forms equal the oracle's (and the multi-lane kernel's)
+    to rounding -- on an ensemble where a good share of the first attempts fail, so that the straggler pass is exercised."""
+    rs = np.random.RandomState(31 + d)
+    n = 3000
+    means = 0.5 + 0.05 * rs.randn(1, d)
+    A = rs.randn(d, d) * (0.05 / np.sqrt(d))
+    covs = (A @ A.T + 2e-4 * np.eye(d))[None]
+    _, chol, inv = ps.mode_statistics(means, covs)
+    dof = np.array([8.0])
+    sigmas = np.array([0.6]) * (2.38 / np.sqrt(d) if kernel == "rwm" else 1.0)
+    assign = np.zeros(n, dtype=np.int32)
+    u = np.clip(means[0] + 0.12 * rs.randn(n, d), 0.002, 0.998)
+    u[: n // 3, rs.randint(d)] = 0.001                                   # a third of the ensemble sits on a wall
+    flags = omc.bc_flags(d, [1], [min(4, d - 1)]) if bc else omc.bc_flags(d)
+    seed, tick, item0 = 777, 5, 4_000_000_000
+    want_up, want_mu, want_mup = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, flags, seed, tick, item0)
+    modes = _Modes(means, chol, inv, dof, dev)
+    st, ft = torch.from_numpy(sigmas).to(dev), torch.from_numpy(flags).to(dev)
+    got = {}
+    for variant in (4, 3):
+        c = ctx_for(d)
+        c.set_option(0, variant)
+        up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+        c.propose(kernel, soa(u, dev), None, modes, st, ft, seed, tick, item0, up, mu_, mup)
+        got[variant] = (aos(up), mu_.cpu().numpy(), mup.cpu().numpy())
+    first_failed = np.mean(np.any((want_up != want_up), axis=1))       # placeholder: failures are visible through the oracle below
+    _ = first_failed
+    np.testing.assert_allclose(got[4][0], want_up, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(got[4][0], got[3][0], rtol=1e-11, atol=1e-13)
+    strict = np.nonzero(flags == 0)[0]
+    assert np.all((got[4][0][:, strict] >= 0) & (got[4][0][:, strict] <= 1))
+    if kernel == "tpcn":
+        np.testing.assert_allclose(got[4][1], want_mu, rtol=1e-9)
+        np.testing.assert_allclose(got[4][2], want_mup, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(got[4][2], got[3][2], rtol=1e-8, atol=1e-8)
+    # the straggler pass really ran: some first attempts (counter-based draws of attempt 0) are out of bounds
+    z0 = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, omc.bc_flags(d, list(range(d)), []), seed, tick, item0)[0]
+    assert np.mean(np.any(np.abs(z0 - want_up) > 1e-9, axis=1)) > 0.05
+
+
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+def test_blocked_kernel_deferred_update_and_step_control(dev, kernel):
+    """The blocked path inside a chain: deferred Metropolis update (pending mask) and the carried Mahalanobis form give the
+    same chain, bit for bit, as the multi-lane... no: as the blocked path with the in-place update."""
+    rs = np.random.RandomState(5)
+    d, n = 50, 4000
+    means = 0.5 + 0.02 * rs.randn(1, d)
+    A = rs.randn(d, d) * (0.03 / np.sqrt(d))
+    covs = (A @ A.T + 1e-4 * np.eye(d))[None]
+    _, chol, inv = ps.mode_statistics(means, covs)
+    modes = _Modes(means, chol, inv, np.array([1e6]), dev)
+    st = torch.from_numpy(np.array([0.5 * (2.38 / np.sqrt(d) if kernel == "rwm" else 1.0)])).to(dev)
+    u0 = np.clip(means[0] + 0.05 * rs.randn(n, d), 0.002, 0.998)
+    c = ctx_for(d)
+    c.set_option(0, 4)
+
+    def like(up):
+        x = 20 * up - 10
+        return -0.5 * (x * x).sum(dim=0) * 0.02
+
+    def chain(deferred):
+        u = soa(u0, dev)
+        logl = like(u).clone()
+        up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+        sums = c.empty(2)
+        pend = torch.zeros(n, dtype=torch.uint8, device=dev) if deferred else None
+        out = []
+        for step in range(3):
+            tick = 30 + 2 * step
+            c.propose(kernel, u, None, modes, st, None, 9, tick, 0, up, mu_, mup, pending=pend)
+            lp = like(up)
+            c.accept(kernel, 0.9, u, None, logl, up, None, lp, mu_, mup, None, 1, modes.dof_dev, 9, tick + 1, 0, sums, pending=pend)
+            out.append((up.clone(), logl.clone(), sums.clone()))
+        if deferred:
+            c.propose(kernel, u, None, modes, st, None, 9, 999, 0, up, mu_, mup, pending=pend)
+            assert int(pend.sum().item()) == 0
+        return u, out
+    ua, ta = chain(False)
+    ub, tb = chain(True)
+    for a, b in zip(ta, tb):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert torch.equal(ua, ub)
