@@ -40,20 +40,19 @@ def resample_sharded(state, w, scheme, rng, n_local):
     rows = idx[slots].contiguous()
     n_send = int(rows.numel())
     send_counts = torch.bincount(slots // n_local, minlength=G)
-    packed = torch.empty(2 * d + 1, max(n_send, 1), dtype=torch.float64, device=ctx.device)
+    # one row per claimed slot: (u, x, logl, slot inside the owner's shard) -- the slot travels with the row, so that one
+    # all-to-all-v places everything (a rank receives from each sender a block in slot order, the blocks interleave)
+    packed = torch.empty(2 * d + 2, max(n_send, 1), dtype=torch.float64, device=ctx.device)
     if n_send:
         ctx.gather(rows, packed[:d], packed[d:2 * d], packed[2 * d])
-    send = packed[:, :n_send].T.contiguous()                   # (n_send, 2d+1) rows: contiguous block per owner
+        packed[2 * d + 1, :n_send] = (slots % n_local).to(torch.float64)
+    send = packed[:, :n_send].T.contiguous()                   # (n_send, 2d+2) rows: contiguous block per owner
     recv_counts = comm.all_to_all_counts(send_counts)
     if int(recv_counts.sum()) != n_local:
         raise RuntimeError(f"resample shuffle: rank {me} would receive {int(recv_counts.sum())} rows, expected {n_local}")
     recv = comm.all_to_all_rows(send, send_counts.tolist(), recv_counts.tolist())
-    # a slot's row comes from exactly one rank; inside the block received from rank r the rows are in slot order, but the
-    # blocks of different senders interleave: put every row at its slot (the senders' slot lists travel with the rows)
-    slot_send = (slots % n_local).to(torch.float64).reshape(-1, 1)
-    slot_recv = comm.all_to_all_rows(slot_send.contiguous(), send_counts.tolist(), recv_counts.tolist()).reshape(-1).long()
     soa = torch.empty(2 * d + 1, n_local, dtype=torch.float64, device=ctx.device)
-    soa[:, slot_recv] = recv.T
+    soa[:, recv[:, 2 * d + 1].long()] = recv[:, :2 * d + 1].T
     return soa[:d], soa[d:2 * d], soa[2 * d]
 
 

@@ -1,0 +1,55 @@
+#!/bin/bash
+# Regenerates the round's evidence under gpurun_out/rNN/final on the GPU box (then copied into profiles/ by
+# tools/assemble_profiles.py).  Usage: gpurun -- 'bash tools/collect_profiles.sh r02'
+set -e
+R=${1:-r02}
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+O=gpurun_out/$R/final
+rm -rf "$O"; mkdir -p "$O"
+# 1. the bench line, plain
+python3 bench.py > "$O/bench_unprofiled.json" 2> "$O/bench_unprofiled.err"
+# 2. the same under the kernel tracer
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -o bench -- python3 bench.py --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/bench_under_rocprof.err"
+# 3. reweight kernel: HBM traffic counters, separate passes
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_rw_fetch" -o f -- python3 bench.py --roofline-only > "$O/rw_fetch.json" 2> "$O/rw_fetch.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_rw_write" -o w -- python3 bench.py --roofline-only > "$O/rw_write.json" 2> "$O/rw_write.err"
+# 4. proposal kernel: instruction counters, this round's library and round 1's (scratch/oldlib, if present)
+PMC="SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SMEM"
+rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d "$O/pmc_prop_new" -o p -- python3 tools/bench_propose.py --scen tight,mid,wide --reps 5 > "$O/prop_new.jsonl" 2> "$O/prop_new.err"
+python3 tools/bench_propose.py --scen tight,mid,wide > "$O/prop_new_plain.jsonl" 2>> "$O/prop_new.err"
+python3 tools/bench_propose.py --scen tight,mid,wide --n 131072 >> "$O/prop_new_plain.jsonl" 2>> "$O/prop_new.err"
+if [ -f scratch/oldlib/libtempest_hip_r01.so ]; then
+  rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d "$O/pmc_prop_old" -o p -- python3 tools/bench_propose.py --legacy --lib scratch/oldlib/libtempest_hip_r01.so --scen tight,mid,wide --reps 5 > "$O/prop_old.jsonl" 2> "$O/prop_old.err"
+  python3 tools/bench_propose.py --legacy --lib scratch/oldlib/libtempest_hip_r01.so --scen tight,mid,wide > "$O/prop_old_plain.jsonl" 2>> "$O/prop_old.err"
+  python3 tools/bench_propose.py --legacy --lib scratch/oldlib/libtempest_hip_r01.so --scen tight,mid,wide --n 131072 >> "$O/prop_old_plain.jsonl" 2>> "$O/prop_old.err"
+fi
+# 5. d > 16 proposal kernels
+for k in rwm tpcn; do
+  python3 tools/bench_propose.py --d 50 --n 65536 --kernel $k --scen tight,mid,wide --reps 10 --variant 3 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+  python3 tools/bench_propose.py --d 50 --n 65536 --kernel $k --scen tight,mid --reps 10 --variant 4 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+done
+python3 tools/bench_propose.py --d 100 --n 262144 --kernel tpcn --scen tight --reps 10 --variant 3 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+python3 tools/bench_propose.py --d 100 --n 262144 --kernel tpcn --scen tight --reps 10 --variant 4 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+# 6. config 2 end to end under the tracer
+for k in rwm tpcn; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c2_$k" -o c2 -- python3 tools/run_config.py c2 $k > "$O/c2_$k.log" 2>&1
+done
+python3 tools/run_config.py c2 rwm > "$O/c2_rwm_plain.log" 2>&1
+python3 tools/run_config.py c2 tpcn > "$O/c2_tpcn_plain.log" 2>&1
+# 7. per-kernel roofline table
+TPH_ROOFLINE_META="$O/roof/meta.json" true
+mkdir -p "$O/roof"
+TPH_ROOFLINE_META="$O/roof/meta.json" python3 tools/roofline_table.py > "$O/roof/plain.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$O/roof/trace" -o t -- python3 tools/roofline_table.py > "$O/roof/trace.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/roof/fetch" -o f -- python3 tools/roofline_table.py > "$O/roof/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/roof/write" -o w -- python3 tools/roofline_table.py > "$O/roof/write.log" 2>&1
+python3 tools/roofline_table.py --collect "$O/roof" --out "$O/roofline_table.json" > "$O/roofline_table.txt"
+rm -rf "$O/roof/trace" "$O/roof/fetch" "$O/roof/write"
+# 8. config 4's 8-GPU shard size, un-sharded and through the sharded code path over RCCL at world size 1
+python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline > "$O/bench_131k.json" 2> "$O/bench_131k.err"
+TEMPEST_AMD_FORCE_COMM=1 python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline > "$O/bench_131k_comm.json" 2> "$O/bench_131k_comm.err"
+# keep the merge small: drop the raw traces that are not summarised further
+find "$O" -name "*kernel_trace.csv" -size +8M -delete
+du -sh "$O"
+echo collected

@@ -1,0 +1,34 @@
+"""One BASELINE.json configuration end to end on one GPU (used under rocprofv3 for profiles/): `run_config.py c2 rwm|tpcn`."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+
+
+def main():
+    import torch
+    import tempest_amd as tp
+    which, kernel = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "tpcn")
+    dev = torch.device("cuda", 0)
+    assert which == "c2"
+    d, n = 50, 65536
+    A = np.random.RandomState(1).randn(d, d)
+    S = A @ A.T / d + 0.5 * np.eye(d)
+    P = torch.from_numpy(np.linalg.inv(S)).to(dev)
+    const = float(-0.5 * np.linalg.slogdet(S)[1] - 0.5 * d * np.log(2 * np.pi))
+    s = tp.Sampler(lambda u: 20 * u - 10, lambda x: -0.5 * ((x @ P) * x).sum(dim=1) + const, d, vectorize=True,
+                   n_particles=n, clustering=False, random_state=0, sample=kernel, backend="torch", batch_prior=True)
+    t0 = time.perf_counter()
+    s.run(n_total=4 * n, progress=False)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    steps = np.asarray(s.state.get_history("steps")); beta = np.asarray(s.state.get_history("beta"))
+    print(f'{{"config": "c2", "kernel": "{kernel}", "n_dim": {d}, "n_particles": {n}, "logz": {s.evidence()[0]}, '
+          f'"analytic_logz": {-d * np.log(20.0)}, "iterations": {len(beta)}, "mcmc_steps": {int(steps[beta > 0].sum())}, '
+          f'"wall_s": {wall}, "pms_per_s": {steps[beta > 0].sum() * n / wall}}}')
+
+
+if __name__ == "__main__":
+    main()
