@@ -110,13 +110,15 @@ def reweight_roofline(device, n_rows, other_rows=(2_621_440, 10_485_760)):
     ctx.close()
     torch.cuda.empty_cache()
     traffic, traffic_source = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_reweight_pmc.json")
-    if os.path.exists(pmc):
+    for name in ("r02_reweight_pmc.json", "r01_reweight_pmc.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(pmc) or traffic is not None:
+            continue
         try:
             rec = json.load(open(pmc))
             if rec.get("n_rows") == n_rows:
                 traffic = rec.get("hbm_bytes_per_launch")
-                traffic_source = ("profiles/r01_reweight_pmc.json: rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of "
+                traffic_source = ("profiles/" + name + ": rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of "
                                   "this kernel on this history in an earlier profiled run, NOT counters of this run")
         except Exception:
             traffic = None

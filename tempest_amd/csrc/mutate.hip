@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(double* __restrict__ u,
 
   // One attempt `att` for particle i (mode c) from its current point uc: z <- the proposal; returns in-bounds?
   // (mcmc.py:239-249 tpCN / :301-312 RWM; att == PROP_MAX_ATTEMPTS: the redraw cap, the current point is proposed.)
-  auto attempt = [&](int64_t i, int c, int att, double b_fac, const double (&uc)[D], double (&z)[D]) -> bool {
+  auto attempt = [&](int64_t i, int c, int att, double b_fac, double (&z)[D]) -> bool {
     const double* __restrict__ mu = means + (size_t)c * D;
     const double* __restrict__ L = chol + (size_t)c * D * D;
     bool ok = true;
@@ -715,9 +715,11 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(double* __restrict__ u,
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j <= r; ++j) acc = fma(L[r * D + j], z[j], acc);
+        const double ur = u[(size_t)r * ld + i];      // loaded where it is used: the current point is not held across the
+                                                      // Box-Muller loop (20 registers for d = 10)
         double v;
-        if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * (uc[r] - mu[r]) + b_fac * acc;
-        else v = uc[r] + b_fac * acc;
+        if (KERNEL == TPH_KERNEL_TPCN) v = mu[r] + a_fac * (ur - mu[r]) + b_fac * acc;
+        else v = ur + b_fac * acc;
         if (HAS_BC) {       // periodic / reflective dimensions (mcmc.py:326-366): a separate instantiation, so that
                             // the usual all-strict case carries none of the fmod code in its unrolled rows
           const uint8_t f = bc[r];
@@ -731,7 +733,10 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(double* __restrict__ u,
       }
     } else {  // redraw cap reached (the reference would loop on): propose the current point
 #pragma unroll
-      for (int j = 0; j < D; ++j) z[j] = (KERNEL == TPH_KERNEL_TPCN) ? (uc[j] - mu[j]) + mu[j] : uc[j];
+      for (int j = 0; j < D; ++j) {
+        const double uj = u[(size_t)j * ld + i];
+        z[j] = (KERNEL == TPH_KERNEL_TPCN) ? (uj - mu[j]) + mu[j] : uj;
+      }
     }
     return ok;
   };
@@ -827,10 +832,7 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(double* __restrict__ u,
       }
       if (busy) {
         c = ONE_MODE ? 0 : assign[i];
-        double uc[D];
-#pragma unroll
-        for (int j = 0; j < D; ++j) uc[j] = u[(size_t)j * ld + i];
-        ok = attempt(i, c, att, s_bfac[pid], uc, z);
+        ok = attempt(i, c, att, s_bfac[pid], z);
       }
       // first in-bounds attempt of each particle: its G lanes are consecutive lanes of the wave (G <= 64 divides 64)
       const unsigned long long okmask = __ballot(ok);

@@ -9,11 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_unprofiled.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_unprofiled.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["n_gpus"] == 1
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - d["timed_mcmc_steps"] * d["config"]["particles_global"] / (d["ms_per_step"] * d["steps"] * 1e-3)) \

@@ -41,10 +41,16 @@ def main():
     lib = _lib.load(a.lib) if not a.legacy else C.CDLL(a.lib)
     if a.legacy:
         for name, (res, args) in _lib.SIGNATURES.items():
-            if name in ("tph_fit_modes", "tph_chol_inv"):
+            if name in ("tph_fit_modes", "tph_chol_inv", "tph_propose", "tph_accept"):
+                continue                      # signatures that changed since round 1
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:            # entry points the round-1 library does not have
                 continue
-            fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        lib.tph_propose.restype = C.c_int
+        lib.tph_propose.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 6 + [
+            C.c_uint64, C.c_uint32, C.c_int64] + [C.c_void_p] * 4
     dev = torch.device("cuda", 0)
     n, d = a.n, a.d
     ctx = C.c_void_p()
