@@ -102,6 +102,26 @@ typedef int (*tph_allgather_fn)(void* user, int64_t send_offset, int64_t recv_of
 int tph_comm_attach(tph_ctx* ctx, int rank, int world, void* buf_dev, int64_t buf_bytes, tph_allreduce_fn allreduce,
                     tph_allgather_fn allgather, void* user);
 int tph_comm_detach(tph_ctx* ctx);
+/* Optional, ranks on ONE node: small-message collectives (<= 32 KB: the reweight triples, the per-step acceptance sums, block
+ * totals, moments) over peer-mapped device memory instead of the callbacks -- one single-block kernel on the ctx stream per
+ * collective: every rank stores its values into its slot of every peer's inbox (xGMI is point to point), raises a sequence
+ * flag, waits for the world's flags in its own inbox and reduces the slots in rank order (bit-identical sums on all ranks).
+ * No host call, no second stream; the kernel takes its sequence number from device memory, so a step that contains one can
+ * be captured in a graph.  Protocol: every rank calls _export (allocates its inbox, returns a 64-byte HIP IPC handle), the
+ * host all-gathers the handles by any means, every rank calls _attach with all of them (rank order).  _attach maps the peers,
+ * runs a self-test exchange and agrees with the other ranks through the attached all-reduce: *ok_out = 1 on every rank, or 0
+ * on every rank (peer access or IPC unavailable: everything keeps going through the callbacks).  A peer that never arrives
+ * makes the waiting kernel give up after TEMPEST_AMD_P2P_TIMEOUT seconds (default 120); the next collective, or
+ * tph_comm_p2p_status, then fails.  tph_comm_detach / tph_ctx_destroy unmap. */
+#define TPH_P2P_HANDLE_BYTES 64
+int tph_comm_p2p_export(tph_ctx* ctx, void* handle_out /* [TPH_P2P_HANDLE_BYTES] host */);
+int tph_comm_p2p_attach(tph_ctx* ctx, const void* handles /* [world][TPH_P2P_HANDLE_BYTES] host */, int* ok_out);
+int tph_comm_p2p_active(const tph_ctx* ctx);
+int tph_comm_p2p_status(tph_ctx* ctx);
+/* in-place all-reduce of a small device array that lives outside the staging block (MCMC step: the (accepted, sum alpha_c)
+ * sums between tph_accept and tph_adapt; replaces a framework call per step).  Peer-to-peer when attached and count fits,
+ * else staged through the all-reduce callback.  No-op without a communicator. */
+int tph_comm_allreduce_dev(tph_ctx* ctx, void* data_dev, int64_t count, int dtype, int op);
 
 /* ---- persistent ensemble: StateManager history (state_manager.py:171-176,356-416) ------------
  * tph_history_append = commit_current_to_history for the array keys u, x, logl, plus the cached
@@ -264,7 +284,10 @@ int tph_adapt(tph_ctx* ctx, int kernel, double* sums_dev /* in; out when partial
                                       s % mailbox_slots, its field [7] = s is stored last (system-scope release), so the host can poll for it */,
               int mailbox_slots,
               const double* partials_dev /* NULL, or tph_accept's block partials of n particles: their column sums
-                                            are formed here (into sums_dev) instead of by a kernel of their own */,
+                                            are formed here (into sums_dev) instead of by a kernel of their own.  With a
+                                            communicator attached they are THIS RANK's sums and the kernel all-reduces them
+                                            with the peers in place (needs tph_comm_p2p_attach): a sharded step then has the
+                                            launches of a single-GPU step and no host call */,
               int64_t n);
 int tph_cluster_counts(tph_ctx* ctx, const int32_t* assign_dev, int64_t n, int K, double* counts_dev);
 

@@ -74,6 +74,11 @@ SIGNATURES = {
     "tph_volume_variation": (c_int, [ptr, ptr, c_i64, ptr, ptr]),
     "tph_comm_attach": (c_int, [ptr, c_int, c_int, ptr, c_i64, ptr, ptr, ptr]),
     "tph_comm_detach": (c_int, [ptr]),
+    "tph_comm_p2p_export": (c_int, [ptr, ptr]),
+    "tph_comm_p2p_attach": (c_int, [ptr, ptr, ptr]),
+    "tph_comm_p2p_active": (c_int, [ptr]),
+    "tph_comm_p2p_status": (c_int, [ptr]),
+    "tph_comm_allreduce_dev": (c_int, [ptr, ptr, c_i64, c_int, c_int]),
     "tph_trim_threshold_global": (c_int, [ptr, ptr, c_i64, c_dbl, c_int, ptr, ptr]),
     "tph_cdf_global": (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr]),
     "tph_resample_select_global": (c_int, [ptr, ptr, c_i64, c_i64, c_int, c_u64, c_u32, c_u32, c_dbl, c_dbl, ptr]),

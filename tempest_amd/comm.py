@@ -14,6 +14,11 @@ import os
 import numpy as np
 
 
+def _P2P_DTYPES():
+    import torch
+    return (torch.float64, torch.int64, torch.int32)
+
+
 def merge_triples_host(parts):
     """Merge per-rank reweight partials [(m, s1, s2)] -> global, per trial beta.
     parts: array (G, nb, 3).  logsumexp-style: M = max m_g ; s1 = sum s1_g e^{m_g-M} ; s2 = sum s2_g e^{2(m_g-M)}."""
@@ -28,10 +33,11 @@ def merge_triples_host(parts):
     return np.stack([M, s1, s2], axis=1)
 
 
-def attach_loopback(ctx, nbytes: int = 64 << 20):
+def attach_loopback(ctx, nbytes: int = 64 << 20, p2p: bool = False):
     """A one-rank communicator without any process group: all-reduce = identity, all-gather = copy.  Routes a single
     GPU through every sharded code path of the library (tests; the global entry points must then reproduce the plain
-    ones up to summation order)."""
+    ones up to summation order).  `p2p`: also attach the peer-to-peer small-message collectives (world 1: the exchange
+    kernel runs against this rank's own inbox)."""
     import ctypes as C
     import torch
     from . import _lib
@@ -50,6 +56,8 @@ def attach_loopback(ctx, nbytes: int = 64 << 20):
     _lib.check(ctx.lib.tph_comm_attach(ctx._ctx, 0, 1, C.c_void_p(buf.data_ptr()), buf.numel(), ar, ag, None),
                "tph_comm_attach")
     ctx._comm_keep = (buf, ar, ag)
+    if p2p and not ctx.p2p_attach([ctx.p2p_export()]):
+        raise RuntimeError("peer-to-peer collectives failed their self-test")
     return buf
 
 
@@ -62,6 +70,7 @@ class Comm:
         self.group = group
         self.world_size = self._dist.get_world_size(group) if self._dist else 1
         self.rank = self._dist.get_rank(group) if self._dist else 0
+        self._p2p_ctx = None          # weakref to the DeviceContext whose library carries the small collectives itself
 
     @property
     def active(self):
@@ -129,7 +138,35 @@ class Comm:
         _lib.check(ctx.lib.tph_comm_attach(ctx._ctx, self.rank, world, C.c_void_p(buf.data_ptr()), buf.numel(), ar, ag,
                                            None), "tph_comm_attach")
         ctx._comm_keep = (buf, ar, ag)         # the library holds raw pointers to all three
+        self._p2p_ctx = None
+        if os.environ.get("TEMPEST_AMD_P2P", "1") != "0":
+            self._attach_p2p(ctx)
         return buf
+
+    def _attach_p2p(self, ctx):
+        """Ranks of one node: let the library exchange its small messages (reweight triples, per-step sums, block totals,
+        moments) through peer-mapped device memory -- one kernel on the ctx stream per collective, no framework call
+        (tph_comm_p2p_*).  Every rank reaches the same verdict: the handles travel through the process group, and the
+        library agrees on the self-test through the all-reduce attached above.  TEMPEST_AMD_P2P=0 turns it off."""
+        import socket
+        import weakref
+        try:
+            handle = ctx.p2p_export()
+        except Exception:
+            handle = None
+        mine = (socket.gethostname(), ctx.device.index, handle)
+        everyone = [None] * self.world_size
+        if self.world_size > 1:
+            self._dist.all_gather_object(everyone, mine, group=self.group)
+        else:
+            everyone = [mine]
+        same_node = len({h for h, _, _ in everyone}) == 1
+        if not same_node or any(h is None for _, _, h in everyone) or self.world_size > 16:
+            return False
+        if ctx.p2p_attach([h for _, _, h in everyone]):
+            self._p2p_ctx = weakref.ref(ctx)
+            return True
+        return False
 
     def all_gather_v(self, t):
         """Concatenate device tensors that differ in their FIRST dimension over the ranks (rank order); every rank gets
@@ -146,8 +183,14 @@ class Comm:
         return torch.cat([allp[r, : counts[r]] for r in range(self.world_size)], dim=0), counts
 
     def all_reduce_sum(self, t):
-        """In-place SUM all-reduce of a tensor (device tensor -> RCCL; CPU tensor -> gloo)."""
+        """In-place SUM all-reduce of a tensor (device tensor -> RCCL; CPU tensor -> gloo); small FP64 / integer device
+        tensors go through the library's peer-to-peer exchange on the ctx stream when that is attached."""
         if self.active:
+            ctx = self._p2p_ctx() if self._p2p_ctx is not None else None
+            if (ctx is not None and t.is_cuda and t.is_contiguous() and t.numel() * t.element_size() <= 32768
+                    and t.dtype in _P2P_DTYPES() and t.device == ctx.device and ctx.p2p_active):
+                ctx.allreduce_dev(t, 0)
+                return t
             if t.is_cuda and self._stage_on_host:
                 h = t.cpu()
                 self._dist.all_reduce(h, op=self._dist.ReduceOp.SUM, group=self.group)

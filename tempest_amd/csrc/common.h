@@ -37,6 +37,8 @@ constexpr int TPH_RED_BLOCKS = 2048;    // 256 CUs x 8 blocks: grid cap of the s
 constexpr int TPH_RED_THREADS = 256;
 constexpr int TPH_WAVE = 64;
 
+struct tph_p2p;                         // p2p.hip: peer-mapped inboxes of the node's ranks
+
 struct tph_ctx {
   int device = 0;
   int d = 0;
@@ -84,6 +86,7 @@ struct tph_ctx {
   double* blk_table = nullptr;      // block table of the last tph_cdf_global: glo[T], ghi[T], total (device)
   int blk_table_cap = 0, blk_T = 0;
   int64_t blk_rows = 0;
+  tph_p2p* p2p = nullptr;           // small-message collectives over peer-mapped memory (tph_comm_p2p_attach), or NULL
   bool comm_active() const { return comm_allreduce != nullptr; }
 };
 
@@ -93,6 +96,10 @@ enum { TPH_OP_SUM = 0, TPH_OP_MAX = 1, TPH_OP_MIN = 2 };
 int tph_comm_require(tph_ctx* ctx, size_t bytes, const char* who);
 int tph_comm_allreduce(tph_ctx* ctx, size_t off, int64_t count, int dtype, int op);
 int tph_comm_allgather(tph_ctx* ctx, size_t send_off, size_t recv_off, int64_t count, int dtype);
+// p2p.hip: one single-block exchange kernel on the ctx stream instead of the callback, for messages of <= 32 KB
+bool tph_p2p_fits(const tph_ctx* ctx, int64_t count, int dtype);
+int tph_p2p_exchange(tph_ctx* ctx, const void* src, void* dst, int64_t count, int dtype, int op /* < 0: all-gather */);
+void tph_p2p_release(tph_ctx* ctx);
 int tph_blocks(tph_ctx* ctx, int64_t n, int* T, int64_t* rows);   // equal-sized iteration blocks of the local history
 
 int tph_scratch_reserve(tph_ctx* ctx, size_t bytes);

@@ -145,6 +145,7 @@ extern "C" int tph_ctx_destroy(tph_ctx* ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  tph_p2p_release(ctx);
   void* bufs[] = {ctx->u, ctx->x, ctx->logl, ctx->cmix, ctx->table_dev, ctx->partials, ctx->small_dev, ctx->scratch, ctx->winv,
                   ctx->blk_table, ctx->vv_buf, ctx->blk_buf};
   for (void* b : bufs) (void)hipFree(b);
@@ -167,6 +168,7 @@ extern "C" int tph_comm_attach(tph_ctx* ctx, int rank, int world, void* buf_dev,
 }
 extern "C" int tph_comm_detach(tph_ctx* ctx) {
   TPH_REQUIRE(ctx, "tph_comm_detach: ctx is NULL");
+  tph_p2p_release(ctx);
   ctx->rank = 0; ctx->world = 1;
   ctx->comm_buf = nullptr; ctx->comm_bytes = 0;
   ctx->comm_allreduce = nullptr; ctx->comm_allgather = nullptr; ctx->comm_user = nullptr;
@@ -179,11 +181,13 @@ int tph_comm_require(tph_ctx* ctx, size_t bytes, const char* who) {
   return 0;
 }
 int tph_comm_allreduce(tph_ctx* ctx, size_t off, int64_t count, int dtype, int op) {
+  if (tph_p2p_fits(ctx, count, dtype)) return tph_p2p_exchange(ctx, ctx->comm_buf + off, ctx->comm_buf + off, count, dtype, op);
   const int rc = ctx->comm_allreduce(ctx->comm_user, (int64_t)off, count, dtype, op);
   TPH_REQUIRE(rc == 0, "all-reduce callback failed (%d)", rc);
   return 0;
 }
 int tph_comm_allgather(tph_ctx* ctx, size_t send_off, size_t recv_off, int64_t count, int dtype) {
+  if (tph_p2p_fits(ctx, count, dtype)) return tph_p2p_exchange(ctx, ctx->comm_buf + send_off, ctx->comm_buf + recv_off, count, dtype, -1);
   const int rc = ctx->comm_allgather(ctx->comm_user, (int64_t)send_off, (int64_t)recv_off, count, dtype);
   TPH_REQUIRE(rc == 0, "all-gather callback failed (%d)", rc);
   return 0;

@@ -130,21 +130,23 @@ __global__ void k_trim_targets(const long long* __restrict__ n_global_dev, int b
   prefix[2 * i + 1] = 0ull;
 }
 // counts[q][v] = #{local weights whose pattern lies in [prefix_q + v << shift, prefix_q + (v+1) << shift)}
+template <typename CT>
 __global__ void __launch_bounds__(256) k_select_count(const double* __restrict__ S, int64_t n, const unsigned long long* __restrict__ prefix,
-                                                      int round, long long* __restrict__ counts) {
+                                                      int round, CT* __restrict__ counts) {
   const int q = blockIdx.x, v = threadIdx.x;
   const int shift = 64 - SEL_BITS * (round + 1);
   const unsigned long long base = prefix[q] + ((unsigned long long)v << shift);
   const int64_t lo = lower_bound_key(S, n, base);
   const unsigned long long upper = base + (1ull << shift);
   const int64_t hi = upper < base ? n : lower_bound_key(S, n, upper);     // wrapped past 2^64: everything from `lo` on
-  counts[(size_t)q * SEL_DIGITS + v] = (long long)(hi - lo);
+  counts[(size_t)q * SEL_DIGITS + v] = (CT)(hi - lo);
 }
-__global__ void __launch_bounds__(256) k_select_update(const long long* __restrict__ counts, int round, long long* __restrict__ remaining,
+template <typename CT>
+__global__ void __launch_bounds__(256) k_select_update(const CT* __restrict__ counts, int round, long long* __restrict__ remaining,
                                                        unsigned long long* __restrict__ prefix) {
   const int q = blockIdx.x;
   __shared__ long long cum[SEL_DIGITS];
-  const long long mine = counts[(size_t)q * SEL_DIGITS + threadIdx.x];
+  const long long mine = (long long)counts[(size_t)q * SEL_DIGITS + threadIdx.x];
   cum[threadIdx.x] = mine;
   __syncthreads();
   for (int o = 1; o < SEL_DIGITS; o <<= 1) {
@@ -244,11 +246,22 @@ extern "C" int tph_trim_threshold_global(tph_ctx* ctx, const double* w_dev, int6
   TPH_LAUNCH_CHECK();
   if (tph_comm_allreduce(ctx, 0, 1, TPH_DT_I64, TPH_OP_SUM)) return -2;
   hipLaunchKernelGGL(k_trim_targets, dim3((bins + 255) / 256), dim3(256), 0, ctx->stream, n_global, bins, remaining, prefix);
+  // 32-bit counters (half the all-reduce: 8 x [2 bins][256]) whenever the GLOBAL history is known to hold < 2^31 rows
+  long long n_all = 0;
+  for (int64_t v : ctx->n_global_t) n_all += v;
+  const bool narrow = n == ctx->size && n_all > 0 && n_all < (1ll << 31);
   for (int round = 0; round < SEL_ROUNDS; ++round) {
-    hipLaunchKernelGGL(k_select_count, dim3(Q), dim3(SEL_DIGITS), 0, ctx->stream, S, n, prefix, round, counts);
-    TPH_LAUNCH_CHECK();
-    if (tph_comm_allreduce(ctx, o_cnt, (int64_t)Q * SEL_DIGITS, TPH_DT_I64, TPH_OP_SUM)) return -2;
-    hipLaunchKernelGGL(k_select_update, dim3(Q), dim3(SEL_DIGITS), 0, ctx->stream, counts, round, remaining, prefix);
+    if (narrow) {
+      hipLaunchKernelGGL(k_select_count<int>, dim3(Q), dim3(SEL_DIGITS), 0, ctx->stream, S, n, prefix, round, (int*)counts);
+      TPH_LAUNCH_CHECK();
+      if (tph_comm_allreduce(ctx, o_cnt, (int64_t)Q * SEL_DIGITS, TPH_DT_I32, TPH_OP_SUM)) return -2;
+      hipLaunchKernelGGL(k_select_update<int>, dim3(Q), dim3(SEL_DIGITS), 0, ctx->stream, (const int*)counts, round, remaining, prefix);
+    } else {
+      hipLaunchKernelGGL(k_select_count<long long>, dim3(Q), dim3(SEL_DIGITS), 0, ctx->stream, S, n, prefix, round, counts);
+      TPH_LAUNCH_CHECK();
+      if (tph_comm_allreduce(ctx, o_cnt, (int64_t)Q * SEL_DIGITS, TPH_DT_I64, TPH_OP_SUM)) return -2;
+      hipLaunchKernelGGL(k_select_update<long long>, dim3(Q), dim3(SEL_DIGITS), 0, ctx->stream, counts, round, remaining, prefix);
+    }
   }
   double* part = (double*)(ctx->comm_buf + o_cnt);
   hipLaunchKernelGGL(k_trim_partials, dim3((bins + 255) / 256), dim3(256), 0, ctx->stream, S, P1, P2, n, n_global, bins, prefix, part);
@@ -1108,8 +1121,25 @@ extern "C" int tph_fit_modes_global(tph_ctx* ctx, const int32_t* counts_dev, con
   TPH_REQUIRE(n > 0 && n <= ctx->size && K >= 1, "tph_fit_modes_global: bad sizes");
   TPH_REQUIRE(K == 1 || labels_dev, "tph_fit_modes_global: K>1 needs labels");
   const int d = ctx->d, G = ctx->world;
+  // working set: this rank's shard, or (large shards) the dense copy of its rows with multiplicity > 0, as in tph_fit_modes --
+  // a local choice: the rows and their order are the same, only the block boundaries of the partial sums move
   const double* src = ctx->u;
-  const int64_t src_ld = ctx->cap;
+  int64_t src_ld = ctx->cap;
+  const int64_t n_hist = n;
+  int64_t m_keep = -1;
+  const int nzb = (int)((n_hist + NZ_ROWS - 1) / NZ_ROWS);
+  int* blockcnt = (int*)ctx->partials;
+  if (n_hist >= FIT_COMPACT_MIN && (size_t)nzb * sizeof(int) <= ctx->partials_bytes) {
+    long long* total = (long long*)ctx->small_dev;
+    hipLaunchKernelGGL(k_nz_count, dim3(nzb), dim3(256), 0, ctx->stream, counts_dev, n_hist, blockcnt);
+    hipLaunchKernelGGL(k_nz_offsets, dim3(1), dim3(1024), 0, ctx->stream, blockcnt, nzb, total);
+    TPH_LAUNCH_CHECK();
+    TPH_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    long long m = *(long long*)ctx->pinned;
+    if (m > 0 && 2 * m <= n_hist) m_keep = m;
+  }
+  if (m_keep > 0) n = m_keep;
   const int nblk = cov_blocks(n);
   const int rblk = tph_grid_for(n, 256, 4, 512);
   const int npl = d * (d + 1) / 2;
@@ -1123,8 +1153,24 @@ extern "C" int tph_fit_modes_global(tph_ctx* ctx, const int32_t* counts_dev, con
   size_t o_vals = take(sizeof(double) * (size_t)d * 2 * MED_CAP);
   size_t o_cnts = take(sizeof(int) * (size_t)d * 2 * MED_CAP);
   size_t o_ovf = take(sizeof(int));
+  size_t o_uc = 0, o_cc = 0, o_lc = 0;
+  if (m_keep > 0) {
+    o_uc = take(sizeof(double) * (size_t)d * (size_t)m_keep);
+    o_cc = take(sizeof(int32_t) * (size_t)m_keep);
+    o_lc = take(sizeof(int32_t) * (size_t)m_keep);
+  }
   if (tph_scratch_reserve(ctx, o)) return -1;
   char* base = (char*)ctx->scratch;
+  if (m_keep > 0) {
+    double* uc = (double*)(base + o_uc);
+    int32_t* cc = (int32_t*)(base + o_cc);
+    int32_t* lc = K > 1 ? (int32_t*)(base + o_lc) : nullptr;
+    hipLaunchKernelGGL(k_nz_scatter, dim3(nzb), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, d, counts_dev, labels_dev, n_hist,
+                       blockcnt, uc, m_keep, cc, lc);
+    TPH_LAUNCH_CHECK();
+    src = uc; src_ld = m_keep; counts_dev = cc;
+    if (K > 1) labels_dev = lc;
+  }
   double* part = (double*)(base + o_part);
   double* part1 = (double*)(base + o_part1);
   double* range = (double*)(base + o_range);
@@ -1295,25 +1341,34 @@ extern "C" int tph_weighted_cov_centered(tph_ctx* ctx, const double* w_dev, int6
   return moments_launch_cov(ctx, w_dev, false, nullptr, 0, n, mean_dev, nullptr, 0, cov_dev, (double*)ctx->scratch, nblk);
 }
 
-extern "C" int tph_weighted_moments_shifted(tph_ctx* ctx, const double* w_dev, int64_t n, const double* centre_dev,
-                                            double* out_dev) {
-  TPH_REQUIRE(ctx && w_dev && centre_dev && out_dev && n > 0 && n <= ctx->size, "tph_weighted_moments_shifted: bad argument");
+// `global`: the shifted raw sums (additive over rows) of all ranks are all-reduced before the finish; the centre must be the
+// same on every rank (it is: the previous GLOBAL mean)
+static int moments_shifted(tph_ctx* ctx, const double* w_dev, int64_t n, const double* centre_dev, double* out_dev, bool global) {
   const int d = ctx->d;
   TPH_REQUIRE(d <= 12, "tph_weighted_moments_shifted: n_dim=%d > 12 (use tph_weighted_sums + tph_weighted_cov_centered)", d);
   const int nc = d * (d + 1) / 2 + d + 1;
   const int nblk = tph_grid_for(n, 256, 8, 1024);
   if (tph_scratch_reserve(ctx, sizeof(double) * ((size_t)nblk + 1) * nc)) return -1;
+  if (global && tph_comm_require(ctx, sizeof(double) * nc, "tph_volume_variation")) return -2;
   double* part = (double*)ctx->scratch;
-  double* csum = part + (size_t)nblk * nc;
+  double* csum = global ? (double*)ctx->comm_buf : part + (size_t)nblk * nc;
   switch (d) {
 #define C(DD) case DD: hipLaunchKernelGGL((k_wmom_small<DD>), dim3(nblk), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, w_dev, n, centre_dev, part); break;
     C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12)
 #undef C
   }
   hipLaunchKernelGGL(k_colsum2, dim3(nc), dim3(256), 0, ctx->stream, part, nblk, nc, csum);
+  TPH_LAUNCH_CHECK();
+  if (global && tph_comm_allreduce(ctx, 0, nc, TPH_DT_F64, TPH_OP_SUM)) return -2;
   hipLaunchKernelGGL(k_wmom_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum, centre_dev, d, out_dev);
   TPH_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int tph_weighted_moments_shifted(tph_ctx* ctx, const double* w_dev, int64_t n, const double* centre_dev,
+                                            double* out_dev) {
+  TPH_REQUIRE(ctx && w_dev && centre_dev && out_dev && n > 0 && n <= ctx->size, "tph_weighted_moments_shifted: bad argument");
+  return moments_shifted(ctx, w_dev, n, centre_dev, out_dev, false);
 }
 
 // sum_s w_s^2 clip(d2_s - n_dim, +-1e6)^2 with d2 the Mahalanobis distance (tools.py:111-115).
@@ -1576,8 +1631,8 @@ extern "C" int tph_volume_variation(tph_ctx* ctx, const double* w_dev, int64_t n
   double* Wb = W + mat;
   double* mom = Wb + tri_blocked_doubles(d);
   // ---- moments
-  if (!comm && d <= 12 && centre_dev) {
-    if (tph_weighted_moments_shifted(ctx, w_dev, n, centre_dev, mom)) return -1;
+  if (d <= 12 && centre_dev) {
+    if (moments_shifted(ctx, w_dev, n, centre_dev, mom, comm)) return -1;
     hipLaunchKernelGGL(k_vv_split, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, mom, d, s0, mean, cov);
     TPH_HIP(hipMemcpyAsync(centre_dev, mean, sizeof(double) * d, hipMemcpyDeviceToDevice, ctx->stream));   // next call's centre
   } else {

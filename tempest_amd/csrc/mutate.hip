@@ -3,6 +3,7 @@
 // adaptive step count), :211-288 (tpCN), :291-323 (RWM), :326-411 (boundary conditions).
 #include "common.h"
 #include "tri.h"
+#include "p2p.h"
 
 // ------------------------------------------------------------------------------- prior draw (beta=0)
 // u ~ U(0,1)^d (mutate.py:102): one Philox call per coordinate pair.
@@ -1094,9 +1095,9 @@ extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, 
 __global__ void __launch_bounds__(1024) k_adapt(int kernel, const double* __restrict__ sums, const double* __restrict__ counts, int K, double n_global,
                         int d, int n_steps, int n_max, double* __restrict__ sigmas, double* __restrict__ state,
                         double* __restrict__ mailbox, int slots, const double* __restrict__ partials, int nblocks,
-                        double* __restrict__ sums_out) {
-  if (state[1] != 0.0) return;          // stopping rule already fired: later (speculative) steps are no-ops
-  if (partials) {                        // single GPU: the column sums of tph_accept's block partials, folded in here
+                        double* __restrict__ sums_out, int exchange, p2p_args peers) {
+  if (state[1] != 0.0) return;          // stopping rule already fired: later (speculative) steps are no-ops (on every rank)
+  if (partials) {                        // the column sums of tph_accept's block partials, folded in here
     __shared__ double sh[16];
     for (int col = 0; col <= K; ++col) {
       double s = 0.0;
@@ -1105,6 +1106,9 @@ __global__ void __launch_bounds__(1024) k_adapt(int kernel, const double* __rest
       if (threadIdx.x == 0) sums_out[col] = s;
     }
     __syncthreads();
+    // sharded run: the ranks' sums meet here, through the peer-mapped inboxes (p2p.h) -- the all-reduce of the step costs
+    // no launch and no host call; every rank adds the slots in rank order, so all adapt identically
+    if (exchange && !p2p_block_exchange(peers, sums_out, sums_out, 1 + K, TPH_OP_SUM)) return;
     sums = sums_out;
   }
   if (threadIdx.x != 0) return;
@@ -1160,8 +1164,18 @@ extern "C" int tph_adapt(tph_ctx* ctx, int kernel, double* sums_dev, const doubl
   TPH_REQUIRE(!mailbox_host || mailbox_slots >= 1, "tph_adapt: mailbox needs at least one slot");
   const int nparts = (int)((n + ACC_THREADS - 1) / ACC_THREADS);
   const int threads = (partials_dev && nparts > 1024) ? 1024 : 256;      // the folded column sums are the only parallel work
+  p2p_args peers{};
+  int exchange = 0;
+  if (partials_dev && ctx->comm_active()) {
+    const p2p_args* a = tph_p2p_ready(ctx, 1 + K, TPH_DT_F64);
+    TPH_REQUIRE(a, "tph_adapt: folding the block partials of a SHARDED step needs the peer-to-peer exchange (tph_comm_p2p_attach); "
+                "without it all-reduce the sums of tph_accept yourself and pass partials_dev = NULL");
+    peers = *a;
+    exchange = 1;
+  }
   hipLaunchKernelGGL(k_adapt, dim3(1), dim3(threads), 0, ctx->stream, kernel, (const double*)sums_dev, counts_dev, K, n_global,
-                     n_dim, n_steps, n_max, sigmas_dev, state_dev, mailbox_host, mailbox_slots, partials_dev, nparts, sums_dev);
+                     n_dim, n_steps, n_max, sigmas_dev, state_dev, mailbox_host, mailbox_slots, partials_dev, nparts, sums_dev,
+                     exchange, peers);
   TPH_LAUNCH_CHECK();
   return 0;
 }

@@ -172,6 +172,38 @@ class HipContext:
         check(self.lib.tph_reweight_time(self._ctx, float(beta), int(nb), int(reps), C.byref(out)), "tph_reweight_time")
         return out.value
 
+    # ------------------------------------------------------------------ small collectives inside the library
+    P2P_HANDLE_BYTES = 64
+
+    def p2p_export(self) -> bytes:
+        """This rank's inbox for the peer-to-peer small-message collectives (tph_comm_p2p_export): a HIP IPC handle."""
+        h = C.create_string_buffer(self.P2P_HANDLE_BYTES)
+        check(self.lib.tph_comm_p2p_export(self._ctx, h), "tph_comm_p2p_export")
+        return h.raw
+
+    def p2p_attach(self, handles) -> bool:
+        """Map the peers' inboxes (handles in rank order) and self-test; True on every rank or False on every rank."""
+        blob = b"".join(handles)
+        ok = C.c_int(0)
+        check(self.lib.tph_comm_p2p_attach(self._ctx, C.c_char_p(blob), C.byref(ok)), "tph_comm_p2p_attach")
+        return bool(ok.value)
+
+    @property
+    def p2p_active(self) -> bool:
+        return bool(self.lib.tph_comm_p2p_active(self._ctx))
+
+    def p2p_status(self):
+        check(self.lib.tph_comm_p2p_status(self._ctx), "tph_comm_p2p_status")
+
+    def allreduce_dev(self, t, op=0):
+        """In-place all-reduce (0 sum, 1 max, 2 min) of a small contiguous device tensor over the attached communicator,
+        on the ctx stream (tph_comm_allreduce_dev)."""
+        dt = {torch.float64: 0, torch.int64: 1, torch.int32: 2}[t.dtype]
+        assert t.is_contiguous() and t.is_cuda
+        check(self.lib.tph_comm_allreduce_dev(self._ctx, C.c_void_p(t.data_ptr()), t.numel(), dt, int(op)),
+              "tph_comm_allreduce_dev")
+        return t
+
     def membw_time(self, mode, n_doubles, reps=20):
         """Average launch duration (ms) of the streaming read (mode 0) / copy (mode 1) ceiling kernel."""
         out = C.c_double(0.0)

@@ -70,8 +70,9 @@ class StepEngine:
     (n, K) and replayed for every later step of the run.  Steps launched past the stopping rule are no-ops on the
     device, so the host may run one step ahead of the 64-byte state read that tells it when to stop.
 
-    With a communicator the adaptation is not part of the graph: the host all-reduces the per-rank sums between the
-    replay and an eagerly launched tph_adapt.  The user callbacks must be pure device functions of their argument
+    With a communicator the per-rank sums are all-reduced between the Metropolis kernel and tph_adapt: by the library's
+    peer-to-peer exchange kernel when that is attached (tph_comm_p2p_*; part of the step and of its graph), else by the
+    host through the process group between the replay and an eagerly launched tph_adapt.  The user callbacks must be pure device functions of their argument
     (they are traced once); `graph=False` keeps the step-by-step launch path."""
 
     SLOTS = 64          # mailbox ring: the host never runs more than a few steps ahead of the record it waits for
@@ -87,6 +88,9 @@ class StepEngine:
         self.loglike, self.prior = log_likelihood, prior_transform
         self.seed, self.item0, self.n_global = seed, item0, n_global
         self.n_steps, self.n_max, self.comm_active = n_steps, n_max, comm_active
+        # with the library's peer-to-peer exchange attached, the all-reduce of the step's sums is a kernel on the ctx stream:
+        # it belongs to the step (and to its graph) like every other launch; otherwise the host calls the process group
+        self.inline_reduce = bool(comm_active and ctx.p2p_active)
         self.up, self.maha_u, self.maha_up = ctx.empty(d, n), ctx.empty(n), ctx.empty(n)
         self.u = self.logl = self.assign = self.modes = None
         if use_graph:       # fixed-address copies of everything a captured step reads or writes
@@ -145,10 +149,10 @@ class StepEngine:
     def _enqueue(self):
         """The launches of one step on the current stream (ticks are offsets: the device adds base + 2 * steps done)."""
         ctx = self.ctx
-        if (self.plugin is not None and not self.comm_active
+        if (self.plugin is not None and (not self.comm_active or self.inline_reduce)
                 and self.plugin.can_fuse_step(self.K, self.assign is not None, self.n)):
-            # proposal, callbacks and Metropolis update in ONE kernel of the user's plugin (hipcallbacks.py); single GPU:
-            # with ranks the per-rank sums must exist before the all-reduce, so the two-kernel form is kept there
+            # proposal, callbacks and Metropolis update in ONE kernel of the user's plugin (hipcallbacks.py); with ranks only
+            # when tph_adapt exchanges the sums itself (otherwise the host needs them between two launches)
             from .device import KERNEL_ID
             self.plugin.step(KERNEL_ID[self.kernel], self.u, self.logl, self.maha_u, self.modes, self.sigmas, self.bc,
                              self.seed, 1, 2, self.item0, self.ctl, self.partials)
@@ -156,9 +160,10 @@ class StepEngine:
             return None, None
         ctx.propose(self.kernel, self.u, self.assign, self.modes, self.sigmas, self.bc, self.seed, 1, self.item0,
                     self.up, self.maha_u, self.maha_up, ctl=self.ctl, pending=self.pending)
-        # one GPU: the block partials of the Metropolis kernel are summed inside tph_adapt (one launch less per step);
-        # several: their sums are all-reduced between the two
-        sums = self.sums if self.comm_active else None
+        # the block partials of the Metropolis kernel are summed inside tph_adapt (one launch less per step), which on a
+        # sharded run also exchanges the sums with the peers (tph_comm_p2p_*); without that exchange the host all-reduces
+        # the column sums between the two launches
+        sums = self.sums if (self.comm_active and not self.inline_reduce) else None
         if self.plugin is not None:       # callbacks compiled into the Metropolis kernel (hipcallbacks.py)
             from .device import KERNEL_ID
             xp = lp = None
@@ -171,7 +176,7 @@ class StepEngine:
             ctx.accept(self.kernel, 0.0, self.u, None, self.logl, self.up, xp, lp, self.maha_u, self.maha_up,
                        self.assign, self.K, self.modes.dof_dev, self.seed, 2, self.item0, sums, ctl=self.ctl,
                        partials=self.partials, pending=self.pending)
-        if not self.comm_active:
+        if not self.comm_active or self.inline_reduce:
             self._adapt(fold=True)
         return xp, lp
 
@@ -199,6 +204,8 @@ class StepEngine:
                 t0 = t0 or now
                 if now - t0 > 0.05:
                     time.sleep(0)                 # long wait: let other Python threads run between polls
+                if now - t0 > 2.0:
+                    self.ctx.p2p_status()         # raises if a peer never arrived at an exchange
                 if now - t0 > 2.0 and torch.cuda.current_stream(self.ctx.device).query() and rec[7] != step:
                     from ._lib import TempestHipError
                     raise TempestHipError(f"MCMC step {step}: the stream is idle and the device never delivered the step's record")
@@ -269,7 +276,7 @@ class StepEngine:
             self._enqueue()
             if self.use_graph and self.runs >= 2:
                 self._capture()
-        if self.comm_active:
+        if self.comm_active and not self.inline_reduce:
             comm.all_reduce_sum(self.sums)
             self._adapt()
 

@@ -88,13 +88,18 @@ def device_volume_variation(ctx, w_dev, n_global, comm=None) -> float:
     if n_global < d + 1:
         return 1e10
     centre = None
-    if d <= 12 and not (comm is not None and comm.active):
-        # one pass for mean and covariance: moments about the previous call's mean (the first stored row the first time);
-        # the library leaves the new mean in the same buffer
+    if d <= 12:
+        # one pass for mean and covariance: moments about the previous call's mean; the library leaves the new mean in the
+        # same buffer.  First call: any point inside the data will do -- the first stored row, or on a sharded run (where the
+        # centre must be the same on every rank) the centre of the unit cube
         centre = getattr(ctx, "_vv_centre", None)
-        if centre is None:                      # any point inside the data will do: the first stored row
-            from .device import KEY_U
-            centre = ctx.posterior_rows(None, 1, key=KEY_U)[0][0].contiguous().clone()
+        if centre is None:
+            if comm is not None and comm.active:
+                import torch
+                centre = torch.full((d,), 0.5, dtype=torch.float64, device=ctx.device)
+            else:
+                from .device import KEY_U
+                centre = ctx.posterior_rows(None, 1, key=KEY_U)[0][0].contiguous().clone()
             ctx._vv_centre = centre
     return float(ctx.volume_variation(w_dev, centre))
 

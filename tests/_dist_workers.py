@@ -225,12 +225,69 @@ def parity_run(name, device=0):
             "post_wsum": float(w.sum())}
 
 
+def p2p_gpu_worker(rank, world, port, out_dir):
+    """`world` processes sharing cuda:0: the library's peer-to-peer small-message collectives (HIP IPC-mapped inboxes,
+    tph_comm_p2p_*) against the values every rank can compute by itself; sizes on both sides of the 32 KB slot."""
+    import json
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from tempest_amd.comm import Comm
+    from tempest_amd.device import HipContext
+    _init(rank, world, port)
+    comm = Comm()
+    ctx = HipContext(3, 0)
+    comm.attach(ctx, nbytes=4 << 20)
+    res = {"p2p": bool(ctx.p2p_active)}
+    assert res["p2p"], "peer-to-peer collectives did not attach"
+    dev = ctx.device
+    tri = world * (world + 1) // 2
+    for rep in range(40):                          # the ring of two slots per source is reused 20 times
+        for n in (1, 3, 257, 4096, 4097, 20000):   # 4097 doubles and more go through the callback
+            base = torch.arange(n, dtype=torch.float64, device=dev) + rep
+            t = base * (rank + 1)
+            comm.all_reduce_sum(t)
+            assert torch.equal(t, base * tri), (rep, n)
+        ti = torch.arange(100, dtype=torch.int64, device=dev) * (rank + 1)
+        ctx.allreduce_dev(ti, 0)
+        assert torch.equal(ti, torch.arange(100, dtype=torch.int64, device=dev) * tri)
+        tm = torch.full((33,), rank + rep, dtype=torch.int32, device=dev)
+        lo = tm.clone()
+        ctx.allreduce_dev(tm, 1)
+        ctx.allreduce_dev(lo, 2)
+        assert int(tm[0]) == world - 1 + rep and int(lo[7]) == rep
+    # the library's own collectives: global reweight triples of a sharded history == one pass over the whole
+    rs = np.random.RandomState(1)
+    n = 4096
+    u = rs.rand(3, n)
+    logl = -5.0 * rs.chisquare(3, size=n)
+    sl = slice(rank * n // world, (rank + 1) * n // world)
+    ctx.history_append(torch.from_numpy(u[:, sl].copy()).to(dev), torch.from_numpy(u[:, sl].copy()).to(dev),
+                       torch.from_numpy(logl[sl].copy()).to(dev), 0.0, 0.0, n_global=n)
+    got = ctx.reweight_eval([0.0, 0.3, 1.0])
+    from oracle import ps
+    cm = ps.log_mixture(logl, [0.0], [0.0], [n])
+    for b, row in zip([0.0, 0.3, 1.0], got):
+        m, s1, s2 = ps.reweight_triple(logl, cm, b)
+        np.testing.assert_allclose(row[0] + np.log(row[1]), m + np.log(s1), rtol=1e-12)
+        np.testing.assert_allclose(row[1] ** 2 / row[2], s1 ** 2 / s2, rtol=1e-11)
+    res["triples"] = [[float(v) for v in row] for row in got]
+    torch.cuda.synchronize()
+    ctx.p2p_status()
+    json.dump(res, open(os.path.join(out_dir, f"p2p{rank}.json"), "w"))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
 def parity_gpu_worker(rank, world, port, out_dir):
-    """`world` ranks sharing cuda:0 over gloo: every case of PARITY_CASES through the sharded path."""
+    """`world` ranks sharing cuda:0 over gloo: every case of PARITY_CASES through the sharded path (small collectives through
+    the library's peer-to-peer exchange; TEMPEST_AMD_P2P=0 in the environment: through the process group)."""
     import json
     import torch.distributed as dist
     _init(rank, world, port)
-    out = {name: parity_run(name) for name in PARITY_CASES}
+    only = os.environ.get("TEMPEST_AMD_TEST_CASES")
+    out = {name: parity_run(name) for name in PARITY_CASES if not only or name in only.split(",")}
     json.dump(out, open(os.path.join(out_dir, f"parity{rank}.json"), "w"))
     dist.barrier()
     dist.destroy_process_group()

@@ -62,6 +62,37 @@ def test_sharded_sampler_two_ranks_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_p2p_small_collectives_between_processes(tmp_path, world):
+    """tph_comm_p2p_*: inboxes mapped across processes through HIP IPC handles, exchange kernels on the ctx stream; all-reduce
+    (sum / max / min; f64, i64, i32) and all-gather results exact, bit-identical on every rank."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    from tests._dist_workers import p2p_gpu_worker
+    _spawn(p2p_gpu_worker, world, tmp_path)
+    rs = [json.load(open(tmp_path / f"p2p{r}.json")) for r in range(world)]
+    assert all(r["p2p"] for r in rs)
+    assert all(r["triples"] == rs[0]["triples"] for r in rs)
+
+
+@pytest.mark.gpu
+def test_world2_through_the_process_group_only(tmp_path, monkeypatch):
+    """The same parity with the peer-to-peer exchange switched off: every collective through the attached callbacks."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    from tests._dist_workers import parity_gpu_worker, parity_run
+    monkeypatch.setenv("TEMPEST_AMD_P2P", "0")
+    monkeypatch.setenv("TEMPEST_AMD_TEST_CASES", "tpcn_mult")
+    _spawn(parity_gpu_worker, 2, tmp_path)
+    r0 = json.load(open(tmp_path / "parity0.json"))
+    assert r0 == json.load(open(tmp_path / "parity1.json"))
+    one = parity_run("tpcn_mult")
+    assert r0["tpcn_mult"]["steps"] == one["steps"] and abs(r0["tpcn_mult"]["logz"] - one["logz"]) <= 1e-9
+
+
+@pytest.mark.gpu
 def test_world2_is_the_same_sampler_as_world1(tmp_path):
     """the sharded sampler fits the proposal on the WHOLE weighted history (global trim threshold, global
     up-sampling draws, all-reduced moments / medians, clustering on the gathered working set) and resamples in the reference's

@@ -42,7 +42,7 @@ def test_plugin_builds_and_exports_abi():
     lib = ctypes.CDLL(str(path))
     for sym in ("tphu_last_error", "tphu_n_dim", "tphu_abi", "tphu_prior", "tphu_like", "tphu_accept", "tphu_step"):
         assert hasattr(lib, sym), sym
-    assert lib.tphu_n_dim() == 4 and lib.tphu_abi() == 1
+    assert lib.tphu_n_dim() == 4 and lib.tphu_abi() == 2
 
 
 @needs_hipcc

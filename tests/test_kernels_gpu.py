@@ -544,15 +544,16 @@ def _history_ctx(d, T, rows, seed, loopback):
     logl = -rs.chisquare(5, size=n) * 3.0
     c.history_load(u, 20 * u - 10, logl, np.linspace(0, 0.5, T), -np.arange(T, dtype=float), [rows] * T)
     if loopback:
-        attach_loopback(c)
+        attach_loopback(c, p2p=(loopback == "p2p"))
     return c, rs
 
 
-@pytest.mark.parametrize("T,rows", [(1, 5000), (7, 3000), (40, 700), (3, 70000)])
-def test_global_entry_points_loopback_match_plain(dev, T, rows):
+@pytest.mark.parametrize("T,rows,p2p", [(1, 5000, False), (7, 3000, True), (40, 700, True), (3, 70000, False)])
+def test_global_entry_points_loopback_match_plain(dev, T, rows, p2p):
     d = 3
     plain, rs = _history_ctx(d, T, rows, 11, False)
-    loop, _ = _history_ctx(d, T, rows, 11, True)
+    loop, _ = _history_ctx(d, T, rows, 11, "p2p" if p2p else True)
+    assert loop.p2p_active == p2p
     n = T * rows
     w = np.exp(rs.randn(n) * 3.0)
     w /= w.sum()
