@@ -179,6 +179,13 @@ int tph_cdf_global(tph_ctx* ctx, const double* w_dev, int64_t n, const double* t
  * divisor of tph_resample_systematic: the total when tools.py:214-217 renormalises, else 1). */
 int tph_resample_select_global(tph_ctx* ctx, const double* cdf_dev, int64_t n, int64_t n_slots, int scheme, uint64_t seed,
                                uint32_t tick, uint32_t tag, double u0, double pscale, int64_t* idx_dev);
+/* The shuffle that follows the selection, ONE-SIDED (needs tph_comm_p2p_attach): every rank writes the rows it holds -- the
+ * slots k with idx[k] >= 0 -- straight into the window of the slot's owner (rank k / n_local) over the peer mapping, one small
+ * exchange is the barrier, and every owner unpacks its window into u / x / logl of its n_local slots (dimension-major, ld_out).
+ * Replaces count exchange + pack + all-to-all-v + scatter; no host synchronisation.  Collective: all ranks call it with the
+ * idx of the same selection.  A slot nobody wrote makes the next collective (or tph_comm_p2p_status) fail. */
+int tph_resample_put_global(tph_ctx* ctx, const int64_t* idx_dev /* [n_slots] */, int64_t n_slots, int64_t n_local,
+                            double* u_out, double* x_out, double* logl_out, int64_t ld_out);
 /* multiplicities of the LOCAL rows among factor * (*kept_count_dev) global multinomial draws (modes.py:196-201) */
 int tph_multinomial_counts_global(tph_ctx* ctx, const double* cdf_dev, int64_t n, const double* kept_count_dev, int factor,
                                   int64_t n_draw_max, uint64_t seed, uint32_t tick, uint32_t tag, int32_t* counts_dev);

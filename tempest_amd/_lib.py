@@ -79,6 +79,7 @@ SIGNATURES = {
     "tph_comm_p2p_active": (c_int, [ptr]),
     "tph_comm_p2p_status": (c_int, [ptr]),
     "tph_comm_allreduce_dev": (c_int, [ptr, ptr, c_i64, c_int, c_int]),
+    "tph_resample_put_global": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr, ptr, c_i64]),
     "tph_trim_threshold_global": (c_int, [ptr, ptr, c_i64, c_dbl, c_int, ptr, ptr]),
     "tph_cdf_global": (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr]),
     "tph_resample_select_global": (c_int, [ptr, ptr, c_i64, c_i64, c_int, c_u64, c_u32, c_u32, c_dbl, c_dbl, ptr]),

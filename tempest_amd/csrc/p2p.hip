@@ -19,6 +19,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 struct tph_p2p {
   p2p_args a{};
@@ -26,11 +27,37 @@ struct tph_p2p {
   bool opened[TPH_P2P_MAX] = {};
   unsigned int* err_host = nullptr;
   bool ready = false;
+  // row window of the one-sided resample shuffle (tph_resample_put_global): [n_local][2 d + 2] doubles on every rank
+  char* win_local = nullptr;
+  size_t win_bytes = 0;
+  char* win[TPH_P2P_MAX] = {};
+  bool win_opened[TPH_P2P_MAX] = {};
+  std::vector<void*> retired;                   // outgrown windows: freed at release (a peer may still hold a mapping)
+  unsigned long long put_seq = 0;
 };
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_p2p(p2p_args a, const T* src, T* dst, int count, int op) {
   (void)p2p_block_exchange(a, src, dst, count, op);
+}
+
+// self-test patterns (tph_comm_p2p_attach)
+__device__ __forceinline__ double p2p_pattern(int rank, int round, int i) { return (double)((rank + 1) * 4096 + round * 7) + 0.25 * i; }
+__global__ void k_p2p_fill(double* __restrict__ src, int n, int rank, int round) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) src[i] = p2p_pattern(rank, round, i);
+}
+__global__ void k_p2p_check(const double* __restrict__ sum, const double* __restrict__ all, int n, int G, int round, int* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double want = 0.0;
+  bool ok = true;
+  for (int r = 0; r < G; ++r) {
+    const double v = p2p_pattern(r, round, i);
+    ok = ok && all[(size_t)r * n + i] == v;
+    want += v;                                   // rank order, as the exchange adds
+  }
+  if (!ok || sum[i] != want) atomicOr(bad, 1);
 }
 
 static size_t p2p_inbox_bytes(int world) { return 2 * (size_t)world * (TPH_P2P_SLOT + TPH_P2P_FLAG); }
@@ -40,8 +67,12 @@ static void p2p_release(tph_ctx* ctx) {
   if (!p) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);      // after this rank's last exchange nobody writes into its inbox any more
-  for (int r = 0; r < TPH_P2P_MAX; ++r)
+  for (int r = 0; r < TPH_P2P_MAX; ++r) {
     if (p->opened[r]) (void)hipIpcCloseMemHandle(p->a.inbox[r]);
+    if (p->win_opened[r]) (void)hipIpcCloseMemHandle(p->win[r]);
+  }
+  if (p->win_local) (void)hipFree(p->win_local);
+  for (void* w : p->retired) (void)hipFree(w);
   if (p->inbox_local) (void)hipFree(p->inbox_local);
   if (p->a.seq) (void)hipFree(p->a.seq);
   if (p->err_host) (void)hipHostFree(p->err_host);
@@ -162,18 +193,27 @@ extern "C" int tph_comm_p2p_attach(tph_ctx* ctx, const void* handles, int* ok_ou
     p->ready = true;
     const unsigned long long keep = p->a.timeout;
     p->a.timeout = (unsigned long long)(20.0 * 1e8);
-    double* probe = (double*)(ctx->comm_buf + 256);              // [0] = rank + 1 -> gathered at [8 .. 8 + G), sum at [0]
-    std::vector<double> host(8 + G, 0.0);
-    host[0] = (double)(ctx->rank + 1);
-    TPH_HIP(hipMemcpyAsync(probe, host.data(), sizeof(double) * (8 + G), hipMemcpyHostToDevice, ctx->stream));
-    int rc = tph_p2p_exchange(ctx, probe, probe + 8, 1, TPH_DT_F64, -1);
-    if (!rc) rc = tph_p2p_exchange(ctx, probe, probe, 1, TPH_DT_F64, TPH_OP_SUM);
+    // 24 back-to-back rounds without a host wait in between (ring reuse under whatever skew the ranks have): an all-gather of
+    // 1024 patterned doubles and an all-reduce of the same, both verified on the device
+    constexpr int PN = 1024, ROUNDS = 24;
+    TPH_REQUIRE(ctx->comm_bytes >= 4096 + sizeof(double) * PN * (size_t)(G + 2), "tph_comm_p2p_attach: staging block too small");
+    double* src = (double*)(ctx->comm_buf + 4096);
+    double* dst = src + PN;                                       // [G][PN], then the all-reduce in place of src
+    int* bad = (int*)(ctx->comm_buf + 1024);
+    TPH_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    int rc = 0;
+    for (int round = 0; round < ROUNDS && !rc; ++round) {
+      hipLaunchKernelGGL(k_p2p_fill, dim3(PN / 256), dim3(256), 0, ctx->stream, src, PN, ctx->rank, round);
+      rc = tph_p2p_exchange(ctx, src, dst, PN, TPH_DT_F64, -1);
+      if (!rc) rc = tph_p2p_exchange(ctx, src, src, PN, TPH_DT_F64, TPH_OP_SUM);
+      hipLaunchKernelGGL(k_p2p_check, dim3(PN / 256), dim3(256), 0, ctx->stream, src, dst, PN, G, round, bad);
+    }
     if (rc) return rc;
-    TPH_HIP(hipMemcpyAsync(host.data(), probe, sizeof(double) * (8 + G), hipMemcpyDeviceToHost, ctx->stream));
+    int bad_host = 1;
+    TPH_HIP(hipMemcpyAsync(&bad_host, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     TPH_HIP(hipStreamSynchronize(ctx->stream));
     p->a.timeout = keep;
-    int good = *p->err_host == 0 && host[0] == 0.5 * G * (G + 1);
-    for (int r = 0; r < G; ++r) good = good && host[8 + r] == (double)(r + 1);
+    int good = *p->err_host == 0 && bad_host == 0;
     p->ready = false;                          // the verdict itself goes through the callback
     TPH_HIP(hipMemcpyAsync(flag, &good, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     if (tph_comm_allreduce(ctx, 0, 1, TPH_DT_I32, TPH_OP_MIN)) return -2;
@@ -211,5 +251,120 @@ extern "C" int tph_comm_allreduce_dev(tph_ctx* ctx, void* data_dev, int64_t coun
   TPH_HIP(hipMemcpyAsync(ctx->comm_buf, data_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   if (tph_comm_allreduce(ctx, 0, count, dtype, op)) return -2;
   TPH_HIP(hipMemcpyAsync(data_dev, ctx->comm_buf, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// One-sided resample shuffle.  After tph_resample_select_global every global slot k has exactly one rank that holds its
+// history row (idx[k] >= 0 there, -1 elsewhere); slot k belongs to rank k / n_local.  Instead of counting, packing and an
+// all-to-all-v through the host, the holder WRITES the row -- (u, x, logl) as one record of 2 d + 2 doubles, the last a
+// sequence tag -- straight into record k % n_local of the owner's window over the peer mapping; one small exchange is the
+// barrier; every owner then transposes its window into the SoA arrays of its active set and checks that each record carries
+// this shuffle's tag.  No host synchronisation, no intermediate copies; records of neighbouring slots are contiguous.
+struct put_args {
+  char* win[TPH_P2P_MAX];
+};
+
+__global__ void __launch_bounds__(256) k_put_rows(put_args w, const double* __restrict__ hu, const double* __restrict__ hx,
+                                                  const double* __restrict__ hl, int64_t cap, int d, const int64_t* __restrict__ idx,
+                                                  int64_t n_slots, int64_t n_local, double tag) {
+  const int rec = 2 * d + 2;
+  const int64_t k0 = (int64_t)blockIdx.x * 64;
+  for (int e = threadIdx.x; e < 64 * rec; e += 256) {            // consecutive lanes: consecutive fields of one record
+    const int r = e / rec, c = e - r * rec;
+    const int64_t k = k0 + r;
+    if (k >= n_slots) break;
+    const int64_t s = idx[k];
+    if (s < 0) continue;
+    const double v = c < d ? hu[(size_t)c * cap + s] : (c < 2 * d ? hx[(size_t)(c - d) * cap + s] : (c == 2 * d ? hl[s] : tag));
+    const int owner = (int)(k / n_local);
+    double* dst = (double*)w.win[owner] + (size_t)(k - (int64_t)owner * n_local) * rec + c;
+    __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// window [n_local][rec] -> u, x (d x ld, dimension-major), logl; a record without this shuffle's tag raises the error word
+__global__ void __launch_bounds__(256) k_unpack_rows(const double* win, int d, int64_t n_local, double tag, double* __restrict__ u,
+                                                     double* __restrict__ x, double* __restrict__ l, int64_t ld, unsigned int* err) {
+  extern __shared__ double tile[];                                // [64][rec + 1]
+  const int rec = 2 * d + 2, pitch = rec + 1;
+  const int64_t i0 = (int64_t)blockIdx.x * 64;
+  for (int e = threadIdx.x; e < 64 * rec; e += 256) {
+    const int r = e / rec, c = e - r * rec;
+    if (i0 + r < n_local)
+      tile[r * pitch + c] = __hip_atomic_load(win + (size_t)(i0 + r) * rec + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * rec; e += 256) {            // consecutive lanes: consecutive particles of one column
+    const int c = e / 64, r = e - c * 64;
+    const int64_t i = i0 + r;
+    if (i >= n_local) continue;
+    const double v = tile[r * pitch + c];
+    if (c < d) u[(size_t)c * ld + i] = v;
+    else if (c < 2 * d) x[(size_t)(c - d) * ld + i] = v;
+    else if (c == 2 * d) l[i] = v;
+    else if (v != tag) *err = 1000u;
+  }
+}
+
+static int p2p_window_reserve(tph_ctx* ctx, size_t need) {
+  tph_p2p* p = ctx->p2p;
+  if (p->win_bytes >= need) return 0;
+  const int G = ctx->world;
+  // every rank takes this branch in the same call (n_local and n_dim are global quantities)
+  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  for (int r = 0; r < G; ++r)
+    if (p->win_opened[r]) { (void)hipIpcCloseMemHandle(p->win[r]); p->win_opened[r] = false; p->win[r] = nullptr; }
+  if (p->win_local) p->retired.push_back(p->win_local);
+  p->win_local = nullptr; p->win_bytes = 0;
+  const size_t bytes = (need + (need >> 2) + 4095) / 4096 * 4096;
+  TPH_HIP(hipExtMallocWithFlags((void**)&p->win_local, bytes, hipDeviceMallocUncached));
+  TPH_HIP(hipMemsetAsync(p->win_local, 0, bytes, ctx->stream));
+  p->win[ctx->rank] = p->win_local;
+  if (G > 1) {
+    hipIpcMemHandle_t h;
+    TPH_HIP(hipIpcGetMemHandle(&h, p->win_local));
+    if (tph_comm_require(ctx, 4096 + sizeof(h) * (size_t)G, "tph_resample_put_global (window handles)")) return -2;
+    TPH_HIP(hipMemcpyAsync(ctx->comm_buf, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    if (tph_p2p_exchange(ctx, ctx->comm_buf, ctx->comm_buf + 4096, sizeof(h) / 8, TPH_DT_I64, -1)) return -2;
+    std::vector<hipIpcMemHandle_t> all(G);
+    TPH_HIP(hipMemcpyAsync(all.data(), ctx->comm_buf + 4096, sizeof(h) * (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < G; ++r) {
+      if (r == ctx->rank) continue;
+      void* ptr = nullptr;
+      TPH_HIP(hipIpcOpenMemHandle(&ptr, all[r], hipIpcMemLazyEnablePeerAccess));
+      p->win[r] = (char*)ptr;
+      p->win_opened[r] = true;
+    }
+  }
+  p->win_bytes = bytes;
+  return 0;
+}
+
+extern "C" int tph_resample_put_global(tph_ctx* ctx, const int64_t* idx_dev, int64_t n_slots, int64_t n_local, double* u_out,
+                                       double* x_out, double* logl_out, int64_t ld_out) {
+  TPH_REQUIRE(ctx && idx_dev && u_out && x_out && logl_out, "tph_resample_put_global: NULL argument");
+  TPH_REQUIRE(ctx->p2p && ctx->p2p->ready, "tph_resample_put_global: needs the peer-to-peer exchange (tph_comm_p2p_attach)");
+  TPH_REQUIRE(n_local > 0 && n_slots == n_local * ctx->world && ld_out >= n_local && ctx->size > 0, "tph_resample_put_global: bad sizes");
+  tph_p2p* p = ctx->p2p;
+  TPH_REQUIRE(*p->err_host == 0, "peer-to-peer exchange failed earlier (code %u)", *p->err_host);
+  const int d = ctx->d, rec = 2 * d + 2;
+  if (p2p_window_reserve(ctx, sizeof(double) * (size_t)n_local * rec)) return -2;
+  const double tag = (double)(++p->put_seq);
+  put_args w{};
+  for (int r = 0; r < ctx->world; ++r) w.win[r] = p->win[r];
+  hipLaunchKernelGGL(k_put_rows, dim3((unsigned)((n_slots + 63) / 64)), dim3(256), 0, ctx->stream, w, ctx->u, ctx->x, ctx->logl, ctx->cap,
+                     d, idx_dev, n_slots, n_local, tag);
+  TPH_LAUNCH_CHECK();
+  // barrier: a rank raises its flag only after its put kernel has completed (stream order), i.e. after its stores have landed
+  double* token = (double*)ctx->comm_buf;
+  TPH_HIP(hipMemsetAsync(token, 0, sizeof(double), ctx->stream));
+  if (tph_p2p_exchange(ctx, token, token, 1, TPH_DT_F64, TPH_OP_SUM)) return -2;
+  const size_t lds = sizeof(double) * 64 * (size_t)(rec + 1);
+  if (lds > 64 * 1024) TPH_HIP(hipFuncSetAttribute((const void*)k_unpack_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((n_local + 63) / 64)), dim3(256), lds, ctx->stream, (const double*)p->win_local, d, n_local,
+                     tag, u_out, x_out, logl_out, ld_out, p->a.err);
+  TPH_LAUNCH_CHECK();
   return 0;
 }

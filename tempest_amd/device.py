@@ -204,6 +204,16 @@ class HipContext:
               "tph_comm_allreduce_dev")
         return t
 
+    def resample_put_global(self, idx, n_local, u=None, x=None, logl=None):
+        """One-sided resample shuffle (tph_resample_put_global): idx from resample_select_global over all n_local * world
+        slots; returns this rank's (u, x, logl) in slot order."""
+        d, n_local = self.n_dim, int(n_local)
+        if u is None:
+            u, x, logl = self.empty(d, n_local), self.empty(d, n_local), self.empty(n_local)
+        check(self.lib.tph_resample_put_global(self._ctx, _ptr(idx, torch.int64), idx.numel(), n_local, _ptr(u), _ptr(x),
+                                               _ptr(logl), u.shape[1]), "tph_resample_put_global")
+        return u, x, logl
+
     def membw_time(self, mode, n_doubles, reps=20):
         """Average launch duration (ms) of the streaming read (mode 0) / copy (mode 1) ceiling kernel."""
         out = C.c_double(0.0)

@@ -9,7 +9,8 @@ Cross-GPU traffic:
   * reweight: all-gather of the (max, s1, s2) triples per pass (merged on the device);
   * train: the small reductions of the global fit (see comm.py);
   * mutation: all-reduce of (accepted, sum alpha_c) per MCMC step;
-  * resample: the selected rows travel once per iteration by all-to-all-v (this module).
+  * resample: the selected rows travel once per iteration: written by their holders straight into the slot owners' windows
+    over the peer mapping (one node, tph_resample_put_global), else by all-to-all-v (this module).
 """
 import numpy as np
 
@@ -36,6 +37,10 @@ def resample_sharded(state, w, scheme, rng, n_local):
         u0 = uniform_scalar(rng.seed, tick, TAG_SYST)
         idx = ctx.resample_select_global(cdf, n_slots, 1, rng.seed, tick, u0=u0,
                                          pscale=tot if abs(tot - 1.0) > SQRTEPS else 1.0, tag=TAG_RESAMPLE)
+    if ctx.p2p_active:
+        # ranks of one node: every holder writes its rows straight into the slot owner's window over the peer mapping
+        # (tph_resample_put_global) -- no counts, no packing, no all-to-all, no host synchronisation
+        return ctx.resample_put_global(idx, n_local)
     slots = torch.nonzero(idx >= 0).reshape(-1)                # my outgoing slots, ascending = grouped by owner
     rows = idx[slots].contiguous()
     n_send = int(rows.numel())

@@ -272,8 +272,29 @@ def p2p_gpu_worker(rank, world, port, out_dir):
         np.testing.assert_allclose(row[0] + np.log(row[1]), m + np.log(s1), rtol=1e-12)
         np.testing.assert_allclose(row[1] ** 2 / row[2], s1 ** 2 / s2, rtol=1e-11)
     res["triples"] = [[float(v) for v in row] for row in got]
+    # one-sided resample shuffle: slot k is held by rank (7 k) % world as its local row (13 k) % n_hist; every rank can
+    # compute what each of its slots must receive.  Three rounds: window reuse, then a larger n_local (window regrowth).
+    ctx2 = HipContext(3, 0)
+    comm2 = Comm()
+    comm2.attach(ctx2, nbytes=4 << 20)
+    n_hist = 1000
+    def rows_of(holder):
+        r = torch.arange(n_hist, dtype=torch.float64, device=dev)
+        return torch.stack([holder * 1e6 + r * 100 + c for c in range(3)])
+    mine = rows_of(rank)
+    ctx2.history_append(mine, mine + 0.5, -mine[0], 0.0, 0.0, n_global=n_hist * world)
+    for n_local in (640, 640, 5000):
+        k = torch.arange(n_local * world, dtype=torch.int64, device=dev)
+        holder, row = (7 * k) % world, (13 * k) % n_hist
+        idx = torch.where(holder == rank, row, torch.full_like(row, -1))
+        u, x, logl = ctx2.resample_put_global(idx, n_local)
+        sl = slice(rank * n_local, (rank + 1) * n_local)
+        want = torch.stack([holder[sl] * 1e6 + row[sl] * 100.0 + c for c in range(3)]).to(torch.float64)
+        assert torch.equal(u, want) and torch.equal(x, want + 0.5) and torch.equal(logl, -want[0]), n_local
     torch.cuda.synchronize()
+    ctx2.p2p_status()
     ctx.p2p_status()
+    ctx2.close()
     json.dump(res, open(os.path.join(out_dir, f"p2p{rank}.json"), "w"))
     dist.barrier()
     ctx.close()

@@ -55,6 +55,7 @@ def test_integration_stubs_run_as_written():
     finally:
         dist.destroy_process_group()
     assert int(ns["claimed"].item()) == n                        # every global slot was claimed by exactly one rank
+    assert ns["ok"].value == 1                                   # the peer-to-peer exchange attached and passed its self-test
     assert abs(ns["total"].value - ns["thr_host"][1]) < 1e-12    # global cumulative weight of the kept rows = kept_sum
     assert torch.isfinite(ns["means"]).all()
     # the global fit of a one-rank "cluster" is the one-GPU fit of the same multiplicities: same medians
@@ -63,5 +64,9 @@ def test_integration_stubs_run_as_written():
     ns["chk"](lib.tph_fit_modes(ctx, P(ns["cnt"]), None, I64(ns["n_loc"]), 1, P(m2), P(c2), P(l2), P(i2), P(w2)))
     assert torch.equal(m2, ns["means"])
     np.testing.assert_allclose(ns["covs"].cpu().numpy(), c2.cpu().numpy(), rtol=1e-11, atol=1e-16)
+    # the one-sided shuffle of a one-rank world is the plain gather of the selected rows
+    ug, xg, lg = f64(d, n), f64(d, n), f64(n)
+    ns["chk"](lib.tph_gather(ctx, P(ns["idx"]), I64(n), P(ug), P(xg), P(lg), I64(n)))
+    assert torch.equal(ug, ns["u_new"]) and torch.equal(xg, ns["x_new"]) and torch.equal(lg, ns["l_new"])
     _ = one_gpu
     lib.tph_ctx_destroy(ctx)
