@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--accept", action="store_true")
     ap.add_argument("--nocarry", action="store_true")
     ap.add_argument("--wpe", type=int, default=0, help="experiment knob (TPH_OPT_REDRAW_LANES)")
+    ap.add_argument("--unstaged", action="store_true", help="TPH_OPT_ML_UNSTAGED = 1 (the redraw-dominated regime of d > 16)")
     ap.add_argument("--pending", type=float, default=0.0,
                     help="fraction of particles with a pending accepted move to resolve (deferred tph_accept), per launch")
     a = ap.parse_args()
@@ -60,6 +61,8 @@ def main():
         lib.tph_set_option(ctx, 0, a.variant)
     if a.wpe:
         lib.tph_set_option(ctx, 2, a.wpe)
+    if a.unstaged:
+        lib.tph_set_option(ctx, 3, 1)
     kid = {"tpcn": 0, "rwm": 1}[a.kernel]
     rs = np.random.RandomState(0)
     for scen in a.scen.split(","):
