@@ -33,6 +33,8 @@ def main():
     cp("bench_unprofiled.json", f"{R}_bench_unprofiled.json")
     cp("bench_under_rocprof.json", f"{R}_bench_under_rocprof.json")
     cp(os.path.join("prof_bench", "bench_kernel_stats.csv"), f"{R}_bench_kernel_stats.csv")
+    if os.path.exists(os.path.join(src, "bench_trace_summary.json")):
+        cp("bench_trace_summary.json", f"{R}_bench_trace_summary.json")
     cp("roofline_table.json", f"{R}_roofline_table.json")
     cp(os.path.join("roof", "meta.json"), f"{R}_roofline_table_meta.json")
     for k in ("rwm", "tpcn"):

@@ -49,6 +49,21 @@ rm -rf "$O/roof/trace" "$O/roof/fetch" "$O/roof/write"
 # 8. config 4's 8-GPU shard size, un-sharded and through the sharded code path over RCCL at world size 1
 python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline > "$O/bench_131k.json" 2> "$O/bench_131k.err"
 TEMPEST_AMD_FORCE_COMM=1 python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline > "$O/bench_131k_comm.json" 2> "$O/bench_131k_comm.err"
+# per-launch summary of the roofline kernel and the proposal kernel out of the bench trace (the raw trace is dropped below)
+python3 - "$O" <<'PY'
+import csv, json, sys
+o = sys.argv[1]
+k2, prop = [], []
+for r in csv.DictReader(open(o + "/prof_bench/bench_kernel_trace.csv")):
+    dur = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
+    if r["Kernel_Name"].startswith("void k_reweight_reduce<1, 8>") and dur > 100.0:
+        k2.append(dur)
+    elif r["Kernel_Name"].startswith("void k_propose_reg<0, 10, true"):
+        prop.append(dur)
+json.dump({"k_reweight_reduce<1, 8> on the 1.07 GB history": {"launches": len(k2), "mean_us": sum(k2) / max(1, len(k2)), "min_us": min(k2), "max_us": max(k2)},
+           "k_propose_reg<0, 10, true, 4, false>": {"launches": len(prop), "mean_us": sum(prop) / max(1, len(prop))}},
+          open(o + "/bench_trace_summary.json", "w"), indent=1)
+PY
 # keep the merge small: drop the raw traces that are not summarised further
 find "$O" -name "*kernel_trace.csv" -size +8M -delete
 du -sh "$O"
