@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--accept", action="store_true")
     ap.add_argument("--nocarry", action="store_true")
     ap.add_argument("--wpe", type=int, default=0, help="experiment knob (TPH_OPT_REDRAW_LANES)")
+    ap.add_argument("--sigma-scale", type=float, default=1.0, help="multiplies the step size (RWM runaway: ~8)")
     ap.add_argument("--unstaged", action="store_true", help="TPH_OPT_ML_UNSTAGED = 1 (the redraw-dominated regime of d > 16)")
     ap.add_argument("--pending", type=float, default=0.0,
                     help="fraction of particles with a pending accepted move to resolve (deferred tph_accept), per launch")
@@ -66,11 +67,11 @@ def main():
     kid = {"tpcn": 0, "rwm": 1}[a.kernel]
     rs = np.random.RandomState(0)
     for scen in a.scen.split(","):
-        scale = {"wide": 0.29, "mid": 0.12, "tight": 0.04}[scen]
+        scale = {"wide": 0.29, "mid": 0.12, "tight": 0.04, "prior": 0.29}[scen]
         A = rs.randn(d, d) / np.sqrt(d)
         cov = (A @ A.T + np.eye(d)) * scale ** 2 / 2.0
         L = np.linalg.cholesky(cov)
-        u0 = np.clip(0.5 + rs.randn(n, d) @ L.T, 0.001, 0.999)
+        u0 = np.clip(0.5 + rs.randn(n, d) @ L.T, 0.001, 0.999) if scen != "prior" else rs.rand(n, d)
         inv = np.linalg.inv(cov)
         W = np.linalg.inv(L)
         t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)   # noqa: E731
@@ -79,7 +80,7 @@ def main():
         chol = t(L.reshape(1, d, d))
         mat = t((inv if a.legacy else W).reshape(1, d, d))
         dof = t(np.array([1e6]))
-        sig = t(np.array([min(2.38 / np.sqrt(d), 0.99)]))
+        sig = t(np.array([min(2.38 / np.sqrt(d), 0.99) * a.sigma_scale]))
         up = torch.empty_like(u)
         mu_, mup = torch.empty(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev)
         ctl = torch.zeros(10, dtype=torch.float64, device=dev)
