@@ -696,17 +696,29 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(double* __restrict__ u,
       // the normals of this attempt: a ROLLED loop over the Box-Muller pairs writing a private array (dynamic index ->
       // scratch memory, 8 B per value and lane, L1/L2-resident): one Philox / log / sincospi body with ~30 live
       // registers instead of ceil(D/2) interleaved copies
-      double zb[2 * NP];
       tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
-#pragma unroll 1
-      for (int p = 0; p < NP; ++p) {
-        double z0, z1;
-        gz.normal2((uint32_t)(att * NP + p), z0, z1);
-        zb[2 * p] = z0;
-        zb[2 * p + 1] = z1;
-      }
+      if constexpr (WPE <= 2) {
+        // few waves per SIMD (shards of <= 128 K particles): the kernel is bound by the LATENCY of one particle's chain, not
+        // by issue slots, and registers are plentiful -- the pairs as independent, interleaved chains
 #pragma unroll
-      for (int j = 0; j < D; ++j) z[j] = zb[j];
+        for (int p = 0; p < NP; ++p) {
+          double z0, z1;
+          gz.normal2((uint32_t)(att * NP + p), z0, z1);
+          z[2 * p] = z0;
+          if (2 * p + 1 < D) z[2 * p + 1] = z1;
+        }
+      } else {
+        double zb[2 * NP];
+#pragma unroll 1
+        for (int p = 0; p < NP; ++p) {
+          double z0, z1;
+          gz.normal2((uint32_t)(att * NP + p), z0, z1);
+          zb[2 * p] = z0;
+          zb[2 * p + 1] = z1;
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) z[j] = zb[j];
+      }
       if (ONE_MODE) L = tph_opaque(L);
       const double sigma = sigmas[c];
       const double a_fac = (KERNEL == TPH_KERNEL_TPCN) ? tph_sqrt(1.0 - sigma * sigma) : 1.0;
@@ -872,7 +884,11 @@ static void launch_propose_reg(tph_ctx* ctx, double* u, const int32_t* assign, i
 #define TPH_REG_LAUNCH(ONE, BC)                                                                                         \
   hipLaunchKernelGGL((k_propose_reg<KERNEL, D, ONE, WPE, BC>), dim3((unsigned)waves), dim3(64), 0, ctx->stream, u, assign, n, ld, \
                      means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, tiles, pend)
-  if (assign == nullptr) { if (bc) TPH_REG_LAUNCH(true, true); else TPH_REG_LAUNCH(true, false); }
+  if (assign == nullptr && !bc && waves <= 2 * (int64_t)ctx->n_simd && ctx->redraw_lanes == 0) {
+    // at most two waves per SIMD: the latency-bound instantiation (independent Box-Muller chains, up to 256 VGPRs)
+    hipLaunchKernelGGL((k_propose_reg<KERNEL, D, true, 2, false>), dim3((unsigned)waves), dim3(64), 0, ctx->stream, u, assign, n, ld,
+                       means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, tiles, pend);
+  } else if (assign == nullptr) { if (bc) TPH_REG_LAUNCH(true, true); else TPH_REG_LAUNCH(true, false); }
   else { if (bc) TPH_REG_LAUNCH(false, true); else TPH_REG_LAUNCH(false, false); }
 #undef TPH_REG_LAUNCH
 }
