@@ -50,6 +50,20 @@ def main():
     # shard-size bench lines
     for name in ("bench_131k", "bench_131k_comm"):
         cp(name + ".json", f"{R}_{name}.json")
+    if os.path.exists(os.path.join(src, "ab_plain1.json")):
+        import statistics
+        ab = {"what": "131 072 particles on one GPU, three interleaved pairs on one box: plain run vs the sharded code path forced "
+                      "(TEMPEST_AMD_FORCE_COMM=1: real RCCL at world size 1 + the peer-to-peer layer)", "runs": []}
+        for i in (1, 2, 3):
+            for k in ("plain", "comm"):
+                d = json.load(open(os.path.join(src, f"ab_{k}{i}.json")))
+                ab["runs"].append({"run": f"{k}{i}", "value": d["value"], "ms_per_step": d["ms_per_step"], "logz": d["logz"],
+                                   "tail_phase_seconds": d["mutation_only"]["phase_seconds"]})
+        pl = [r["ms_per_step"] for r in ab["runs"] if r["run"].startswith("plain")]
+        cm = [r["ms_per_step"] for r in ab["runs"] if r["run"].startswith("comm")]
+        ab["median_ms_per_step"] = {"plain": statistics.median(pl), "sharded_path": statistics.median(cm),
+                                    "ratio": statistics.median(cm) / statistics.median(pl)}
+        json.dump(ab, open(os.path.join(dst, f"{R}_bench_131k_ab.json"), "w"), indent=1)
     # reweight kernel traffic
     rw = {}
     for tag, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):

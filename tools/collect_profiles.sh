@@ -49,6 +49,11 @@ rm -rf "$O/roof/trace" "$O/roof/fetch" "$O/roof/write"
 # 8. config 4's 8-GPU shard size, un-sharded and through the sharded code path over RCCL at world size 1
 python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline > "$O/bench_131k.json" 2> "$O/bench_131k.err"
 TEMPEST_AMD_FORCE_COMM=1 python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline > "$O/bench_131k_comm.json" 2> "$O/bench_131k_comm.err"
+# ... and three interleaved pairs without the HIP-callback leg (single runs differ by several % on a shared box)
+for i in 1 2 3; do
+  python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline --no-hip-callbacks > "$O/ab_plain$i.json" 2>> "$O/ab.err"
+  TEMPEST_AMD_FORCE_COMM=1 python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline --no-hip-callbacks > "$O/ab_comm$i.json" 2>> "$O/ab.err"
+done
 # per-launch summary of the roofline kernel and the proposal kernel out of the bench trace (the raw trace is dropped below)
 python3 - "$O" <<'PY'
 import csv, json, sys
