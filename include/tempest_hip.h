@@ -183,7 +183,9 @@ int tph_resample_select_global(tph_ctx* ctx, const double* cdf_dev, int64_t n, i
  * slots k with idx[k] >= 0 -- straight into the window of the slot's owner (rank k / n_local) over the peer mapping, one small
  * exchange is the barrier, and every owner unpacks its window into u / x / logl of its n_local slots (dimension-major, ld_out).
  * Replaces count exchange + pack + all-to-all-v + scatter; no host synchronisation.  Collective: all ranks call it with the
- * idx of the same selection.  A slot nobody wrote makes the next collective (or tph_comm_p2p_status) fail. */
+ * idx of the same selection.  A slot nobody wrote makes the next collective (or tph_comm_p2p_status) fail.
+ * Returns 0, or 1 on EVERY rank when the row windows cannot be allocated / mapped (agreed between the ranks; nothing was
+ * written: shuffle through an all-to-all instead), or < 0 on error. */
 int tph_resample_put_global(tph_ctx* ctx, const int64_t* idx_dev /* [n_slots] */, int64_t n_slots, int64_t n_local,
                             double* u_out, double* x_out, double* logl_out, int64_t ld_out);
 /* multiplicities of the LOCAL rows among factor * (*kept_count_dev) global multinomial draws (modes.py:196-201) */

@@ -33,6 +33,7 @@ struct tph_p2p {
   char* win[TPH_P2P_MAX] = {};
   bool win_opened[TPH_P2P_MAX] = {};
   std::vector<void*> retired;                   // outgrown windows: freed at release (a peer may still hold a mapping)
+  bool win_failed = false;                      // the ranks agreed that the windows cannot be mapped: callers use their all-to-all
   unsigned long long put_seq = 0;
 };
 
@@ -281,6 +282,7 @@ __global__ void __launch_bounds__(256) k_put_rows(put_args w, const double* __re
     double* dst = (double*)w.win[owner] + (size_t)(k - (int64_t)owner * n_local) * rec + c;
     __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  __threadfence_system();     // the stores have landed before this kernel counts as complete (the barrier follows in stream order)
 }
 
 // window [n_local][rec] -> u, x (d x ld, dimension-major), logl; a record without this shuffle's tag raises the error word
@@ -307,9 +309,14 @@ __global__ void __launch_bounds__(256) k_unpack_rows(const double* win, int d, i
   }
 }
 
-static int p2p_window_reserve(tph_ctx* ctx, size_t need) {
+// Grows the row window and maps the peers' windows.  Allocation and mapping can fail on one rank only, so the ranks AGREE on the
+// outcome (a MIN over the peer-to-peer exchange itself) before anybody uses a window: *usable = 1 on every rank or 0 on every
+// rank -- then for good (win_failed), and the caller shuffles through its all-to-all instead.
+static int p2p_window_reserve(tph_ctx* ctx, size_t need, int* usable) {
   tph_p2p* p = ctx->p2p;
-  if (p->win_bytes >= need) return 0;
+  *usable = 0;
+  if (p->win_failed) return 0;
+  if (p->win_bytes >= need) { *usable = 1; return 0; }
   const int G = ctx->world;
   // every rank takes this branch in the same call (n_local and n_dim are global quantities)
   TPH_HIP(hipStreamSynchronize(ctx->stream));
@@ -318,27 +325,51 @@ static int p2p_window_reserve(tph_ctx* ctx, size_t need) {
   if (p->win_local) p->retired.push_back(p->win_local);
   p->win_local = nullptr; p->win_bytes = 0;
   const size_t bytes = (need + (need >> 2) + 4095) / 4096 * 4096;
-  TPH_HIP(hipExtMallocWithFlags((void**)&p->win_local, bytes, hipDeviceMallocUncached));
-  TPH_HIP(hipMemsetAsync(p->win_local, 0, bytes, ctx->stream));
+  int ok = 1;
+  if (getenv("TEMPEST_AMD_P2P_NOWINDOW") && ctx->rank == 0) ok = 0;      // tests: one rank fails, all must fall back
+  if (!ok || hipExtMallocWithFlags((void**)&p->win_local, bytes, hipDeviceMallocUncached) != hipSuccess) {
+    (void)hipGetLastError();
+    p->win_local = nullptr;
+    ok = 0;
+  } else {
+    TPH_HIP(hipMemsetAsync(p->win_local, 0, bytes, ctx->stream));
+  }
   p->win[ctx->rank] = p->win_local;
+  if (tph_comm_require(ctx, 8192 + sizeof(hipIpcMemHandle_t) * (size_t)G, "tph_resample_put_global (window handles)")) return -2;
   if (G > 1) {
     hipIpcMemHandle_t h;
-    TPH_HIP(hipIpcGetMemHandle(&h, p->win_local));
-    if (tph_comm_require(ctx, 4096 + sizeof(h) * (size_t)G, "tph_resample_put_global (window handles)")) return -2;
+    memset(&h, 0, sizeof(h));
+    if (ok && hipIpcGetMemHandle(&h, p->win_local) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
     TPH_HIP(hipMemcpyAsync(ctx->comm_buf, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
     if (tph_p2p_exchange(ctx, ctx->comm_buf, ctx->comm_buf + 4096, sizeof(h) / 8, TPH_DT_I64, -1)) return -2;
     std::vector<hipIpcMemHandle_t> all(G);
     TPH_HIP(hipMemcpyAsync(all.data(), ctx->comm_buf + 4096, sizeof(h) * (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
     TPH_HIP(hipStreamSynchronize(ctx->stream));
-    for (int r = 0; r < G; ++r) {
+    for (int r = 0; r < G && ok; ++r) {
       if (r == ctx->rank) continue;
       void* ptr = nullptr;
-      TPH_HIP(hipIpcOpenMemHandle(&ptr, all[r], hipIpcMemLazyEnablePeerAccess));
+      if (hipIpcOpenMemHandle(&ptr, all[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = 0; break; }
       p->win[r] = (char*)ptr;
       p->win_opened[r] = true;
     }
   }
+  // agreement
+  double flag = (double)ok;
+  double* tok = (double*)ctx->comm_buf;
+  TPH_HIP(hipMemcpyAsync(tok, &flag, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (tph_p2p_exchange(ctx, tok, tok, 1, TPH_DT_F64, TPH_OP_MIN)) return -2;
+  TPH_HIP(hipMemcpyAsync(&flag, tok, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  if (flag != 1.0) {
+    for (int r = 0; r < G; ++r)
+      if (p->win_opened[r]) { (void)hipIpcCloseMemHandle(p->win[r]); p->win_opened[r] = false; p->win[r] = nullptr; }
+    if (p->win_local) p->retired.push_back(p->win_local);
+    p->win_local = nullptr;
+    p->win_failed = true;
+    return 0;
+  }
   p->win_bytes = bytes;
+  *usable = 1;
   return 0;
 }
 
@@ -350,7 +381,9 @@ extern "C" int tph_resample_put_global(tph_ctx* ctx, const int64_t* idx_dev, int
   tph_p2p* p = ctx->p2p;
   TPH_REQUIRE(*p->err_host == 0, "peer-to-peer exchange failed earlier (code %u)", *p->err_host);
   const int d = ctx->d, rec = 2 * d + 2;
-  if (p2p_window_reserve(ctx, sizeof(double) * (size_t)n_local * rec)) return -2;
+  int usable = 0;
+  if (p2p_window_reserve(ctx, sizeof(double) * (size_t)n_local * rec, &usable)) return -2;
+  if (!usable) return 1;                          // not an error: every rank returns 1 and shuffles through its all-to-all
   const double tag = (double)(++p->put_seq);
   put_args w{};
   for (int r = 0; r < ctx->world; ++r) w.win[r] = p->win[r];

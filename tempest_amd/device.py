@@ -206,12 +206,15 @@ class HipContext:
 
     def resample_put_global(self, idx, n_local, u=None, x=None, logl=None):
         """One-sided resample shuffle (tph_resample_put_global): idx from resample_select_global over all n_local * world
-        slots; returns this rank's (u, x, logl) in slot order."""
+        slots; returns this rank's (u, x, logl) in slot order, or None when the ranks agreed that the windows cannot be mapped."""
         d, n_local = self.n_dim, int(n_local)
         if u is None:
             u, x, logl = self.empty(d, n_local), self.empty(d, n_local), self.empty(n_local)
-        check(self.lib.tph_resample_put_global(self._ctx, _ptr(idx, torch.int64), idx.numel(), n_local, _ptr(u), _ptr(x),
-                                               _ptr(logl), u.shape[1]), "tph_resample_put_global")
+        rc = self.lib.tph_resample_put_global(self._ctx, _ptr(idx, torch.int64), idx.numel(), n_local, _ptr(u), _ptr(x),
+                                              _ptr(logl), u.shape[1])
+        if rc == 1:            # agreed between the ranks: no row windows on this node -> the caller's all-to-all
+            return None
+        check(rc, "tph_resample_put_global")
         return u, x, logl
 
     def membw_time(self, mode, n_doubles, reps=20):

@@ -40,7 +40,9 @@ def resample_sharded(state, w, scheme, rng, n_local):
     if ctx.p2p_active:
         # ranks of one node: every holder writes its rows straight into the slot owner's window over the peer mapping
         # (tph_resample_put_global) -- no counts, no packing, no all-to-all, no host synchronisation
-        return ctx.resample_put_global(idx, n_local)
+        got = ctx.resample_put_global(idx, n_local)
+        if got is not None:
+            return got
     slots = torch.nonzero(idx >= 0).reshape(-1)                # my outgoing slots, ascending = grouped by owner
     rows = idx[slots].contiguous()
     n_send = int(rows.numel())

@@ -295,6 +295,21 @@ def p2p_gpu_worker(rank, world, port, out_dir):
     ctx2.p2p_status()
     ctx.p2p_status()
     ctx2.close()
+    # a rank that cannot provide its window (forced on rank 0): every rank gets "unavailable" and nothing hangs
+    os.environ["TEMPEST_AMD_P2P_NOWINDOW"] = "1"
+    ctx3 = HipContext(3, 0)
+    comm3 = Comm()
+    comm3.attach(ctx3, nbytes=4 << 20)
+    ctx3.history_append(mine, mine + 0.5, -mine[0], 0.0, 0.0, n_global=n_hist * world)
+    k = torch.arange(64 * world, dtype=torch.int64, device=dev)
+    idx = torch.where((7 * k) % world == rank, (13 * k) % n_hist, torch.full_like(k, -1))
+    assert ctx3.resample_put_global(idx, 64) is None and ctx3.resample_put_global(idx, 64) is None
+    t = torch.ones(3, dtype=torch.float64, device=dev)
+    comm3.all_reduce_sum(t)                          # the small collectives are unaffected
+    assert t.tolist() == [float(world)] * 3
+    del os.environ["TEMPEST_AMD_P2P_NOWINDOW"]
+    res["fallback"] = True
+    ctx3.close()
     json.dump(res, open(os.path.join(out_dir, f"p2p{rank}.json"), "w"))
     dist.barrier()
     ctx.close()
