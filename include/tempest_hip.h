@@ -82,6 +82,11 @@ int tph_synchronize(tph_ctx* ctx);
 /* TPH_OPT_MODES_EPOCH: v > 0 = version of the mode statistics passed to tph_propose; the blocked copies of L and L^-1 are
  * rebuilt only when it (or the chol pointer) changes.  0 (default) = rebuilt on every call. */
 #define TPH_OPT_MODES_EPOCH 5
+/* TPH_OPT_ROW_MIRROR: 1 (default) = tph_gather and tph_resample_put_global read a row-major mirror of (u, x, logl) that the
+ * library keeps beside the dimension-major history (filled lazily, + (2 n_dim + 1) * 8 bytes per row; dropped by itself when
+ * it cannot be allocated): a gathered row is one contiguous record instead of 2 n_dim + 1 scattered sectors; 0 = gather from
+ * the dimension-major arrays */
+#define TPH_OPT_ROW_MIRROR 6
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- multi-GPU: one process per GPU --------------------------------------

@@ -46,6 +46,12 @@ struct tph_ctx {
   // history, dimension-major with leading dimension `cap`
   int64_t cap = 0, size = 0;
   double *u = nullptr, *x = nullptr, *logl = nullptr, *cmix = nullptr;
+  // row-major MIRROR of (u, x, logl) for the indexed consumers (resample gather, one-sided shuffle): a random history row is
+  // 2 d + 1 scattered 8-byte reads in the dimension-major arrays (one 64-byte sector each), but ONE contiguous record here.
+  // Filled lazily, up to rows_size, by tph_rows_sync (resample.hip); dropped if it cannot be allocated.
+  double* rows = nullptr;
+  int64_t rows_cap = 0, rows_size = 0;
+  int rows_mode = 1;                // TPH_OPT_ROW_MIRROR: 1 = use the mirror (default), 0 = gather from the dimension-major arrays
   // iteration table (host mirrors + device copy of (beta_t, -logZ_t + log n_t))
   std::vector<double> beta_t, logz_t;
   std::vector<int64_t> n_local_t, n_global_t;
@@ -103,6 +109,7 @@ void tph_p2p_release(tph_ctx* ctx);
 int tph_blocks(tph_ctx* ctx, int64_t n, int* T, int64_t* rows);   // equal-sized iteration blocks of the local history
 
 int tph_scratch_reserve(tph_ctx* ctx, size_t bytes);
+const double* tph_rows_sync(tph_ctx* ctx);          // resample.hip: mirror up to date for rows [0, size), or NULL (not in use)
 int tph_tri_inv(tph_ctx* ctx, const double* chol_dev, int K, double* winv_dev);   // modes.hip
 
 // --------------------------------------------------------------------------------- device helpers

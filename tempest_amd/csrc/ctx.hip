@@ -147,7 +147,7 @@ extern "C" int tph_ctx_destroy(tph_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   tph_p2p_release(ctx);
   void* bufs[] = {ctx->u, ctx->x, ctx->logl, ctx->cmix, ctx->table_dev, ctx->partials, ctx->small_dev, ctx->scratch, ctx->winv,
-                  ctx->blk_table, ctx->vv_buf, ctx->blk_buf};
+                  ctx->blk_table, ctx->vv_buf, ctx->blk_buf, ctx->rows};
   for (void* b : bufs) (void)hipFree(b);
   (void)hipHostFree(ctx->pinned);
   if (ctx->table_host) (void)hipHostFree(ctx->table_host);
@@ -217,6 +217,7 @@ extern "C" int tph_set_option(tph_ctx* ctx, int option, int value) {
     case TPH_OPT_REDUCE_GRID: ctx->reduce_grid = value; break;
     case TPH_OPT_REDRAW_LANES: ctx->redraw_lanes = value; break;
     case TPH_OPT_ML_UNSTAGED: ctx->ml_unstaged = value; break;
+    case TPH_OPT_ROW_MIRROR: ctx->rows_mode = value ? 1 : 0; break;
     case TPH_OPT_BLOCKED: ctx->blocked = value; break;
     case TPH_OPT_MODES_EPOCH: ctx->modes_epoch = value; break;
     default: TPH_REQUIRE(false, "tph_set_option: unknown option %d", option);
@@ -236,6 +237,7 @@ extern "C" int tph_history_iterations(const tph_ctx* ctx) { return ctx ? (int)ct
 extern "C" int tph_history_clear(tph_ctx* ctx) {
   TPH_REQUIRE(ctx, "tph_history_clear: ctx is NULL");
   ctx->size = 0;
+  ctx->rows_size = 0;
   ctx->beta_t.clear(); ctx->logz_t.clear(); ctx->n_local_t.clear(); ctx->n_global_t.clear();
   ctx->table_uploaded = 0;
   return 0;

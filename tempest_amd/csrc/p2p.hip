@@ -267,8 +267,9 @@ struct put_args {
 };
 
 __global__ void __launch_bounds__(256) k_put_rows(put_args w, const double* __restrict__ hu, const double* __restrict__ hx,
-                                                  const double* __restrict__ hl, int64_t cap, int d, const int64_t* __restrict__ idx,
-                                                  int64_t n_slots, int64_t n_local, double tag) {
+                                                  const double* __restrict__ hl, int64_t cap, const double* __restrict__ mirror,
+                                                  int d, const int64_t* __restrict__ idx, int64_t n_slots, int64_t n_local,
+                                                  double tag) {
   const int rec = 2 * d + 2;
   const int64_t k0 = (int64_t)blockIdx.x * 64;
   for (int e = threadIdx.x; e < 64 * rec; e += 256) {            // consecutive lanes: consecutive fields of one record
@@ -277,7 +278,10 @@ __global__ void __launch_bounds__(256) k_put_rows(put_args w, const double* __re
     if (k >= n_slots) break;
     const int64_t s = idx[k];
     if (s < 0) continue;
-    const double v = c < d ? hu[(size_t)c * cap + s] : (c < 2 * d ? hx[(size_t)(c - d) * cap + s] : (c == 2 * d ? hl[s] : tag));
+    double v;                                                     // from the row-major mirror when there is one (one record)
+    if (c == 2 * d + 1) v = tag;
+    else if (mirror) v = mirror[(size_t)s * (rec - 1) + c];
+    else v = c < d ? hu[(size_t)c * cap + s] : (c < 2 * d ? hx[(size_t)(c - d) * cap + s] : hl[s]);
     const int owner = (int)(k / n_local);
     double* dst = (double*)w.win[owner] + (size_t)(k - (int64_t)owner * n_local) * rec + c;
     __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -387,8 +391,9 @@ extern "C" int tph_resample_put_global(tph_ctx* ctx, const int64_t* idx_dev, int
   const double tag = (double)(++p->put_seq);
   put_args w{};
   for (int r = 0; r < ctx->world; ++r) w.win[r] = p->win[r];
+  const double* mirror = tph_rows_sync(ctx);
   hipLaunchKernelGGL(k_put_rows, dim3((unsigned)((n_slots + 63) / 64)), dim3(256), 0, ctx->stream, w, ctx->u, ctx->x, ctx->logl, ctx->cap,
-                     d, idx_dev, n_slots, n_local, tag);
+                     mirror, d, idx_dev, n_slots, n_local, tag);
   TPH_LAUNCH_CHECK();
   // barrier: a rank raises its flag only after its put kernel has completed (stream order), i.e. after its stores have landed
   double* token = (double*)ctx->comm_buf;

@@ -369,7 +369,96 @@ extern "C" int tph_multinomial_counts_global(tph_ctx* ctx, const double* cdf_dev
   return 0;
 }
 
-// K7: gather rows of the history; coalesced writes, indexed reads
+// ---- row-major mirror of the history (ctx->rows): records of 2 d + 1 doubles (u, x, logl) ------------------------------------
+// A random history row costs 2 d + 1 scattered 8-byte reads in the dimension-major arrays -- one 64-byte sector each, 8.4x the
+// algorithmic bytes by the counters (profiles/r02_roofline_table.json) -- but one contiguous 16 d + 8 byte record here.  The
+// mirror is filled lazily from the dimension-major arrays (the rows appended since the last use), 64 rows per block through an
+// LDS tile so that both sides are coalesced.
+constexpr int ROWS_TILE = 64;
+__global__ void __launch_bounds__(256) k_rows_pack(const double* __restrict__ hu, const double* __restrict__ hx,
+                                                   const double* __restrict__ hl, int64_t cap, int d, int64_t off, int64_t n,
+                                                   double* __restrict__ rows) {
+  extern __shared__ double tile[];                                // [64][rec + 1]
+  const int rec = 2 * d + 1, pitch = rec + 1;
+  const int64_t i0 = off + (int64_t)blockIdx.x * ROWS_TILE;
+  const int64_t end = off + n;
+  for (int e = threadIdx.x; e < ROWS_TILE * rec; e += 256) {      // consecutive lanes: consecutive rows of one column
+    const int c = e / ROWS_TILE, r = e - c * ROWS_TILE;
+    const int64_t i = i0 + r;
+    if (i < end) tile[r * pitch + c] = c < d ? hu[(size_t)c * cap + i] : (c < 2 * d ? hx[(size_t)(c - d) * cap + i] : hl[i]);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < ROWS_TILE * rec; e += 256) {      // consecutive lanes: consecutive fields of one record
+    const int r = e / rec, c = e - r * rec;
+    if (i0 + r < end) rows[(size_t)(i0 + r) * rec + c] = tile[r * pitch + c];
+  }
+}
+
+const double* tph_rows_sync(tph_ctx* ctx) {
+  if (!ctx->rows_mode || ctx->size <= 0) return nullptr;
+  const int d = ctx->d, rec = 2 * d + 1;
+  if (ctx->rows_cap < ctx->size) {                                // grow with the history's own capacity
+    double* fresh = nullptr;
+    const int64_t nc = ctx->cap > ctx->size ? ctx->cap : ctx->size;
+    if (hipMalloc((void**)&fresh, sizeof(double) * (size_t)nc * rec) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->rows_mode = 0;                                         // no room for a mirror: the dimension-major gather from now on
+      if (ctx->rows) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->rows); }
+      ctx->rows = nullptr; ctx->rows_cap = 0; ctx->rows_size = 0;
+      return nullptr;
+    }
+    if (ctx->rows) {
+      if (ctx->rows_size > 0 &&
+          hipMemcpyAsync(fresh, ctx->rows, sizeof(double) * (size_t)ctx->rows_size * rec, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->rows_size = 0;
+      }
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipFree(ctx->rows);
+    }
+    ctx->rows = fresh;
+    ctx->rows_cap = nc;
+  }
+  if (ctx->rows_size < ctx->size) {
+    const int64_t n = ctx->size - ctx->rows_size;
+    const size_t lds = sizeof(double) * ROWS_TILE * (size_t)(rec + 1);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)k_rows_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    hipLaunchKernelGGL(k_rows_pack, dim3((unsigned)((n + ROWS_TILE - 1) / ROWS_TILE)), dim3(256), lds, ctx->stream, ctx->u, ctx->x,
+                       ctx->logl, ctx->cap, d, ctx->rows_size, n, ctx->rows);
+    if (hipGetLastError() != hipSuccess) return nullptr;
+    ctx->rows_size = ctx->size;
+  }
+  return ctx->rows;
+}
+
+// K7: gather rows of the history.  From the mirror: 64 output rows per block, records in (contiguous), LDS transpose,
+// dimension-major out (coalesced).
+__global__ void __launch_bounds__(256) k_gather_rows(const double* __restrict__ rows, int d, const int64_t* __restrict__ idx,
+                                                     int64_t n_out, double* __restrict__ u, double* __restrict__ x,
+                                                     double* __restrict__ l, int64_t ld) {
+  extern __shared__ double tile[];
+  const int rec = 2 * d + 1, pitch = rec + 1;
+  const int64_t i0 = (int64_t)blockIdx.x * ROWS_TILE;
+  for (int e = threadIdx.x; e < ROWS_TILE * rec; e += 256) {
+    const int r = e / rec, c = e - r * rec;
+    if (i0 + r < n_out) tile[r * pitch + c] = rows[(size_t)idx[i0 + r] * rec + c];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < ROWS_TILE * rec; e += 256) {
+    const int c = e / ROWS_TILE, r = e - c * ROWS_TILE;
+    const int64_t i = i0 + r;
+    if (i >= n_out) continue;
+    const double v = tile[r * pitch + c];
+    if (c < d) u[(size_t)c * ld + i] = v;
+    else if (c < 2 * d) x[(size_t)(c - d) * ld + i] = v;
+    else l[i] = v;
+  }
+}
+// ... and from the dimension-major arrays (no mirror): coalesced writes, indexed reads
 __global__ void __launch_bounds__(256) k_gather(const double* __restrict__ hu, const double* __restrict__ hx,
                                                 const double* __restrict__ hl, int64_t cap, int d,
                                                 const int64_t* __restrict__ idx, int64_t n_out,
@@ -389,8 +478,18 @@ extern "C" int tph_gather(tph_ctx* ctx, const int64_t* idx_dev, int64_t n_out, d
                           double* logl_out, int64_t ld_out) {
   TPH_REQUIRE(ctx && idx_dev && u_out && x_out && logl_out, "tph_gather: NULL argument");
   TPH_REQUIRE(n_out > 0 && ld_out >= n_out && ctx->size > 0, "tph_gather: bad sizes");
-  hipLaunchKernelGGL(k_gather, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx->stream, ctx->u, ctx->x, ctx->logl,
-                     ctx->cap, ctx->d, idx_dev, n_out, u_out, x_out, logl_out, ld_out);
+  // the mirror pays once the gather is a sizeable fraction of the rows it has to pack first
+  const double* rows = (ctx->rows_mode && 8 * n_out >= ctx->size - ctx->rows_size) ? tph_rows_sync(ctx) : nullptr;
+  if (rows) {
+    const int rec = 2 * ctx->d + 1;
+    const size_t lds = sizeof(double) * ROWS_TILE * (size_t)(rec + 1);
+    if (lds > 64 * 1024) TPH_HIP(hipFuncSetAttribute((const void*)k_gather_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n_out + ROWS_TILE - 1) / ROWS_TILE)), dim3(256), lds, ctx->stream, rows, ctx->d,
+                       idx_dev, n_out, u_out, x_out, logl_out, ld_out);
+  } else {
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx->stream, ctx->u, ctx->x, ctx->logl,
+                       ctx->cap, ctx->d, idx_dev, n_out, u_out, x_out, logl_out, ld_out);
+  }
   TPH_LAUNCH_CHECK();
   return 0;
 }

@@ -773,3 +773,42 @@ def test_blocked_kernel_deferred_update_and_step_control(dev, kernel):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
     assert torch.equal(ua, ub)
+
+
+@pytest.mark.parametrize("d", [3, 10, 50])
+def test_gather_through_the_row_mirror_equals_the_dimension_major_gather(dev, d):
+    """tph_gather from the lazily filled row-major mirror (TPH_OPT_ROW_MIRROR, default) against the dimension-major gather:
+    the same rows bit for bit -- after appends (the mirror catches up with the new rows only), after a reload and a clear."""
+    from tempest_amd.device import HipContext, OPT_ROW_MIRROR
+    rs = np.random.RandomState(5)
+    c = HipContext(d, 0)
+
+    def append(n, beta):
+        u = torch.from_numpy(rs.rand(d, n)).to(dev)
+        c.history_append(u, 20 * u - 10, torch.from_numpy(rs.randn(n)).to(dev), beta, 0.0)
+
+    def both(n_out):
+        idx = torch.from_numpy(rs.randint(0, c.size, size=n_out)).to(dev)
+        out = []
+        for mode in (1, 0):
+            c.set_option(OPT_ROW_MIRROR, mode)
+            u, x, l = c.empty(d, n_out), c.empty(d, n_out), c.empty(n_out)
+            c.gather(idx, u, x, l)
+            out.append((u, x, l))
+        c.set_option(OPT_ROW_MIRROR, 1)
+        for a, b in zip(*out):
+            assert torch.equal(a, b)
+        hu = torch.from_numpy(c.history_read(0, 0, c.size, soa=True)).to(dev)         # [d][size]
+        assert torch.equal(out[0][0], hu[:, idx])
+    append(3000, 0.0)
+    both(1000)
+    append(70001, 0.1)                   # mirror grows and packs only the new rows
+    both(4097)
+    both(63)                             # small gather far behind nothing: still the mirror (it is up to date)
+    append(129, 0.2)
+    both(5000)
+    n = 900
+    u = rs.rand(n, d)
+    c.history_load(u, 20 * u - 10, rs.randn(n), [0.0, 0.3], [0.0, -1.0], [400, 500])
+    both(777)
+    c.close()

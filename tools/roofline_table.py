@@ -44,7 +44,9 @@ ALGO = {
     "void tph_scan::k_apply<0>": ("K6 scan pass 3 (local scan + offset)", 16.0 * NH, "16 B per row", "stream"),
     "k_resample_multinomial": ("K6 inverse-CDF lookups of the resampling draws", 8.0 * N, "8 B out per draw (+ ~3 index lines read per draw)", "indexed"),
     "k_multinomial_counts": ("K6 inverse-CDF lookups of the x4 up-sampling", 0.0, "one atomic per draw (+ ~3 index lines read per draw)", "indexed"),
-    "k_gather": ("K7 gather of the resampled rows", 2.0 * (2 * D + 1) * 8.0 * N, "2 (2d+1) 8 B per output row", "indexed"),
+    "k_gather_rows": ("K7 gather of the resampled rows (from the row-major mirror)", 2.0 * (2 * D + 1) * 8.0 * N, "2 (2d+1) 8 B per output row", "indexed"),
+    "k_rows_pack": ("K7 mirror fill: the iteration's new rows, dimension-major -> records", 2.0 * (2 * D + 1) * 8.0 * N, "2 (2d+1) 8 B per new row", "stream"),
+    "k_gather(": ("K7 gather of the resampled rows (dimension-major history, no mirror)", 2.0 * (2 * D + 1) * 8.0 * N, "2 (2d+1) 8 B per output row", "indexed"),
     "void k_propose_reg<0, 10, true, 4, false>": ("K9 proposal (tpCN, d = 10)", (16.0 * D + 20.0) * N, "16d + 20 B per particle (VALU-bound)", "stream"),
     "void k_accept<0>": ("K10 Metropolis decision (deferred update)", 49.0 * N, "32 B read + 16 B written + 1 B mask per particle", "stream"),
     "k_adapt": ("K10 sigma adaptation + column sums of the block partials", 16.0 * (N // 256), "16 B per 256 particles", "stream"),
