@@ -226,7 +226,8 @@ int tph_resample_multinomial(tph_ctx* ctx, const double* cdf_dev, int64_t n, int
 int tph_resample_select(tph_ctx* ctx, const double* cdf_dev, int64_t n, int64_t n_slots, int scheme, uint64_t seed,
                         uint32_t tick, uint32_t tag, double u0, double w_before, double w_upto, double w_total,
                         int is_last, int64_t* idx_dev);
-/* u_out[j][i] = u_hist[j][idx_i] etc. (steps/resample.py:86-99) */
+/* u_out[j][i] = u_hist[j][idx_i] etc. (steps/resample.py:86-99).  Reads the row-major mirror of the history (one contiguous
+ * record per gathered row; TPH_OPT_ROW_MIRROR) after bringing it up to date with the rows appended since its last use. */
 int tph_gather(tph_ctx* ctx, const int64_t* idx_dev, int64_t n_out, double* u_out, double* x_out,
                double* logl_out, int64_t ld_out);
 /* posterior extraction (core.py:187-242): rows idx_i (idx_dev NULL = the first m rows) of the history's u or x
