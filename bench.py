@@ -195,6 +195,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    # TEMPEST_AMD_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo -- walks the N > 1 control flow (sharding, the peer-to-peer
+    # layer between processes, max-over-ranks timing, the extra legs) on a one-GPU box; its numbers mean nothing
+    rehearsal = os.environ.get("TEMPEST_AMD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("TEMPEST_AMD_FORCE_COMM") == "1"
     if use_dist:
@@ -202,7 +207,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     import tempest_amd as tp
@@ -250,7 +258,7 @@ def main():
         dt = time.perf_counter() - t0
         gc.enable()
         if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, np.asarray(s.state._scalars["steps"][it0:]), np.asarray(s.state._scalars["beta"][it0:])
@@ -307,7 +315,7 @@ def main():
            "unit": "particle-mutation-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
            "scaling": "strong" if a.particles_per_gpu <= 0 else "weak", "vs_baseline": None,
-           "dtype": "f64", "data": "synthetic",
+           "dtype": "f64", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo, not a measurement)",
            "config": {"workload": f"rosenbrock10d_n{n_global} (BASELINE config 4: 10-D Rosenbrock, {n_global} particles "
                                   f"sharded over {world} GPU(s), {n_local} per GPU)",
                       "n_dim": 10, "particles_per_gpu": n_local, "particles_global": n_global, "sample": "tpcn",
@@ -351,7 +359,7 @@ def main():
     if rank == 0:
         if not a.no_roofline:
             out["roofline"] = reweight_roofline(local_rank, a.roofline_rows)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:       # the CPU baseline belongs to the N = 1 line only
             out["cpu_baseline"] = cpu_baseline()
     if use_dist:
         dist.barrier()

@@ -33,3 +33,38 @@ def test_bench_cli_defaults():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout + out.stderr          # bench.py routes everything but the JSON line to stderr
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
+    """The N > 1 control flow of bench.py (BASELINE config 4 sharded: strong scaling, max-over-ranks timing, the HIP-callback and
+    weak-scaling legs, the peer-to-peer layer between two processes) walked on ONE GPU: TEMPEST_AMD_BENCH_REHEARSAL=1 puts every
+    rank on cuda:0 over gloo.  The numbers mean nothing; the line must have the contract's shape and the sharded run must agree
+    with the one-rank run of the same global ensemble on the evidence."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, TEMPEST_AMD_BENCH_REHEARSAL="1", TEMPEST_AMD_P2P_TIMEOUT="60")
+    common = ["--steps", "2", "--warmup", "1", "--particles", "32768", "--no-roofline", "--no-cpu-baseline"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-2000:]
+    d2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and "REHEARSAL" in d2["data"]
+    assert d2["config"]["particles_global"] == 32768 and d2["config"]["particles_per_gpu"] == 16384
+    assert d2["hip_callbacks"]["value"] and d2["hip_callbacks"]["same_schedule_as_value_run"]
+    assert d2["weak_scaling"]["particles_global"] == 65536 and d2["weak_scaling"]["value"] > 0
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-hip-callbacks"] + common, capture_output=True,
+                         text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d1["iterations_total"] == d2["iterations_total"] and d1["timed_mcmc_steps"] == d2["timed_mcmc_steps"]
+    assert abs(d1["logz"] - d2["logz"]) < 1e-9          # the sharded sampler is the same sampler
