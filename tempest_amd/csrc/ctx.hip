@@ -1,6 +1,7 @@
 // Context + persistent particle history (reference: tempest/state_manager.py:171-176,267-320,356-416)
 // and the cached log-mixture denominator of the MIS weights (state_manager.py:466-471).
 #include "common.h"
+#include <stdlib.h>
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -118,6 +119,7 @@ extern "C" int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void
   TPH_HIP(hipSetDevice(device));
   tph_ctx* c = new tph_ctx();
   c->device = device;
+  if (const char* env = getenv("TEMPEST_AMD_ROW_MIRROR")) c->rows_mode = atoi(env) ? 1 : 0;     // debugging aid (TPH_OPT_ROW_MIRROR)
   c->d = n_dim;
   c->stream = (hipStream_t)hip_stream;
   {

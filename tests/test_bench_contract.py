@@ -67,4 +67,6 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     assert d1["iterations_total"] == d2["iterations_total"] and d1["timed_mcmc_steps"] == d2["timed_mcmc_steps"]
-    assert abs(d1["logz"] - d2["logz"]) < 1e-9          # the sharded sampler is the same sampler
+    # the sharded sampler is the same sampler: equal to rounding at this size and seed (DESIGN.md section 7 describes the one
+    # way two world sizes can part -- a rounding-level tie at the trim percentile -- and where it was seen)
+    assert abs(d1["logz"] - d2["logz"]) < 1e-9

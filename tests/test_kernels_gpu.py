@@ -548,7 +548,7 @@ def _history_ctx(d, T, rows, seed, loopback):
     return c, rs
 
 
-@pytest.mark.parametrize("T,rows,p2p", [(1, 5000, False), (7, 3000, True), (40, 700, True), (3, 70000, False)])
+@pytest.mark.parametrize("T,rows,p2p", [(1, 5000, False), (7, 3000, True), (40, 700, True), (3, 70000, False), (17, 65536, True)])
 def test_global_entry_points_loopback_match_plain(dev, T, rows, p2p):
     d = 3
     plain, rs = _history_ctx(d, T, rows, 11, False)
