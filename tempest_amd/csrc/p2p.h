@@ -10,7 +10,7 @@ constexpr size_t TPH_P2P_FLAG = 128;
 struct p2p_args {
   char* inbox[TPH_P2P_MAX];
   int world, rank;
-  unsigned long long* seq;                      // device: exchanges completed by this rank
+  unsigned long long* seq;                      // device: [0] exchanges completed by this rank, [1] != 0 after a timed-out one
   unsigned int* err;                            // pinned host word (device address): != 0 after a timed-out exchange
   unsigned long long timeout;                   // wall_clock64 ticks (100 MHz)
 };
@@ -31,8 +31,9 @@ __device__ __forceinline__ bool p2p_block_exchange(const p2p_args& a, const T* s
   __shared__ int s_bad;
   const int tid = threadIdx.x, nt = blockDim.x;
   __syncthreads();                              // src may have been written by other threads of the block
-  if (tid == 0) { s_seq = *a.seq + 1ull; s_bad = 0; }
+  if (tid == 0) { s_seq = *a.seq + 1ull; s_bad = a.seq[1] != 0ull; }
   __syncthreads();
+  if (s_bad) return false;                      // an earlier exchange timed out: fail at once instead of waiting again
   const unsigned long long seq = s_seq;
   const size_t e = (size_t)(seq & 1ull);
   const size_t flags = 2 * (size_t)a.world * TPH_P2P_SLOT;
@@ -58,7 +59,7 @@ __device__ __forceinline__ bool p2p_block_exchange(const p2p_args& a, const T* s
   }
   __syncthreads();
   if (s_bad) {
-    if (tid == 0) { *a.err = (unsigned int)s_bad; __threadfence_system(); *a.seq = seq; }
+    if (tid == 0) { *a.err = (unsigned int)s_bad; a.seq[1] = 1ull; __threadfence_system(); *a.seq = seq; }
     return false;
   }
   const char* in = a.inbox[a.rank] + e * a.world * TPH_P2P_SLOT;

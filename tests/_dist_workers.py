@@ -310,6 +310,42 @@ def p2p_gpu_worker(rank, world, port, out_dir):
     del os.environ["TEMPEST_AMD_P2P_NOWINDOW"]
     res["fallback"] = True
     ctx3.close()
+    # a peer that never arrives: the waiting kernel gives up after the timeout, the error is reported (not a hang), and every
+    # later exchange of that context fails at once
+    import time
+    from tempest_amd._lib import TempestHipError
+    keep = os.environ.get("TEMPEST_AMD_P2P_TIMEOUT")
+    os.environ["TEMPEST_AMD_P2P_TIMEOUT"] = "2"
+    ctx4 = HipContext(3, 0)
+    comm4 = Comm()
+    comm4.attach(ctx4, nbytes=4 << 20)
+    assert ctx4.p2p_active
+    dist.barrier()
+    if rank == 0:
+        t = torch.ones(4, dtype=torch.float64, device=dev)
+        t0 = time.perf_counter()
+        ctx4.allreduce_dev(t, 0)                     # nobody else takes part
+        torch.cuda.synchronize()
+        assert 1.5 < time.perf_counter() - t0 < 30.0
+        try:
+            ctx4.p2p_status()
+            raise AssertionError("the timed-out exchange was not reported")
+        except TempestHipError as e:
+            assert "timed out" in str(e)
+        t0 = time.perf_counter()
+        try:
+            ctx4.allreduce_dev(t, 0)
+            raise AssertionError("an exchange after the failure was accepted")
+        except TempestHipError:
+            pass
+        assert time.perf_counter() - t0 < 1.0
+    dist.barrier()
+    if keep is None:
+        del os.environ["TEMPEST_AMD_P2P_TIMEOUT"]
+    else:
+        os.environ["TEMPEST_AMD_P2P_TIMEOUT"] = keep
+    res["timeout_reported"] = True
+    ctx4.close()
     json.dump(res, open(os.path.join(out_dir, f"p2p{rank}.json"), "w"))
     dist.barrier()
     ctx.close()
