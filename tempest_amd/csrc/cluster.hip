@@ -46,11 +46,30 @@ __global__ void __launch_bounds__(GMM_THREADS) k_gmm_estep(const double* __restr
       const double* pr = params + (size_t)k * ps;
       const double* mu = pr + 1;
       const double* P = pr + 1 + d;
+      // (x - mu)^T P (x - mu), 8 rows of P at a time: P is symmetric, so the 8 entries P[r0 .. r0+7][j] are the contiguous
+      // P[j][r0 .. r0+7] -- one wave-uniform 64-byte (scalar) load and one LDS read of x_j feed 8 FMAs.  (The row-by-row form
+      // re-read x_j, mu_j and one matrix element per FMA: 1.3 TFLOP/s at d = 32.)
       double maha = 0.0;
-      for (int r = 0; r < d; ++r) {
-        double s = 0.0;
-        for (int j = 0; j < d; ++j) s += P[r * d + j] * (xs[j * GMM_THREADS] - mu[j]);
-        maha += (xs[r * GMM_THREADS] - mu[r]) * s;
+      for (int r0 = 0; r0 < d; r0 += 8) {
+        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (r0 + 8 <= d) {
+          for (int j = 0; j < d; ++j) {
+            const double xc = xs[j * GMM_THREADS] - mu[j];
+            const double* __restrict__ Pj = P + (size_t)j * d + r0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = fma(Pj[q], xc, acc[q]);
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) maha = fma(xs[(r0 + q) * GMM_THREADS] - mu[r0 + q], acc[q], maha);
+        } else {
+          const int nq = d - r0;
+          for (int j = 0; j < d; ++j) {
+            const double xc = xs[j * GMM_THREADS] - mu[j];
+            const double* __restrict__ Pj = P + (size_t)j * d + r0;
+            for (int q = 0; q < nq; ++q) acc[q] = fma(Pj[q], xc, acc[q]);
+          }
+          for (int q = 0; q < nq; ++q) maha = fma(xs[(r0 + q) * GMM_THREADS] - mu[r0 + q], acc[q], maha);
+        }
       }
       double logpdf = -0.5 * ((double)d * 1.8378770664093454836 + pr[1 + d + d * d] + maha);
       if (mode == 0) { if (k < GMM_KMAX_RESP) pk[k] = exp(pr[0]) * exp(logpdf); }

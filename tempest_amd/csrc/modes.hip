@@ -420,6 +420,146 @@ __global__ void __launch_bounds__(256) k_wcov(const double* __restrict__ hu, int
   }
 }
 
+// n_dim >= 16: the same staged tile, but a thread owns a 4 x 4 BLOCK of the lower triangle over a slice of the tile's rows:
+// per row 1 + 4 + 4 LDS reads feed 16 FMAs (the pair-per-thread form above reads w, x_a, x_b for every single FMA and is
+// LDS-bound: 0.5 TFLOP/s at d = 32).  Items = (block pair, row slice); slices exist only while there are fewer block pairs
+// than threads (d <= 64) and meet in a fixed order through an LDS copy of the triangle (no float atomics).
+constexpr int COV_TB = 4;
+__host__ __device__ inline int cov_tile_slices(int d) {
+  const int nbk = (d + COV_TB - 1) / COV_TB, pairs = nbk * (nbk + 1) / 2;
+  int sl = 1;
+  while (sl < 16 && pairs * sl * 2 <= 256) sl *= 2;
+  return sl;
+}
+template <typename WT>
+__global__ void __launch_bounds__(256) k_wcov_tiled(const double* __restrict__ hu, int64_t cap, int d, const WT* __restrict__ wt,
+                                                    const int32_t* __restrict__ labels, int label, int64_t n,
+                                                    const double* __restrict__ mean, double* __restrict__ partials) {
+  extern __shared__ double sh[];
+  double* xs = sh;                               // [d][65]
+  double* ws = sh + (size_t)d * COV_LD;          // [64]
+  double* tri = ws + COV_ROWS;                   // [npl], only when the tile's rows are sliced
+  const int npl = d * (d + 1) / 2;
+  const int nbk = (d + COV_TB - 1) / COV_TB, pairs = nbk * (nbk + 1) / 2;
+  const int SL = cov_tile_slices(d), rows_per = COV_ROWS / SL;
+  const int items = pairs * SL;
+  constexpr int MAXI = 2;                         // items per thread: 325 block pairs at d = 100
+  int ia[MAXI], ib[MAXI], isl[MAXI];
+  double acc[MAXI][COV_TB][COV_TB];
+#pragma unroll
+  for (int k = 0; k < MAXI; ++k) {
+    const int it = threadIdx.x + k * 256;
+    const int p = it / SL;
+    isl[k] = it - p * SL;
+    int a = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= p) ++a;
+    while (a * (a + 1) / 2 > p) --a;
+    ia[k] = it < items ? a : -1;
+    ib[k] = p - a * (a + 1) / 2;
+#pragma unroll
+    for (int q = 0; q < COV_TB; ++q)
+#pragma unroll
+      for (int r = 0; r < COV_TB; ++r) acc[k][q][r] = 0.0;
+  }
+  const int64_t ntiles = (n + COV_ROWS - 1) / COV_ROWS;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t r0 = t * COV_ROWS;
+    __syncthreads();
+    for (int e = threadIdx.x; e < d * COV_ROWS; e += blockDim.x) {
+      int j = e / COV_ROWS, r = e % COV_ROWS;
+      int64_t i = r0 + r;
+      xs[j * COV_LD + r] = i < n ? hu[(size_t)j * cap + i] - mean[j] : 0.0;
+    }
+    if (threadIdx.x < COV_ROWS) {
+      int64_t i = r0 + threadIdx.x;
+      double w = 0.0;
+      if (i < n && (!labels || labels[i] == label)) w = (double)wt[i];
+      ws[threadIdx.x] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+      if (ia[k] < 0) continue;
+      // slice s takes rows s, s + SL, s + 2 SL ... of the tile: the slices of one block pair read neighbouring LDS words
+      const int a0 = ia[k] * COV_TB, b0 = ib[k] * COV_TB, rlo = isl[k];
+      // rows of the blocks beyond d (last block of an n_dim that is no multiple of 4) read row d-1: computed, never stored
+      const double* xa[COV_TB];
+      const double* xb[COV_TB];
+#pragma unroll
+      for (int q = 0; q < COV_TB; ++q) {
+        xa[q] = xs + (size_t)(a0 + q < d ? a0 + q : d - 1) * COV_LD + rlo;
+        xb[q] = xs + (size_t)(b0 + q < d ? b0 + q : d - 1) * COV_LD + rlo;
+      }
+      for (int r = 0; r < rows_per; ++r) {
+        const double w = ws[rlo + r * SL];
+        double va[COV_TB], vb[COV_TB];
+#pragma unroll
+        for (int q = 0; q < COV_TB; ++q) { va[q] = w * xa[q][r * SL]; vb[q] = xb[q][r * SL]; }
+#pragma unroll
+        for (int q = 0; q < COV_TB; ++q)
+#pragma unroll
+          for (int c = 0; c < COV_TB; ++c) acc[k][q][c] = fma(va[q], vb[c], acc[k][q][c]);
+      }
+    }
+  }
+  double* mine = partials + (size_t)blockIdx.x * npl;
+  if (SL == 1) {
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+      if (ia[k] < 0) continue;
+#pragma unroll
+      for (int q = 0; q < COV_TB; ++q)
+#pragma unroll
+        for (int c = 0; c < COV_TB; ++c) {
+          const int a = ia[k] * COV_TB + q, b = ib[k] * COV_TB + c;
+          if (a < d && b <= a) mine[a * (a + 1) / 2 + b] = acc[k][q][c];
+        }
+    }
+    return;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < npl; e += blockDim.x) tri[e] = 0.0;
+  for (int s = 0; s < SL; ++s) {                  // slice by slice: every entry has one owner per slice -> fixed order, no atomics
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+      if (ia[k] < 0 || isl[k] != s) continue;
+#pragma unroll
+      for (int q = 0; q < COV_TB; ++q)
+#pragma unroll
+        for (int c = 0; c < COV_TB; ++c) {
+          const int a = ia[k] * COV_TB + q, b = ib[k] * COV_TB + c;
+          if (a < d && b <= a) tri[a * (a + 1) / 2 + b] += acc[k][q][c];
+        }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < npl; e += blockDim.x) mine[e] = tri[e];
+}
+
+// launches the second-moment kernel for n_dim > 12 (block partials [nblk][npl] when tiled, [nblk * S][npl] otherwise):
+// returns the number of partial rows per block
+template <typename WT>
+static int launch_wcov(tph_ctx* ctx, const double* src, int64_t src_ld, const WT* wt, const int32_t* labels, int label, int64_t n,
+                       const double* mean, double* partials, int nblk, int* rows_per_block) {
+  const int d = ctx->d, npl = d * (d + 1) / 2;
+  if (d >= 16) {
+    const int SL = cov_tile_slices(d);
+    const size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS + (SL > 1 ? npl : 0));
+    if (lds > 64 * 1024)
+      TPH_HIP(hipFuncSetAttribute((const void*)k_wcov_tiled<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_wcov_tiled<WT>, dim3(nblk), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials);
+    *rows_per_block = 1;
+    return 0;
+  }
+  const size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS);
+  if (lds > 64 * 1024)
+    TPH_HIP(hipFuncSetAttribute((const void*)k_wcov<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_wcov<WT>, dim3(nblk), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials);
+  *rows_per_block = cov_slices(npl);
+  return 0;
+}
+
 // Small n_dim (<= 12): one lane per row, the d(d+1)/2 accumulators live in registers, the stream over u is
 // coalesced per coordinate and nothing is staged: HBM-bound.  One block partial of npl sums per block.
 template <typename WT, int D>
@@ -560,20 +700,12 @@ static int moments_launch_cov(tph_ctx* ctx, const void* wt, bool wt_is_int, cons
     TPH_LAUNCH_CHECK();
     return 0;
   }
-  size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS);
-  if (wt_is_int) {
-    if (lds > 64 * 1024)
-      TPH_HIP(hipFuncSetAttribute((const void*)k_wcov<int32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_wcov<int32_t>, dim3(nblk), dim3(256), lds, ctx->stream, src, src_ld, d, (const int32_t*)wt,
-                       labels, label, n, mean_dev, partials);
-  } else {
-    if (lds > 64 * 1024)
-      TPH_HIP(hipFuncSetAttribute((const void*)k_wcov<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_wcov<double>, dim3(nblk), dim3(256), lds, ctx->stream, src, src_ld, d, (const double*)wt, labels,
-                       label, n, mean_dev, partials);
-  }
+  int rpb = S;
+  if (wt_is_int ? launch_wcov<int32_t>(ctx, src, src_ld, (const int32_t*)wt, labels, label, n, mean_dev, partials, nblk, &rpb)
+                : launch_wcov<double>(ctx, src, src_ld, (const double*)wt, labels, label, n, mean_dev, partials, nblk, &rpb))
+    return -1;
   double* csum = partials + (size_t)nblk * S * npl;
-  hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, partials, nblk * S, npl, csum);
+  hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, partials, nblk * rpb, npl, csum);
   hipLaunchKernelGGL(k_cov_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum, sums_dev, d, student, cov_dev);
   TPH_LAUNCH_CHECK();
   return 0;
@@ -1209,11 +1341,9 @@ extern "C" int tph_fit_modes_global(tph_ctx* ctx, const int32_t* counts_dev, con
         TPH_REQUIRE(ok, "covariance: no register kernel for n_dim=%d", d);
         hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk, npl, csum);
       } else {
-        size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS);
-        if (lds > 64 * 1024)
-          TPH_HIP(hipFuncSetAttribute((const void*)k_wcov<int32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_wcov<int32_t>, dim3(nblk), dim3(256), lds, ctx->stream, src, src_ld, d, counts_dev, lab, k, n, mean, part);
-        hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk * S, npl, csum);
+        int rpb = S;
+        if (launch_wcov<int32_t>(ctx, src, src_ld, counts_dev, lab, k, n, mean, part, nblk, &rpb)) return -1;
+        hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk * rpb, npl, csum);
       }
       TPH_LAUNCH_CHECK();
       if (tph_comm_allreduce(ctx, c_big, npl, TPH_DT_F64, TPH_OP_SUM)) return -2;
@@ -1665,12 +1795,9 @@ extern "C" int tph_volume_variation(tph_ctx* ctx, const double* w_dev, int64_t n
       TPH_REQUIRE(ok, "covariance: no register kernel for n_dim=%d", d);
       hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk, npl, csum);
     } else {
-      size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS);
-      if (lds > 64 * 1024)
-        TPH_HIP(hipFuncSetAttribute((const void*)k_wcov<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_wcov<double>, dim3(nblk), dim3(256), lds, ctx->stream, ctx->u, ctx->cap, d, w_dev, (const int32_t*)nullptr, 0,
-                         n, mean, part);
-      hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk * S, npl, csum);
+      int rpb = S;
+      if (launch_wcov<double>(ctx, ctx->u, ctx->cap, w_dev, (const int32_t*)nullptr, 0, n, mean, part, nblk, &rpb)) return -1;
+      hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk * rpb, npl, csum);
     }
     TPH_LAUNCH_CHECK();
     if (comm && tph_comm_allreduce(ctx, 4096, npl, TPH_DT_F64, TPH_OP_SUM)) return -2;
