@@ -95,17 +95,16 @@ class GaussianMixture:
         """weights, means, covariances from wr = responsibilities x sample weights (cluster.py:200-235)."""
         ctx = ws.ctx
         d = ctx.n_dim
-        tot = np.empty(K)
-        means = np.empty((K, d))
-        covs = np.empty((K, d, d))
-        sums = [ctx.x_weighted_sums(ws.X, ws.wr[k]) for k in range(K)]
-        for k in range(K):
-            s = sums[k].cpu().numpy()
-            tot[k] = s[0]
-            means[k] = s[1:] / (s[0] + 1e-10)
-        for k in range(K):
-            c = ctx.x_weighted_cov(ws.X, ws.wr[k], ws.to_dev(means[k])).cpu().numpy().reshape(d, d)
-            covs[k] = c / (tot[k] + 1e-10)
+        import torch
+        # the means are formed on the device (the same two IEEE operations as on the host) and feed the covariance kernels
+        # directly: ONE device-to-host copy per M-step instead of a round trip per component and moment
+        sums = torch.stack([ctx.x_weighted_sums(ws.X, ws.wr[k]) for k in range(K)])            # (K, 1 + d)
+        means_dev = (sums[:, 1:] / (sums[:, :1] + 1e-10)).contiguous()
+        covs_dev = torch.stack([ctx.x_weighted_cov(ws.X, ws.wr[k], means_dev[k]) for k in range(K)])   # (K, d * d)
+        host = torch.cat([sums.reshape(-1), means_dev.reshape(-1), covs_dev.reshape(-1)]).cpu().numpy()
+        tot = host[: K * (1 + d)].reshape(K, 1 + d)[:, 0].copy()
+        means = host[K * (1 + d): K * (1 + d) + K * d].reshape(K, d).copy()
+        covs = host[K * (1 + d) + K * d:].reshape(K, d, d) / (tot[:, None, None] + 1e-10)
         return tot / tot.sum(), means, covs
 
     def _seed_row(self, ws, prob, u):
