@@ -87,6 +87,10 @@ int tph_synchronize(tph_ctx* ctx);
  * it cannot be allocated): a gathered row is one contiguous record instead of 2 n_dim + 1 scattered sectors; 0 = gather from
  * the dimension-major arrays */
 #define TPH_OPT_ROW_MIRROR 6
+/* TPH_OPT_COV_KERNEL: centred second moments at 16 <= n_dim <= 100: 0 = automatic (= 1), 1 = 4 x 4 register blocks per thread
+ * (VALU), 2 = FP64 matrix cores (v_mfma_f64_16x16x4: the product is a SYRK; measured no faster -- both are bound by the fill of
+ * the staged tile); the parity tests run both */
+#define TPH_OPT_COV_KERNEL 7
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- multi-GPU: one process per GPU --------------------------------------

@@ -537,12 +537,92 @@ __global__ void __launch_bounds__(256) k_wcov_tiled(const double* __restrict__ h
   for (int e = threadIdx.x; e < npl; e += blockDim.x) mine[e] = tri[e];
 }
 
+// n_dim >= 16 on the matrix cores: C = X^T diag(w) X is a genuine FP64 SYRK, the one GEMM-shaped product of the path.
+// v_mfma_f64_16x16x4: D(16 x 16) += A(16 x 4) B(4 x 16) per instruction, lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16]
+// and holds D[4 v + l / 16][l % 16], v = 0..3 (layout probed on gfx950, scratch test).  The staged tile of 64 rows is xs[dim][row];
+// for the block pair (Ab >= Bb) of 16 x 16 blocks of the triangle, A = (w x)[Ab dims][4 rows], B = x[4 rows][Bb dims]: two LDS
+// reads and one multiply per 1024 multiply-adds.  The 4 waves of a block share the block pairs.  MEASURED: no faster than the
+// register-blocked VALU kernel above (74 vs 74 us at 262 144 x 32-D, 218 vs 224 us at 131 072 x 100-D, incl. the column sums):
+// with either, the arithmetic hides behind the fill of the 64-row tile, which is what bounds both (0.9 TB/s: two barriers
+// per 16 KB tile, no overlap of the next tile's loads).  Kept as TPH_OPT_COV_KERNEL = 2 and in the parity tests; the default is
+// the VALU kernel.
+typedef double tph_v4d __attribute__((ext_vector_type(4)));
+constexpr int COV_MF_MAXP = 9;                  // block pairs per wave: 36 pairs (n_dim <= 128) over 4 waves
+template <typename WT>
+__global__ void __launch_bounds__(256) k_wcov_mfma(const double* __restrict__ hu, int64_t cap, int d, const WT* __restrict__ wt,
+                                                   const int32_t* __restrict__ labels, int label, int64_t n,
+                                                   const double* __restrict__ mean, double* __restrict__ partials) {
+  extern __shared__ double sh[];
+  const int NB = (d + 15) / 16, dp = NB * 16, pairs = NB * (NB + 1) / 2;
+  double* xs = sh;                               // [dp][65], dims >= d are zero
+  double* ws = sh + (size_t)dp * COV_LD;         // [64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  int offa[COV_MF_MAXP], offb[COV_MF_MAXP];      // LDS offsets of this lane's A / B element at row 0
+  tph_v4d acc[COV_MF_MAXP];
+#pragma unroll
+  for (int k = 0; k < COV_MF_MAXP; ++k) {
+    const int p = wave + 4 * k;
+    int a = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= p) ++a;
+    while (a * (a + 1) / 2 > p) --a;
+    const int b = p - a * (a + 1) / 2;
+    offa[k] = p < pairs ? (a * 16 + li) * COV_LD + lk : -1;
+    offb[k] = (b * 16 + li) * COV_LD + lk;
+    acc[k] = tph_v4d{0.0, 0.0, 0.0, 0.0};
+  }
+  const int64_t ntiles = (n + COV_ROWS - 1) / COV_ROWS;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t r0 = t * COV_ROWS;
+    __syncthreads();
+    for (int e = threadIdx.x; e < dp * COV_ROWS; e += blockDim.x) {
+      const int j = e / COV_ROWS, r = e % COV_ROWS;
+      const int64_t i = r0 + r;
+      xs[j * COV_LD + r] = (j < d && i < n) ? hu[(size_t)j * cap + i] - mean[j] : 0.0;
+    }
+    if (threadIdx.x < COV_ROWS) {
+      const int64_t i = r0 + threadIdx.x;
+      double w = 0.0;
+      if (i < n && (!labels || labels[i] == label)) w = (double)wt[i];
+      ws[threadIdx.x] = w;
+    }
+    __syncthreads();
+    for (int r = 0; r < COV_ROWS; r += 4) {
+      const double w = ws[r + lk];
+#pragma unroll
+      for (int k = 0; k < COV_MF_MAXP; ++k) {
+        if (offa[k] >= 0) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(w * xs[offa[k] + r], xs[offb[k] + r], acc[k], 0, 0, 0);
+      }
+    }
+  }
+  const int npl = d * (d + 1) / 2;
+  double* mine = partials + (size_t)blockIdx.x * npl;
+#pragma unroll
+  for (int k = 0; k < COV_MF_MAXP; ++k) {
+    if (offa[k] < 0) continue;
+    const int a0 = (offa[k] - lk) / COV_LD - li, b0 = (offb[k] - lk) / COV_LD - li;     // first dims of the two blocks
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int a = a0 + 4 * v + lk, b = b0 + li;
+      if (a < d && b <= a) mine[a * (a + 1) / 2 + b] = acc[k][v];
+    }
+  }
+}
+
 // launches the second-moment kernel for n_dim > 12 (block partials [nblk][npl] when tiled, [nblk * S][npl] otherwise):
 // returns the number of partial rows per block
 template <typename WT>
 static int launch_wcov(tph_ctx* ctx, const double* src, int64_t src_ld, const WT* wt, const int32_t* labels, int label, int64_t n,
                        const double* mean, double* partials, int nblk, int* rows_per_block) {
   const int d = ctx->d, npl = d * (d + 1) / 2;
+  if (d >= 16 && d <= 128 && ctx->cov_kernel == 2) {      // matrix cores on request (TPH_OPT_COV_KERNEL: 0 auto = 1 register blocks | 2 MFMA)
+    const size_t lds = sizeof(double) * ((size_t)((d + 15) / 16 * 16) * COV_LD + COV_ROWS);
+    if (lds > 64 * 1024)
+      TPH_HIP(hipFuncSetAttribute((const void*)k_wcov_mfma<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_wcov_mfma<WT>, dim3(nblk), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials);
+    *rows_per_block = 1;
+    return 0;
+  }
   if (d >= 16) {
     const int SL = cov_tile_slices(d);
     const size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS + (SL > 1 ? npl : 0));

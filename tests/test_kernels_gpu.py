@@ -812,3 +812,41 @@ def test_gather_through_the_row_mirror_equals_the_dimension_major_gather(dev, d)
     c.history_load(u, 20 * u - 10, rs.randn(n), [0.0, 0.3], [0.0, -1.0], [400, 500])
     both(777)
     c.close()
+
+
+@pytest.mark.parametrize("d", [16, 19, 32, 50, 77, 100])
+def test_second_moments_on_the_matrix_cores_equal_the_vector_kernel(dev, d):
+    """TPH_OPT_COV_KERNEL: the FP64-MFMA form of the centred second moments (n_dim >= 16) against the register-blocked VALU
+    kernel and against NumPy: integer multiplicities (proposal fit) and real weights (mixture M-step), ragged row counts."""
+    from tempest_amd.device import HipContext, OPT_COV_KERNEL
+    rs = np.random.RandomState(d)
+    n = 64 * 37 + 29
+    c = HipContext(d, 0)
+    A = rs.randn(d, d) * 0.05
+    u = np.clip(0.5 + rs.randn(n, d) @ A.T + 0.1 * rs.randn(n, 1), 0.0, 1.0)
+    c.history_load(u, 20 * u - 10, rs.randn(n), [0.0], [0.0], [n])
+    counts = rs.poisson(np.exp(rs.randn(n) - 0.5)).astype(np.int32)
+    ct = torch.from_numpy(counts).to(dev)
+    got = {}
+    for mode in (1, 2):
+        c.set_option(OPT_COV_KERNEL, mode)
+        means, covs, chol, inv, winv = c.fit_modes(ct, None, 1, n)
+        got[mode] = covs.cpu().numpy()[0].reshape(d, d)
+    np.testing.assert_allclose(got[2], got[1], rtol=1e-11, atol=1e-16)
+    ref = np.cov(u.T, fweights=counts, ddof=0)
+    scale = np.abs(ref).max()
+    assert np.abs(got[2] - ref).max() / scale < 2.0 / counts.sum() + 1e-12        # student.py's normalisation differs by O(1/N)
+    # real weights: the M-step entry point
+    X = torch.from_numpy(np.ascontiguousarray(u.T)).to(dev)
+    w = torch.from_numpy(rs.rand(n) * (rs.rand(n) < 0.7)).to(dev)
+    mu = torch.from_numpy(u.mean(axis=0)).to(dev)
+    out = {}
+    for mode in (1, 2):
+        c.set_option(OPT_COV_KERNEL, mode)
+        out[mode] = c.x_weighted_cov(X, w, mu).cpu().numpy().reshape(d, d)
+    np.testing.assert_allclose(out[2], out[1], rtol=1e-11, atol=1e-16)
+    wn = w.cpu().numpy()
+    xc = u - u.mean(axis=0)
+    np.testing.assert_allclose(out[2], (xc * wn[:, None]).T @ xc, rtol=1e-10, atol=1e-14)
+    assert np.allclose(out[2], out[2].T)
+    c.close()
