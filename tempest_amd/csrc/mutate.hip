@@ -207,8 +207,9 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ 
                                                            const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                            int64_t item0, double* __restrict__ up,
                                                            double* __restrict__ maha_u, double* __restrict__ maha_up,
-                                                           uint8_t* __restrict__ pend, const uint8_t* __restrict__ todo) {
-  // todo != NULL: straggler pass behind k_propose_blk -- only the particles it flagged (their attempt 0 left the cube),
+                                                           uint8_t* __restrict__ pend, const int32_t* __restrict__ todo) {
+  // todo != NULL: straggler pass behind k_propose_blk -- only the particles it LISTED (todo[0] = count, todo[1..] = rows whose
+  // attempt 0 left the cube; a block beyond the list exits at once: 16 384 blocks scanning flags cost 69 us at 262 144 x 32-D),
   // starting from attempt 1; everything else of the step (pending moves, attempt 0 of the others) is done already
   extern __shared__ double sh[];
   constexpr int PPB = ML_THREADS / LPP;
@@ -223,17 +224,15 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ 
   // PPB particles of the block instead of re-reading d*d doubles per particle.
   double* mat0 = sh + (size_t)3 * PPB * dp;
   double* mat1 = mat0 + (size_t)d * (d + 1);
-  const int64_t i = (int64_t)blockIdx.x * PPB + p;
-  const bool live = i < n && (!todo || todo[i < n ? i : n - 1] != 0);
-  const int64_t ii = i < n ? i : n - 1;              // dead groups shadow a particle, never store
-  if (todo) {                                        // a block without stragglers has nothing to do
-    __shared__ int s_any;
-    if (threadIdx.x == 0) s_any = 0;
-    __syncthreads();
-    if (live) s_any = 1;
-    __syncthreads();
-    if (!s_any) return;
+  int64_t i = (int64_t)blockIdx.x * PPB + p;
+  bool live = i < n;
+  if (todo) {
+    const int64_t cnt = todo[0];
+    if ((int64_t)blockIdx.x * PPB >= cnt) return;     // the whole block (uniform): nothing listed for it
+    live = i < cnt;
+    i = live ? (int64_t)todo[1 + i] : n - 1;
   }
+  const int64_t ii = i < n ? i : n - 1;              // dead groups shadow a particle, never store
   const int c = (STAGE == 0 && assign) ? assign[ii] : 0;
   const double* __restrict__ mu = means + (size_t)c * d;
   const double* __restrict__ Lg = chol + (size_t)c * d * d;
@@ -425,7 +424,7 @@ template <int KERNEL, int LPP>
 static int launch_propose_ml(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n, int64_t ld, const double* means,
                              const double* chol, const double* winv, const double* dof, const double* sigmas,
                              const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0, double* up, double* mu_,
-                             double* mup, uint8_t* pend, const uint8_t* todo = nullptr) {
+                             double* mup, uint8_t* pend, const int32_t* todo = nullptr) {
   constexpr int PPB = ML_THREADS / LPP;
   const int d = ctx->d;
   const size_t base = sizeof(double) * 3 * (size_t)PPB * (d | 1);
@@ -466,7 +465,7 @@ __global__ void __launch_bounds__(64 * WV) k_propose_blk(double* __restrict__ u,
                                                          const double* __restrict__ sigmas, const uint8_t* __restrict__ bc,
                                                          uint64_t seed, tph_stepctl tick, int64_t item0, double* __restrict__ up,
                                                          double* __restrict__ maha_u, double* __restrict__ maha_up,
-                                                         uint8_t* __restrict__ pend, uint8_t* __restrict__ todo) {
+                                                         uint8_t* __restrict__ pend, int32_t* __restrict__ todo) {
   extern __shared__ double sh[];
   double* zs = sh;                               // [d][64] normals, later u' - mu
   double* vs = sh + (size_t)d * 64;              // [d][64] u - mu (first step of a run), then the proposal
@@ -556,7 +555,7 @@ __global__ void __launch_bounds__(64 * WV) k_propose_blk(double* __restrict__ u,
     if (live && all_ok) up[(size_t)j * ld + i] = v;
     if (KERNEL == TPH_KERNEL_TPCN) zs[(size_t)j * 64 + lane] = v - means[j];      // the normals are done with
   }
-  if (wid == 0 && live) todo[i] = all_ok ? 0 : 1;
+  if (wid == 0 && live && !all_ok) todo[1 + atomicAdd(&todo[0], 1)] = (int32_t)i;     // the straggler list (order is irrelevant)
   if (blockIdx.x == 0 && tick.ctl) {             // regime probe: mean attempts implied by this block's failures, 1 / (1 - f)
     __syncthreads();
     if (wid == 0) {
@@ -591,7 +590,8 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   // blocked copies of L and L^-1 (tri.h) and the straggler flags, owned by the ctx.  The copies are rebuilt on every call
   // unless the caller versions its mode statistics (TPH_OPT_MODES_EPOCH > 0 and unchanged since the last call)
   const size_t tb = tri_blocked_doubles(d);
-  const size_t need = sizeof(double) * 2 * tb + (size_t)n;
+  TPH_REQUIRE(n < (1ll << 31), "tph_propose (blocked): %lld particles on one device", (long long)n);
+  const size_t need = sizeof(double) * 2 * tb + sizeof(int32_t) * ((size_t)n + 2);
   if (ctx->blk_bytes < need) {
     TPH_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->blk_buf) TPH_HIP(hipFree(ctx->blk_buf));
@@ -601,7 +601,8 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   }
   double* Lb = (double*)ctx->blk_buf;
   double* Wb = Lb + tb;
-  uint8_t* todo = (uint8_t*)(Wb + tb);
+  int32_t* todo = (int32_t*)(Wb + tb);               // [0] = number of stragglers of this step, [1..] their rows
+  TPH_HIP(hipMemsetAsync(todo, 0, sizeof(int32_t), ctx->stream));
   if (ctx->modes_epoch <= 0 || ctx->blk_epoch != ctx->modes_epoch || ctx->blk_src != (const void*)chol) {
     hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, chol, d, Lb);
     if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, winv, d, Wb);
