@@ -136,10 +136,15 @@ __global__ void __launch_bounds__(256) k_select_count(const double* __restrict__
   const int q = blockIdx.x, v = threadIdx.x;
   const int shift = 64 - SEL_BITS * (round + 1);
   const unsigned long long base = prefix[q] + ((unsigned long long)v << shift);
-  const int64_t lo = lower_bound_key(S, n, base);
-  const unsigned long long upper = base + (1ull << shift);
-  const int64_t hi = upper < base ? n : lower_bound_key(S, n, upper);     // wrapped past 2^64: everything from `lo` on
-  counts[(size_t)q * SEL_DIGITS + v] = (CT)(hi - lo);
+  // one search per digit boundary: the upper edge of digit v is the lower edge of digit v + 1
+  __shared__ long long edge[SEL_DIGITS + 1];
+  edge[v] = lower_bound_key(S, n, base);
+  if (v == SEL_DIGITS - 1) {
+    const unsigned long long upper = base + (1ull << shift);
+    edge[SEL_DIGITS] = upper < base ? n : lower_bound_key(S, n, upper);   // wrapped past 2^64: everything from there on
+  }
+  __syncthreads();
+  counts[(size_t)q * SEL_DIGITS + v] = (CT)(edge[v + 1] - edge[v]);
 }
 template <typename CT>
 __global__ void __launch_bounds__(256) k_select_update(const CT* __restrict__ counts, int round, long long* __restrict__ remaining,
