@@ -269,36 +269,52 @@ struct put_args {
 __global__ void __launch_bounds__(256) k_put_rows(put_args w, const double* __restrict__ hu, const double* __restrict__ hx,
                                                   const double* __restrict__ hl, int64_t cap, const double* __restrict__ mirror,
                                                   int d, const int64_t* __restrict__ idx, int64_t n_slots, int64_t n_local,
-                                                  double tag) {
-  const int rec = 2 * d + 2;
+                                                  double tag, int self) {
+  const int rec = 2 * d + 2, half = rec / 2;                    // rec is even: a lane carries TWO fields, one 16-byte store
+  typedef double v2d __attribute__((ext_vector_type(2)));
   const int64_t k0 = (int64_t)blockIdx.x * 64;
-  for (int e = threadIdx.x; e < 64 * rec; e += 256) {            // consecutive lanes: consecutive fields of one record
-    const int r = e / rec, c = e - r * rec;
+  auto field = [&](int64_t s, int c) -> double {                  // from the row-major mirror when there is one (one record)
+    if (c == 2 * d + 1) return tag;
+    if (mirror) return mirror[(size_t)s * (rec - 1) + c];
+    return c < d ? hu[(size_t)c * cap + s] : (c < 2 * d ? hx[(size_t)(c - d) * cap + s] : hl[s]);
+  };
+  for (int e = threadIdx.x; e < 64 * half; e += 256) {           // consecutive lanes: consecutive field pairs of one record
+    const int r = e / half, c = 2 * (e - r * half);
     const int64_t k = k0 + r;
     if (k >= n_slots) break;
     const int64_t s = idx[k];
     if (s < 0) continue;
-    double v;                                                     // from the row-major mirror when there is one (one record)
-    if (c == 2 * d + 1) v = tag;
-    else if (mirror) v = mirror[(size_t)s * (rec - 1) + c];
-    else v = c < d ? hu[(size_t)c * cap + s] : (c < 2 * d ? hx[(size_t)(c - d) * cap + s] : hl[s]);
     const int owner = (int)(k / n_local);
-    double* dst = (double*)w.win[owner] + (size_t)(k - (int64_t)owner * n_local) * rec + c;
-    __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (owner == self) continue;                                  // rows that stay on this rank never pass through a window
+    // records are 16 d + 16 bytes, the window is page-aligned: even fields sit on 16-byte boundaries.  Plain stores: the window
+    // is uncached (write-through) memory, and the fence below orders them before the kernel counts as complete
+    v2d* dst = (v2d*)((double*)w.win[owner] + (size_t)(k - (int64_t)owner * n_local) * rec + c);
+    *dst = v2d{field(s, c), field(s, c + 1)};
   }
   __threadfence_system();     // the stores have landed before this kernel counts as complete (the barrier follows in stream order)
 }
 
 // window [n_local][rec] -> u, x (d x ld, dimension-major), logl; a record without this shuffle's tag raises the error word
 __global__ void __launch_bounds__(256) k_unpack_rows(const double* win, int d, int64_t n_local, double tag, double* __restrict__ u,
-                                                     double* __restrict__ x, double* __restrict__ l, int64_t ld, unsigned int* err) {
+                                                     double* __restrict__ x, double* __restrict__ l, int64_t ld, unsigned int* err,
+                                                     const int64_t* __restrict__ idx_mine, const double* __restrict__ mirror,
+                                                     const double* __restrict__ hu, const double* __restrict__ hx,
+                                                     const double* __restrict__ hl, int64_t cap) {
+  // idx_mine: the selection's entries of THIS rank's slots; a slot whose row this rank holds itself (idx >= 0) is gathered
+  // straight from the history (through the mirror when there is one), the others come out of the window
   extern __shared__ double tile[];                                // [64][rec + 1]
   const int rec = 2 * d + 2, pitch = rec + 1;
   const int64_t i0 = (int64_t)blockIdx.x * 64;
   for (int e = threadIdx.x; e < 64 * rec; e += 256) {
     const int r = e / rec, c = e - r * rec;
-    if (i0 + r < n_local)
-      tile[r * pitch + c] = __hip_atomic_load(win + (size_t)(i0 + r) * rec + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (i0 + r >= n_local) continue;
+    const int64_t s = idx_mine[i0 + r];
+    double v;
+    if (s < 0) v = __hip_atomic_load(win + (size_t)(i0 + r) * rec + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (c == 2 * d + 1) v = tag;
+    else if (mirror) v = mirror[(size_t)s * (rec - 1) + c];
+    else v = c < d ? hu[(size_t)c * cap + s] : (c < 2 * d ? hx[(size_t)(c - d) * cap + s] : hl[s]);
+    tile[r * pitch + c] = v;
   }
   __syncthreads();
   for (int e = threadIdx.x; e < 64 * rec; e += 256) {            // consecutive lanes: consecutive particles of one column
@@ -392,9 +408,11 @@ extern "C" int tph_resample_put_global(tph_ctx* ctx, const int64_t* idx_dev, int
   put_args w{};
   for (int r = 0; r < ctx->world; ++r) w.win[r] = p->win[r];
   const double* mirror = tph_rows_sync(ctx);
-  hipLaunchKernelGGL(k_put_rows, dim3((unsigned)((n_slots + 63) / 64)), dim3(256), 0, ctx->stream, w, ctx->u, ctx->x, ctx->logl, ctx->cap,
-                     mirror, d, idx_dev, n_slots, n_local, tag);
-  TPH_LAUNCH_CHECK();
+  if (ctx->world > 1) {                                 // rows for OTHER ranks' slots go into their windows
+    hipLaunchKernelGGL(k_put_rows, dim3((unsigned)((n_slots + 63) / 64)), dim3(256), 0, ctx->stream, w, ctx->u, ctx->x, ctx->logl,
+                       ctx->cap, mirror, d, idx_dev, n_slots, n_local, tag, ctx->rank);
+    TPH_LAUNCH_CHECK();
+  }
   // barrier: a rank raises its flag only after its put kernel has completed (stream order), i.e. after its stores have landed
   double* token = (double*)ctx->comm_buf;
   TPH_HIP(hipMemsetAsync(token, 0, sizeof(double), ctx->stream));
@@ -402,7 +420,8 @@ extern "C" int tph_resample_put_global(tph_ctx* ctx, const int64_t* idx_dev, int
   const size_t lds = sizeof(double) * 64 * (size_t)(rec + 1);
   if (lds > 64 * 1024) TPH_HIP(hipFuncSetAttribute((const void*)k_unpack_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((n_local + 63) / 64)), dim3(256), lds, ctx->stream, (const double*)p->win_local, d, n_local,
-                     tag, u_out, x_out, logl_out, ld_out, p->a.err);
+                     tag, u_out, x_out, logl_out, ld_out, p->a.err, idx_dev + (int64_t)ctx->rank * n_local, mirror, ctx->u, ctx->x, ctx->logl,
+                     ctx->cap);
   TPH_LAUNCH_CHECK();
   return 0;
 }
