@@ -28,6 +28,37 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(d["logz"] - d["analytic_logz"]) < 0.5
 
 
+def test_committed_profiles_are_self_consistent():
+    """The evidence under profiles/ that the docs quote: rates follow from bytes and durations, counter traffic is the corrected
+    FETCH + WRITE, the roofline kernel's counters match its algorithmic bytes, the A/B set carries its medians."""
+    t = json.load(open(os.path.join(ROOT, "profiles", "r02_roofline_table.json")))
+    assert t["peak_GBs"] == 8000.0 and len(t["kernels"]) >= 18
+    names = " ".join(k["kernel"] for k in t["kernels"])
+    for needed in ("k_logmix_append", "k_reweight_reduce<1, 8>", "k_weights", "k_gather_rows", "k_rows_pack", "k_propose_reg", "k_accept",
+                   "k_wmom_small", "k_cv_sum_small", "k_membw<0>", "k_membw<1>"):
+        assert needed in names, needed
+    for k in t["kernels"]:
+        if k["algorithmic_bytes_per_launch"]:
+            rate = k["algorithmic_bytes_per_launch"] / k["mean_duration_us"] / 1e3
+            assert abs(rate - k["achieved_GBs_algorithmic"]) <= 0.01 * rate + 0.1, k["kernel"]
+            assert abs(k["frac_of_8TBs"] - k["achieved_GBs_algorithmic"] / 8000.0) < 1e-3
+        assert abs(k["counter_bytes_per_launch"] - (k["FETCH_SIZE_bytes_x2"] + k["WRITE_SIZE_bytes"])) < 1.0
+    k2 = next(k for k in t["kernels"] if k["kernel"].startswith("void k_reweight_reduce<1, 8>"))
+    assert 0.99 < k2["traffic_over_algorithmic"] < 1.02
+    rw = json.load(open(os.path.join(ROOT, "profiles", "r02_reweight_pmc.json")))
+    assert rw["n_rows"] == 67108864 and 0.999 < rw["traffic_over_algorithmic"] < 1.01
+    assert abs(rw["hbm_bytes_per_launch"] - (rw["hbm_read_bytes_per_launch"] + rw["hbm_write_bytes_per_launch"])) < 1.0
+    ab = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_131k_ab.json")))
+    plain = sorted(r["ms_per_step"] for r in ab["runs"] if r["run"].startswith("plain"))
+    comm = sorted(r["ms_per_step"] for r in ab["runs"] if r["run"].startswith("comm"))
+    assert len(plain) == 3 and len(comm) == 3 and abs(ab["median_ms_per_step"]["plain"] - plain[1]) < 1e-9
+    assert len({r["logz"] for r in ab["runs"]}) == 1                     # the sharded code path changes no bit of the evidence
+    assert ab["median_ms_per_step"]["ratio"] < 1.2
+    p = json.load(open(os.path.join(ROOT, "profiles", "r02_propose_pmc.json")))
+    for scen in ("tight", "mid", "wide"):
+        assert p["round2"]["pmc"][scen]["SQ_INSTS_VALU"] < 0.85 * p["round1"]["pmc"][scen]["SQ_INSTS_VALU"]
+
+
 def test_bench_cli_defaults():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0
