@@ -2,6 +2,7 @@
 // Reference: tempest/steps/mutate.py:76-200 (Mutator.run), tempest/mcmc.py:104-208 (runner loop,
 // adaptive step count), :211-288 (tpCN), :291-323 (RWM), :326-411 (boundary conditions).
 #include "common.h"
+#include <stdlib.h>
 #include "tri.h"
 #include "p2p.h"
 
@@ -699,8 +700,8 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(double* __restrict__ u,
       // registers instead of ceil(D/2) interleaved copies
       tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
       if constexpr (WPE <= 2) {
-        // few waves per SIMD (shards of <= 128 K particles): the kernel is bound by the LATENCY of one particle's chain, not
-        // by issue slots, and registers are plentiful -- the pairs as independent, interleaved chains
+        // the pairs as independent, interleaved chains: the kernel is bound by the LATENCY of one particle's dependent chain
+        // as much as by issue slots (see launch_propose_reg for where this form is used)
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
           double z0, z1;
@@ -885,8 +886,12 @@ static void launch_propose_reg(tph_ctx* ctx, double* u, const int32_t* assign, i
 #define TPH_REG_LAUNCH(ONE, BC)                                                                                         \
   hipLaunchKernelGGL((k_propose_reg<KERNEL, D, ONE, WPE, BC>), dim3((unsigned)waves), dim3(64), 0, ctx->stream, u, assign, n, ld, \
                      means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, tiles, pend)
-  if (assign == nullptr && !bc && waves <= 2 * (int64_t)ctx->n_simd && ctx->redraw_lanes == 0) {
-    // at most two waves per SIMD: the latency-bound instantiation (independent Box-Muller chains, up to 256 VGPRs)
+  // The instantiation with the Box-Muller pairs as independent, interleaved chains (template argument 2): wherever it stays
+  // within 128 VGPRs -- RWM at every n_dim, tpCN up to n_dim = 11 -- it keeps four waves per SIMD AND fills their issue slots
+  // (1 048 576 x 10-D: 82.8 -> 71.3 us with every first attempt in bounds, 197 -> 157 us with half of them out); above that
+  // (tpCN, n_dim 12..16: 129-168 VGPRs) only where occupancy does not matter, i.e. at most two waves per SIMD.
+  constexpr bool ilp_fits = KERNEL == TPH_KERNEL_RWM || D <= 11;
+  if (assign == nullptr && !bc && ctx->redraw_lanes == 0 && (ilp_fits || waves <= 2 * (int64_t)ctx->n_simd)) {
     hipLaunchKernelGGL((k_propose_reg<KERNEL, D, true, 2, false>), dim3((unsigned)waves), dim3(64), 0, ctx->stream, u, assign, n, ld,
                        means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, tiles, pend);
   } else if (assign == nullptr) { if (bc) TPH_REG_LAUNCH(true, true); else TPH_REG_LAUNCH(true, false); }
