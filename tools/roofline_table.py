@@ -47,7 +47,7 @@ ALGO = {
     "k_gather_rows": ("K7 gather of the resampled rows (from the row-major mirror)", 2.0 * (2 * D + 1) * 8.0 * N, "2 (2d+1) 8 B per output row", "indexed"),
     "k_rows_pack": ("K7 mirror fill: the iteration's new rows, dimension-major -> records", 2.0 * (2 * D + 1) * 8.0 * N, "2 (2d+1) 8 B per new row", "stream"),
     "k_gather(": ("K7 gather of the resampled rows (dimension-major history, no mirror)", 2.0 * (2 * D + 1) * 8.0 * N, "2 (2d+1) 8 B per output row", "indexed"),
-    "void k_propose_reg<0, 10, true, 4, false>": ("K9 proposal (tpCN, d = 10)", (16.0 * D + 20.0) * N, "16d + 20 B per particle (VALU-bound)", "stream"),
+    "void k_propose_reg<0, 10, true": ("K9 proposal (tpCN, d = 10)", (16.0 * D + 20.0) * N, "16d + 20 B per particle (VALU-bound)", "stream"),
     "void k_accept<0>": ("K10 Metropolis decision (deferred update)", 49.0 * N, "32 B read + 16 B written + 1 B mask per particle", "stream"),
     "k_adapt": ("K10 sigma adaptation + column sums of the block partials", 16.0 * (N // 256), "16 B per 256 particles", "stream"),
     "void k_wsum<int>": ("K11 first moments of the up-sampled set", (8.0 * D + 4.0) * NH, "8d + 4 B per row (compacted set: fewer rows)", "stream"),
