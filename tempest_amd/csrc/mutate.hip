@@ -492,11 +492,19 @@ __global__ void __launch_bounds__(64 * WV) k_propose_blk(double* __restrict__ u,
   // ---- the normals of attempt 0, pairs dealt to the waves
   {
     tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + ii));
-    for (int p = wid; p < npairs; p += WV) {
-      double z0, z1;
+    // two pairs per trip, as independent straight-line chains (the second one clamped, stored only when it exists): the
+    // Box-Muller chain is latency-bound at this kernel's occupancy, like the d <= 16 kernel's
+    for (int p = wid; p < npairs; p += 2 * WV) {
+      const int p2 = p + WV < npairs ? p + WV : p;
+      double z0, z1, y0, y1;
       gz.normal2((uint32_t)p, z0, z1);
+      gz.normal2((uint32_t)p2, y0, y1);
       zs[(size_t)(2 * p) * 64 + lane] = z0;
       if (2 * p + 1 < d) zs[(size_t)(2 * p + 1) * 64 + lane] = z1;
+      if (p2 != p) {
+        zs[(size_t)(2 * p2) * 64 + lane] = y0;
+        if (2 * p2 + 1 < d) zs[(size_t)(2 * p2 + 1) * 64 + lane] = y1;
+      }
     }
   }
   __syncthreads();
