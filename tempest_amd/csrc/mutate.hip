@@ -617,7 +617,10 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
     if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, winv, d, Wb);
     ctx->blk_epoch = ctx->modes_epoch; ctx->blk_src = (const void*)chol;
   }
-  const int wv = d <= 64 ? 4 : 8;
+  // waves per 64-particle tile: one 8-row chunk per wave up to 128 rows (the chunks of a triangular matrix are unequal: with
+  // fewer waves the longest chain of chunks bounds the tile; measured 65 536 x 50-D: 4 -> 8 waves 76 -> 70 us (tpCN), 53 -> 46 us
+  // (RWM); 262 144 x 100-D: 8 -> 16 waves 720 -> 644 us, 467 -> 393 us; at d = 32 four waves have a chunk each and win)
+  const int wv = d <= 32 ? 4 : d <= 64 ? 8 : 16;
   const size_t lds = sizeof(double) * ((size_t)2 * d * 64 + (size_t)(wv + 1) * 64);
   const dim3 grid((unsigned)((n + 63) / 64));
 #define TPH_BLK_LAUNCH(WV)                                                                                              \
@@ -627,7 +630,7 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
     hipLaunchKernelGGL((k_propose_blk<KERNEL, WV>), grid, dim3(64 * WV), lds, ctx->stream, u, n, ld, d, means, Lb, Wb, dof,   \
                        sigmas, bc, seed, tick, item0, up, mu_, mup, pend, todo);                                        \
   } while (0)
-  if (wv == 4) TPH_BLK_LAUNCH(4); else TPH_BLK_LAUNCH(8);
+  if (wv == 4) TPH_BLK_LAUNCH(4); else if (wv == 8) TPH_BLK_LAUNCH(8); else TPH_BLK_LAUNCH(16);
 #undef TPH_BLK_LAUNCH
   TPH_LAUNCH_CHECK();
   // straggler pass: the flagged particles continue with attempt 1, 2, ... in the multi-lane kernel (un-staged: few blocks

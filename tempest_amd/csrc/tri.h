@@ -29,7 +29,7 @@ static __global__ void __launch_bounds__(256) k_tri_block(const double* __restri
   }
 }
 
-// chunks c = c0, c0 + cstep, ... of  y = T x ; f(r, y_r) is called for every row r < d of those chunks.
+// the chunks of  y = T x  that fall to wave c0 of cstep; f(r, y_r) is called for every row r < d of those chunks.
 // Four columns per trip: their 4 x 64 B of matrix come as back-to-back scalar loads behind ONE wait (a scalar load that
 // is waited for alone costs its full ~200-cycle latency per 8 FMAs), then 32 FMAs.
 template <class F>
@@ -37,7 +37,13 @@ __device__ __forceinline__ void tri_apply(const double* __restrict__ Tb, int d, 
                                           int cstep, F&& f) {
   const int nch = (d + TRI_RB - 1) / TRI_RB;
   constexpr int JU = 4;
-  for (int c = c0; c < nch; c += cstep) {
+  // chunk c costs ~(c + 1) columns: the chunks are dealt from the LAST one down, boustrophedon over the waves (wave c0 of
+  // cstep takes positions c0, 2 cstep - 1 - c0, 2 cstep + c0, ... of the descending order), so the waves of a workgroup finish
+  // together (d = 50 on 4 waves: 7 + 7 + 7 + 7 columns-of-8 instead of 6 + 8 + 10 + 4)
+  for (int k = 0;; ++k) {
+    const int pos = k * cstep + ((k & 1) ? cstep - 1 - c0 : c0);
+    if (pos >= nch) break;
+    const int c = nch - 1 - pos;
     const double* __restrict__ Tc = Tb + (size_t)c * d * TRI_RB;
     const int jmax = (c + 1) * TRI_RB < d ? (c + 1) * TRI_RB : d;
     double acc[TRI_RB];
