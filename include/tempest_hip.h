@@ -252,6 +252,10 @@ int tph_prior_draw(tph_ctx* ctx, double* u_dev, int64_t n, int64_t ld, uint64_t 
 /* rows with +-inf logl replaced by uniformly chosen finite rows; stats_dev = (n_finite, n) (mutate.py:122-148) */
 int tph_inf_repair(tph_ctx* ctx, double* u_dev, double* x_dev, double* logl_dev, int64_t n, int64_t ld,
                    uint64_t seed, uint32_t tick, int64_t item0, double* stats_dev /*[2]*/);
+/* the same, and src_dev[i] = the row that now sits in row i (i itself for untouched rows): what the caller needs to move
+ * per-particle data the library does not hold -- the likelihood's blobs, mutate.py:135-136 */
+int tph_inf_repair_src(tph_ctx* ctx, double* u_dev, double* x_dev, double* logl_dev, int64_t n, int64_t ld,
+                       uint64_t seed, uint32_t tick, int64_t item0, double* stats_dev /*[2]*/, int64_t* src_dev /*[n] or NULL*/);
 /* Step control (optional, ctl_dev may be NULL): tph_adapt's state_dev block, extended to TPH_STEP_STATE_LEN doubles,
  * passed to tph_propose / tph_accept makes one MCMC step replayable as a captured hipGraph with no per-step kernel
  * arguments: the RNG tick used is  tick + state[7] + 2 * state[0]  (state[0] = steps completed, advanced by tph_adapt;

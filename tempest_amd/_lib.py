@@ -50,6 +50,7 @@ SIGNATURES = {
     "tph_multinomial_counts": (c_int, [ptr, ptr, c_i64, ptr, c_int, c_i64, c_u64, c_u32, c_u32, ptr]),
     "tph_prior_draw": (c_int, [ptr, ptr, c_i64, c_i64, c_u64, c_u32, c_i64]),
     "tph_inf_repair": (c_int, [ptr, ptr, ptr, ptr, c_i64, c_i64, c_u64, c_u32, c_i64, ptr]),
+    "tph_inf_repair_src": (c_int, [ptr, ptr, ptr, ptr, c_i64, c_i64, c_u64, c_u32, c_i64, ptr, ptr]),
     "tph_propose": (c_int, [ptr, c_int, ptr, ptr, c_i64, c_i64, c_int, ptr, ptr, ptr, ptr, ptr, ptr,
                             c_u64, c_u32, c_i64, ptr, ptr, ptr, ptr, ptr]),
     "tph_accept": (c_int, [ptr, c_int, c_dbl, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i64, c_i64,

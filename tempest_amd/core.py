@@ -95,8 +95,9 @@ class CallbackAdapter:
             [self.cfg.prior_transform(r) for r in uh])
         return torch.from_numpy(np.ascontiguousarray(np.asarray(xh, dtype=np.float64).T)).to(self.device)
 
-    def loglike(self, x_soa):
-        """(d, n) SoA parameter tensor -> (n,) log-likelihood tensor (FP64, on the device)."""
+    def loglike(self, x_soa, return_blobs=False):
+        """(d, n) SoA parameter tensor -> (n,) log-likelihood tensor (FP64, on the device); with `return_blobs` the pair
+        (tensor, blobs): the likelihood's auxiliary outputs as a host array (None without them), core.py:317-358."""
         import torch
         if self.backend is None:
             self._probe()
@@ -105,12 +106,12 @@ class CallbackAdapter:
             ll = cfg.log_likelihood(x_soa.T)
             if ll.dtype != torch.float64:
                 ll = ll.to(torch.float64)
-            return ll.reshape(-1).contiguous()
+            ll = ll.reshape(-1).contiguous()
+            return (ll, None) if return_blobs else ll
         xh = np.ascontiguousarray(x_soa.cpu().numpy().T)
         ll, blobs = self.loglike_host(xh)
-        if blobs is not None:
-            raise NotImplementedError("likelihood blobs are not supported on the GPU path")
-        return torch.from_numpy(np.ascontiguousarray(ll, dtype=np.float64).reshape(-1)).to(self.device)
+        ll = torch.from_numpy(np.ascontiguousarray(ll, dtype=np.float64).reshape(-1)).to(self.device)
+        return (ll, blobs) if return_blobs else ll
 
     def loglike_host(self, x):
         """The reference's SamplerCore._log_like on host arrays (core.py:317-358)."""

@@ -42,10 +42,12 @@ __global__ void __launch_bounds__(256) k_finite_list(const double* __restrict__ 
 __global__ void __launch_bounds__(256) k_inf_repair(double* __restrict__ u, double* __restrict__ x, double* __restrict__ logl,
                                                     int64_t n, int64_t ld, int d, const double* __restrict__ flag,
                                                     const double* __restrict__ rank, const int64_t* __restrict__ list,
-                                                    uint64_t seed, uint32_t tick, int64_t item0, double* __restrict__ stats) {
+                                                    uint64_t seed, uint32_t tick, int64_t item0, double* __restrict__ stats,
+                                                    int64_t* __restrict__ src) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t n_fin = (int64_t)rank[n - 1];
   if (i == 0) { stats[0] = (double)n_fin; stats[1] = (double)n; }
+  if (i < n && src) src[i] = i;
   if (i >= n || flag[i] != 0.0 || n_fin == 0) return;
   tph_rng g(seed, tick, TPH_TAG_REPAIR, (uint64_t)(item0 + i));
   double U, U1;
@@ -58,10 +60,11 @@ __global__ void __launch_bounds__(256) k_inf_repair(double* __restrict__ u, doub
     x[(size_t)j * ld + i] = x[(size_t)j * ld + s];
   }
   logl[i] = logl[s];
+  if (src) src[i] = s;
 }
 
-extern "C" int tph_inf_repair(tph_ctx* ctx, double* u_dev, double* x_dev, double* logl_dev, int64_t n, int64_t ld,
-                              uint64_t seed, uint32_t tick, int64_t item0, double* stats_dev) {
+extern "C" int tph_inf_repair_src(tph_ctx* ctx, double* u_dev, double* x_dev, double* logl_dev, int64_t n, int64_t ld,
+                                  uint64_t seed, uint32_t tick, int64_t item0, double* stats_dev, int64_t* src_dev) {
   TPH_REQUIRE(ctx && u_dev && x_dev && logl_dev && stats_dev && n > 0 && ld >= n, "tph_inf_repair: bad argument");
   // layout inside the big scratch: [tile sums (used by tph_cdf)] ... we take our arrays after a 1 MiB offset
   size_t tiles_bytes = sizeof(double) * (size_t)((n + 2047) / 2048 + 1);
@@ -77,9 +80,13 @@ extern "C" int tph_inf_repair(tph_ctx* ctx, double* u_dev, double* x_dev, double
   if (rc) return rc;
   hipLaunchKernelGGL(k_finite_list, dim3(grid), dim3(256), 0, ctx->stream, flag, rank, n, list);
   hipLaunchKernelGGL(k_inf_repair, dim3(grid), dim3(256), 0, ctx->stream, u_dev, x_dev, logl_dev, n, ld, ctx->d, flag, rank,
-                     list, seed, tick, item0, stats_dev);
+                     list, seed, tick, item0, stats_dev, src_dev);
   TPH_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int tph_inf_repair(tph_ctx* ctx, double* u_dev, double* x_dev, double* logl_dev, int64_t n, int64_t ld,
+                              uint64_t seed, uint32_t tick, int64_t item0, double* stats_dev) {
+  return tph_inf_repair_src(ctx, u_dev, x_dev, logl_dev, n, ld, seed, tick, item0, stats_dev, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------- proposals

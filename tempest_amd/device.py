@@ -346,11 +346,17 @@ class HipContext:
         check(self.lib.tph_prior_draw(self._ctx, _ptr(u, torch.float64), u.shape[1], u.shape[1], seed, tick, item0),
               "tph_prior_draw")
 
-    def inf_repair(self, u, x, logl, seed, tick, item0=0):
+    def inf_repair(self, u, x, logl, seed, tick, item0=0, return_src=False):
+        """(n_finite, n) on the device; with `return_src` also src (int64, n): the row that now sits in each row."""
         stats = self.empty(2)
-        check(self.lib.tph_inf_repair(self._ctx, _ptr(u), _ptr(x), _ptr(logl), logl.numel(), u.shape[1], seed, tick,
-                                      item0, _ptr(stats)), "tph_inf_repair")
-        return stats
+        if not return_src:
+            check(self.lib.tph_inf_repair(self._ctx, _ptr(u), _ptr(x), _ptr(logl), logl.numel(), u.shape[1], seed, tick,
+                                          item0, _ptr(stats)), "tph_inf_repair")
+            return stats
+        src = torch.empty(logl.numel(), dtype=torch.int64, device=self.device)
+        check(self.lib.tph_inf_repair_src(self._ctx, _ptr(u), _ptr(x), _ptr(logl), logl.numel(), u.shape[1], seed, tick,
+                                          item0, _ptr(stats), _ptr(src, torch.int64)), "tph_inf_repair_src")
+        return stats, src
 
     def propose(self, kernel, u, assign, modes, sigmas, bc, seed, tick, item0, uprime, maha_u, maha_up, ctl=None,
                 pending=None):

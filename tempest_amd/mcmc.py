@@ -303,10 +303,16 @@ class DeviceMCMC:
         self.bc = torch.from_numpy(flags).to(ctx.device) if flags.any() else None
         self.sigma_0 = 2.38 / np.sqrt(d)
 
-    def run(self, u, x, logl, assignments):
+    def run(self, u, x, logl, assignments, blobs=None):
         """u, x: (d, n) device tensors (updated in place); logl (n,); assignments int32 (n,) or None.
+        `blobs` (host array, one entry per particle): the likelihood's auxiliary outputs; those of accepted moves replace
+        the current ones (mcmc.py:176-177) -- the log-likelihood callback is then called with return_blobs=True and must
+        return (tensor, blobs); the evolved array is left in `self.blobs`.
         Returns (efficiency, acceptance, iterations, n_calls) like mcmc.py:196-208."""
         import torch
+        self.blobs = None if blobs is None else np.array(blobs, copy=True)
+        if blobs is not None and (self.engines is not None or self.plugin is not None):
+            raise ValueError("blobs follow the step-by-step path (host callbacks): engines and plugin must be None")
         ctx, modes, d = self.ctx, self.modes, self.ctx.n_dim
         n = u.shape[1]
         n_global = n if self.n_global is None else self.n_global
@@ -347,9 +353,17 @@ class DeviceMCMC:
                                    partials=partials)
             else:
                 xp = self.prior(up)                   # (d, n) SoA tensor
-                lp = self.loglike(xp)                 # (n,) tensor
+                if self.blobs is None:
+                    lp = self.loglike(xp)             # (n,) tensor
+                else:
+                    lp, bp = self.loglike(xp, return_blobs=True)
                 ctx.accept(self.kernel, self.beta, u, x, logl, up, xp, lp, maha_u, maha_up, assign, K, modes.dof_dev,
                            self.rng.seed, self.rng.next(), self.item0, sums if active else None, partials=partials)
+                if self.blobs is not None:
+                    # an accepted row now holds its proposal, bit for bit (a proposal equal to the current point -- the
+                    # redraw cap -- has the current point's blob anyway)
+                    moved = (u == up).all(dim=0).cpu().numpy()
+                    self.blobs[moved] = np.asarray(bp)[moved]
             if active:
                 self.comm.all_reduce_sum(sums)
             # one GPU: tph_adapt sums the Metropolis kernel's block partials itself (one launch less per step)
@@ -434,10 +448,11 @@ def parallel_mcmc(u, x, logl, blobs, assignments, beta, mode_stats, log_likeliho
         xh = np.array([prior_transform(row) for row in uh])
         return torch.from_numpy(np.ascontiguousarray(xh.T)).to(dev)
 
-    def like_dev(xp):
+    def like_dev(xp, return_blobs=False):
         xh = np.ascontiguousarray(xp.cpu().numpy().T)
-        ll, _ = log_likelihood(xh)
-        return torch.from_numpy(np.ascontiguousarray(ll, dtype=np.float64)).to(dev)
+        ll, bl = log_likelihood(xh)
+        ll = torch.from_numpy(np.ascontiguousarray(ll, dtype=np.float64)).to(dev)
+        return (ll, bl) if return_blobs else ll
 
     to_soa = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64).T)).to(dev)  # noqa: E731
     ut, xt = to_soa(u), to_soa(x)
@@ -447,6 +462,6 @@ def parallel_mcmc(u, x, logl, blobs, assignments, beta, mode_stats, log_likeliho
         raise ValueError("mode_stats lives on another device")
     run = DeviceMCMC(ctx, "rwm" if sample == "rwm" else "tpcn", beta, mode_stats, like_dev, prior_dev, n_steps, n_max,
                      periodic, reflective, progress_bar=progress_bar, verbose=verbose)
-    eff, acc, it, calls = run.run(ut, xt, lt, at)
+    eff, acc, it, calls = run.run(ut, xt, lt, at, blobs=blobs)
     back = lambda t: np.ascontiguousarray(t.cpu().numpy().T)  # noqa: E731
-    return back(ut), back(xt), lt.cpu().numpy(), blobs, eff, acc, it, calls
+    return back(ut), back(xt), lt.cpu().numpy(), run.blobs, eff, acc, it, calls

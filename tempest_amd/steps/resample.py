@@ -39,14 +39,15 @@ class Resampler:
         if beta == 0.0:       # warm-up: the mutator draws fresh prior samples (resample.py:69-72)
             st.set_current("assignments", torch.zeros(n, dtype=torch.int32, device=st.device), copy=False)
             return
-        if self.have_blobs:
-            raise NotImplementedError("blobs are not carried on the GPU path (vectorize=True forbids them)")
         ctx = st.ctx
         ctx.use_current_stream()
         rng = self._rng()
         w = _as_device_weights(weights, ctx)
         comm = st.comm
         if comm is not None and comm.active:
+            if self.have_blobs:
+                raise NotImplementedError("likelihood blobs live on the host of the rank that computed them and are not "
+                                          "moved by the sharded resampling: run blobs on one GPU")
             from ..sharding import resample_sharded
             u, x, logl = resample_sharded(st, w, self.resample, rng, n)
         else:
@@ -64,6 +65,8 @@ class Resampler:
             d = st.n_dim
             u, x, logl = ctx.empty(d, n), ctx.empty(d, n), ctx.empty(n)
             ctx.gather(idx, u, x, logl)
+            if self.have_blobs:      # host data: the same history rows (resample.py:77,98-99)
+                st.set_current("blobs", st.get_history("blobs", flat=True)[idx.cpu().numpy()])
         if self.clustering and self.clusterer is not None:
             assign = self.clusterer.predict_device(u.contiguous(), st.ctx)
         else:

@@ -225,3 +225,109 @@ def test_reference_written_state_file_loads_and_resumes(tmp_path, fname):
     back = dill.load(open(out, "rb"))
     assert {"_current", "_history", "n_dim"} <= set(back) and back["n_dim"] == d
     assert len(back["_history"]["u"]) == s.state.get_history_length() and back["_history"]["u"][0].shape == (n, d)
+
+
+# ----------------------------------------------------------------------------------------------- likelihood blobs
+def _blob_of(x):
+    """What the test likelihood attaches to a point: a deterministic function of x, so `blobs == f(x)` row by row says that
+    every blob travelled with its particle (inf repair, accepted moves, resampling, history, posterior)."""
+    x = np.atleast_2d(x)
+    return 2.0 * x[:, 0] + 1.0, np.sum(x ** 2, axis=1)
+
+
+def _ll_with_blobs(x):
+    a, b = _blob_of(x)
+    ll = -0.5 * float(np.sum((x - 1.0) ** 2))
+    if x[0] < -8.0:                     # a tenth of the prior mass has no finite likelihood: exercises the beta = 0 repair
+        ll = -np.inf
+    return ll, float(a[0]), float(b[0])
+
+
+def test_blobs_follow_their_particles_through_a_run():
+    """blobs_dtype (reference tests/test_sample_method.py:267-285, mcmc.py:176-177, steps/mutate.py:135-136,
+    steps/resample.py:77-99, core.py:205-230): the likelihood's auxiliary outputs are carried with the particles."""
+    import tempest_amd as tp
+    s = tp.Sampler(prior20, _ll_with_blobs, 2, n_particles=64, clustering=False, random_state=0,
+                   blobs_dtype=[("a", float), ("b", float)])
+    s.run(n_total=256, progress=False)
+    state = s.sample()
+    blobs = state["blobs"]
+    assert blobs is not None and len(blobs) == s.n_particles and blobs.dtype.names == ("a", "b")
+    a, b = _blob_of(state["x"])
+    np.testing.assert_array_equal(blobs["a"], a)
+    np.testing.assert_array_equal(blobs["b"], b)
+    assert np.all(np.isfinite(state["logl"]))
+    # the whole history, and every form of posterior()
+    xh, bh = s.state.get_history("x", flat=True), s.state.get_history("blobs", flat=True)
+    np.testing.assert_array_equal(bh["a"], _blob_of(xh)[0])
+    for kw in ({}, {"resample": True}, {"trim_importance_weights": False}, {"resample": True, "trim_importance_weights": False}):
+        x, w, logl, bl = s.posterior(return_blobs=True, **kw)
+        assert len(bl) == len(x) == len(w)
+        np.testing.assert_array_equal(bl["a"], _blob_of(x)[0])
+        np.testing.assert_array_equal(bl["b"], _blob_of(x)[1])
+    assert abs(s.evidence()[0] - (np.log(2 * np.pi) - 2 * np.log(20))) < 0.7
+    # without blobs_dtype the extra outputs are ignored (mcmc.py:84-90) and the state has no blobs
+    s2 = tp.Sampler(prior20, _ll_with_blobs, 2, n_particles=32, clustering=False, random_state=0)
+    s2.run(n_total=64, progress=False)
+    assert s2.sample()["blobs"] is None
+
+
+def test_blobs_at_step_level_and_through_parallel_mcmc():
+    """reference tests/test_steps.py:513-541 (Resampler with have_blobs), :726-760 (Mutator warm-up with blobs) and the
+    blobs argument of parallel_mcmc (mcmc.py:414-508)."""
+    from tempest_amd.mcmc import parallel_mcmc
+    from tempest_amd.modes import ModeStatistics
+    from tempest_amd.state_manager import StateManager
+    from tempest_amd.steps import Mutator, Resampler
+    rs = np.random.RandomState(5)
+    d, n_hist, n_active = 3, 200, 50
+    st = StateManager(d)
+    u = rs.rand(n_hist, d)
+    x = 20 * u - 10
+    blobs = np.stack([x[:, 0] * 3.0, x[:, 1] - x[:, 2], np.arange(n_hist, dtype=float)], axis=1)      # 3 auxiliary features
+    st.update_current({"u": u, "x": x, "logl": -0.5 * np.sum(x ** 2, axis=1), "blobs": blobs, "beta": 0.5, "logz": 0.0,
+                       "iter": 0})
+    st.commit_current_to_history()
+    w = rs.rand(n_hist)
+    w /= w.sum()
+    for scheme in ("mult", "syst"):
+        Resampler(st, n_active, resample=scheme, clustering=False, have_blobs=True).run(w)
+        got, xr = st.get_current("blobs"), st.get_current("x")
+        assert got.shape == (n_active, 3)
+        rows = got[:, 2].astype(int)                                   # the history row each blob came from
+        np.testing.assert_array_equal(xr, x[rows])
+        np.testing.assert_array_equal(got, blobs[rows])
+
+    def prior(uu):
+        return 20 * uu - 10
+
+    def like(xx):                                                      # reference convention: (logl, blobs) for a batch
+        xx = np.atleast_2d(xx)
+        ll = -0.5 * np.sum(xx ** 2, axis=1)
+        ll[xx[:, 0] > 7.0] = np.inf                                    # +inf rows are repaired as well (mutate.py:122)
+        return ll, np.stack([xx[:, 0] * 3.0, xx[:, 1] - xx[:, 2]], axis=1)
+    st2 = StateManager(d)
+    st2.update_current({"iter": 0, "beta": 0.0, "logz": 0.0, "calls": 0})
+    Mutator(st2, prior, like, n_particles=n_active, n_dim=d, have_blobs=True).run(None)
+    xb, bb = st2.get_current("x"), st2.get_current("blobs")
+    assert bb.shape == (n_active, 2) and np.all(np.isfinite(st2.get_current("logl")))
+    np.testing.assert_array_equal(bb[:, 0], xb[:, 0] * 3.0)
+    np.testing.assert_array_equal(bb[:, 1], xb[:, 1] - xb[:, 2])
+    assert st2.get_current("logz") < 0.0                              # some prior draws had no finite likelihood
+
+    n = 64
+    u0 = rs.rand(n, d)
+    x0 = prior(u0)
+    l0, b0 = like(x0)
+    l0 = np.where(np.isfinite(l0), l0, -50.0)
+    modes = ModeStatistics.from_global(u0, np.full(n, 1.0 / n), seed=3)
+
+    def like_mcmc(xx):                                                 # proposals into the excluded region are rejected
+        ll, bl = like(xx)
+        return np.where(np.isfinite(ll), ll, -np.inf), bl
+    out = parallel_mcmc(u0, x0, l0, b0, np.zeros(n, dtype=int), 0.3, modes, like_mcmc, prior, n_steps=2, n_max=40,
+                        sample="rwm", verbose=False)
+    un, xn, ln, bn = out[:4]
+    assert bn.shape == b0.shape and np.any(xn != x0)                   # something moved
+    np.testing.assert_array_equal(bn[:, 0], xn[:, 0] * 3.0)
+    np.testing.assert_array_equal(bn[:, 1], xn[:, 1] - xn[:, 2])
