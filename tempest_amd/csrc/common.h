@@ -49,6 +49,7 @@ struct tph_ctx {
   // row-major MIRROR of (u, x, logl) for the indexed consumers (resample gather, one-sided shuffle): a random history row is
   // 2 d + 1 scattered 8-byte reads in the dimension-major arrays (one 64-byte sector each), but ONE contiguous record here.
   // Filled lazily, up to rows_size, by tph_rows_sync (resample.hip); dropped if it cannot be allocated.
+  int mc_sorted = 1;                // TPH_OPT_SORTED_DRAWS
   int cov_kernel = 0;               // TPH_OPT_COV_KERNEL: second moments at n_dim >= 16: 0 auto (= 1) | 1 register blocks | 2 MFMA
   double* rows = nullptr;
   int64_t rows_cap = 0, rows_size = 0;

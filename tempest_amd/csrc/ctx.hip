@@ -120,6 +120,7 @@ extern "C" int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void
   tph_ctx* c = new tph_ctx();
   c->device = device;
   if (const char* env = getenv("TEMPEST_AMD_ROW_MIRROR")) c->rows_mode = atoi(env) ? 1 : 0;     // debugging aid (TPH_OPT_ROW_MIRROR)
+  if (const char* env = getenv("TEMPEST_AMD_SORTED_DRAWS")) c->mc_sorted = atoi(env) ? 1 : 0;  // debugging aid (TPH_OPT_SORTED_DRAWS)
   c->d = n_dim;
   c->stream = (hipStream_t)hip_stream;
   {
@@ -221,6 +222,7 @@ extern "C" int tph_set_option(tph_ctx* ctx, int option, int value) {
     case TPH_OPT_ML_UNSTAGED: ctx->ml_unstaged = value; break;
     case TPH_OPT_ROW_MIRROR: ctx->rows_mode = value ? 1 : 0; break;
     case TPH_OPT_COV_KERNEL: ctx->cov_kernel = value; break;
+    case TPH_OPT_SORTED_DRAWS: ctx->mc_sorted = value ? 1 : 0; break;
     case TPH_OPT_BLOCKED: ctx->blocked = value; break;
     case TPH_OPT_MODES_EPOCH: ctx->modes_epoch = value; break;
     default: TPH_REQUIRE(false, "tph_set_option: unknown option %d", option);

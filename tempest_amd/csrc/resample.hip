@@ -5,6 +5,8 @@
 #include "common.h"
 #include "scan.h"
 #include "cdf_index.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 
 extern "C" int tph_cdf(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev, double* cdf_dev) {
   TPH_REQUIRE(ctx && w_dev && cdf_dev && n > 0, "tph_cdf: bad argument");
@@ -337,19 +339,20 @@ __global__ void __launch_bounds__(256) k_counts_global(tph_cdf_index ix, const d
                                                        int rank, int world, const double* __restrict__ kept_count_dev, int factor,
                                                        int64_t n_draw_max, uint64_t seed, uint32_t tick, uint32_t tag,
                                                        int32_t* __restrict__ counts) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t n_draw = kept_count_dev ? (int64_t)(kept_count_dev[0]) * factor : n_draw_max;
-  if (r >= n_draw || r >= n_draw_max) return;
-  tph_rng g(seed, tick, tag, (uint64_t)r);
-  double U, U1;
-  g.uniform2(0, U, U1);
-  const double p = U * table[2 * T];
-  const int t = owner_block<true>(table, T, rank, world, p);
-  if (t < 0) return;
-  int64_t k = tph_count_below<false>(ix, 1.0, p);
-  const int64_t first = (int64_t)t * rows, last = first + rows - 1;
-  k = k < first ? first : (k > last ? last : k);
-  atomicAdd(&counts[k], 1);
+  if (n_draw > n_draw_max) n_draw = n_draw_max;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_draw; r += (int64_t)gridDim.x * blockDim.x) {   // as above
+    tph_rng g(seed, tick, tag, (uint64_t)r);
+    double U, U1;
+    g.uniform2(0, U, U1);
+    const double p = U * table[2 * T];
+    const int t = owner_block<true>(table, T, rank, world, p);
+    if (t < 0) continue;
+    int64_t k = tph_count_below<false>(ix, 1.0, p);
+    const int64_t first = (int64_t)t * rows, last = first + rows - 1;
+    k = k < first ? first : (k > last ? last : k);
+    atomicAdd(&counts[k], 1);
+  }
 }
 
 extern "C" int tph_multinomial_counts_global(tph_ctx* ctx, const double* cdf_dev, int64_t n, const double* kept_count_dev,
@@ -363,7 +366,9 @@ extern "C" int tph_multinomial_counts_global(tph_ctx* ctx, const double* cdf_dev
   if (tph_scratch_reserve(ctx, sizeof(double) * tph_cdf_index_doubles(n))) return -1;
   tph_cdf_index ix;
   if (tph_cdf_index_build(ctx, cdf_dev, n, (double*)ctx->scratch, &ix)) return -1;
-  hipLaunchKernelGGL(k_counts_global, dim3((unsigned)((n_draw_max + 255) / 256)), dim3(256), 0, ctx->stream, ix, ctx->blk_table,
+  int64_t blocks = (n_draw_max + 255) / 256;
+  if (blocks > 16 * (int64_t)ctx->n_simd) blocks = 16 * (int64_t)ctx->n_simd;
+  hipLaunchKernelGGL(k_counts_global, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ix, ctx->blk_table,
                      ctx->blk_T, ctx->blk_rows, ctx->rank, ctx->world, kept_count_dev, factor, n_draw_max, seed, tick, tag, counts_dev);
   TPH_LAUNCH_CHECK();
   return 0;
@@ -563,16 +568,102 @@ __global__ void __launch_bounds__(256) k_multinomial_counts(tph_cdf_index ix,
                                                             const double* __restrict__ kept_count_dev, int factor,
                                                             int64_t n_draw_max, uint64_t seed, uint32_t tick, uint32_t tag,
                                                             int32_t* __restrict__ counts) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // grid strides: the number of draws is only known on the device, and a grid sized for n_draw_max (4 x the history) whose
+  // blocks find nothing to do is not free -- 10^6 empty workgroups are ~0.25 ms
   int64_t n_draw = kept_count_dev ? (int64_t)(kept_count_dev[0]) * factor : n_draw_max;
-  if (r >= n_draw || r >= n_draw_max) return;
-  tph_rng g(seed, tick, tag, (uint64_t)r);
-  double U, U1;
-  g.uniform2(0, U, U1);
+  if (n_draw > n_draw_max) n_draw = n_draw_max;
   const int64_t n = ix.n[0];
-  int64_t k = tph_count_below<false>(ix, ix.lvl[0][n - 1], U);
-  if (k >= n) k = n - 1;
-  atomicAdd(&counts[k], 1);
+  const double total = ix.lvl[0][n - 1];
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_draw; r += (int64_t)gridDim.x * blockDim.x) {
+    tph_rng g(seed, tick, tag, (uint64_t)r);
+    double U, U1;
+    g.uniform2(0, U, U1);
+    int64_t k = tph_count_below<false>(ix, total, U);
+    if (k >= n) k = n - 1;
+    atomicAdd(&counts[k], 1);
+  }
+}
+
+// Many draws (millions: the x4 up-sampling of a 10^6-particle run): each lookup above is ~4.7 random 64-byte sectors
+// (FETCH_SIZE: 3.0 GB per call at 2.6 x 10^7 rows) and the kernel is bound by exactly that.  The counts do not depend on the
+// ORDER of the draws, so they are generated as their 53-bit integers k (U = k 2^-53, tph_k53), sorted on their top 32 bits and
+// merged against the cdf: a thread walks 16 consecutive sorted draws, the first through the index, the others by a galloping
+// search from the previous row (same predicate on the same values => same row; a draw out of order inside its 2^-32 bucket
+// gallops backwards), equal rows are added once.  The reads of neighbouring threads share lines.
+constexpr int MC_CHUNK = 16;
+constexpr int64_t MC_SORT_MIN = 1 << 20;
+constexpr int MC_SORT_LO = 29;            // the draws are sorted on bits [MC_SORT_LO, 53) of their integers
+__global__ void __launch_bounds__(256) k_mc_draws(int64_t n_draw, uint64_t seed, uint32_t tick, uint32_t tag,
+                                                  uint64_t* __restrict__ keys) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_draw; r += (int64_t)gridDim.x * blockDim.x) {
+    tph_rng g(seed, tick, tag, (uint64_t)r);
+    const tph_u4 q = tph_philox(g.item, 0, g.tick, g.tag, g.k0, g.k1);      // uniform2(0, U, .): U = tph_k53(q.x, q.y) 2^-53
+    keys[r] = ((uint64_t)(q.x >> 5) << 26) | (uint64_t)(q.y >> 6);
+  }
+}
+__global__ void __launch_bounds__(256) k_mc_merge(tph_cdf_index ix, const uint64_t* __restrict__ keys, int64_t n_draw,
+                                                  int32_t* __restrict__ counts) {
+  const int64_t r0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * MC_CHUNK;
+  if (r0 >= n_draw) return;
+  const int64_t n = ix.n[0];
+  const double* __restrict__ a = ix.lvl[0];
+  const double total = a[n - 1];
+  int64_t K = 0, kp = -1;            // K = #{i : a_i / total <= U} of the previous draw; kp = the row being counted
+  int run = 0;
+  auto draw = [&](const uint64_t key, const bool first) {
+    const double U = (double)key * 0x1.0p-53;
+    auto below = [&](int64_t i) { return a[i] / total <= U; };
+    int64_t lo, hi;                                                       // the count lies in [lo, hi]
+    if (first) {
+      lo = hi = tph_count_below<false>(ix, total, U);
+    } else if (K < n && below(K)) {                                       // beyond the previous row: gallop forward
+      lo = K + 1;
+      int64_t step = 1;
+      while (lo + step <= n && below(lo + step - 1)) { lo += step; step *= 2; }
+      hi = lo + step - 1 < n ? lo + step - 1 : n;
+    } else if (K == 0 || below(K - 1)) {                                  // the previous row again
+      lo = hi = K;
+    } else {                                                              // a draw out of order inside its bucket: backwards
+      hi = K - 1;
+      int64_t step = 1;
+      for (;;) {
+        const int64_t p = hi - step;
+        if (p < 0) { lo = 0; break; }
+        if (below(p)) { lo = p + 1; break; }
+        hi = p;
+        step *= 2;
+      }
+    }
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (below(mid)) lo = mid + 1; else hi = mid;
+    }
+    K = lo;
+    const int64_t kc = K >= n ? n - 1 : K;
+    if (kc == kp) {
+      ++run;
+    } else {
+      if (run) atomicAdd(&counts[kp], run);
+      kp = kc;
+      run = 1;
+    }
+  };
+  if (r0 + MC_CHUNK <= n_draw) {
+    // the thread's 128 bytes of keys in 16-byte loads issued together (8-byte loads spread over the loop fetch every sector
+    // eight times: the lines of 64 threads x 128 B do not survive in L1 between them)
+    const ulonglong2* __restrict__ kv = reinterpret_cast<const ulonglong2*>(keys + r0);      // r0 is a multiple of 16
+    ulonglong2 v[MC_CHUNK / 2];
+#pragma unroll
+    for (int j = 0; j < MC_CHUNK / 2; ++j) v[j] = kv[j];
+#pragma unroll
+    for (int j = 0; j < MC_CHUNK / 2; ++j) {
+      draw(v[j].x, j == 0);
+      draw(v[j].y, false);
+    }
+  } else {
+    for (int j = 0; r0 + j < n_draw; ++j) draw(keys[r0 + j], j == 0);
+  }
+  if (run) atomicAdd(&counts[kp], run);
 }
 
 extern "C" int tph_multinomial_counts(tph_ctx* ctx, const double* cdf_dev, int64_t n, const double* kept_count_dev,
@@ -580,11 +671,47 @@ extern "C" int tph_multinomial_counts(tph_ctx* ctx, const double* cdf_dev, int64
                                       int32_t* counts_dev) {
   TPH_REQUIRE(ctx && cdf_dev && counts_dev && n > 0 && n_draw_max > 0, "tph_multinomial_counts: bad argument");
   TPH_HIP(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * (size_t)n, ctx->stream));
+  if (n_draw_max >= MC_SORT_MIN && ctx->mc_sorted) {
+    // the sort is sized on the host: one 8-byte read of the count (the stream has to drain once; ~20 us against ~1 ms)
+    int64_t n_draw = n_draw_max;
+    if (kept_count_dev) {
+      TPH_HIP(hipMemcpyAsync(ctx->pinned, kept_count_dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      TPH_HIP(hipStreamSynchronize(ctx->stream));
+      n_draw = (int64_t)ctx->pinned[0] * factor;
+      if (n_draw > n_draw_max) n_draw = n_draw_max;
+    }
+    if (n_draw <= 0) return 0;
+    if (n_draw >= MC_SORT_MIN) {
+      size_t temp_bytes = 0;
+      uint64_t* nullk = nullptr;
+      TPH_HIP(rocprim::radix_sort_keys(nullptr, temp_bytes, nullk, nullk, (size_t)n_draw, MC_SORT_LO, 53, ctx->stream));
+      const size_t a_ix = (sizeof(double) * tph_cdf_index_doubles(n) + 255) / 256 * 256;
+      const size_t a_keys = (sizeof(uint64_t) * (size_t)n_draw + 255) / 256 * 256;
+      if (tph_scratch_reserve(ctx, a_ix + 2 * a_keys + temp_bytes)) return -1;
+      char* base = (char*)ctx->scratch;
+      uint64_t* keys = (uint64_t*)(base + a_ix);
+      uint64_t* sorted = (uint64_t*)(base + a_ix + a_keys);
+      void* tmp = base + a_ix + 2 * a_keys;
+      tph_cdf_index ix;
+      if (tph_cdf_index_build(ctx, cdf_dev, n, (double*)base, &ix)) return -1;
+      int64_t blocks = (n_draw + 255) / 256;
+      if (blocks > 16 * (int64_t)ctx->n_simd) blocks = 16 * (int64_t)ctx->n_simd;
+      hipLaunchKernelGGL(k_mc_draws, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_draw, seed, tick, tag, keys);
+      TPH_HIP(rocprim::radix_sort_keys(tmp, temp_bytes, keys, sorted, (size_t)n_draw, MC_SORT_LO, 53, ctx->stream));
+      const int64_t threads = (n_draw + MC_CHUNK - 1) / MC_CHUNK;
+      hipLaunchKernelGGL(k_mc_merge, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, ix, sorted, n_draw,
+                         counts_dev);
+      TPH_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (tph_scratch_reserve(ctx, sizeof(double) * tph_cdf_index_doubles(n))) return -1;
   tph_cdf_index ix;
   if (tph_cdf_index_build(ctx, cdf_dev, n, (double*)ctx->scratch, &ix)) return -1;
-  hipLaunchKernelGGL(k_multinomial_counts, dim3((unsigned)((n_draw_max + 255) / 256)), dim3(256), 0, ctx->stream, ix,
-                     kept_count_dev, factor, n_draw_max, seed, tick, tag, counts_dev);
+  int64_t blocks = (n_draw_max + 255) / 256;
+  if (blocks > 16 * (int64_t)ctx->n_simd) blocks = 16 * (int64_t)ctx->n_simd;      // 8 resident workgroups per CU, twice over
+  hipLaunchKernelGGL(k_multinomial_counts, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ix, kept_count_dev, factor,
+                     n_draw_max, seed, tick, tag, counts_dev);
   TPH_LAUNCH_CHECK();
   return 0;
 }
