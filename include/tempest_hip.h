@@ -91,7 +91,7 @@ int tph_synchronize(tph_ctx* ctx);
  * (VALU), 2 = FP64 matrix cores (v_mfma_f64_16x16x4: the product is a SYRK; measured no faster -- both are bound by the fill of
  * the staged tile); the parity tests run both */
 #define TPH_OPT_COV_KERNEL 7
-/* TPH_OPT_SORTED_DRAWS: 1 (default) = tph_multinomial_counts with >= 2^20 draws generates them as 53-bit integers, sorts them
+/* TPH_OPT_SORTED_DRAWS: 1 (default) = tph_multinomial_counts with >= 2^23 draws generates them as 53-bit integers, sorts them
  * and merges them against the cdf (the counts do not depend on the order of the draws; one 8-byte device-to-host read of the
  * kept count sizes the sort); 0 = one indexed lookup per draw in draw order.  Same counts either way. */
 #define TPH_OPT_SORTED_DRAWS 8

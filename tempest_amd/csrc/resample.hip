@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(256) k_multinomial_counts(tph_cdf_index ix,
 // search from the previous row (same predicate on the same values => same row; a draw out of order inside its 2^-32 bucket
 // gallops backwards), equal rows are added once.  The reads of neighbouring threads share lines.
 constexpr int MC_CHUNK = 16;
-constexpr int64_t MC_SORT_MIN = 1 << 20;
+constexpr int64_t MC_SORT_MIN = 1 << 23;      // below ~7 x 10^6 draws the sort's launches and the host read cost more than they save
 constexpr int MC_SORT_LO = 29;            // the draws are sorted on bits [MC_SORT_LO, 53) of their integers
 __global__ void __launch_bounds__(256) k_mc_draws(int64_t n_draw, uint64_t seed, uint32_t tick, uint32_t tag,
                                                   uint64_t* __restrict__ keys) {

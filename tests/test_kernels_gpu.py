@@ -295,12 +295,12 @@ def test_fit_modes_large_narrow_with_duplicates(dev):
 
 @pytest.mark.parametrize("kept", [True, False])
 def test_multinomial_counts_sorted_draws_equal_the_draw_order_lookups(dev, kept):
-    """TPH_OPT_SORTED_DRAWS: >= 2^20 draws are sorted and merged against the cdf instead of looked up one by one -- the same
+    """TPH_OPT_SORTED_DRAWS: >= 2^23 draws are sorted and merged against the cdf instead of looked up one by one -- the same
     counts, row by row, on a heavy-tailed trimmed weight vector (flat stretches of the cdf where rows are trimmed away, a
     few rows that take thousands of draws), with the number of draws on the device (kept rows x 4) or given."""
     from tempest_amd.device import OPT_SORTED_DRAWS
     rs = np.random.RandomState(77)
-    n = 3_000_000
+    n = 6_000_000
     w = np.exp(2.0 * rs.randn(n))
     w[rs.randint(n, size=20)] *= 1e3                   # a few dominant rows
     w[rs.rand(n) < 0.3] = 0.0                           # rows without weight
@@ -310,14 +310,14 @@ def test_multinomial_counts_sorted_draws_equal_the_draw_order_lookups(dev, kept)
     thr = c.trim_threshold(wt, ess=0.99)
     cdf = c.cdf(wt, thr=thr[0:1])
     kc = thr[2:3] if kept else None
-    nd = 4 * n if kept else 2_500_000
+    nd = 4 * n if kept else 9_000_000
     got = {}
     for mode in (1, 0):
         c.set_option(OPT_SORTED_DRAWS, mode)
         got[mode] = c.multinomial_counts(cdf, seed=11, tick=3, kept_count=kc, factor=4, n_draw_max=nd).cpu().numpy()
     c.set_option(OPT_SORTED_DRAWS, 1)
     n_draw = 4 * int(thr[2].item()) if kept else nd
-    assert n_draw >= 1 << 20, n_draw                    # the sorted path really ran
+    assert n_draw >= 1 << 23, n_draw                    # the sorted path really ran
     assert got[1].sum() == n_draw
     np.testing.assert_array_equal(got[1], got[0])
     assert got[1].max() > 1000 and (got[1] == 0).mean() > 0.3

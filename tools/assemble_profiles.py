@@ -64,6 +64,16 @@ def main():
         ab["median_ms_per_step"] = {"plain": statistics.median(pl), "sharded_path": statistics.median(cm),
                                     "ratio": statistics.median(cm) / statistics.median(pl)}
         json.dump(ab, open(os.path.join(dst, f"{R}_bench_131k_ab.json"), "w"), indent=1)
+    if os.path.exists(os.path.join(src, "sd_off1.json")):
+        sd = {"what": "bench line (1 048 576 particles) with TEMPEST_AMD_SORTED_DRAWS=0 (one indexed lookup per up-sampling draw) and =1 "
+                      "(draws sorted and merged against the cdf: the default), interleaved on one box", "runs": []}
+        for i in (1, 2):
+            for k in ("off", "on"):
+                d = json.load(open(os.path.join(src, f"sd_{k}{i}.json")))
+                sd["runs"].append({"run": f"{k}{i}", "value": d["value"], "ms_per_step": d["ms_per_step"], "logz": d["logz"],
+                                   "hip_callbacks": d["hip_callbacks"]["value"], "whole_run": d["whole_run"]["value"],
+                                   "tail_phase_seconds": d["mutation_only"]["phase_seconds"]})
+        json.dump(sd, open(os.path.join(dst, f"{R}_sorted_draws_ab.json"), "w"), indent=1)
     # reweight kernel traffic
     rw = {}
     for tag, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):

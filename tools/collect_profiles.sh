@@ -54,6 +54,11 @@ for i in 1 2 3; do
   python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline --no-hip-callbacks > "$O/ab_plain$i.json" 2>> "$O/ab.err"
   TEMPEST_AMD_FORCE_COMM=1 python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline --no-hip-callbacks > "$O/ab_comm$i.json" 2>> "$O/ab.err"
 done
+# 9. the up-sampling multiplicities: draw-order lookups vs sorted draws, two interleaved pairs of the bench line on this box
+for i in 1 2; do
+  TEMPEST_AMD_SORTED_DRAWS=0 python3 bench.py --no-roofline --no-cpu-baseline > "$O/sd_off$i.json" 2>> "$O/sd.err"
+  TEMPEST_AMD_SORTED_DRAWS=1 python3 bench.py --no-roofline --no-cpu-baseline > "$O/sd_on$i.json" 2>> "$O/sd.err"
+done
 # per-launch summary of the roofline kernel and the proposal kernel out of the bench trace (the raw trace is dropped below)
 python3 - "$O" <<'PY'
 import csv, json, sys
@@ -61,7 +66,7 @@ o = sys.argv[1]
 k2, prop = [], []
 for r in csv.DictReader(open(o + "/prof_bench/bench_kernel_trace.csv")):
     dur = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
-    if r["Kernel_Name"].startswith("void k_reweight_reduce<1, 8>") and dur > 100.0:
+    if r["Kernel_Name"].startswith("void k_reweight_reduce<1, 8>") and dur > 140.0:      # the 1.07 GB history only
         k2.append(dur)
     elif r["Kernel_Name"].startswith("void k_propose_reg<0, 10, true"):
         prop.append(dur)

@@ -43,7 +43,9 @@ ALGO = {
     "void tph_scan::k_tile_sums<0>": ("K6 scan pass 1 (tile sums)", 8.0 * NH, "8 B per row", "stream"),
     "void tph_scan::k_apply<0>": ("K6 scan pass 3 (local scan + offset)", 16.0 * NH, "16 B per row", "stream"),
     "k_resample_multinomial": ("K6 inverse-CDF lookups of the resampling draws", 8.0 * N, "8 B out per draw (+ ~3 index lines read per draw)", "indexed"),
-    "k_multinomial_counts": ("K6 inverse-CDF lookups of the x4 up-sampling", 0.0, "one atomic per draw (+ ~3 index lines read per draw)", "indexed"),
+    "k_multinomial_counts": ("K6 x4 up-sampling, one indexed lookup per draw (TPH_OPT_SORTED_DRAWS = 0)", 0.0, "one atomic per draw (+ ~3 index lines read per draw)", "indexed"),
+    "k_mc_draws": ("K6 x4 up-sampling: the draws as 53-bit integers", 0.0, "8 B written per draw", "stream"),
+    "k_mc_merge": ("K6 x4 up-sampling: sorted draws merged against the cdf", 0.0, "8 B per draw + 12 B per history row walked", "stream"),
     "k_gather_rows": ("K7 gather of the resampled rows (from the row-major mirror)", 2.0 * (2 * D + 1) * 8.0 * N, "2 (2d+1) 8 B per output row", "indexed"),
     "k_rows_pack": ("K7 mirror fill: the iteration's new rows, dimension-major -> records", 2.0 * (2 * D + 1) * 8.0 * N, "2 (2d+1) 8 B per new row", "stream"),
     "k_gather(": ("K7 gather of the resampled rows (dimension-major history, no mirror)", 2.0 * (2 * D + 1) * 8.0 * N, "2 (2d+1) 8 B per output row", "indexed"),
@@ -98,6 +100,10 @@ def drive():
         uo, xo, lo = c.empty(D, N), c.empty(D, N), c.empty(N)
         c.gather(idx, uo, xo, lo)
         cdfm = c.cdf(w, thr[0:1])
+        from tempest_amd.device import OPT_SORTED_DRAWS
+        c.set_option(OPT_SORTED_DRAWS, 0)                 # the draw-order form, for the table only
+        c.multinomial_counts(cdfm, rng.seed, rng.tick, kept_count=thr[2:3], factor=4, n_draw_max=4 * NH)
+        c.set_option(OPT_SORTED_DRAWS, 1)
         counts = c.multinomial_counts(cdfm, rng.seed, rng.next(), kept_count=thr[2:3], factor=4, n_draw_max=4 * NH)
         means, covs, chol, inv, winv = c.fit_modes(counts)
         m_keep = int((counts > 0).sum().item())
@@ -157,6 +163,11 @@ def collect(base, out):
     ALGO["k_nz_scatter"] = (label, 4.0 * NH + (16.0 * D + 4.0) * rows_fit, "4 B per history row + (16d + 4) B per kept row", kind)
     label, _, unit, kind = ALGO["k_multinomial_counts"]
     ALGO["k_multinomial_counts"] = (label, 0.0, f"{meta['draws']} draws: one atomic each (+ ~3 index lines read per draw)", kind)
+    label, _, unit, kind = ALGO["k_mc_draws"]
+    ALGO["k_mc_draws"] = (label, 8.0 * meta["draws"], f"8 B written per draw ({meta['draws']} draws)", kind)
+    label, _, unit, kind = ALGO["k_mc_merge"]
+    ALGO["k_mc_merge"] = (label, 8.0 * meta["draws"] + 12.0 * NH, f"8 B per draw ({meta['draws']}) + 12 B per history row (an upper bound: "
+                          "rows between two draws are skipped by the galloping search)", kind)
     dur, _ = _read(os.path.join(base, "trace"))
     _, fetch = _read(os.path.join(base, "fetch"), "FETCH_SIZE")
     _, write = _read(os.path.join(base, "write"), "WRITE_SIZE")
