@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--roofline-rows", type=int, default=67_108_864)      # 1.07 GB of (logl, logmix)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="MCMC step replayed as a hipGraph (Sampler(graph=...)); auto = the library's size rule")
     ap.add_argument("--no-finish", action="store_true", help="skip running on to termination for logZ")
     ap.add_argument("--no-hip-callbacks", action="store_true",
                     help="skip the second run with the callbacks compiled into the step (tempest_amd.HipCallbacks)")
@@ -225,7 +227,8 @@ def main():
 
     def make(callbacks, n_glob):
         return tp.Sampler(callbacks[0], callbacks[1], 10, n_particles=n_glob, vectorize=True, clustering=False,
-                          random_state=a.seed, backend="torch", batch_prior=True, device=local_rank)
+                          random_state=a.seed, backend="torch", batch_prior=True, device=local_rank,
+                          graph={"auto": None, "on": True, "off": False}[a.graph])
     s = make((prior20, rosenbrock_torch), n_global)
 
     def sync():
