@@ -880,3 +880,36 @@ def test_second_moments_on_the_matrix_cores_equal_the_vector_kernel(dev, d):
     np.testing.assert_allclose(out[2], (xc * wn[:, None]).T @ xc, rtol=1e-10, atol=1e-14)
     assert np.allclose(out[2], out[2].T)
     c.close()
+
+
+def test_fit_mvstud_drop_in_against_the_reference_outputs(dev):
+    """tempest_amd.student.fit_mvstud (student.py:6-116, effective form F5) on the data sets whose reference outputs are in
+    g7_modes.npz (Gaussian, t3, narrow 10-D, degenerate -> ridge), then the shapes the reference's tests/test_student.py
+    feeds it: 1-D, 2-D, correlated, columns of very different scale, constant columns."""
+    from tempest_amd.student import fit_mvstud
+    g = np.load(os.path.join(G, "g7_modes.npz"))
+    for k in range(int(g["n_fit"])):
+        mu, Sig, nu = fit_mvstud(g[f"fit{k}_data"], tolerance=1e-8, max_iter=5)
+        assert nu == np.inf == float(g[f"fit{k}_nu"])
+        np.testing.assert_allclose(mu, g[f"fit{k}_mu"], rtol=1e-14, atol=0)
+        ref = g[f"fit{k}_Sigma"]
+        if np.min(np.diag(ref)) < 1e-25:
+            # five constant columns: NumPy's covariance leaves rounding noise of 1e-31 there, which happens to pass its
+            # Cholesky test; the device's centred moments are exactly zero, so the matrix is singular and the reference's own
+            # rule (student.py:60-64) adds max(1e-6, 1e-6 |tr|) to the diagonal
+            ref = ref + max(1e-6, 1e-6 * abs(np.trace(ref))) * np.eye(ref.shape[0])
+        np.testing.assert_allclose(Sig, ref, rtol=1e-9, atol=1e-18)
+    rs = np.random.RandomState(12)
+    cases = [rs.randn(500, 1) * 2.0 + 3.0,
+             rs.randn(300, 2),
+             rs.multivariate_normal([0.0, 0.0, 0.0], [[1.0, 0.8, 0.3], [0.8, 1.0, 0.5], [0.3, 0.5, 1.0]], size=1000),
+             rs.randn(400, 3) * np.array([1e-3, 1.0, 1e3]),
+             np.tile(np.array([[1.0, 2.0, 3.0]]), (100, 1))]
+    for data in cases:
+        mu, Sig, nu = fit_mvstud(data)
+        wmu, wSig, wnu = ps.fit_mvstud_effective(data)
+        assert mu.shape == (data.shape[1],) and Sig.shape == (data.shape[1],) * 2 and nu == wnu
+        np.testing.assert_allclose(mu, wmu, rtol=1e-14, atol=0)
+        np.testing.assert_allclose(Sig, wSig, rtol=1e-9, atol=1e-16)
+        np.linalg.cholesky(Sig)                                  # positive definite, as the reference guarantees
+    np.testing.assert_array_equal(fit_mvstud(cases[2])[1], fit_mvstud(cases[2])[1])      # reproducible
