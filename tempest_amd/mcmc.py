@@ -465,3 +465,22 @@ def parallel_mcmc(u, x, logl, blobs, assignments, beta, mode_stats, log_likeliho
     eff, acc, it, calls = run.run(ut, xt, lt, at, blobs=blobs)
     back = lambda t: np.ascontiguousarray(t.cpu().numpy().T)  # noqa: E731
     return back(ut), back(xt), lt.cpu().numpy(), run.blobs, eff, acc, it, calls
+
+
+def parallel_t_preconditioned_crank_nicolson(u, x, logl, blobs, assignments, beta, mode_stats, log_likelihood, prior_transform,
+                                             progress_bar=None, n_steps: int = 100, n_max: int = 1000, periodic=None,
+                                             reflective=None, verbose: bool = True):
+    """tempest.mcmc.parallel_t_preconditioned_crank_nicolson (mcmc.py:511-589): parallel_mcmc with the tpCN kernel."""
+    return parallel_mcmc(u, x, logl, blobs, assignments, beta, mode_stats, log_likelihood, prior_transform,
+                         progress_bar=progress_bar, n_steps=n_steps, n_max=n_max, sample="tpcn", periodic=periodic,
+                         reflective=reflective, verbose=verbose)
+
+
+def parallel_random_walk_metropolis(u, x, logl, blobs, assignments, beta, mode_stats, log_likelihood, prior_transform,
+                                    progress_bar=None, n_steps: int = 1000, n_max: int = 10000, periodic=None,
+                                    reflective=None, verbose: bool = True):
+    """tempest.mcmc.parallel_random_walk_metropolis (mcmc.py:592-676): parallel_mcmc with the RWM kernel (note the
+    reference's larger defaults for n_steps / n_max)."""
+    return parallel_mcmc(u, x, logl, blobs, assignments, beta, mode_stats, log_likelihood, prior_transform,
+                         progress_bar=progress_bar, n_steps=n_steps, n_max=n_max, sample="rwm", periodic=periodic,
+                         reflective=reflective, verbose=verbose)

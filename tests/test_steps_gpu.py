@@ -179,3 +179,30 @@ def test_mode_statistics_from_arrays_and_parallel_mcmc():
     ms2 = ModeStatistics.from_global(u, np.ones(n))
     np.testing.assert_allclose(ms2.means[0], np.median(u, axis=0), atol=0.01)
     assert ms2.degrees_of_freedom[0] == 1e6
+
+
+def test_named_mcmc_wrappers_equal_parallel_mcmc():
+    """parallel_t_preconditioned_crank_nicolson / parallel_random_walk_metropolis (mcmc.py:511-676) are parallel_mcmc with the
+    kernel fixed: same seed, same chain."""
+    from tempest_amd import mcmc
+    from tempest_amd.modes import ModeStatistics
+    rs = np.random.RandomState(4)
+    d, n = 3, 256
+    u = np.clip(0.5 + 0.05 * rs.randn(n, d), 0, 1)
+    x = 20 * u - 10
+    logl = -0.5 * np.sum(x ** 2, axis=1)
+    ms = ModeStatistics.from_global(u, np.ones(n), seed=2)
+    like = lambda xx: (-0.5 * np.sum(xx ** 2, axis=1), None)      # noqa: E731
+    prior = lambda uu: 20 * uu - 10                                # noqa: E731
+    args = (u, x, logl, None, np.zeros(n, dtype=int), 0.7, ms, like, prior)
+    for wrapper, name in ((mcmc.parallel_t_preconditioned_crank_nicolson, "tpcn"), (mcmc.parallel_random_walk_metropolis, "rwm")):
+        np.random.seed(11)
+        a = wrapper(*args, n_steps=2, n_max=20, verbose=False)
+        np.random.seed(11)
+        b = mcmc.parallel_mcmc(*args, n_steps=2, n_max=20, sample=name, verbose=False)
+        for va, vb in zip(a, b):
+            if va is None:
+                assert vb is None
+            else:
+                np.testing.assert_array_equal(np.asarray(va), np.asarray(vb))
+        assert a[0].shape == (n, d) and a[6] >= 2 * d
