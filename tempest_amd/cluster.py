@@ -371,6 +371,38 @@ class HierarchicalGaussianMixture:
         Xt = torch.from_numpy(np.ascontiguousarray(X.T)).to(ctx.device)
         return self.predict_device(Xt, ctx).cpu().numpy().astype(np.int64)
 
+    def predict_proba(self, X):
+        """(n, n_clusters_) membership probabilities (cluster.py:602-696): softmax over k of
+        log(weight_k + 1e-10) + log N(x; mean_k, cov_k + 1e-6 I) in normalised coordinates -- the responsibilities of the
+        device E-step with unit sample weights; rows whose densities all underflow get their predict() label."""
+        import torch
+        from .tools import _ctx
+        if not getattr(self, "_gmm_ready", False) or not self.cluster_centers_:
+            raise ValueError("The model has not been fitted yet.")
+        X = np.asarray(X, dtype=np.float64)
+        n, K = X.shape[0], self.n_clusters_
+        ctx = _ctx(X.shape[1])
+        Xt = torch.from_numpy(np.ascontiguousarray(X.T)).to(ctx.device)
+        wr = torch.empty(K, n, dtype=torch.float64, device=ctx.device)
+        stats = torch.zeros(3, dtype=torch.float64, device=ctx.device)
+        ones = torch.ones(n, dtype=torch.float64, device=ctx.device)
+        ctx.gmm_estep(Xt, ones, None, 0, self._params_dev, K, 0, eps=0.0, wr=wr, stats=stats, shift=self._shift_dev,
+                      scale=self._scale_dev)
+        P = wr.T.cpu().numpy()
+        bad = ~np.isfinite(P).all(axis=1) | (P.sum(axis=1) == 0.0)
+        if bad.any():
+            lab = torch.empty(n, dtype=torch.int32, device=ctx.device)
+            ctx.gmm_estep(Xt, None, None, 0, self._params_dev, K, 2, label_out=lab, shift=self._shift_dev, scale=self._scale_dev)
+            P[bad] = np.eye(K)[lab.cpu().numpy()[bad]]
+        P /= P.sum(axis=1, keepdims=True)
+        if self._remap is not None:                      # components merged into the labels predict() hands out
+            rm = self._remap.cpu().numpy()
+            Q = np.zeros((n, int(rm.max()) + 1))
+            for k in range(K):
+                Q[:, rm[k]] += P[:, k]
+            P = Q
+        return P
+
     # ----------------------------------------------------------------------------- device path
     def predict_device(self, x_soa, ctx=None):
         """argmax_k log(weight_k + 1e-10) + log N(x; mean_k, cov_k + 1e-6 I) in normalised coordinates
