@@ -54,12 +54,12 @@ def _pack_params(terms, means, covs, reg):
 class _WorkingSet:
     """Compact SoA data (d, M) on the device + weights + per-point cluster labels."""
 
-    def __init__(self, ctx, X, sw):
+    def __init__(self, ctx, X, sw, n_components=2):
         import torch
         self.ctx, self.X, self.sw = ctx, X, sw
         self.M = X.shape[1]
         self.labels = torch.zeros(self.M, dtype=torch.int32, device=ctx.device)
-        self.wr = ctx.empty(2, self.M)
+        self.wr = ctx.empty(max(2, int(n_components)), self.M)
         self.stats = ctx.empty(3)
         self.tmp_labels = torch.empty(self.M, dtype=torch.int32, device=ctx.device)
 
@@ -69,13 +69,14 @@ class _WorkingSet:
 
 
 class GaussianMixture:
-    """Weighted EM for a full-covariance GMM on the device (cluster.py:5-340).  Host-array `fit`/`predict`/`bic`
+    """Weighted EM for a Gaussian mixture on the device (cluster.py:5-340; covariance_type full | tied | diag | spherical: the
+    E-step kernel takes full precision matrices, the M-step reduces the weighted scatter matrices to the stored form).  Host-array `fit`/`predict`/`bic`
     mirror the reference's interface; the hierarchical model drives `_fit_ws` on a shared working set."""
 
     def __init__(self, n_components=1, covariance_type="full", max_iter=1000, n_init=1, tol=1e-3, reg_covar=1e-6,
                  random_state=None):
-        if covariance_type != "full":
-            raise NotImplementedError("only covariance_type='full' (the one the sampler uses, core.py:64) is on the GPU path")
+        if covariance_type not in ("full", "tied", "diag", "spherical"):
+            raise ValueError(f"unknown covariance_type {covariance_type!r}")
         self.n_components = n_components
         self.covariance_type = covariance_type
         self.max_iter = max_iter
@@ -104,8 +105,31 @@ class GaussianMixture:
         host = torch.cat([sums.reshape(-1), means_dev.reshape(-1), covs_dev.reshape(-1)]).cpu().numpy()
         tot = host[: K * (1 + d)].reshape(K, 1 + d)[:, 0].copy()
         means = host[K * (1 + d): K * (1 + d) + K * d].reshape(K, d).copy()
-        covs = host[K * (1 + d) + K * d:].reshape(K, d, d) / (tot[:, None, None] + 1e-10)
-        return tot / tot.sum(), means, covs
+        scatter = host[K * (1 + d) + K * d:].reshape(K, d, d)          # sum_i wr_ki (x_i - mu_k)(x_i - mu_k)^T
+        return tot / tot.sum(), means, self._covariances_from_scatter(scatter, tot, ws.M)
+
+    def _covariances_from_scatter(self, scatter, tot, n_samples):
+        """cluster.py:215-252: the stored form of each covariance type, from the weighted scatter matrices."""
+        K, d = scatter.shape[0], scatter.shape[1]
+        if self.covariance_type == "full":
+            return scatter / (tot[:, None, None] + 1e-10)
+        if self.covariance_type == "tied":                     # one (d, d) matrix; the reference divides by the row count
+            return scatter.sum(axis=0) / n_samples
+        diag = np.einsum("kjj->kj", scatter)
+        if self.covariance_type == "diag":                     # (K, d)
+            return diag / (tot[:, None] + 1e-10)
+        return diag.sum(axis=1) / (tot * d + 1e-10)            # spherical: (K,)
+
+    def _full(self, covs, d):
+        """(K, d, d) matrices of the stored covariances (cluster.py:254-264)."""
+        K = self.n_components
+        if self.covariance_type == "full":
+            return covs
+        if self.covariance_type == "tied":
+            return np.broadcast_to(covs, (K, d, d))
+        if self.covariance_type == "diag":
+            return np.stack([np.diag(c) for c in covs])
+        return np.stack([np.eye(d) * c for c in covs])
 
     def _seed_row(self, ws, prob, u):
         """X[searchsorted(cumsum(prob), u * total)] (cluster.py:142-157)."""
@@ -140,7 +164,7 @@ class GaussianMixture:
                 # E-step with the current parameters; its weighted log-likelihood is the lower bound the reference
                 # computes right after the M-step that produced them (cluster.py:104-121)
                 with np.errstate(divide="ignore"):
-                    p = _pack_params(np.log(weights), means, covs, self.reg_covar)
+                    p = _pack_params(np.log(weights), means, self._full(covs, d), self.reg_covar)
                 ctx.gmm_estep(ws.X, swc, ws.labels, label, ws.to_dev(p), K, 0, eps=1e-10, wr=ws.wr, stats=ws.stats)
                 stats = ws.stats.cpu().numpy()
                 if it > 0:
@@ -160,12 +184,14 @@ class GaussianMixture:
         """cluster.py:330-340: -2 * (unweighted log-likelihood of the members) + n_parameters * log(n)."""
         d = self.means_.shape[1]
         K = self.n_components
-        n_par = (K - 1) + K * d + K * d * (d + 1) / 2
+        cov_par = {"full": K * d * (d + 1) / 2, "tied": d * (d + 1) / 2, "diag": K * d, "spherical": K}[self.covariance_type]
+        n_par = (K - 1) + K * d + cov_par
         return -2.0 * self._ll_unweighted + n_par * math.log(self._n_members)
 
     def _predict_ws(self, ws, label, out):
         with np.errstate(divide="ignore"):
-            p = _pack_params(np.log(self.weights_ + 1e-10), self.means_, self.covariances_, self.reg_covar)
+            p = _pack_params(np.log(self.weights_ + 1e-10), self.means_, self._full(self.covariances_, self.means_.shape[1]),
+                             self.reg_covar)
         ws.ctx.gmm_estep(ws.X, None, ws.labels, label, ws.to_dev(p), self.n_components, 2, label_out=out)
 
     # ---------------------------------------------------------------------------- host-array API
@@ -180,7 +206,7 @@ class GaussianMixture:
             raise ValueError("sample_weight must have the same length as X")
         sw = sw / sw.sum()
         Xt = torch.from_numpy(np.ascontiguousarray(X.T)).to(ctx.device)
-        return _WorkingSet(ctx, Xt, torch.from_numpy(sw).to(ctx.device))
+        return _WorkingSet(ctx, Xt, torch.from_numpy(sw).to(ctx.device), self.n_components)
 
     def fit(self, X, sample_weight=None):
         ws = self._ws_from_host(X, sample_weight)
@@ -194,7 +220,7 @@ class GaussianMixture:
     def bic(self, X):
         ws = self._ws_from_host(X, None)
         with np.errstate(divide="ignore"):
-            p = _pack_params(np.log(self.weights_), self.means_, self.covariances_, self.reg_covar)
+            p = _pack_params(np.log(self.weights_), self.means_, self._full(self.covariances_, self.means_.shape[1]), self.reg_covar)
         ws.ctx.gmm_estep(ws.X, ws.sw, None, 0, ws.to_dev(p), self.n_components, 0, wr=ws.wr, stats=ws.stats)
         st = ws.stats.cpu().numpy()
         self._ll_unweighted, self._n_members = float(st[1]), int(st[2])
@@ -373,28 +399,25 @@ class HierarchicalGaussianMixture:
 
     def predict_proba(self, X):
         """(n, n_clusters_) membership probabilities (cluster.py:602-696): softmax over k of
-        log(weight_k + 1e-10) + log N(x; mean_k, cov_k + 1e-6 I) in normalised coordinates -- the responsibilities of the
-        device E-step with unit sample weights; rows whose densities all underflow get their predict() label."""
+        log(weight_k + 1e-10) + log N(x; mean_k, cov_k + 1e-6 I) in normalised coordinates, from the packed parameters the
+        E-step kernel uses (any number of clusters; a few tensor operations on the device -- not a hot path)."""
         import torch
         from .tools import _ctx
         if not getattr(self, "_gmm_ready", False) or not self.cluster_centers_:
             raise ValueError("The model has not been fitted yet.")
         X = np.asarray(X, dtype=np.float64)
-        n, K = X.shape[0], self.n_clusters_
-        ctx = _ctx(X.shape[1])
-        Xt = torch.from_numpy(np.ascontiguousarray(X.T)).to(ctx.device)
-        wr = torch.empty(K, n, dtype=torch.float64, device=ctx.device)
-        stats = torch.zeros(3, dtype=torch.float64, device=ctx.device)
-        ones = torch.ones(n, dtype=torch.float64, device=ctx.device)
-        ctx.gmm_estep(Xt, ones, None, 0, self._params_dev, K, 0, eps=0.0, wr=wr, stats=stats, shift=self._shift_dev,
-                      scale=self._scale_dev)
-        P = wr.T.cpu().numpy()
-        bad = ~np.isfinite(P).all(axis=1) | (P.sum(axis=1) == 0.0)
-        if bad.any():
-            lab = torch.empty(n, dtype=torch.int32, device=ctx.device)
-            ctx.gmm_estep(Xt, None, None, 0, self._params_dev, K, 2, label_out=lab, shift=self._shift_dev, scale=self._scale_dev)
-            P[bad] = np.eye(K)[lab.cpu().numpy()[bad]]
-        P /= P.sum(axis=1, keepdims=True)
+        n, d, K = X.shape[0], X.shape[1], self.n_clusters_
+        ctx = _ctx(d)
+        Xn = torch.from_numpy(np.ascontiguousarray(X.T)).to(ctx.device)
+        if self._shift_dev is not None:
+            Xn = (Xn - self._shift_dev[:, None]) * self._scale_dev[:, None]
+        par = self._params_dev.to(ctx.device)
+        logp = torch.empty(K, n, dtype=torch.float64, device=ctx.device)
+        for k in range(K):
+            diff = Xn - par[k, 1:1 + d, None]
+            maha = (diff * (par[k, 1 + d:1 + d + d * d].reshape(d, d) @ diff)).sum(dim=0)
+            logp[k] = par[k, 0] - 0.5 * (maha + par[k, 1 + d + d * d] + d * LOG2PI)
+        P = torch.softmax(logp, dim=0).T.cpu().numpy()
         if self._remap is not None:                      # components merged into the labels predict() hands out
             rm = self._remap.cpu().numpy()
             Q = np.zeros((n, int(rm.max()) + 1))
