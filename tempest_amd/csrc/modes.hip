@@ -297,6 +297,7 @@ __global__ void __launch_bounds__(256) k_wsum(const double* __restrict__ hu, int
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     if (labels && labels[i] != label) continue;
     double w = (double)wt[i];
+    if (__ballot(w != 0.0) == 0ull) continue;       // rows without weight add exactly zero and do not move min / max
     if (col) {
       double v = src[i];
       s += w * v;
@@ -392,17 +393,19 @@ __global__ void __launch_bounds__(256) k_wcov(const double* __restrict__ hu, int
   const int64_t ntiles = (n + COV_ROWS - 1) / COV_ROWS;
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int64_t r0 = t * COV_ROWS;
-    __syncthreads();
+    double w = 0.0;
+    if (threadIdx.x < COV_ROWS) {
+      int64_t i = r0 + threadIdx.x;
+      if (i < n && (!labels || labels[i] == label)) w = (double)wt[i];
+    }
+    // a tile whose rows all have weight zero adds exactly zero: it is neither staged nor multiplied (also the barrier that
+    // protects xs / ws from the previous tile's readers)
+    if (!__syncthreads_or(w != 0.0)) continue;
+    if (threadIdx.x < COV_ROWS) ws[threadIdx.x] = w;
     for (int e = threadIdx.x; e < d * COV_ROWS; e += blockDim.x) {
       int j = e / COV_ROWS, r = e % COV_ROWS;
       int64_t i = r0 + r;
       xs[j * COV_LD + r] = i < n ? hu[(size_t)j * cap + i] - mean[j] : 0.0;
-    }
-    if (threadIdx.x < COV_ROWS) {
-      int64_t i = r0 + threadIdx.x;
-      double w = 0.0;
-      if (i < n && (!labels || labels[i] == label)) w = (double)wt[i];
-      ws[threadIdx.x] = w;
     }
     __syncthreads();
 #pragma unroll
@@ -661,6 +664,7 @@ __global__ void __launch_bounds__(256) k_wcov_small(const double* __restrict__ h
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     double w = (!labels || labels[i] == label) ? (double)wt[i] : 0.0;
+    if (__ballot(w != 0.0) == 0ull) continue;       // 64 rows without weight: exactly zero, their coordinates are not read
     double xc[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) xc[j] = hu[(size_t)j * cap + i] - m[j];
@@ -710,6 +714,9 @@ __global__ void __launch_bounds__(256) k_wmom_small(const double* __restrict__ h
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const double w = wt[i];
+    // 64 consecutive rows without weight (whole early iterations, once exp(logw - max) underflows) add exactly zero to every
+    // sum: their coordinates are not read (8 instead of 8 D + 8 bytes per row; same sums bit for bit)
+    if (__ballot(w != 0.0) == 0ull) continue;
     double xc[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) xc[j] = hu[(size_t)j * cap + i] - c[j];
@@ -1750,6 +1757,8 @@ __global__ void __launch_bounds__(256) k_cv_sum_blk(const double* __restrict__ h
   const int64_t ntiles = (n + 63) / 64;
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int64_t i = t * 64 + lane;
+    const double ww = i < n ? w[i] : 0.0;
+    if (__ballot(ww != 0.0) == 0ull) continue;     // the four waves see the same 64 weights: uniform over the block
     __syncthreads();
     for (int j = wid; j < d; j += 4) xs[(size_t)j * 64 + lane] = i < n ? hu[(size_t)j * cap + i] - mean[j] : 0.0;
     __syncthreads();
@@ -1760,7 +1769,6 @@ __global__ void __launch_bounds__(256) k_cv_sum_blk(const double* __restrict__ h
     if (wid == 0 && i < n) {
       const double tot = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
       const double dev = fmin(fmax(tot - (double)d, -1e6), 1e6);
-      const double ww = w[i];
       acc += (ww * ww) * (dev * dev);
     }
   }
@@ -1780,6 +1788,8 @@ __global__ void __launch_bounds__(256) k_cv_sum_small(const double* __restrict__
   double acc = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double ww = w[i];
+    if (__ballot(ww != 0.0) == 0ull) continue;      // 64 rows without weight: the term is exactly zero (as in k_wmom_small)
     double xc[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) xc[j] = hu[(size_t)j * cap + i] - m[j];
@@ -1792,7 +1802,6 @@ __global__ void __launch_bounds__(256) k_cv_sum_small(const double* __restrict__
       d2 = fma(y, y, d2);
     }
     const double dev = fmin(fmax(d2 - (double)D, -1e6), 1e6);
-    const double ww = w[i];
     acc += (ww * ww) * (dev * dev);
   }
   __shared__ double sh[4];
