@@ -283,9 +283,11 @@ class SamplerCore:
         """Continue while (1 - beta >= 1e-4) or ESS(beta=1) < n_total (core.py:360-374)."""
         if self.state.get_history_length() == 0:
             return True
-        ess, _ = self._logz_at(1.0)
         beta = self.state.get_current("beta")
-        return 1.0 - beta >= 1e-4 or ess < getattr(self, "n_total", 0)
+        if 1.0 - beta >= 1e-4:            # the first clause decides: ESS(beta = 1) -- one pass over the history -- is not needed
+            return True
+        ess, _ = self._logz_at(1.0)
+        return ess < getattr(self, "n_total", 0)
 
     # ------------------------------------------------------------------------------ outputs
     def compute_posterior(self, resample=False, return_blobs=False, trim_importance_weights=True, return_logw=False,
