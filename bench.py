@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--roofline-rows", type=int, default=67_108_864)      # 1.07 GB of (logl, logmix)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-second-run", action="store_true", help="skip the warm repeat of the whole run (whole_run_warm)")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
                     help="MCMC step replayed as a hipGraph (Sampler(graph=...)); auto = the library's size rule")
     ap.add_argument("--no-finish", action="store_true", help="skip running on to termination for logZ")
@@ -310,6 +311,30 @@ def main():
                               "seconds": t_run, "iterations": int(len(all_beta)),
                               "note": "first sample() to the reference's stopping rule on this rank, one-time costs (history "
                                       "allocation, module load, callback probing) included"}
+        if not a.no_second_run:
+            # the same run once more in this process (new Sampler, same seed): what Sampler.run() costs once the process has
+            # loaded its kernels -- the first iteration of the first run spends ~0.5 s in torch's lazy loading of the code
+            # objects behind the user's eager callbacks (measured: 0.27 s for five elementwise kernels) and the first rocPRIM sort
+            s_w = make((prior20, rosenbrock_torch), n_global)
+            sync()
+            t_w0 = time.perf_counter()
+            s_w.run(n_total=n_total, progress=False)              # the public entry point, to the reference's stopping rule
+            logz_w = s_w.evidence()[0]
+            sync()
+            t_w = time.perf_counter() - t_w0
+            if use_dist:
+                tt = torch.tensor([t_w], dtype=torch.float64, device="cpu" if rehearsal else dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t_w = float(tt.item())
+            w_steps = np.asarray(s_w.state._scalars["steps"]); w_beta = np.asarray(s_w.state._scalars["beta"])
+            extra["whole_run_warm"] = {"value": float(np.sum(w_steps[w_beta > 0])) * n_global / t_w,
+                                       "unit": "particle-mutation-steps/s", "seconds": t_w, "iterations": int(len(w_beta)),
+                                       "same_logz_as_first_run": bool(logz_w == logz),
+                                       "note": "a second complete run in the same process: Sampler(...).run(n_total) + evidence() on a "
+                                               "fresh Sampler with the same seed, no per-phase synchronisation -- the whole "
+                                               "run without the process's one-time costs"}
+            del s_w
+            torch.cuda.empty_cache()
         extra.update({"logz": logz, "logz_abs_err_vs_analytic": abs(logz - ANALYTIC_LOGZ),
                       "analytic_logz": float(ANALYTIC_LOGZ), "iterations_total": len(s.state._scalars["beta"]),
                       "reference_logz_ensemble_N1000": {"mean": -29.804, "std": 0.115, "seeds": 16,
