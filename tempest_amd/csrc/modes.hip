@@ -297,7 +297,6 @@ __global__ void __launch_bounds__(256) k_wsum(const double* __restrict__ hu, int
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     if (labels && labels[i] != label) continue;
     double w = (double)wt[i];
-    if (__ballot(w != 0.0) == 0ull) continue;       // rows without weight add exactly zero and do not move min / max
     if (col) {
       double v = src[i];
       s += w * v;
@@ -393,19 +392,17 @@ __global__ void __launch_bounds__(256) k_wcov(const double* __restrict__ hu, int
   const int64_t ntiles = (n + COV_ROWS - 1) / COV_ROWS;
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int64_t r0 = t * COV_ROWS;
-    double w = 0.0;
-    if (threadIdx.x < COV_ROWS) {
-      int64_t i = r0 + threadIdx.x;
-      if (i < n && (!labels || labels[i] == label)) w = (double)wt[i];
-    }
-    // a tile whose rows all have weight zero adds exactly zero: it is neither staged nor multiplied (also the barrier that
-    // protects xs / ws from the previous tile's readers)
-    if (!__syncthreads_or(w != 0.0)) continue;
-    if (threadIdx.x < COV_ROWS) ws[threadIdx.x] = w;
+    __syncthreads();
     for (int e = threadIdx.x; e < d * COV_ROWS; e += blockDim.x) {
       int j = e / COV_ROWS, r = e % COV_ROWS;
       int64_t i = r0 + r;
       xs[j * COV_LD + r] = i < n ? hu[(size_t)j * cap + i] - mean[j] : 0.0;
+    }
+    if (threadIdx.x < COV_ROWS) {
+      int64_t i = r0 + threadIdx.x;
+      double w = 0.0;
+      if (i < n && (!labels || labels[i] == label)) w = (double)wt[i];
+      ws[threadIdx.x] = w;
     }
     __syncthreads();
 #pragma unroll
@@ -664,7 +661,6 @@ __global__ void __launch_bounds__(256) k_wcov_small(const double* __restrict__ h
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     double w = (!labels || labels[i] == label) ? (double)wt[i] : 0.0;
-    if (__ballot(w != 0.0) == 0ull) continue;       // 64 rows without weight: exactly zero, their coordinates are not read
     double xc[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) xc[j] = hu[(size_t)j * cap + i] - m[j];
@@ -714,9 +710,8 @@ __global__ void __launch_bounds__(256) k_wmom_small(const double* __restrict__ h
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const double w = wt[i];
-    // 64 consecutive rows without weight (whole early iterations, once exp(logw - max) underflows) add exactly zero to every
-    // sum: their coordinates are not read (8 instead of 8 D + 8 bytes per row; same sums bit for bit)
-    if (__ballot(w != 0.0) == 0ull) continue;
+    // (no test for weightless rows here, unlike k_cv_sum_small: a branch in front of the coordinate loads costs this kernel
+    // 10 % on a history without such rows -- the loads of consecutive trips no longer overlap -- and it runs mostly on those)
     double xc[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) xc[j] = hu[(size_t)j * cap + i] - c[j];
@@ -1789,7 +1784,9 @@ __global__ void __launch_bounds__(256) k_cv_sum_small(const double* __restrict__
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const double ww = w[i];
-    if (__ballot(ww != 0.0) == 0ull) continue;      // 64 rows without weight: the term is exactly zero (as in k_wmom_small)
+    // 64 consecutive rows without weight (whole early iterations, once exp(logw - max) underflows) add exactly zero: their
+    // coordinates are not read (8 instead of 8 D + 8 bytes per row; same sum bit for bit).  Measured neutral without such rows.
+    if (__ballot(ww != 0.0) == 0ull) continue;
     double xc[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) xc[j] = hu[(size_t)j * cap + i] - m[j];
