@@ -93,7 +93,8 @@ int tph_synchronize(tph_ctx* ctx);
 #define TPH_OPT_COV_KERNEL 7
 /* TPH_OPT_SORTED_DRAWS: 1 (default) = tph_multinomial_counts with >= 2^23 draws generates them as 53-bit integers, sorts them
  * and merges them against the cdf (the counts do not depend on the order of the draws; one 8-byte device-to-host read of the
- * kept count sizes the sort); 0 = one indexed lookup per draw in draw order.  Same counts either way. */
+ * kept count sizes the sort); 0 = one indexed lookup per draw in draw order; a value > 1 = that many draws as the threshold
+ * instead of 2^23 (tests).  Same counts either way. */
 #define TPH_OPT_SORTED_DRAWS 8
 int tph_set_option(tph_ctx* ctx, int option, int value);
 

@@ -222,7 +222,7 @@ extern "C" int tph_set_option(tph_ctx* ctx, int option, int value) {
     case TPH_OPT_ML_UNSTAGED: ctx->ml_unstaged = value; break;
     case TPH_OPT_ROW_MIRROR: ctx->rows_mode = value ? 1 : 0; break;
     case TPH_OPT_COV_KERNEL: ctx->cov_kernel = value; break;
-    case TPH_OPT_SORTED_DRAWS: ctx->mc_sorted = value ? 1 : 0; break;
+    case TPH_OPT_SORTED_DRAWS: ctx->mc_sorted = value < 0 ? 0 : value; break;
     case TPH_OPT_BLOCKED: ctx->blocked = value; break;
     case TPH_OPT_MODES_EPOCH: ctx->modes_epoch = value; break;
     default: TPH_REQUIRE(false, "tph_set_option: unknown option %d", option);

@@ -671,7 +671,8 @@ extern "C" int tph_multinomial_counts(tph_ctx* ctx, const double* cdf_dev, int64
                                       int32_t* counts_dev) {
   TPH_REQUIRE(ctx && cdf_dev && counts_dev && n > 0 && n_draw_max > 0, "tph_multinomial_counts: bad argument");
   TPH_HIP(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * (size_t)n, ctx->stream));
-  if (n_draw_max >= MC_SORT_MIN && ctx->mc_sorted) {
+  const int64_t sort_min = ctx->mc_sorted > 1 ? (int64_t)ctx->mc_sorted : MC_SORT_MIN;     // > 1: the threshold itself (tests)
+  if (ctx->mc_sorted && n_draw_max >= sort_min) {
     // the sort is sized on the host: one 8-byte read of the count (the stream has to drain once; ~20 us against ~1 ms)
     int64_t n_draw = n_draw_max;
     if (kept_count_dev) {
@@ -681,7 +682,7 @@ extern "C" int tph_multinomial_counts(tph_ctx* ctx, const double* cdf_dev, int64
       if (n_draw > n_draw_max) n_draw = n_draw_max;
     }
     if (n_draw <= 0) return 0;
-    if (n_draw >= MC_SORT_MIN) {
+    if (n_draw >= sort_min) {
       size_t temp_bytes = 0;
       uint64_t* nullk = nullptr;
       TPH_HIP(rocprim::radix_sort_keys(nullptr, temp_bytes, nullk, nullk, (size_t)n_draw, MC_SORT_LO, 53, ctx->stream));

@@ -323,6 +323,41 @@ def test_multinomial_counts_sorted_draws_equal_the_draw_order_lookups(dev, kept)
     assert got[1].max() > 1000 and (got[1] == 0).mean() > 0.3
 
 
+def test_multinomial_counts_sorted_draws_edge_cases(dev):
+    """The sorted-draw merge at its edges (threshold lowered to 2 draws through the option): fewer draws than one thread's
+    chunk, exactly one chunk, one more, a count that is no multiple of 16; all the mass on one row; weightless rows at both ends
+    of the cdf; two rows; a single row.  Always the counts of the draw-order lookups."""
+    from tempest_amd.device import OPT_SORTED_DRAWS
+    rs = np.random.RandomState(5)
+    c = ctx_for(3)
+    cases = []
+    w = rs.rand(1000); cases.append(w / w.sum())
+    w = np.zeros(5000); w[1234] = 1.0; cases.append(w)
+    w = rs.rand(4096); w[:700] = 0.0; w[-900:] = 0.0; cases.append(w / w.sum())
+    cases.append(np.array([0.25, 0.75]))
+    cases.append(np.array([1.0]))
+    w = np.exp(8.0 * rs.randn(20000)); cases.append(w / w.sum())
+    for w in cases:
+        cdf = c.cdf(torch.from_numpy(w).to(dev))
+        for n_draw in (2, 15, 16, 17, 1000, 4099):
+            got = {}
+            for mode in (2, 0):
+                c.set_option(OPT_SORTED_DRAWS, mode)
+                got[mode] = c.multinomial_counts(cdf, seed=3, tick=n_draw, kept_count=None, factor=1, n_draw_max=n_draw).cpu().numpy()
+            assert got[2].sum() == n_draw
+            np.testing.assert_array_equal(got[2], got[0])
+            assert np.all(got[2][w == 0.0] == 0)
+    kc = torch.tensor([123.0], dtype=torch.float64, device=dev)          # the draw count from the device: 4 x 123
+    cdf = c.cdf(torch.from_numpy(cases[0]).to(dev))
+    c.set_option(OPT_SORTED_DRAWS, 2)
+    a = c.multinomial_counts(cdf, seed=3, tick=9, kept_count=kc, factor=4, n_draw_max=4000).cpu().numpy()
+    c.set_option(OPT_SORTED_DRAWS, 0)
+    b = c.multinomial_counts(cdf, seed=3, tick=9, kept_count=kc, factor=4, n_draw_max=4000).cpu().numpy()
+    c.set_option(OPT_SORTED_DRAWS, 1)
+    assert a.sum() == 492
+    np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("d,K", [(10, 1), (10, 3), (37, 1)])
 def test_fit_modes_compacts_sparse_upsampled_sets(dev, d, K):
     """Histories >= 262 144 rows whose multiplicities are mostly zero go through the order-preserving stream compaction
