@@ -751,7 +751,7 @@ def test_volume_variation_one_call_vs_oracle(dev, d):
 
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
 @pytest.mark.parametrize("bc", [None, "mixed"])
-@pytest.mark.parametrize("d", [19, 50, 100])
+@pytest.mark.parametrize("d", [19, 33, 50, 65, 100])       # 4 / 8 / 8 / 16 / 16 waves per tile: 3, 5, 7, 9, 13 row chunks
 def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d):
     """TPH_OPT_PROPOSE_VARIANT 4: attempt 0 of every particle in the blocked kernel (lane = particle, L and L^-1 through the
     scalar cache), the particles it leaves out of bounds finished by the multi-lane kernel from attempt 1 on.  Same draws and
