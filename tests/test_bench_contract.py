@@ -26,6 +26,12 @@ def test_committed_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["logz"] - d["analytic_logz"]) < 0.5
+    # the extras the docs quote: whole-run figures (cold, and repeated in the same process with the same evidence), the
+    # mutation-only rate and the HIP-callback leg on the same schedule
+    assert d["whole_run"]["value"] > 0 and d["whole_run_warm"]["same_logz_as_first_run"] is True
+    assert d["whole_run_warm"]["iterations"] == d["whole_run"]["iterations"] == d["iterations_total"]
+    assert d["whole_run_warm"]["seconds"] < d["whole_run"]["seconds"]
+    assert d["mutation_only"]["value"] > d["value"] and d["hip_callbacks"]["same_schedule_as_value_run"] is True
 
 
 def test_committed_profiles_are_self_consistent():
