@@ -237,12 +237,19 @@ class StepEngine:
     def _capture(self):
         """Stream capture of one step (torch.cuda.CUDAGraph without torch.cuda.graph's empty_cache(), which would hand
         the allocator's cached blocks back to the driver in the middle of a run)."""
+        import gc
         import torch
         ctx = self.ctx
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(device=ctx.device)
         side.wait_stream(torch.cuda.current_stream(ctx.device))
         began = False
+        # No finaliser may run while the stream is capturing: one that frees device memory or synchronises (a tensor, a
+        # HipContext or a CUDAGraph of an earlier Sampler that the cyclic collector happens to reach now) is an illegal call
+        # during capture and aborts the process.  As torch.cuda.graph() does: collect first, then keep the collector off.
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.stream(side):
                 ctx.use_current_stream()          # the capturing stream
@@ -263,6 +270,8 @@ class StepEngine:
             warnings.warn(f"MCMC step could not be captured as a graph ({type(e).__name__}: {e}); "
                           "launching step by step", stacklevel=2)
         finally:
+            if gc_was_on:
+                gc.enable()
             ctx.use_current_stream()
             torch.cuda.current_stream(ctx.device).wait_stream(side)
 
