@@ -63,6 +63,10 @@ def test_sharded_path_over_rccl_world1_equals_unsharded():
     res = json.loads(line[len("RESULT "):])
     for key in ("tpcn_mult", "rwm_syst"):
         a, b = res[key + "_0"], res[key + "_1"]
-        assert a == b, (key, a, b)
+        # evidence, iteration count and posterior size to the last bit; the weighted mean to rounding (the posterior weights are
+        # normalised by the kept sum of the trim, which the one-GPU function forms from segment sums of the sorted weights and
+        # the global one from the counters of its radix select: two summation orders)
+        assert a[0] == b[0] and a[1] == b[1] and a[3] == b[3], (key, a, b)
+        assert abs(a[2] - b[2]) <= 1e-12 * abs(a[2]), (key, a, b)
         truth = 2 * (np.log(np.pi / np.sqrt(10.0)) - np.log(400.0))
         assert abs(a[0] - truth) < 0.6      # the algorithm's own positive bias is ~0.2-0.3 here
