@@ -168,7 +168,7 @@ extern "C" int tph_trim_threshold(tph_ctx* ctx, const double* w_dev, int64_t n, 
                a_thr = al(sizeof(double) * (size_t)bins), a_slots = al(sizeof(double) * 2 * (size_t)nslots),
                a_seg = al(sizeof(double) * 2 * (size_t)bins);
   const size_t lds = sizeof(double) * (2 * (size_t)bins + 512);
-  TPH_REQUIRE(lds <= 64 * 1024, "tph_trim_threshold: bins=%d too many candidates", bins);
+  TPH_REQUIRE(lds <= 150 * 1024, "tph_trim_threshold: bins=%d: at most ~9000 candidates", bins);
   if (tph_scratch_reserve(ctx, a_n + a_tmp + a_first + a_thr + a_slots + a_seg)) return -1;
   char* base = (char*)ctx->scratch;
   double* S = (double*)base;
@@ -181,6 +181,8 @@ extern "C" int tph_trim_threshold(tph_ctx* ctx, const double* w_dev, int64_t n, 
   hipLaunchKernelGGL(k_trim_bounds, dim3(1), dim3(256), 0, ctx->stream, S, n, bins, first, thrs);
   hipLaunchKernelGGL(k_trim_segsums, dim3(nblk), dim3(256), 0, ctx->stream, S, n, per, first, bins, slots);
   hipLaunchKernelGGL(k_trim_segreduce, dim3(bins), dim3(64), 0, ctx->stream, slots, first, per, seg);
+  if (lds > 64 * 1024)
+    TPH_HIP(hipFuncSetAttribute((const void*)k_trim_decide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_trim_decide, dim3(1), dim3(256), lds, ctx->stream, seg, first, thrs, n, ess, bins, out_dev);
   TPH_LAUNCH_CHECK();
   if (out_host) {

@@ -234,6 +234,22 @@ def test_trim_threshold_golden(dev):
             np.testing.assert_allclose(ess_total, ps.effective_sample_size(w), rtol=1e-12)
 
 
+def test_trim_many_candidates_and_tiny_inputs(dev):
+    """The segmented form of the kept sums at its edges: more candidates than rows, a single row, all weights equal (every
+    candidate has the same first kept row), 5000 candidates (dynamic LDS above 64 KB) -- against the sorted-array oracle."""
+    rs = np.random.RandomState(12)
+    c = ctx_for(1)
+    cases = [(np.array([1.0]), 0.99, 10), (np.full(7, 1.0 / 7), 0.5, 1000), (rs.rand(50), 0.9, 1000),
+             (np.exp(2 * rs.randn(200_000)), 0.99, 5000), (np.exp(rs.randn(40_000)), 0.999, 1)]
+    for w, ess, bins in cases:
+        w = w / w.sum()
+        _, out = c.trim_threshold(torch.from_numpy(w).to(dev), ess, bins, sync=True)
+        thr, ksum, kcnt = ps.trim_threshold_sorted(w, ess, bins, normalized=True)
+        assert out[0] == thr and int(out[2]) == kcnt, (len(w), bins)
+        np.testing.assert_allclose(out[1], ksum, rtol=1e-12)
+        np.testing.assert_allclose(out[3], ps.effective_sample_size(w), rtol=1e-12)
+
+
 def test_trim_large_vs_oracle(dev):
     rs = np.random.RandomState(4)
     w = np.exp(3 * rs.randn(1_500_000)); w /= w.sum()
