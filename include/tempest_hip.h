@@ -125,7 +125,8 @@ int tph_comm_detach(tph_ctx* ctx);
  * host all-gathers the handles by any means, every rank calls _attach with all of them (rank order).  _attach maps the peers,
  * runs a self-test exchange and agrees with the other ranks through the attached all-reduce: *ok_out = 1 on every rank, or 0
  * on every rank (peer access or IPC unavailable: everything keeps going through the callbacks).  A peer that never arrives
- * makes the waiting kernel give up after TEMPEST_AMD_P2P_TIMEOUT seconds (default 120); the next collective, or
+ * makes the waiting kernel give up after TEMPEST_AMD_P2P_TIMEOUT seconds (default 120, or a longer
+ * TEMPEST_AMD_STEP_TIMEOUT); the next collective, or
  * tph_comm_p2p_status, then fails.  tph_comm_detach / tph_ctx_destroy unmap. */
 #define TPH_P2P_HANDLE_BYTES 64
 int tph_comm_p2p_export(tph_ctx* ctx, void* handle_out /* [TPH_P2P_HANDLE_BYTES] host */);
@@ -315,7 +316,9 @@ int tph_adapt(tph_ctx* ctx, int kernel, double* sums_dev /* in; out when partial
                                             are formed here (into sums_dev) instead of by a kernel of their own.  With a
                                             communicator attached they are THIS RANK's sums and the kernel all-reduces them
                                             with the peers in place (needs tph_comm_p2p_attach): a sharded step then has the
-                                            launches of a single-GPU step and no host call */,
+                                            launches of a single-GPU step and no host call.  Returns 1 (nothing launched) when
+                                            that exchange is not attached or 1 + K doubles exceed its 32 KB slot: all-reduce the
+                                            sums of tph_accept yourself and call again with partials_dev = NULL */,
               int64_t n);
 int tph_cluster_counts(tph_ctx* ctx, const int32_t* assign_dev, int64_t n, int K, double* counts_dev);
 

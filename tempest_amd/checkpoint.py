@@ -31,9 +31,40 @@ VERSION = 1
 SUFFIX = ".ckpt"
 
 
-def is_native(path) -> bool:
+def _old(path) -> Path:
+    path = Path(path)
+    return path.with_name(path.name + ".old")
+
+
+def _resolve(path) -> Path:
+    """The directory holding the newest COMPLETE checkpoint under this name: `path`, or -- if a writer died between the two
+    renames of save() -- the previous checkpoint it had just moved aside to `<path>.old`."""
     p = Path(path)
+    if p.is_dir() and (p / "meta.json").exists():
+        return p
+    o = _old(p)
+    if o.is_dir() and (o / "meta.json").exists():
+        return o
+    return p
+
+
+def is_native(path) -> bool:
+    p = _resolve(path)
     return p.is_dir() and (p / "meta.json").exists()
+
+
+def _fsync_path(p):
+    """Flush a file (or a directory's entries) to stable storage; best effort on file systems that refuse it."""
+    try:
+        fd = os.open(str(p), os.O_RDONLY)
+    except OSError:
+        return
+    try:
+        os.fsync(fd)
+    except OSError:
+        pass
+    finally:
+        os.close(fd)
 
 
 def wants_native(path, fmt=None, comm=None) -> bool:
@@ -83,6 +114,9 @@ def save(core, path):
     path = Path(path)
     tmp = path.with_name(path.name + ".tmp")
     if rank == 0:
+        old = _old(path)
+        if not path.exists() and old.exists():
+            os.rename(old, path)         # an earlier writer died between its two renames: its previous checkpoint is the good one
         if tmp.exists():
             shutil.rmtree(tmp)
         tmp.mkdir(parents=True)
@@ -107,6 +141,8 @@ def save(core, path):
         np.ascontiguousarray(t.detach().to(torch.int32).cpu().numpy(), dtype="<i4").tofile(f"{stem}.cur_assign.i32")
     if st._blobs or st._current.get("blobs") is not None:
         np.save(f"{stem}.blobs.npy", np.array([st._blobs, st._current.get("blobs")], dtype=object), allow_pickle=True)
+    for f in tmp.glob(f"shard{rank:04d}.*"):      # this rank's shard files reach the disk before the directory is renamed
+        _fsync_path(f)
     _barrier(comm)
     if rank == 0:
         cur = {k: _json_scalar(v) for k, v in st._current.items()
@@ -127,13 +163,16 @@ def save(core, path):
             json.dump(meta, f, indent=1)
             f.flush()
             os.fsync(f.fileno())
-        # replace without a window in which no complete checkpoint exists: old -> .old, new -> path, then drop .old
-        old = path.with_name(path.name + ".old")
-        if old.exists():
-            shutil.rmtree(old)
+        _fsync_path(tmp)
+        # replace: old -> .old, new -> path, then drop .old.  Between the two renames the complete checkpoint is `.old`:
+        # load() / is_native() fall back to it, and the next save() moves it back before it touches anything.
+        old = _old(path)
         if path.exists():
+            if old.exists():
+                shutil.rmtree(old)
             os.rename(path, old)
         os.rename(tmp, path)
+        _fsync_path(path.parent)
         if old.exists():
             shutil.rmtree(old)
     _barrier(comm)
@@ -147,7 +186,7 @@ def load(core, path):
     active = comm is not None and comm.active
     rank = comm.rank if active else 0
     world = comm.world_size if active else 1
-    path = Path(path)
+    path = _resolve(path)
     with open(path / "meta.json") as f:
         meta = json.load(f)
     if meta.get("format") != FORMAT:

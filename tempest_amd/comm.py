@@ -182,11 +182,13 @@ class Comm:
         allp = self.all_gather(pad)
         return torch.cat([allp[r, : counts[r]] for r in range(self.world_size)], dim=0), counts
 
-    def all_reduce_sum(self, t):
+    def all_reduce_sum(self, t, host_paced=False):
         """In-place SUM all-reduce of a tensor (device tensor -> RCCL; CPU tensor -> gloo); small FP64 / integer device
-        tensors go through the library's peer-to-peer exchange on the ctx stream when that is attached."""
+        tensors go through the library's peer-to-peer exchange on the ctx stream when that is attached -- unless the caller
+        says the ranks are `host_paced` (user callbacks running on the host between two collectives: the ranks may then be
+        minutes apart, which the device-side spin of the exchange kernel must not be asked to sit out)."""
         if self.active:
-            ctx = self._p2p_ctx() if self._p2p_ctx is not None else None
+            ctx = self._p2p_ctx() if (self._p2p_ctx is not None and not host_paced) else None
             if (ctx is not None and t.is_cuda and t.is_contiguous() and t.numel() * t.element_size() <= 32768
                     and t.dtype in _P2P_DTYPES() and t.device == ctx.device and ctx.p2p_active):
                 ctx.allreduce_dev(t, 0)

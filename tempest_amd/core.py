@@ -124,23 +124,25 @@ class CallbackAdapter:
             results = list(map(cfg.log_likelihood, x))
         if results and isinstance(results[0], (tuple, list)) and len(results[0]) > 1:
             logl = np.array([float(r[0]) for r in results])
-            blob = [r[1:] for r in results]
-            dt = cfg.blobs_dtype
-            if dt is None:
-                try:
-                    dt = np.atleast_1d(blob[0]).dtype
-                except ValueError:
-                    dt = np.dtype("object")
-                if dt.kind in "US":
-                    dt = np.dtype("object")
-            blob = np.array(blob, dtype=dt)
-            shape = blob.shape[1:]
-            if len(shape):
-                axes = np.arange(len(shape))[np.array(shape) == 1] + 1
-                if len(axes):
-                    blob = np.squeeze(blob, tuple(axes))
-            return logl, blob
+            return logl, _pack_blobs([r[1:] for r in results], cfg.blobs_dtype)
         return np.array([float(v) for v in results]), None
+
+
+def _pack_blobs(rows, dtype=None):
+    """The per-sample auxiliary outputs of a non-vectorised likelihood as ONE host array with the sample axis first.
+    The element type is the configured `blobs_dtype`, else that of the first sample (text and anything NumPy cannot type
+    become `object`); axes of length one behind the sample axis are dropped, so one scalar per sample gives shape (n,).
+    Behaviour of the reference's blob handling (core.py:335-352); host data the device path never sees."""
+    if dtype is None:
+        try:
+            dtype = np.asarray(rows[0]).dtype
+        except ValueError:               # ragged sample
+            dtype = np.dtype(object)
+        if dtype.kind in ("U", "S"):
+            dtype = np.dtype(object)
+    arr = np.array(rows, dtype=dtype)
+    shape = arr.shape[:1] + tuple(m for m in arr.shape[1:] if m != 1)
+    return arr if shape == arr.shape else arr.reshape(shape)
 
 
 class SamplerCore:

@@ -81,6 +81,7 @@ struct tph_ctx {
   const void* blk_src = nullptr;
   void* blk_buf = nullptr;          // blocked copies of L and L^-1 + the straggler flags
   size_t blk_bytes = 0;
+  std::vector<void*> retired;       // outgrown buffers a captured hipGraph of an earlier step may still address: freed with the ctx
   double* vv_buf = nullptr;         // small persistent buffers of tph_volume_variation (moments, factors, blocked L^-1)
   size_t vv_bytes = 0;
   uint64_t vv_seq = 0;

@@ -152,6 +152,7 @@ extern "C" int tph_ctx_destroy(tph_ctx* ctx) {
   void* bufs[] = {ctx->u, ctx->x, ctx->logl, ctx->cmix, ctx->table_dev, ctx->partials, ctx->small_dev, ctx->scratch, ctx->winv,
                   ctx->blk_table, ctx->vv_buf, ctx->blk_buf, ctx->rows};
   for (void* b : bufs) (void)hipFree(b);
+  for (void* b : ctx->retired) (void)hipFree(b);
   (void)hipHostFree(ctx->pinned);
   if (ctx->table_host) (void)hipHostFree(ctx->table_host);
   delete ctx;

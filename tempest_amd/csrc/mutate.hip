@@ -610,7 +610,7 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   const size_t need = sizeof(double) * 2 * tb + sizeof(int32_t) * ((size_t)n + 2);
   if (ctx->blk_bytes < need) {
     TPH_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->blk_buf) TPH_HIP(hipFree(ctx->blk_buf));
+    if (ctx->blk_buf) ctx->retired.push_back(ctx->blk_buf);   // a captured step of a smaller engine may still point here
     ctx->blk_buf = nullptr; ctx->blk_bytes = 0; ctx->blk_epoch = -1;
     TPH_HIP(hipMalloc((void**)&ctx->blk_buf, need));
     ctx->blk_bytes = need;
@@ -619,10 +619,17 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   double* Wb = Lb + tb;
   int32_t* todo = (int32_t*)(Wb + tb);               // [0] = number of stragglers of this step, [1..] their rows
   TPH_HIP(hipMemsetAsync(todo, 0, sizeof(int32_t), ctx->stream));
-  if (ctx->modes_epoch <= 0 || ctx->blk_epoch != ctx->modes_epoch || ctx->blk_src != (const void*)chol) {
+  // A launch that is being CAPTURED into a hipGraph always records the rebuild: a replayed step never re-enters this host
+  // code, so an epoch test made here would freeze the copies of the capture-time statistics while the caller refreshes the
+  // fixed-address chol / winv between runs (the straggler pass and tpCN's carried form read those) -- two covariances inside
+  // one Metropolis ratio.  The copies made under capture are not trusted by later eager calls either.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  TPH_HIP(hipStreamIsCapturing(ctx->stream, &cap));
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  if (capturing || ctx->modes_epoch <= 0 || ctx->blk_epoch != ctx->modes_epoch || ctx->blk_src != (const void*)chol) {
     hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, chol, d, Lb);
     if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, winv, d, Wb);
-    ctx->blk_epoch = ctx->modes_epoch; ctx->blk_src = (const void*)chol;
+    ctx->blk_epoch = capturing ? -1 : ctx->modes_epoch; ctx->blk_src = (const void*)chol;
   }
   // waves per 64-particle tile: one 8-row chunk per wave up to 128 rows (the chunks of a triangular matrix are unequal: with
   // fewer waves the longest chain of chunks bounds the tile; measured 65 536 x 50-D: 4 -> 8 waves 76 -> 70 us (tpCN), 53 -> 46 us
@@ -947,7 +954,7 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
     const size_t bytes = sizeof(double) * (size_t)K * ctx->d * ctx->d;
     if (ctx->winv_bytes < bytes) {
       TPH_HIP(hipStreamSynchronize(ctx->stream));
-      if (ctx->winv) TPH_HIP(hipFree(ctx->winv));
+      if (ctx->winv) ctx->retired.push_back(ctx->winv);
       ctx->winv = nullptr; ctx->winv_bytes = 0;
       TPH_HIP(hipMalloc((void**)&ctx->winv, bytes));
       ctx->winv_bytes = bytes;
@@ -1207,9 +1214,16 @@ extern "C" int tph_adapt(tph_ctx* ctx, int kernel, double* sums_dev, const doubl
   p2p_args peers{};
   int exchange = 0;
   if (partials_dev && ctx->comm_active()) {
+    // not attached, or 1 + K doubles do not fit one 32 KB slot: a usage condition the caller can act on (code 1: all-reduce the
+    // sums of tph_accept yourself and pass partials_dev = NULL); an exchange that FAILED earlier keeps its own message
+    if (!tph_p2p_fits(ctx, 1 + K, TPH_DT_F64)) {
+      tph_set_error("tph_adapt: folding the block partials of a SHARDED step needs the peer-to-peer exchange (tph_comm_p2p_attach) and "
+                    "1 + K = %d doubles within one %zu-byte slot; all-reduce the sums of tph_accept yourself and pass partials_dev = NULL",
+                    1 + K, (size_t)TPH_P2P_SLOT);
+      return 1;
+    }
     const p2p_args* a = tph_p2p_ready(ctx, 1 + K, TPH_DT_F64);
-    TPH_REQUIRE(a, "tph_adapt: folding the block partials of a SHARDED step needs the peer-to-peer exchange (tph_comm_p2p_attach); "
-                "without it all-reduce the sums of tph_accept yourself and pass partials_dev = NULL");
+    if (!a) return -2;                    // the sticky error of a timed-out exchange (text set by tph_p2p_ready)
     peers = *a;
     exchange = 1;
   }

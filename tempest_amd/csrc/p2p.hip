@@ -81,6 +81,18 @@ static void p2p_release(tph_ctx* ctx) {
   ctx->p2p = nullptr;
 }
 void tph_p2p_release(tph_ctx* ctx) { p2p_release(ctx); }
+// text of the sticky error word: 1 + rank that never raised its flag, or TPH_P2P_ERR_TAG (a shuffled row with a foreign tag)
+constexpr unsigned int TPH_P2P_ERR_TAG = 1000u;
+static int p2p_fail(unsigned int code) {
+  if (code == TPH_P2P_ERR_TAG)
+    tph_set_error("one-sided resample shuffle: a slot of this rank's window was not written for this exchange (window tag mismatch: "
+                  "a peer selected different rows or ran a different sequence of shuffles)");
+  else
+    tph_set_error("a peer-to-peer exchange timed out: rank %u never raised its flag (a peer died, ran a different sequence of "
+                  "collectives, or is more than TEMPEST_AMD_P2P_TIMEOUT seconds behind)", code - 1);
+  return -2;
+}
+
 
 bool tph_p2p_fits(const tph_ctx* ctx, int64_t count, int dtype) {
   return ctx->p2p && ctx->p2p->ready && count > 0 && (size_t)count * (dtype == TPH_DT_I32 ? 4 : 8) <= TPH_P2P_SLOT;
@@ -89,8 +101,7 @@ bool tph_p2p_fits(const tph_ctx* ctx, int64_t count, int dtype) {
 const p2p_args* tph_p2p_ready(tph_ctx* ctx, int64_t count, int dtype) {
   if (!tph_p2p_fits(ctx, count, dtype)) return nullptr;
   if (*ctx->p2p->err_host != 0) {
-    tph_set_error("a peer-to-peer exchange timed out: rank %u never raised its flag (a peer died or ran a different sequence of "
-                  "collectives)", *ctx->p2p->err_host - 1);
+    (void)p2p_fail(*ctx->p2p->err_host);
     return nullptr;
   }
   return &ctx->p2p->a;
@@ -100,8 +111,7 @@ const p2p_args* tph_p2p_ready(tph_ctx* ctx, int64_t count, int dtype) {
 int tph_p2p_exchange(tph_ctx* ctx, const void* src, void* dst, int64_t count, int dtype, int op) {
   tph_p2p* p = ctx->p2p;
   TPH_REQUIRE(p && p->ready, "peer-to-peer collectives are not attached");
-  TPH_REQUIRE(*p->err_host == 0, "a peer-to-peer exchange timed out: rank %u never raised its flag (a peer died or ran a different "
-              "sequence of collectives)", *p->err_host - 1);
+  if (*p->err_host != 0) return p2p_fail(*p->err_host);
   switch (dtype) {
     case TPH_DT_F64: hipLaunchKernelGGL(k_p2p<double>, dim3(1), dim3(256), 0, ctx->stream, p->a, (const double*)src, (double*)dst, (int)count, op); break;
     case TPH_DT_I64: hipLaunchKernelGGL(k_p2p<long long>, dim3(1), dim3(256), 0, ctx->stream, p->a, (const long long*)src, (long long*)dst, (int)count, op); break;
@@ -164,7 +174,11 @@ extern "C" int tph_comm_p2p_attach(tph_ctx* ctx, const void* handles, int* ok_ou
   *ok_out = 0;
   const int G = ctx->world;
   p->a.world = G; p->a.rank = ctx->rank;
+  // how far apart two ranks may arrive at an exchange before it is declared dead.  A step of a sharded run may legitimately take
+  // long on one rank (first-use compilation of a callback, a shared GPU): TEMPEST_AMD_P2P_TIMEOUT sets the bound explicitly,
+  // else a longer TEMPEST_AMD_STEP_TIMEOUT (the host's own patience with a step, mcmc.py: wait_record) extends the default
   double secs = 120.0;
+  if (const char* env = getenv("TEMPEST_AMD_STEP_TIMEOUT")) secs = atof(env) > secs ? atof(env) : secs;
   if (const char* env = getenv("TEMPEST_AMD_P2P_TIMEOUT")) secs = atof(env) > 0 ? atof(env) : secs;
   p->a.timeout = (unsigned long long)(secs * 1e8);
   int ok = 1;
@@ -235,8 +249,7 @@ extern "C" int tph_comm_p2p_active(const tph_ctx* ctx) { return ctx && ctx->p2p 
 extern "C" int tph_comm_p2p_status(tph_ctx* ctx) {
   TPH_REQUIRE(ctx, "tph_comm_p2p_status: ctx is NULL");
   if (!ctx->p2p || !ctx->p2p->ready) return 0;
-  TPH_REQUIRE(*ctx->p2p->err_host == 0, "a peer-to-peer exchange timed out: rank %u never raised its flag (a peer died or ran a "
-              "different sequence of collectives)", *ctx->p2p->err_host - 1);
+  if (*ctx->p2p->err_host != 0) return p2p_fail(*ctx->p2p->err_host);
   return 0;
 }
 
@@ -325,7 +338,7 @@ __global__ void __launch_bounds__(256) k_unpack_rows(const double* win, int d, i
     if (c < d) u[(size_t)c * ld + i] = v;
     else if (c < 2 * d) x[(size_t)(c - d) * ld + i] = v;
     else if (c == 2 * d) l[i] = v;
-    else if (v != tag) *err = 1000u;
+    else if (v != tag) *err = TPH_P2P_ERR_TAG;
   }
 }
 
@@ -399,7 +412,7 @@ extern "C" int tph_resample_put_global(tph_ctx* ctx, const int64_t* idx_dev, int
   TPH_REQUIRE(ctx->p2p && ctx->p2p->ready, "tph_resample_put_global: needs the peer-to-peer exchange (tph_comm_p2p_attach)");
   TPH_REQUIRE(n_local > 0 && n_slots == n_local * ctx->world && ld_out >= n_local && ctx->size > 0, "tph_resample_put_global: bad sizes");
   tph_p2p* p = ctx->p2p;
-  TPH_REQUIRE(*p->err_host == 0, "peer-to-peer exchange failed earlier (code %u)", *p->err_host);
+  if (*p->err_host != 0) return p2p_fail(*p->err_host);
   const int d = ctx->d, rec = 2 * d + 2;
   int usable = 0;
   if (p2p_window_reserve(ctx, sizeof(double) * (size_t)n_local * rec, &usable)) return -2;

@@ -90,7 +90,7 @@ class StepEngine:
         self.n_steps, self.n_max, self.comm_active = n_steps, n_max, comm_active
         # with the library's peer-to-peer exchange attached, the all-reduce of the step's sums is a kernel on the ctx stream:
         # it belongs to the step (and to its graph) like every other launch; otherwise the host calls the process group
-        self.inline_reduce = bool(comm_active and ctx.p2p_active)
+        self.inline_reduce = bool(comm_active and ctx.p2p_active and 8 * (1 + K) <= 32768)   # one exchange slot (p2p.h)
         self.up, self.maha_u, self.maha_up = ctx.empty(d, n), ctx.empty(n), ctx.empty(n)
         self.u = self.logl = self.assign = self.modes = None
         if use_graph:       # fixed-address copies of everything a captured step reads or writes
@@ -134,9 +134,12 @@ class StepEngine:
         else:
             self.u, self.logl, self.assign, self.modes = u, logl, assign, modes
         if self.ctx.n_dim > 16:        # new mode statistics: the library rebuilds its blocked copies of L and L^-1 once
-            from .device import OPT_MODES_EPOCH
+            from .device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_MODES_EPOCH
             StepEngine._epoch += 1
             self.ctx.set_option(OPT_MODES_EPOCH, StepEngine._epoch)
+            # the proposal regime is an option of the ctx, which engines of other shapes share: re-assert this engine's
+            self.ctx.set_option(OPT_BLOCKED, 1 if self.blocked else 0)
+            self.ctx.set_option(OPT_ML_UNSTAGED, 1 if self.unstaged else 0)
         self.sigmas.fill_(sigma_init)
         self.pending.zero_()
         self.counts.copy_(counts)
@@ -373,8 +376,8 @@ class DeviceMCMC:
                     # redraw cap -- has the current point's blob anyway)
                     moved = (u == up).all(dim=0).cpu().numpy()
                     self.blobs[moved] = np.asarray(bp)[moved]
-            if active:
-                self.comm.all_reduce_sum(sums)
+            if active:          # this path runs host callbacks (or blobs): the ranks are paced by them, not by the device
+                self.comm.all_reduce_sum(sums, host_paced=True)
             # one GPU: tph_adapt sums the Metropolis kernel's block partials itself (one launch less per step)
             ctx.adapt(self.kernel, sums, counts, K, n_global, self.n_steps, self.n_max, sigmas, state,
                       partials=None if active else partials, n=n)

@@ -172,6 +172,18 @@ def test_native_checkpoint_roundtrip_and_resume(tmp_path):
     s4 = tp.Sampler(prior20, lambda x: -0.5 * (x ** 2).sum(dim=1), 4, n_particles=64, vectorize=True, clustering=False)
     with pytest.raises(ValueError, match="n_dim"):
         s4.load_state(path)
+    # a writer that died between the two renames of save() left the complete checkpoint as `<name>.old`: readers fall
+    # back to it, and the next save() moves it back before it clears anything
+    import os
+    os.rename(path, tmp_path / "run.ckpt.old")
+    s5 = mk()
+    s5.load_state(path)
+    np.testing.assert_array_equal(s5.state.get_history("x", flat=True), s.state.get_history("x", flat=True))
+    s5.save_state(path)
+    assert path.is_dir() and not (tmp_path / "run.ckpt.old").exists() and not (tmp_path / "run.ckpt.tmp").exists()
+    s6 = mk()
+    s6.load_state(path)
+    np.testing.assert_array_equal(s6.state.get_history("x", flat=True), s.state.get_history("x", flat=True))
 
 
 @pytest.mark.parametrize("fname", ["ref_state_small.state", "ref_state_small_core.state"])

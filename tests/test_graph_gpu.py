@@ -54,6 +54,33 @@ def test_graph_run_is_bit_identical(kernel, clustering, like, d):
     np.testing.assert_array_equal(runs[0][2], runs[1][2])
 
 
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+def test_graph_replay_of_the_blocked_proposal_follows_new_mode_statistics(kernel):
+    """d > 16, every dimension reflective: every first attempt is in bounds, so the engine switches to the blocked proposal
+    kernel during its first run and captures the step with it in the second.  The row-blocked copies of L and L^-1 that kernel
+    reads are rebuilt by host code a replayed graph never re-enters: each PS iteration loads new mode statistics, and the
+    replayed step must see them (the rebuild is recorded into the graph) -- whole runs bit-identical to step-by-step launches."""
+    import tempest_amd as tp
+    d = 20
+    mean = torch.linspace(-3, 3, d, dtype=torch.float64, device="cuda:0")
+
+    def like(x):
+        return -0.5 * (((x - mean) / 0.7) ** 2).sum(dim=1)
+    runs = []
+    for graph in (False, True):
+        s = tp.Sampler(prior20, like, d, n_particles=512, vectorize=True, clustering=False, random_state=11,
+                       sample=kernel, graph=graph, reflective=list(range(d)))
+        s.run(n_total=2048, progress=False)
+        runs.append((s.evidence()[0], _history(s), s.posterior()[0], s))
+    eng = list(runs[1][3]._core.mutator._engines.values())
+    assert eng and any(e.graph is not None and e.blocked and e.runs >= 4 for e in eng), \
+        "the blocked proposal kernel was never replayed as a graph over several iterations"
+    assert runs[0][0] == runs[1][0]
+    for k in runs[0][1]:
+        np.testing.assert_array_equal(runs[0][1][k], runs[1][1][k], err_msg=k)
+    np.testing.assert_array_equal(runs[0][2], runs[1][2])
+
+
 def test_uncapturable_callback_falls_back():
     """A likelihood that synchronises with the host cannot be stream-captured: the engine warns once and keeps launching
     step by step, with the same numbers."""

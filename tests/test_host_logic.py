@@ -23,6 +23,14 @@ def test_checkpoint_format_selection(tmp_path):
     from tempest_amd import checkpoint as ck
     assert ck.wants_native(tmp_path / "a.ckpt") and not ck.wants_native(tmp_path / "a.state")
     assert ck.wants_native(tmp_path / "a.state", "native") and not ck.wants_native(tmp_path / "a.ckpt", "dill")
+    # a checkpoint caught between the two renames of save() exists as `<name>.old` only: still found
+    assert not ck.is_native(tmp_path / "run.ckpt")
+    (tmp_path / "run.ckpt.old").mkdir()
+    (tmp_path / "run.ckpt.old" / "meta.json").write_text("{}")
+    assert ck.is_native(tmp_path / "run.ckpt") and ck._resolve(tmp_path / "run.ckpt").name == "run.ckpt.old"
+    (tmp_path / "run.ckpt").mkdir()
+    (tmp_path / "run.ckpt" / "meta.json").write_text("{}")
+    assert ck._resolve(tmp_path / "run.ckpt").name == "run.ckpt"
     with pytest.raises(ValueError):
         ck.wants_native(tmp_path / "a", "hdf5")
     (tmp_path / "d").mkdir()
