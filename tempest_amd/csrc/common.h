@@ -81,6 +81,14 @@ struct tph_ctx {
   const void* blk_src = nullptr;
   void* blk_buf = nullptr;          // blocked copies of L and L^-1 + the straggler flags
   size_t blk_bytes = 0;
+  // stage-machine proposal kernel (propose_sm.hip): TPH_OPT_STAGED_REDRAW / _SM_LANES / _SM_THRESHOLD and its persistent buffers
+  int staged = 0, sm_lanes = 0, sm_thr = 0;
+  void* sm_small = nullptr;         // queue words | L in 4-row blocks | L^-1 in 8-row blocks
+  size_t sm_small_bytes = 0;
+  double* sm_scr = nullptr;         // per-lane columns of the rows an attempt has passed
+  size_t sm_scr_bytes = 0;
+  int sm_epoch = -1, sm_kernel = -1;
+  const void* sm_src = nullptr;
   std::vector<void*> retired;       // outgrown buffers a captured hipGraph of an earlier step may still address: freed with the ctx
   double* vv_buf = nullptr;         // small persistent buffers of tph_volume_variation (moments, factors, blocked L^-1)
   size_t vv_bytes = 0;
@@ -114,6 +122,10 @@ int tph_blocks(tph_ctx* ctx, int64_t n, int* T, int64_t* rows);   // equal-sized
 int tph_scratch_reserve(tph_ctx* ctx, size_t bytes);
 const double* tph_rows_sync(tph_ctx* ctx);          // resample.hip: mirror up to date for rows [0, size), or NULL (not in use)
 int tph_tri_inv(tph_ctx* ctx, const double* chol_dev, int K, double* winv_dev);   // modes.hip
+// propose_sm.hip: the whole proposal of a redraw-dominated step at 16 < d <= 64, one mode (pending moves, forms, u')
+int tph_propose_sm(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
+                   const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
+                   const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend);
 
 // --------------------------------------------------------------------------------- device helpers
 #if defined(__HIPCC__)
@@ -309,6 +321,13 @@ __device__ __forceinline__ double maha_w(const double* __restrict__ W, const dou
     m = fma(acc, acc, m);
   }
   return m;
+}
+
+// Zeroing a few device words on the stream: a KERNEL, not hipMemsetAsync -- inside a captured hipGraph the memset node of
+// this ROCm release is not reliably ordered against the kernel nodes around it (the work-queue words of propose_sm.hip came
+// back holding stale data on the second replay of a captured step; the same launch sequence issued eagerly was fine).
+static __global__ void k_zero_words(unsigned int* __restrict__ p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
 }
 
 // ---- wave / block reductions (wave64) ----

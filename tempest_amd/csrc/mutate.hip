@@ -618,7 +618,7 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   double* Lb = (double*)ctx->blk_buf;
   double* Wb = Lb + tb;
   int32_t* todo = (int32_t*)(Wb + tb);               // [0] = number of stragglers of this step, [1..] their rows
-  TPH_HIP(hipMemsetAsync(todo, 0, sizeof(int32_t), ctx->stream));
+  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)todo, 1);
   // A launch that is being CAPTURED into a hipGraph always records the rebuild: a replayed step never re-enters this host
   // code, so an epoch test made here would freeze the copies of the capture-time statistics while the caller refreshes the
   // fixed-address chol / winv between runs (the straggler pass and tpCN's carried form read those) -- two covariances inside
@@ -964,6 +964,9 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
   }
   const int variant = ctx->propose_variant;   // 0 auto | 1 one-lane LDS | 2 one-lane registers (d<=16) | 3 multi-lane | 4 blocked
   const bool use_reg = (variant == 2 || variant == 0) && ctx->d <= 16;
+  if (!use_reg && ctx->d > 16 && ctx->d <= 64 && !assign_dev && K == 1 && (variant == 5 || (variant == 0 && ctx->staged && !ctx->blocked)))
+    return tph_propose_sm(ctx, kernel, u_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick0, ctl_dev,
+                          item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev);
   if (!use_reg && ctx->d > 16 && ctx->d <= 100 && !assign_dev && K == 1 && (variant == 4 || (variant == 0 && ctx->blocked))) {
     if (kernel == TPH_KERNEL_TPCN)
       return launch_propose_blk<TPH_KERNEL_TPCN>(ctx, u_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed,

@@ -1,0 +1,467 @@
+// Redraw-dominated proposals at 16 < d <= 64, one mode: every lane walks the rows of its own attempt.
+// Reference: tempest/mcmc.py:225-249 (tpCN), :301-312 (RWM): a walker's proposal is REDRAWN until it lies in the unit cube.
+//
+// In the first iterations of a high-dimensional run nearly every attempt leaves the cube (50-D at sigma_0: ~98 %, i.e. ~60
+// attempts per particle and step; 100-D: ~290), and almost all of them fail early: L is lower-triangular, so coordinate r of
+// an attempt needs only the normals z_0..z_r, and an attempt that violates a bound at row r* is decided after r*/2 Box-Muller
+// pairs and r*^2/2 FMAs.  What such a step costs is therefore the number of Box-Muller pairs it generates (848 SIMD cycles
+// per wave-call for two normals, against ~5 per FMA).  k_propose_ml (lane groups walking their particle's attempts) spends
+// several times the pairs an ideal schedule needs: the particles of a wave diverge in their attempt counts and every round
+// draws a full group of pairs.  Here:
+//   * a LANE owns an attempt; its normals z_0..z_r live in the lane's column of an LDS tile zs[j][lane];
+//   * every step, EVERY busy lane draws the next two Box-Muller pairs of its attempt (two independent chains) and evaluates
+//     the next four rows -- whatever row it has reached: the Cholesky factor sits in LDS (one copy per workgroup, zero above
+//     the diagonal) and a lane reads ITS rows; the column loop runs to the deepest lane's row, shallower lanes multiply
+//     zeros.  An attempt stops at its first out-of-bounds coordinate and the lane starts its next attempt in the next step;
+//   * G consecutive lanes work on ONE particle: lane g tries attempts g, g+G, g+2G, ... and the first in-bounds attempt IN
+//     ATTEMPT ORDER wins -- exactly the proposal the sequential loop returns (counter-based draws keyed by the attempt
+//     number).  Lanes whose attempt number has passed the best success so far stop at once;
+//   * particles come from a global queue in chunks of 16 (one atomic per chunk), so waves finish together;
+//   * the rows an attempt has passed are parked in the lane's record of a global scratch (32 B per step) and copied to u'
+//     when the particle is decided.
+// Draws, attempt order and the arithmetic of a row (ascending-j FMA chain, v = fma(b, (L z)_r, base_r)) are those of the
+// other proposal kernels: the same proposal to rounding.  tpCN's Mahalanobis forms are left to k_maha_tile (tri.h products).
+// Two earlier forms, measured on 65 536 x 50-D from the prior (99 attempts per particle; k_propose_ml 3.5 ms): z in
+// REGISTERS with one unrolled case per stage -- the compiler issued every scalar matrix load of a case ahead of its first FMA
+// and spilled ~100 SGPRs through v_writelane / v_readlane, four spill instructions per FMA; and a "stage machine" that ran the
+// rows stage by stage with wave-uniform matrix rows through the scalar cache -- 4.7 ms: at the 5 waves per CU the z tile
+// allows, every stage's serial chain of scalar-load, LDS and store latencies (6 300 cycles per stage pass) was exposed.
+#include "common.h"
+#include "tri.h"
+
+constexpr int SM_CAP = PROP_MAX_ATTEMPTS;      // attempts 0 .. SM_CAP-1, then the current point is proposed
+constexpr int SM_CHUNK = 4;                    // particles per queue grab (small: the last chunks set the kernel's tail)
+constexpr int SM_ROWS = 4;                     // rows per step (two Box-Muller pairs)
+
+__device__ __forceinline__ void sm_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// LDS copy of L for per-lane row access.  An instruction reads, for every lane, 16 bytes of row 4 s_lane + q at the same
+// column pair: with a plain row-major layout the rows of different stages would fall on two or four bank groups.  Row r is
+// therefore stored at  r * stride + 2 * ((r / 4) mod 8) + j  with stride a multiple of 4 doubles: eight consecutive stages
+// then start on eight different 16-byte bank groups (lanes at the same stage read the same address: a broadcast).
+__host__ __device__ static inline int sm_stride(int dc) { return (dc + 14 + 3) & ~3; }
+__host__ __device__ static inline int sm_skew(int r) { return 2 * ((r >> 2) & 7); }
+
+// Lg[dc][dc]: L padded with zeros above the diagonal and beyond d (the kernels below multiply, they do not branch); one workgroup
+static __global__ void __launch_bounds__(256) k_sm_pad(const double* __restrict__ chol, int d, int dc, double* __restrict__ Lg) {
+  for (int e = threadIdx.x; e < dc * dc; e += blockDim.x) {
+    const int r = e / dc, j = e - r * dc;
+    Lg[e] = (r < d && j <= r) ? chol[(size_t)r * d + j] : 0.0;
+  }
+}
+
+template <int KERNEL>
+__global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u, int64_t n, int64_t ld, int d,
+                                                    const double* __restrict__ means, const double* __restrict__ Lg,
+                                                    const double* __restrict__ sigmas, const uint8_t* __restrict__ bc,
+                                                    uint64_t seed, tph_stepctl tick, int64_t item0, double* __restrict__ up,
+                                                    const double* __restrict__ bfac, double* __restrict__ vscr,
+                                                    double* __restrict__ bscr, int lgG,
+                                                    unsigned long long* __restrict__ queue /* [0] next chunk, [1] sum of
+                                                    attempts, [2] particles decided */) {
+  extern __shared__ double sm_lds[];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = 1 << lgG;
+  const int nst = (d + SM_ROWS - 1) / SM_ROWS, dc = SM_ROWS * nst, npairs = (d + 1) >> 1;
+  const int stride = sm_stride(dc);
+  double* Lt = sm_lds;                                         // [dc][stride] (+ skew): the workgroup's copy of L
+  double* zs = Lt + (size_t)dc * stride + (size_t)wid * dc * 64;    // [dc][64] normals of this wave's attempts
+  for (int e = threadIdx.x; e < dc * dc; e += blockDim.x) {
+    const int r = e / dc, j = e - r * dc;
+    Lt[(size_t)r * stride + sm_skew(r) + j] = Lg[e];
+  }
+  for (int e = lane; e < dc * 64; e += 64) zs[e] = 0.0;        // stale columns are multiplied by zeros of L: they must be finite
+  __syncthreads();
+  const uint32_t tk = tick;              // the step's RNG tick, read from the control block ONCE: inside the loop its two loads would
+                                         // wait for every load in flight (vmcnt counts in order), the prefetched coordinates included
+  const size_t wave_id = (size_t)blockIdx.x * (blockDim.x >> 6) + wid;
+  double* __restrict__ vrec = vscr + (wave_id * 64 + lane) * (size_t)dc;      // this lane's record of passed rows
+  // the groups' particles as contiguous records base[r] = mu_r + a (u_r - mu_r) (tpCN) or u_r (RWM), written when a group takes a
+  // particle: a step reads four consecutive doubles of it (one 32-byte sector, shared by the group's lanes), where the
+  // dimension-major u costs four scattered 64-byte sectors per lane and step -- 8 GB per launch at 65 536 x 50-D from the prior
+  double* __restrict__ brec = bscr + (wave_id * 32 + (size_t)(lane >> lgG)) * (size_t)dc;
+  const double sigma = sigmas[0];
+  const double a_fac = (KERNEL == TPH_KERNEL_TPCN) ? tph_sqrt(1.0 - sigma * sigma) : 1.0;
+  const int64_t nchunks = (n + SM_CHUNK - 1) / SM_CHUNK;
+  const int g = lane >> lgG;
+  const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane & ~(G - 1));
+  const bool leader = (lane & (G - 1)) == 0;
+
+  // the wave's pool: the chunk grabbed last
+  int64_t pool_row = 0;
+  int pool_next = 0, pool_cnt = 0;
+  bool exhausted = false;
+  unsigned long long n_att = 0, n_dec = 0;
+#ifdef SM_PROFILE
+  long long pf_bm = 0, pf_rows = 0, pf_refill = 0, pf_steps = 0, pf_epi = 0, pf_e1 = 0, pf_e0 = 0, pf_t = clock64();
+#define SM_PF(acc) do { const long long now_ = clock64(); acc += now_ - pf_t; pf_t = now_; } while (0)
+#else
+#define SM_PF(acc) do { } while (0)
+#endif
+
+  // per-lane state; `best` (lowest successful attempt of the lane's particle so far) is kept equal on the G lanes of a group
+  int64_t row = -1;                // particle this lane works on (-1: none)
+  int att = 0, stage = 0, won = -1, best = SM_CAP;
+  bool active = false;
+  double b_fac = 0.0;
+
+#pragma unroll 1
+  for (;;) {
+    // ---- groups whose particle is decided: write u', take the next particle
+    {
+      const unsigned long long act = __ballot(active);
+      const bool gdone = (act & gmask) == 0ull;
+      const bool more = !exhausted || pool_next < pool_cnt;
+      unsigned long long todo = __ballot(leader && gdone && (row >= 0 || more));
+      bool refilled = false;
+      if (todo) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the parked rows below were stored by other lanes
+#pragma unroll 1
+      while (todo) {
+        const int L = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const int gg = L >> lgG;
+        const int64_t orow = __shfl(row, L, 64);
+        if (orow >= 0) {
+          const int obest = __shfl(best, L, 64);
+          if (obest < SM_CAP) {
+            const unsigned long long wm = __ballot(won == obest && g == gg);
+            const int wl = __ffsll((long long)wm) - 1;
+            const double bw = __shfl(b_fac, wl, 64);
+            // rows 0..7 of the winning attempt are not parked (see below): from its normals, still in the winner's column,
+            // with the row's own FMA chain (lane = row)
+            const int rtop = d < 2 * SM_ROWS ? d : 2 * SM_ROWS;
+            if (lane < rtop) {
+              const int r = lane;
+              const double* __restrict__ Lrow = Lt + (size_t)r * stride + sm_skew(r);
+              double acc = 0.0;
+              for (int j = 0; j <= r; ++j) acc = fma(Lrow[j], zs[(size_t)j * 64 + wl], acc);
+              const double bs = bscr[(wave_id * 32 + (size_t)gg) * (size_t)dc + r];
+              double x = fma(bw, acc, bs);
+              const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
+              if (f == TPH_BC_PERIODIC) x = bc_periodic(x);
+              else if (f == TPH_BC_REFLECTIVE) x = bc_reflective(x);
+              up[(size_t)r * ld + orow] = x;
+            }
+            const double* __restrict__ src = vscr + (wave_id * 64 + wl) * (size_t)dc;
+            for (int r = rtop + lane; r < d; r += 64)
+              up[(size_t)r * ld + orow] = __hip_atomic_load(src + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            n_att += (unsigned long long)(obest + 1);
+          } else {                   // redraw cap reached (the reference would loop on): the current point is proposed
+            for (int r = lane; r < d; r += 64) {
+              const double uj = u[(size_t)r * ld + orow];
+              up[(size_t)r * ld + orow] = (KERNEL == TPH_KERNEL_TPCN) ? (uj - means[r]) + means[r] : uj;
+            }
+            n_att += (unsigned long long)SM_CAP;
+          }
+          n_dec += 1ull;
+        }
+        // next particle of the pool; an empty pool is refilled from the global queue (one atomic per chunk)
+        if (pool_next >= pool_cnt && !exhausted) {
+          unsigned long long c = 0;
+          if (lane == 0) c = atomicAdd(&queue[0], 1ull);
+          c = __shfl(c, 0, 64);
+          if ((int64_t)c >= nchunks) {
+            exhausted = true;
+          } else {
+            pool_row = (int64_t)c * SM_CHUNK;
+            pool_cnt = (int)((n - pool_row) < SM_CHUNK ? (n - pool_row) : SM_CHUNK);
+            pool_next = 0;
+          }
+        }
+        int64_t nrow = -1;
+        if (pool_next < pool_cnt) {
+          nrow = pool_row + pool_next;
+          ++pool_next;
+          double* __restrict__ rec = bscr + (wave_id * 32 + (size_t)gg) * (size_t)dc;
+          for (int r = lane; r < dc; r += 64) {
+            const double uj = r < d ? u[(size_t)r * ld + nrow] : 0.0;
+            rec[r] = (KERNEL == TPH_KERNEL_TPCN && r < d) ? fma(a_fac, uj - means[r], means[r]) : uj;
+          }
+          refilled = true;
+        }
+        if (g == gg) {
+          row = nrow; won = -1; stage = 0; best = SM_CAP;
+          b_fac = nrow >= 0 ? (KERNEL == TPH_KERNEL_TPCN ? bfac[nrow] : sigma) : 0.0;
+          att = lane & (G - 1);
+          active = nrow >= 0 && att < SM_CAP;
+        }
+      }
+      if (refilled) {                  // the records just written are read by other lanes of this wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      SM_PF(pf_refill);
+      if (!__any(row >= 0)) break;
+    }
+
+    // ---- this step's rows r0 .. r0+3 of every busy lane; their base coordinates are requested now and used
+    // after the products
+    const int r0 = SM_ROWS * stage;
+    const double2 b01 = *(const double2*)(brec + r0), b23 = *(const double2*)(brec + r0 + 2);
+    // the next two Box-Muller pairs of the attempt (pairs 2 stage, 2 stage + 1), into the lane's column
+    if (active) {
+      tph_rng gz(seed, tk, TPH_TAG_NORMAL, (uint64_t)(item0 + row));
+      const uint32_t base_draw = (uint32_t)att * (uint32_t)npairs;
+      const int p0 = 2 * stage, last = npairs - 1;
+      double t0, t1, t2, t3;
+      gz.normal2(base_draw + (uint32_t)p0, t0, t1);
+      gz.normal2(base_draw + (uint32_t)(p0 < last ? p0 + 1 : last), t2, t3);
+      zs[(size_t)(r0 + 0) * 64 + lane] = t0;
+      zs[(size_t)(r0 + 1) * 64 + lane] = t1;
+      zs[(size_t)(r0 + 2) * 64 + lane] = t2;
+      zs[(size_t)(r0 + 3) * 64 + lane] = t3;
+    }
+    sm_wave_sync();
+    SM_PF(pf_bm);
+
+    // ---- L z, each lane ITS rows (LDS copy of L); the column loop runs to the deepest busy lane's row.  (Rows r0+2, r0+3 from a
+    // padded copy in global memory instead -- two pipes for the two 16-byte loads per row and column pair -- doubled the loop's
+    // time: per-lane 16-byte loads through L1 are slower than the LDS reads they were meant to relieve.)
+    int smax = active ? stage : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(smax, o, 64); smax = other > smax ? other : smax; }
+    const int jm = SM_ROWS * (__builtin_amdgcn_readfirstlane(smax) + 1);
+    const double* __restrict__ Lr = Lt + (size_t)r0 * stride + sm_skew(r0);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
+    for (int j = 0; j < jm; j += 2) {
+      const double z0 = zs[(size_t)j * 64 + lane], z1 = zs[(size_t)(j + 1) * 64 + lane];
+      const double2 l0 = *(const double2*)(Lr + j), l1 = *(const double2*)(Lr + stride + j);
+      const double2 l2 = *(const double2*)(Lr + 2 * stride + j), l3 = *(const double2*)(Lr + 3 * stride + j);
+      a0 = fma(l0.x, z0, a0); a1 = fma(l1.x, z0, a1); a2 = fma(l2.x, z0, a2); a3 = fma(l3.x, z0, a3);
+      a0 = fma(l0.y, z1, a0); a1 = fma(l1.y, z1, a1); a2 = fma(l2.y, z1, a2); a3 = fma(l3.y, z1, a3);
+    }
+    SM_PF(pf_rows);
+    int mine = INT32_MAX;             // this lane's successful attempt of the step, if any
+#ifdef SM_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SM_PF(pf_e0);
+#endif
+    if (active) {
+      const double acc[SM_ROWS] = {a0, a1, a2, a3};
+      double v[SM_ROWS];
+      bool ok = true;
+#pragma unroll
+      for (int q = 0; q < SM_ROWS; ++q) {
+        const int r = r0 + q;
+        v[q] = 0.0;
+        if (r < d) {
+          const double bs = q == 0 ? b01.x : q == 1 ? b01.y : q == 2 ? b23.x : b23.y;
+          double x = fma(b_fac, acc[q], bs);
+          const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
+          if (f == TPH_BC_PERIODIC) x = bc_periodic(x);
+          else if (f == TPH_BC_REFLECTIVE) x = bc_reflective(x);
+          else ok = ok && (x >= 0.0) && (x <= 1.0);
+          v[q] = x;
+        }
+      }
+      // park the rows this attempt has passed -- from the third stage on: four in five steps are first or second stages (or
+      // die), and rows 0..7 of the one attempt that wins are recomputed when the particle is decided
+      if (ok && stage >= 2) {
+        *(double2*)(vrec + r0) = make_double2(v[0], v[1]);
+        *(double2*)(vrec + r0 + 2) = make_double2(v[2], v[3]);
+      }
+      if (ok) {
+        if (++stage == nst) {       // every row in bounds: this attempt is a success
+          won = att;
+          mine = att;
+          active = false;
+          stage = 0;                // (an idle lane still walks rows 0..3 with the others: keep its row index inside the tables)
+        }
+      } else {
+        att += G;
+        stage = 0;
+      }
+    }
+    SM_PF(pf_e1);
+    // the group's lowest success so far (xor-shuffles inside the group); attempts numbered above it are moot, also in flight
+    for (int o = 1; o < G; o <<= 1) { const int other = __shfl_xor(mine, o, 64); mine = other < mine ? other : mine; }
+    best = mine < best ? mine : best;
+    if (row >= 0 && won < 0) active = att < (best < SM_CAP ? best : SM_CAP);
+    SM_PF(pf_epi);
+#ifdef SM_PROFILE
+    ++pf_steps;
+#endif
+  }
+  if (lane == 0) {
+    atomicAdd(&queue[1], n_att);
+    atomicAdd(&queue[2], n_dec);
+#ifdef SM_PROFILE
+    atomicAdd(&queue[3], (unsigned long long)pf_bm); atomicAdd(&queue[4], (unsigned long long)pf_rows);
+    atomicAdd(&queue[5], (unsigned long long)pf_refill); atomicAdd(&queue[6], (unsigned long long)pf_steps);
+    atomicAdd(&queue[7], (unsigned long long)pf_epi);
+    atomicAdd(&queue[8], (unsigned long long)pf_e0); atomicAdd(&queue[9], (unsigned long long)pf_e1);
+#endif
+  }
+}
+
+// ---- Mahalanobis forms of a tile of 64 particles, |L^-1 (v - mu)|^2 through the blocked product of tri.h, and the chores
+// around the stage-machine kernel.  MODE 0 (before it): resolve the deferred Metropolis moves (u <- u' where pending); tpCN:
+// the form at u -> maha_u on the first step of a run (afterwards it is carried), then the Gamma draw and the step scale
+// b = sigma sqrt(s) of every particle -> bfac_out (mcmc.py:228-236; one draw per particle and step, reused by its redraws).
+// MODE 1 (after it): the form at u' -> maha_up (tpCN; 0 for RWM), and the step's mean attempts per particle -> state[8]
+// (regime probe for the host).
+template <int KERNEL, int WV, int MODE>
+__global__ void __launch_bounds__(64 * WV) k_maha_tile(double* __restrict__ u, int64_t n, int64_t ld, int d,
+                                                       const double* __restrict__ means, const double* __restrict__ Wb,
+                                                       double* __restrict__ up, double* __restrict__ maha, tph_stepctl tick,
+                                                       uint8_t* __restrict__ pend, const unsigned long long* __restrict__ queue,
+                                                       const double* __restrict__ dof, const double* __restrict__ sigmas,
+                                                       uint64_t seed, int64_t item0, double* __restrict__ bfac_out) {
+  extern __shared__ double sh[];
+  double* xs = sh;                                 // [d][64]
+  double* sc = sh + (size_t)d * 64;                // [WV][64]
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = i < n;
+  const int64_t ii = live ? i : n - 1;
+  if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl && queue)
+    const_cast<double*>(tick.ctl)[8] = queue[2] ? (double)queue[1] / (double)queue[2] : 0.0;
+#ifdef SM_PROFILE
+  if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0 && queue)
+    printf("SM_PROFILE attempts %llu particles %llu | wave-cycles: bm %llu rows %llu epilogue %llu (wait %llu + bounds %llu + rest) refill %llu | steps %llu\n", queue[1],
+           queue[2], queue[3], queue[4], queue[7] + queue[8] + queue[9], queue[8], queue[9], queue[5], queue[6]);
+#endif
+  const bool form = KERNEL == TPH_KERNEL_TPCN && (MODE == 1 || !tick.carry());
+  if (MODE == 0) {
+    const bool pd = pend && live && pend[i];
+    for (int j = wid; j < d; j += WV) {
+      double uj = u[(size_t)j * ld + ii];
+      if (pd) { uj = up[(size_t)j * ld + i]; u[(size_t)j * ld + i] = uj; }
+      if (form) xs[(size_t)j * 64 + lane] = uj - means[j];
+    }
+    __syncthreads();
+    if (pd && wid == 0) pend[i] = 0;
+  } else if (form) {
+    for (int j = wid; j < d; j += WV) xs[(size_t)j * 64 + lane] = up[(size_t)j * ld + ii] - means[j];
+    __syncthreads();
+  }
+  if (KERNEL != TPH_KERNEL_TPCN) {
+    if (maha && wid == 0 && live) maha[i] = 0.0;
+    return;
+  }
+  double m = 0.0;
+  if (form) {
+    double part = 0.0;
+    tri_apply(Wb, d, xs, lane, wid, WV, [&](int, double y) { part = fma(y, y, part); });
+    sc[(size_t)wid * 64 + lane] = part;
+    __syncthreads();
+    if (wid == 0) {
+      for (int w = 0; w < WV; ++w) m += sc[(size_t)w * 64 + lane];
+      if (live) maha[i] = m;
+    }
+  } else if (wid == 0) {
+    m = maha[ii];
+  }
+  if (MODE == 0 && wid == 0 && live) {
+    const double nu = dof[0], sigma = sigmas[0];
+    tph_rng gr(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
+    const double gam = tph_gamma_mt(gr, 0.5 * ((double)d + nu)) * tph_div(2.0, nu + m);
+    bfac_out[i] = sigma * tph_sqrt(tph_rcp(gam));
+  }
+}
+
+template <int KERNEL, int MODE>
+static int launch_maha_tile(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* Wb, double* up,
+                            double* maha, tph_stepctl tick, uint8_t* pend, const unsigned long long* queue, const double* dof,
+                            const double* sigmas, uint64_t seed, int64_t item0, double* bfac_out) {
+  const int d = ctx->d;
+  const int wv = d <= 32 ? 4 : d <= 64 ? 8 : 16;
+  const size_t lds = sizeof(double) * ((size_t)d * 64 + (size_t)wv * 64);
+  const dim3 grid((unsigned)((n + 63) / 64));
+#define TPH_MT(WV)                                                                                                       \
+  do {                                                                                                                   \
+    if (lds > 64 * 1024)                                                                                                 \
+      TPH_HIP(hipFuncSetAttribute((const void*)k_maha_tile<KERNEL, WV, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_maha_tile<KERNEL, WV, MODE>), grid, dim3(64 * WV), lds, ctx->stream, u, n, ld, d, means, Wb, up, maha, \
+                       tick, pend, queue, dof, sigmas, seed, item0, bfac_out);                                           \
+  } while (0)
+  if (wv == 4) TPH_MT(4); else if (wv == 8) TPH_MT(8); else TPH_MT(16);
+#undef TPH_MT
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int KERNEL>
+static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,
+                      const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
+                      double* up, double* maha_u, double* maha_up, uint8_t* pend) {
+  const int d = ctx->d;
+  const int nst = (d + SM_ROWS - 1) / SM_ROWS, dc = SM_ROWS * nst, stride = sm_stride(dc);
+  const int64_t nchunks = (n + SM_CHUNK - 1) / SM_CHUNK;
+  // workgroup = as many waves as fit around one LDS copy of L with a z tile each (one workgroup per CU)
+  const size_t lt_bytes = sizeof(double) * (size_t)dc * stride, z_bytes = sizeof(double) * (size_t)dc * 64;
+  TPH_REQUIRE(lt_bytes + z_bytes <= 160 * 1024, "tph_propose (row walker): n_dim=%d does not fit the LDS", d);
+  int wv = (int)((160 * 1024 - lt_bytes) / z_bytes);
+  if (wv > 8) wv = 8;
+  const int cus = ctx->n_simd / 4;
+  int64_t groups = (nchunks + wv - 1) / wv;                  // never more waves than there are chunks
+  if (groups > cus) groups = cus;
+  const int64_t waves = groups * wv;
+  // lanes per particle (log2): enough particles per group to balance the groups of a wave; few speculative attempts when the
+  // wave has many particles
+  int lgG = ctx->sm_lanes;
+  if (lgG <= 0) {
+    const double pw = (double)n / (double)waves;
+    lgG = pw >= 96.0 ? 2 : pw >= 24.0 ? 3 : 4;
+  }
+  if (lgG > 6) lgG = 6;
+  const size_t lds = lt_bytes + (size_t)wv * z_bytes;
+  // persistent buffers: blocked copies of L and L^-1 (tri.h), the queue words, the per-lane columns of passed rows
+  const size_t tb8 = tri_blocked_doubles(d);
+  const size_t need_small = sizeof(double) * (tb8 + (size_t)dc * dc) + 128;
+  if (ctx->sm_small_bytes < need_small) {
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->sm_small) ctx->retired.push_back(ctx->sm_small);
+    ctx->sm_small = nullptr; ctx->sm_small_bytes = 0; ctx->sm_epoch = -1;
+    TPH_HIP(hipMalloc((void**)&ctx->sm_small, need_small));
+    ctx->sm_small_bytes = need_small;
+  }
+  const size_t need_scr = sizeof(double) * (size_t)dc * (size_t)waves * (64 + 32);
+  if (ctx->sm_scr_bytes < need_scr) {
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->sm_scr) ctx->retired.push_back(ctx->sm_scr);
+    ctx->sm_scr = nullptr; ctx->sm_scr_bytes = 0;
+    TPH_HIP(hipMalloc((void**)&ctx->sm_scr, need_scr));
+    ctx->sm_scr_bytes = need_scr;
+  }
+  unsigned long long* queue = (unsigned long long*)ctx->sm_small;
+  double* Wb = (double*)((char*)ctx->sm_small + 128);
+  double* Lg = Wb + tb8;
+  // a launch being captured into a hipGraph records the rebuild (a replayed step never re-enters this host code)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  TPH_HIP(hipStreamIsCapturing(ctx->stream, &cap));
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  if (capturing || ctx->modes_epoch <= 0 || ctx->sm_epoch != ctx->modes_epoch || ctx->sm_src != (const void*)chol ||
+      ctx->sm_kernel != KERNEL) {
+    hipLaunchKernelGGL(k_sm_pad, dim3(1), dim3(256), 0, ctx->stream, chol, d, dc, Lg);
+    if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, winv, d, Wb);
+    ctx->sm_epoch = capturing ? -1 : ctx->modes_epoch; ctx->sm_src = (const void*)chol; ctx->sm_kernel = KERNEL;
+  }
+  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)queue, 32);
+  // pending moves; tpCN: the form at u (first step of a run) and every particle's step scale, parked in maha_up until the
+  // closing pass overwrites it with the form at u'
+  if (pend || KERNEL == TPH_KERNEL_TPCN || maha_u)
+    if (launch_maha_tile<KERNEL, 0>(ctx, u, n, ld, means, Wb, up, maha_u, tick, pend, nullptr, dof, sigmas, seed, item0, maha_up)) return -1;
+  if (lds > 64 * 1024)
+    TPH_HIP(hipFuncSetAttribute((const void*)k_propose_sm<KERNEL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_propose_sm<KERNEL>), dim3((unsigned)groups), dim3(64 * wv), lds, ctx->stream, (const double*)u, n, ld, d, means,
+                     (const double*)Lg, sigmas, bc, seed, tick, item0, up, (const double*)maha_up, ctx->sm_scr,
+                     ctx->sm_scr + (size_t)dc * (size_t)waves * 64, lgG, queue);
+  TPH_LAUNCH_CHECK();
+  if (KERNEL == TPH_KERNEL_TPCN || maha_up || tick.ctl)
+    if (launch_maha_tile<KERNEL, 1>(ctx, u, n, ld, means, Wb, up, maha_up, tick, nullptr, queue, dof, sigmas, seed, item0, nullptr)) return -1;
+  return 0;
+}
+
+int tph_propose_sm(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
+                   const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
+                   const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend) {
+  const tph_stepctl tick{tick0, ctl};
+  if (kernel == TPH_KERNEL_TPCN)
+    return propose_sm<TPH_KERNEL_TPCN>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend);
+  return propose_sm<TPH_KERNEL_RWM>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend);
+}

@@ -22,6 +22,9 @@ OPT_MODES_EPOCH = 5            # TPH_OPT_MODES_EPOCH
 OPT_ROW_MIRROR = 6             # TPH_OPT_ROW_MIRROR
 OPT_COV_KERNEL = 7             # TPH_OPT_COV_KERNEL
 OPT_SORTED_DRAWS = 8           # TPH_OPT_SORTED_DRAWS
+OPT_STAGED_REDRAW = 9          # TPH_OPT_STAGED_REDRAW
+OPT_SM_LANES = 10              # TPH_OPT_SM_LANES
+OPT_SM_THRESHOLD = 11          # TPH_OPT_SM_THRESHOLD
 BC_STRICT, BC_PERIODIC, BC_REFLECTIVE = 0, 1, 2
 
 TAG_PRIOR, TAG_NORMAL, TAG_GAMMA, TAG_ACCEPT, TAG_RESAMPLE, TAG_UPSAMPLE, TAG_REPAIR, TAG_SYST = 1, 2, 3, 4, 5, 6, 7, 8

@@ -109,6 +109,7 @@ class StepEngine:
         self.ctl_host = torch.zeros(STEP_STATE_LEN, dtype=torch.float64).pin_memory()
         self.unstaged = False          # d > 16 proposal kernel without LDS-staged matrices (redraw-dominated steps)
         self.blocked = False           # d > 16: blocked kernel for attempt 0 + straggler pass (steps that are ~one attempt)
+        self.staged, self.sm_lanes = False, 0      # 16 < d <= 64: row-walker kernel for redraw-dominated steps, its lanes per particle (log2)
         self.mailbox = torch.zeros(self.SLOTS, 8, dtype=torch.float64).pin_memory()   # written by tph_adapt, polled here
         self.mailbox_np = self.mailbox.numpy()
         self.use_graph, self.graph, self.graph_error = bool(use_graph), None, None
@@ -134,12 +135,14 @@ class StepEngine:
         else:
             self.u, self.logl, self.assign, self.modes = u, logl, assign, modes
         if self.ctx.n_dim > 16:        # new mode statistics: the library rebuilds its blocked copies of L and L^-1 once
-            from .device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_MODES_EPOCH
+            from .device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_MODES_EPOCH, OPT_SM_LANES, OPT_STAGED_REDRAW
             StepEngine._epoch += 1
             self.ctx.set_option(OPT_MODES_EPOCH, StepEngine._epoch)
             # the proposal regime is an option of the ctx, which engines of other shapes share: re-assert this engine's
             self.ctx.set_option(OPT_BLOCKED, 1 if self.blocked else 0)
             self.ctx.set_option(OPT_ML_UNSTAGED, 1 if self.unstaged else 0)
+            self.ctx.set_option(OPT_STAGED_REDRAW, 1 if self.staged else 0)
+            self.ctx.set_option(OPT_SM_LANES, self.sm_lanes)
         self.sigmas.fill_(sigma_init)
         self.pending.zero_()
         self.counts.copy_(counts)
@@ -219,19 +222,32 @@ class StepEngine:
         return rec[:6].copy()
 
     def _regime(self, mean_attempts):
-        """The d > 16 proposal kernel reports the mean number of attempts per particle of the step.  While most attempts are
-        redraws that stop after a few rows, run it un-staged (matrices from global memory: a quarter of the LDS, four times
-        the resident waves -- 2x at d = 100); once a step is about one attempt, LDS-staged matrices win.  Launch geometry
-        is baked into a captured graph, so a graph keeps whatever it was captured with."""
+        """The d > 16 proposal kernels report the mean number of attempts per particle of the step, and the host picks the
+        kernel for the next steps from it (launch geometry is baked into a captured graph, so a graph keeps whatever it was
+        captured with):
+          * (nearly) every first attempt in bounds, one mode: attempt 0 of all particles in the blocked kernel (matrix
+            operands through the scalar cache), the few others finished by the multi-lane kernel (on below 1.3, off above 2);
+          * most attempts are redraws, one mode, n_dim <= 64: the row-walker kernel (propose_sm.hip: a lane per attempt,
+            several attempts of a particle in flight -- as many as the attempt count makes worthwhile);
+          * otherwise the multi-lane kernel, un-staged (matrices from global memory: a quarter of the LDS, four times the
+            resident waves) while redraws dominate, LDS-staged once a step is about one attempt."""
         if self.graph is not None or self.ctx.n_dim <= 16 or not mean_attempts > 0.0:
             return
-        from .device import OPT_BLOCKED, OPT_ML_UNSTAGED
-        # one mode and (nearly) every first attempt in bounds: attempt 0 of all particles in the blocked kernel (matrix
-        # operands through the scalar cache), the few others finished by the multi-lane kernel (hysteresis 1.3 / 2.0)
+        import os
+        from .device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_SM_LANES, OPT_STAGED_REDRAW
         want_blk = self.K == 1 and mean_attempts < (2.0 if self.blocked else 1.3)
         if want_blk != self.blocked:
             self.blocked = want_blk
             self.ctx.set_option(OPT_BLOCKED, 1 if want_blk else 0)
+        want_sm = (self.K == 1 and self.ctx.n_dim <= 64 and mean_attempts > (4.0 if self.staged else 6.0)
+                   and os.environ.get("TEMPEST_AMD_STAGED", "1") != "0")      # debugging aid (TPH_OPT_STAGED_REDRAW)
+        lanes = 0
+        if want_sm:         # lanes per particle = attempts in flight: about half the expected count, 2 .. 8 (16 on small shards)
+            lanes = 1 if mean_attempts < 8.0 else 2 if mean_attempts < 16.0 else 3 if (mean_attempts < 48.0 or self.n >= 49152) else 4
+        if want_sm != self.staged or lanes != self.sm_lanes:
+            self.staged, self.sm_lanes = want_sm, lanes
+            self.ctx.set_option(OPT_STAGED_REDRAW, 1 if want_sm else 0)
+            self.ctx.set_option(OPT_SM_LANES, lanes)
         want = mean_attempts > (4.0 if self.unstaged else 8.0)      # hysteresis
         if want != self.unstaged:
             self.unstaged = want

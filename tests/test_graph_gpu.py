@@ -81,6 +81,75 @@ def test_graph_replay_of_the_blocked_proposal_follows_new_mode_statistics(kernel
     np.testing.assert_array_equal(runs[0][2], runs[1][2])
 
 
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+@pytest.mark.parametrize("variant", [5, 4, 3])
+def test_d_gt_16_proposal_paths_replayed_from_a_graph_equal_eager_launches(kernel, variant):
+    """tph_propose at n_dim > 16 captured ONCE (row-walker kernel 5, blocked kernel + straggler pass 4, multi-lane kernel 3) and
+    replayed after the caller has rewritten its fixed-address inputs -- new mode statistics, new positions, new step-control
+    block: every replay must equal the eager launch on the same inputs bit for bit.  Pins the two things a replay cannot get
+    from the host: the library's derived copies of L / L^-1 (rebuilt inside the graph) and its per-launch work-queue words
+    (zeroed by a kernel: a captured hipMemsetAsync node was seen to run out of order on the second replay)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from types import SimpleNamespace
+    from oracle import ps
+    from tempest_amd.device import HipContext
+    dev = torch.device("cuda", 0)
+    d, n = 32, 1000
+    rs = np.random.RandomState(3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+
+    def mk_modes(scale):
+        A = rs.randn(d, d) / np.sqrt(d)
+        cov = ((A @ A.T + np.eye(d)) * (scale ** 2 / 2.0))[None]
+        means = 0.5 + 0.02 * rs.randn(1, d)
+        _, chol, _ = ps.mode_statistics(means, cov)
+        return means, chol, np.linalg.inv(chol[0])[None]
+    c = HipContext(d, device=0)
+    c.set_option(0, variant)
+    c.set_option(10, 1)
+    m0 = mk_modes(0.29)
+    modes = SimpleNamespace(K=1, means_dev=t(m0[0]), chol_dev=t(m0[1]), winv_dev=t(m0[2]), dof_dev=t(np.array([1e6])))
+    u, up, mu_, mup = t(rs.rand(d, n)), c.empty(d, n), c.empty(n), c.empty(n)
+    sig = t(np.array([2.38 / np.sqrt(d) if kernel == "rwm" else 0.6]))
+    ctl = c.zeros(10)
+    pend = torch.zeros(n, dtype=torch.uint8, device=dev)
+
+    def call():
+        c.propose(kernel, u, None, modes, sig, None, 77, 1, 0, up, mu_, mup, ctl=ctl, pending=pend)
+    call()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        c.use_current_stream()
+        g.capture_begin()
+        call()
+        g.capture_end()
+    c.use_current_stream()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for trial in range(4):
+        m = mk_modes(0.29 if trial < 2 else 0.12)             # trials 2, 3: most first attempts in bounds
+        modes.means_dev.copy_(t(m[0])); modes.chol_dev.copy_(t(m[1])); modes.winv_dev.copy_(t(m[2]))
+        u.copy_(t(np.clip(0.5 + (rs.rand(d, n) - 0.5) * (1.0 if trial < 2 else 0.5), 0.0, 1.0)))
+        ctl[0], ctl[7] = float(trial), 10.0 * trial           # steps done (the form at u is carried from trial 1 on), tick base
+        c.set_option(5, 100 + trial)                          # TPH_OPT_MODES_EPOCH: what StepEngine.load() does
+        keep = mu_.clone()
+        g.replay()
+        torch.cuda.synchronize()
+        a = (up.clone(), mu_.clone(), mup.clone(), float(ctl[8]))
+        mu_.copy_(keep)
+        call()
+        torch.cuda.synchronize()
+        b = (up.clone(), mu_.clone(), mup.clone(), float(ctl[8]))
+        for x, y in zip(a[:3], b[:3]):
+            assert torch.equal(x, y), (trial, variant)
+        if variant != 4 or trial < 2:
+            assert a[3] == b[3] and a[3] >= 1.0
+    c.close()
+
+
 def test_uncapturable_callback_falls_back():
     """A likelihood that synchronises with the host cannot be stream-captured: the engine warns once and keeps launching
     step by step, with the same numbers."""

@@ -856,6 +856,135 @@ def test_blocked_kernel_deferred_update_and_step_control(dev, kernel):
     assert torch.equal(ua, ub)
 
 
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+@pytest.mark.parametrize("bc", [None, "mixed"])
+@pytest.mark.parametrize("d,lanes", [(19, 0), (33, 2), (50, 0), (50, 5), (64, 3)])
+def test_stage_machine_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, lanes):
+    """TPH_OPT_PROPOSE_VARIANT 5 (propose_sm.hip): the redraw loop of mcmc.py:239-249 run as a stage machine -- a lane per
+    attempt, several attempts of a particle in flight, eight rows at a time with early exit, the first in-bounds attempt in
+    attempt order wins.  Same counter-based draws and row arithmetic as the other kernels: on an ensemble where most attempts
+    leave the cube (tens of attempts per particle, some particles at the 256-attempt cap) the proposals and both
+    Mahalanobis forms equal the oracle's sequential loop and the multi-lane kernel to rounding."""
+    from tempest_amd.device import HipContext
+    rs = np.random.RandomState(131 + d)
+    n = 1500 if d < 64 else 1100            # not a multiple of the 16-particle queue chunks
+    means = 0.5 + 0.05 * rs.randn(1, d)
+    A = rs.randn(d, d) / np.sqrt(d)
+    covs = ((A @ A.T + np.eye(d)) * (0.29 ** 2 / 2.0))[None]       # as broad as the prior: the early iterations of a run
+    _, chol, inv = ps.mode_statistics(means, covs)
+    dof = np.array([1e6])
+    sigmas = np.array([2.38 / np.sqrt(d)]) * (1.0 if kernel == "rwm" else 1.0)
+    assign = np.zeros(n, dtype=np.int32)
+    u = rs.rand(n, d)
+    u[:40] = np.clip(u[:40], 0.45, 0.55)                             # a few easy particles: attempt 0 or 1 succeeds
+    flags = omc.bc_flags(d, [1], [min(4, d - 1)]) if bc else omc.bc_flags(d)
+    seed, tick, item0 = 991, 7, 3_000_000_000
+    want_up, want_mu, want_mup = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, flags, seed, tick, item0)
+    capped = np.all(want_up == u, axis=1) if kernel == "rwm" else np.zeros(n, bool)
+    modes = _Modes(means, chol, inv, dof, dev)
+    st, ft = torch.from_numpy(sigmas).to(dev), torch.from_numpy(flags).to(dev)
+    got = {}
+    for variant in (5, 3):
+        c = HipContext(d, device=0)
+        c.set_option(0, variant)
+        c.set_option(10, lanes)            # TPH_OPT_SM_LANES
+        up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+        state = c.zeros(10)
+        c.propose(kernel, soa(u, dev), None, modes, st, ft, seed, tick, item0, up, mu_, mup, ctl=state)
+        got[variant] = (aos(up), mu_.cpu().numpy(), mup.cpu().numpy(), state.cpu().numpy())
+        c.close()
+    np.testing.assert_allclose(got[5][0], want_up, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(got[5][0], got[3][0], rtol=1e-11, atol=1e-13)
+    strict = np.nonzero(flags == 0)[0]
+    assert np.all((got[5][0][:, strict] >= 0) & (got[5][0][:, strict] <= 1))
+    if kernel == "tpcn":
+        np.testing.assert_allclose(got[5][1], want_mu, rtol=1e-9)
+        np.testing.assert_allclose(got[5][2], want_mup, rtol=1e-8, atol=1e-8)
+    else:
+        assert not got[5][1].any() and not got[5][2].any()
+    # the regime really is the redraw one: many attempts per particle on average (the kernel's own probe, state[8])
+    assert got[5][3][8] > (3.0 if bc is None else 2.0), got[5][3][8]
+    _ = capped
+
+
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+def test_stage_machine_redraw_cap_proposes_the_current_point(dev, kernel):
+    """All 256 attempts out of bounds (a step size far too large: the RWM runaway of DESIGN section 9): the current point is
+    proposed, like the other kernels do, and the probe reports the cap."""
+    from tempest_amd.device import HipContext
+    rs = np.random.RandomState(4)
+    d, n = 40, 777
+    means = np.full((1, d), 0.5)
+    covs = (np.eye(d) * 0.08)[None]
+    _, chol, inv = ps.mode_statistics(means, covs)
+    modes = _Modes(means, chol, inv, np.array([1e6]), dev)
+    u = rs.rand(n, d)
+    st = torch.from_numpy(np.array([0.99 if kernel == "tpcn" else 30.0])).to(dev)
+    c = HipContext(d, device=0)
+    c.set_option(0, 5)
+    up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+    state = c.zeros(10)
+    c.propose(kernel, soa(u, dev), None, modes, st, None, 5, 3, 0, up, mu_, mup, ctl=state)
+    got = aos(up)
+    if kernel == "rwm":
+        np.testing.assert_array_equal(got, u)
+        assert state.cpu().numpy()[8] == 256.0
+    else:                                     # tpCN at sigma 0.99 contracts towards the mean: most attempts do succeed
+        want = omc.propose(kernel, u, np.zeros(n, np.int32), means, chol, inv, np.array([1e6]), np.array([0.99]), omc.bc_flags(d), 5, 3, 0)[0]
+        np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-13)
+    c.close()
+
+
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+def test_stage_machine_kernel_deferred_update_and_step_control(dev, kernel):
+    """The stage-machine path inside a chain: the deferred Metropolis update (pending mask resolved by its opening pass) and
+    the carried Mahalanobis form give the same chain, bit for bit, as the in-place update; and a chain through it equals the
+    chain through the multi-lane kernel to rounding in its first step."""
+    rs = np.random.RandomState(15)
+    d, n = 50, 3000
+    means = 0.5 + 0.02 * rs.randn(1, d)
+    A = rs.randn(d, d) / np.sqrt(d)
+    covs = ((A @ A.T + np.eye(d)) * (0.2 ** 2 / 2.0))[None]
+    _, chol, inv = ps.mode_statistics(means, covs)
+    modes = _Modes(means, chol, inv, np.array([1e6]), dev)
+    st = torch.from_numpy(np.array([0.8 * 2.38 / np.sqrt(d)])).to(dev)
+    u0 = rs.rand(n, d)
+    c = ctx_for(d)
+    c.set_option(0, 5)
+
+    def like(up):
+        x = 20 * up - 10
+        return -0.5 * (x * x).sum(dim=0) * 0.02
+
+    def chain(deferred):
+        u = soa(u0, dev)
+        logl = like(u).clone()
+        up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+        sums = c.empty(2)
+        pend = torch.zeros(n, dtype=torch.uint8, device=dev) if deferred else None
+        ctl = c.zeros(10)
+        ctl[6] = 0.9                             # beta of the run (tph_accept reads it from the block)
+        out = []
+        for step in range(3):
+            ctl[0] = float(step)                 # steps done: from the second step on the form at u is carried
+            c.propose(kernel, u, None, modes, st, None, 9, 30, 0, up, mu_, mup, ctl=ctl, pending=pend)
+            lp = like(up)
+            c.accept(kernel, 0.9, u, None, logl, up, None, lp, mu_, mup, None, 1, modes.dof_dev, 9, 31, 0, sums, ctl=ctl, pending=pend)
+            out.append((up.clone(), logl.clone(), sums.clone(), mu_.clone()))
+        if deferred:
+            c.propose(kernel, u, None, modes, st, None, 9, 999, 0, up, mu_, mup, pending=pend)
+            assert int(pend.sum().item()) == 0
+        return u, out
+    ua, ta = chain(False)
+    ub, tb = chain(True)
+    for a, b in zip(ta, tb):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert torch.equal(ua, ub)
+    assert 0 < float(ta[0][2][0]) < n
+    c.set_option(0, 0)
+
+
 @pytest.mark.parametrize("d", [3, 10, 50])
 def test_gather_through_the_row_mirror_equals_the_dimension_major_gather(dev, d):
     """tph_gather from the lazily filled row-major mirror (TPH_OPT_ROW_MIRROR, default) against the dimension-major gather:

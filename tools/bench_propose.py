@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--wpe", type=int, default=0, help="experiment knob (TPH_OPT_REDRAW_LANES)")
     ap.add_argument("--sigma-scale", type=float, default=1.0, help="multiplies the step size (RWM runaway: ~8)")
     ap.add_argument("--unstaged", action="store_true", help="TPH_OPT_ML_UNSTAGED = 1 (the redraw-dominated regime of d > 16)")
+    ap.add_argument("--lanes", type=int, default=0, help="TPH_OPT_SM_LANES (log2 lanes per particle of the stage-machine kernel)")
+    ap.add_argument("--thr", type=int, default=0, help="TPH_OPT_SM_THRESHOLD")
     ap.add_argument("--pending", type=float, default=0.0,
                     help="fraction of particles with a pending accepted move to resolve (deferred tph_accept), per launch")
     a = ap.parse_args()
@@ -64,6 +66,10 @@ def main():
         lib.tph_set_option(ctx, 2, a.wpe)
     if a.unstaged:
         lib.tph_set_option(ctx, 3, 1)
+    if a.lanes:
+        lib.tph_set_option(ctx, 10, a.lanes)
+    if a.thr:
+        lib.tph_set_option(ctx, 11, a.thr)
     kid = {"tpcn": 0, "rwm": 1}[a.kernel]
     rs = np.random.RandomState(0)
     for scen in a.scen.split(","):
@@ -123,7 +129,7 @@ def main():
             ts.append(e0.elapsed_time(e1) * 1e3)
         out = {"what": "tph_propose", "lib": os.path.basename(a.lib or "libtempest_hip.so"), "kernel": a.kernel, "n": n, "d": d,
                "scenario": scen, "variant": a.variant, "carry": not a.nocarry, "pending_fraction": a.pending, "median_us": round(float(np.median(ts)), 2),
-               "min_us": round(float(np.min(ts)), 2), "first_attempt_in_bounds": inb, "fell_back_to_current": same,
+               "min_us": round(float(np.min(ts)), 2), "first_attempt_in_bounds": inb, "mean_attempts_probe": float(ctl[8].item()), "fell_back_to_current": same,
                "algorithmic_bytes": (16 * d + 4 + 16) * n,
                "GBps_algorithmic": round((16 * d + 20) * n / np.median(ts) / 1e3, 1)}
         print(json.dumps(out), flush=True)
