@@ -113,8 +113,19 @@ def uniform1(seed, items, tick, tag, draw=0):
     return uniform_pair(seed, np.asarray(items, dtype=np.uint64), draw, tick, tag)[0]
 
 
+def gamma_candidate(seed, items, att, tick, tag=TAG_GAMMA):
+    """The candidate of one Marsaglia-Tsang attempt from ONE Philox call (device: tph_rng::gamma_candidate): a normal
+    x = sqrt(-2 ln u1) cos(2 pi u2) with a 53-bit u1 in (0,1] and a 32-bit angle u2, and log of a (0,1] uniform of 32 bits."""
+    seed = int(seed)
+    r0, r1, r2, r3 = philox4x32(items, att, tick, tag, seed & 0xFFFFFFFF, seed >> 32)
+    u1 = (_k53(r0, r1).astype(np.float64) + 1.0) * TWO_M53
+    x = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * (r2.astype(np.float64) * 2.0 ** -32))
+    logu = np.log((r3.astype(np.float64) + 1.0) * 2.0 ** -32)
+    return x, logu
+
+
 def gamma_mt(seed, items, shape, tick, tag=TAG_GAMMA, max_attempts=64):
-    """Gamma(shape, 1) by Marsaglia-Tsang; attempt a uses draws 2a (normal) and 2a+1 (uniform).
+    """Gamma(shape, 1) by Marsaglia-Tsang; attempt a uses draw a (one Philox call for its normal and its uniform).
 
     shape < 1 is boosted: G(a) = G(a+1) * U^(1/a) with U from draw 2*max_attempts.
     Restates what np.random.gamma supplies to mcmc.py:236 (same law, different stream).
@@ -130,13 +141,11 @@ def gamma_mt(seed, items, shape, tick, tag=TAG_GAMMA, max_attempts=64):
     for att in range(max_attempts):
         if not todo.any():
             break
-        x, _ = normal_pair(seed, items, 2 * att, tick, tag)
-        uu, _ = uniform_pair(seed, items, 2 * att + 1, tick, tag)
-        uu = uu + TWO_M53  # (0,1]
+        x, logu = gamma_candidate(seed, items, att, tick, tag)
         v = 1.0 + c * x
         v = v * v * v
         with np.errstate(invalid="ignore", divide="ignore"):
-            ok = (v > 0.0) & (np.log(uu) < 0.5 * x * x + d - d * v + d * np.log(v))
+            ok = (v > 0.0) & (logu < 0.5 * x * x + d - d * v + d * np.log(v))
         take = todo & ok
         out[take] = (d * v)[take]
         todo &= ~ok

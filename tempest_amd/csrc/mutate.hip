@@ -286,35 +286,25 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ 
     gshape = 0.5 * ((double)d + nu);
     a_fac = tph_sqrt(1.0 - sigma * sigma);
   }
-  // first attempt: normal pairs (tag NORMAL, draws 0..npairs-1) and, for tpCN, the Gamma candidate
-  // (tag GAMMA: draw 0 = normal, draw 1 = uniform) are generated by different lanes at once
+  // first attempt: normal pairs (tag NORMAL, draws 0..npairs-1) and, for tpCN, the Gamma candidate (tag GAMMA, draw 0: one
+  // Philox call) are generated by different lanes at once
   const uint64_t item = (uint64_t)(item0 + ii);
   tph_rng gz(seed, tick, TPH_TAG_NORMAL, item);
   tph_rng gg(seed, tick, TPH_TAG_GAMMA, item);
   double g_x = 0.0, g_logu = 0.0;
-  const int nq = npairs + (KERNEL == TPH_KERNEL_TPCN ? 2 : 0);
+  const int nq = npairs + (KERNEL == TPH_KERNEL_TPCN ? 1 : 0);
   for (int q = todo ? npairs + l : l; q < nq; q += LPP) {     // straggler pass: attempt 0 is over, only the Gamma candidate
-    const bool is_norm = q < npairs;
-    const tph_rng& g = is_norm ? gz : gg;
-    const uint32_t draw = is_norm ? (uint32_t)q : (uint32_t)(q - npairs);
-    tph_u4 r = tph_philox(g.item, draw, g.tick, g.tag, g.k0, g.k1);
-    double a = tph_k53(r.x, r.y), b = tph_k53(r.z, r.w);
-    if (q == npairs + 1) {                       // Gamma uniform: (k + 1) * 2^-53 in (0, 1]
-      g_logu = tph_log((a + 1.0) * 0x1.0p-53);
-    } else {                                      // Box-Muller
-      double rad = tph_sqrt(-2.0 * tph_log((a + 1.0) * 0x1.0p-53));
-      double sn, cs;
-      sincospi(2.0 * (b * 0x1.0p-53), &sn, &cs);
-      if (is_norm) {
-        zs[2 * q] = rad * cs;
-        if (2 * q + 1 < d) zs[2 * q + 1] = rad * sn;
-      } else {
-        g_x = rad * cs;
-      }
+    if (q < npairs) {
+      double z0, z1;
+      gz.normal2((uint32_t)q, z0, z1);
+      zs[2 * q] = z0;
+      if (2 * q + 1 < d) zs[2 * q + 1] = z1;
+    } else {
+      gg.gamma_candidate(0u, g_x, g_logu);
     }
   }
   if (KERNEL == TPH_KERNEL_TPCN) {
-    // bring the candidate's two pieces to every lane of the group (owners: lanes npairs % LPP, (npairs+1) % LPP)
+    // bring the candidate's two pieces to every lane of the group (owner: lane npairs % LPP; the others hold zeros)
     g_x = group_sum<LPP>(g_x);
     g_logu = group_sum<LPP>(g_logu);
     double gam;
