@@ -195,6 +195,9 @@ class SamplerCore:
 
     # ---------------------------------------------------------------------------- run loop
     def _ensure_callbacks(self):
+        w = getattr(self, "_warm", None)
+        if w is not None:
+            w.wait()                      # the process's one-time start-up, running in parallel since the construction
         if self.callbacks is None:
             self.callbacks = CallbackAdapter(self.config, self.state.device, self._get_distribute_func)
             self.mutator.device_callbacks = (self.callbacks.prior, self.callbacks.loglike)

@@ -140,6 +140,16 @@ extern "C" int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void
     delete c;
     return -1;
   }
+  if (capacity_hint > 0) {
+    // the big scratch (sort buffers, scans, compaction lists) for a history of that size too: grown on demand it doubles a
+    // dozen times during a run, each time behind a stream synchronisation, a hipFree and a hipMalloc of up to gigabytes.
+    // 48 B per reserved row covers the largest user (the radix sorts of the trim and of the up-sampling draws); never more
+    // than a sixteenth of the free memory, and a failure here is not an error (the on-demand growth still works).
+    size_t free_b = 0, total_b = 0;
+    size_t want = (size_t)48 * (size_t)capacity_hint;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 16) want = free_b / 16;
+    if (want > ((size_t)1 << 20) && tph_scratch_reserve(c, want)) (void)hipGetLastError();
+  }
   *out = c;
   return 0;
 }

@@ -59,6 +59,7 @@ class HipContext:
         self.n_dim = int(n_dim)
         torch.cuda.set_device(self.device)
         self._ctx = C.c_void_p()
+        self.rows_hint = int(capacity_hint)         # rows the history is reserved for (0: grows on demand)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.tph_ctx_create(self.device.index, self.n_dim, int(capacity_hint), C.c_void_p(stream),
                                       C.byref(self._ctx)), "tph_ctx_create")
@@ -85,6 +86,11 @@ class HipContext:
         n = int(n)
         p2 = 1 << max(10, (n - 1).bit_length())          # next power of two >= n
         cap = p2 * 3 // 4 if p2 * 3 // 4 >= n else p2
+        # with a reserved history (rows_hint) every such array is sized for THAT from the start: a handful of blocks are
+        # allocated once, at the first iteration that needs them, instead of a new bucket every time the history doubles
+        # (each a hipMalloc of up to half a gigabyte in the middle of the run)
+        if n <= self.rows_hint:
+            cap = max(cap, self.rows_hint)
         return torch.empty(cap, dtype=dtype, device=self.device)[:n]
 
     def zeros(self, *shape, dtype=torch.float64):

@@ -86,6 +86,15 @@ class Sampler:
         state = StateManager(n_dim, device=device, comm=comm, capacity_hint=64 * max(1, config.n_particles // world))
         self._core = SamplerCore(config, state)
         self.state = state
+        # process start-up (first-use code-object loads, copy path, device context) in parallel, behind the construction
+        from . import _warm
+        self._core._warm = _warm.start(config, state)
+
+    @property
+    def startup_breakdown(self) -> dict:
+        """What the parallel start-up of this Sampler's process cost (tempest_amd/_warm.py); empty for later Samplers."""
+        w = getattr(self._core, "_warm", None)
+        return w.breakdown() if w is not None else {}
 
     # ------------------------------------------------------------------------------- methods
     def run(self, n_total: int = 4096, progress: bool = True, resume_state_path: Union[str, Path, None] = None,

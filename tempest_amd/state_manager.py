@@ -33,6 +33,8 @@ class StateManager:
         self.n_dim = n_dim
         self._device_arg = device
         self._capacity_hint = capacity_hint
+        import threading
+        self._ctx_lock = threading.Lock()
         self._ctx = None
         self.comm = comm
         self._current = dict.fromkeys(CURRENT_STATE_KEYS, None)
@@ -46,11 +48,14 @@ class StateManager:
     @property
     def ctx(self):
         if self._ctx is None:
-            from .device import HipContext
-            self._ctx = HipContext(self.n_dim, self._device_arg, self._clamped_hint())
-            if self.comm is not None and self.comm.active:
-                # the library issues its own small collectives (reweight triples, global trim / fit / cumulative weights)
-                self.comm.attach(self._ctx)
+            with self._ctx_lock:          # the start-up warm-up (_warm.py) may be creating it in its own thread
+                if self._ctx is None:
+                    from .device import HipContext
+                    ctx = HipContext(self.n_dim, self._device_arg, self._clamped_hint())
+                    if self.comm is not None and self.comm.active:
+                        # the library issues its own small collectives (reweight triples, global trim / fit / cumulative weights)
+                        self.comm.attach(ctx)
+                    self._ctx = ctx
         return self._ctx
 
     def _clamped_hint(self) -> int:
