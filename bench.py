@@ -185,6 +185,9 @@ def main():
     ap.add_argument("--no-hip-callbacks", action="store_true",
                     help="skip the second run with the callbacks compiled into the step (tempest_amd.HipCallbacks)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--clustering", action="store_true",
+                    help="run with the Sampler's default clustering=True (SURVEY 8d fixes clustering=False for config 4: the "
+                         "headline line is produced without this flag; rehearsals use it to walk the clustered code path)")
     ap.add_argument("--roofline-only", action="store_true", help="only the reweight-kernel microbench (for rocprofv3 --pmc)")
     a = ap.parse_args()
     if a.roofline_only:
@@ -206,14 +209,21 @@ def main():
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("TEMPEST_AMD_FORCE_COMM") == "1"
     if use_dist:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # a rank that never arrives must end the job, not hang it: the device-side exchange gives up after 30 s (a step of
+        # this workload takes milliseconds on every rank), the host's wait for a step record after 60 s, a process-group
+        # collective after 120 s (RCCL's first collective builds its rings); main() turns any of them into exit code 1
+        os.environ.setdefault("TEMPEST_AMD_P2P_TIMEOUT", "30")
+        os.environ.setdefault("TEMPEST_AMD_STEP_TIMEOUT", "60")
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("TEMPEST_AMD_PG_TIMEOUT", "120")))
         if rehearsal:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
     dev = torch.device("cuda", local_rank)
 
     import tempest_amd as tp
@@ -227,7 +237,7 @@ def main():
     n_total = 4 * n_global                                                  # n_total = 4 N
 
     def make(callbacks, n_glob):
-        return tp.Sampler(callbacks[0], callbacks[1], 10, n_particles=n_glob, vectorize=True, clustering=False,
+        return tp.Sampler(callbacks[0], callbacks[1], 10, n_particles=n_glob, vectorize=True, clustering=bool(a.clustering),
                           random_state=a.seed, backend="torch", batch_prior=True, device=local_rank,
                           graph={"auto": None, "on": True, "off": False}[a.graph])
     t_make0 = time.perf_counter()
@@ -272,6 +282,27 @@ def main():
     t_run0 = t_make0          # `whole_run` is timed from BEFORE the Sampler's construction: its parallel start-up begins there
     dt, steps_t, beta_t = timed(s)
     startup = s.startup_breakdown
+    comm_block = None
+    if use_dist:
+        # what the sharded run actually did between the ranks during everything up to here (initialisation, warm-up, timed steps)
+        st = s.state.ctx.comm_stats()
+        its = max(1, len(s.state._scalars["steps"]))
+        p2p_here = 1 if s.state.ctx.p2p_active else 0
+        flag = torch.tensor([p2p_here, -p2p_here], dtype=torch.int64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # min over ranks of p2p and of -p2p: all on, all off, or mixed
+        p2p_all, p2p_any = bool(flag[0].item() == 1), bool(flag[1].item() == -1)
+        comm_block = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                      "p2p_active_on_every_rank": p2p_all, "p2p_active_on_some_rank": p2p_any,
+                      "small_collectives_path": ("peer-to-peer exchange kernels (HIP IPC inboxes over xGMI)" if p2p_all else
+                                                 "process group (the ranks agreed that the peer mapping is not usable)"),
+                      "per_iteration_on_rank0": {"p2p_exchanges": round(st["p2p_exchanges"] / its, 1),
+                                                 "process_group_collectives_by_the_library": round(st["callback_collectives"] / its, 1),
+                                                 "process_group_bytes": round(st["callback_bytes"] / its),
+                                                 "shuffle_rows": round(st["shuffle_rows"] / its), "shuffle_bytes": round(st["shuffle_bytes"] / its)},
+                      "iterations_counted": its,
+                      "note": "library counters (tph_comm_stats) of rank 0 over the initialisation, warm-up and timed iterations; "
+                              "shuffle_rows = this rank's slots refilled per iteration, (world-1)/world of them cross xGMI on average"}
+        assert p2p_all == p2p_any, "the ranks disagree about the peer-to-peer layer"      # tph_comm_p2p_attach agrees by construction
     pms = float(np.sum(steps_t[beta_t > 0])) * n_global
     value = pms / dt
 
@@ -351,8 +382,10 @@ def main():
            "config": {"workload": f"rosenbrock10d_n{n_global} (BASELINE config 4: 10-D Rosenbrock, {n_global} particles "
                                   f"sharded over {world} GPU(s), {n_local} per GPU)",
                       "n_dim": 10, "particles_per_gpu": n_local, "particles_global": n_global, "sample": "tpcn",
-                      "resample": "mult", "clustering": False, "n_total": n_total, "step": "one PS iteration"}}
+                      "resample": "mult", "clustering": bool(a.clustering), "n_total": n_total, "step": "one PS iteration"}}
     out.update(extra)
+    if comm_block is not None:
+        out["comm"] = comm_block
     out["config"]["callbacks"] = "torch-ROCm tensor callbacks (the drop-in contract: prior20, rosenbrock_torch)"
     if not a.no_hip_callbacks:
         # same workload, same seed, same protocol, with the two callbacks written as HIP device functions and compiled
@@ -400,5 +433,19 @@ def main():
         emit(out)
 
 
+def _main_or_die():
+    """Any failure -- a peer that never arrived, a collective that timed out, a device error -- ends THIS rank with exit code 1
+    at once (os._exit: no interpreter shutdown that could wait on a dead communicator, and never a re-exec)."""
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
+
+
 if __name__ == "__main__":
-    main()
+    _main_or_die()

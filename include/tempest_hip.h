@@ -142,6 +142,11 @@ int tph_comm_p2p_export(tph_ctx* ctx, void* handle_out /* [TPH_P2P_HANDLE_BYTES]
 int tph_comm_p2p_attach(tph_ctx* ctx, const void* handles /* [world][TPH_P2P_HANDLE_BYTES] host */, int* ok_out);
 int tph_comm_p2p_active(const tph_ctx* ctx);
 int tph_comm_p2p_status(tph_ctx* ctx);
+/* Traffic counters of this ctx since creation (or since the last call with reset != 0): out[0] = small collectives that went
+ * through the peer-to-peer exchange kernels (incl. those folded into tph_adapt), out[1] = collectives through the attached
+* callbacks, out[2] = bytes through the callbacks, out[3] = slots of this rank refilled by the one-sided resample shuffle (on
+ * average (world-1)/world of them arrive from peers), out[4] = bytes of those records.  What `bench.py --gpus N` reports as its `comm` block. */
+int tph_comm_stats(tph_ctx* ctx, int64_t* out /*[5] host*/, int reset);
 /* in-place all-reduce of a small device array that lives outside the staging block (MCMC step: the (accepted, sum alpha_c)
  * sums between tph_accept and tph_adapt; replaces a framework call per step).  Peer-to-peer when attached and count fits,
  * else staged through the all-reduce callback.  No-op without a communicator. */

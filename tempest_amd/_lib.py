@@ -79,6 +79,7 @@ SIGNATURES = {
     "tph_comm_p2p_attach": (c_int, [ptr, ptr, ptr]),
     "tph_comm_p2p_active": (c_int, [ptr]),
     "tph_comm_p2p_status": (c_int, [ptr]),
+    "tph_comm_stats": (c_int, [ptr, ptr, c_int]),
     "tph_comm_allreduce_dev": (c_int, [ptr, ptr, c_i64, c_int, c_int]),
     "tph_resample_put_global": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr, ptr, c_i64]),
     "tph_trim_threshold_global": (c_int, [ptr, ptr, c_i64, c_dbl, c_int, ptr, ptr]),

@@ -197,12 +197,14 @@ int tph_comm_require(tph_ctx* ctx, size_t bytes, const char* who) {
 int tph_comm_allreduce(tph_ctx* ctx, size_t off, int64_t count, int dtype, int op) {
   if (tph_p2p_fits(ctx, count, dtype)) return tph_p2p_exchange(ctx, ctx->comm_buf + off, ctx->comm_buf + off, count, dtype, op);
   const int rc = ctx->comm_allreduce(ctx->comm_user, (int64_t)off, count, dtype, op);
+  ctx->stat[1] += 1; ctx->stat[2] += count * (dtype == TPH_DT_I32 ? 4 : 8);
   TPH_REQUIRE(rc == 0, "all-reduce callback failed (%d)", rc);
   return 0;
 }
 int tph_comm_allgather(tph_ctx* ctx, size_t send_off, size_t recv_off, int64_t count, int dtype) {
   if (tph_p2p_fits(ctx, count, dtype)) return tph_p2p_exchange(ctx, ctx->comm_buf + send_off, ctx->comm_buf + recv_off, count, dtype, -1);
   const int rc = ctx->comm_allgather(ctx->comm_user, (int64_t)send_off, (int64_t)recv_off, count, dtype);
+  ctx->stat[1] += 1; ctx->stat[2] += count * (dtype == TPH_DT_I32 ? 4 : 8) * (int64_t)ctx->world;
   TPH_REQUIRE(rc == 0, "all-gather callback failed (%d)", rc);
   return 0;
 }
@@ -215,6 +217,12 @@ int tph_blocks(tph_ctx* ctx, int64_t n, int* T, int64_t* rows) {
     TPH_REQUIRE(v == r, "sharded runs need the same number of particles in every iteration (%lld vs %lld)", (long long)v, (long long)r);
   *T = (int)ctx->n_local_t.size();
   *rows = r;
+  return 0;
+}
+
+extern "C" int tph_comm_stats(tph_ctx* ctx, int64_t* out, int reset) {
+  TPH_REQUIRE(ctx && out, "tph_comm_stats: NULL argument");
+  for (int i = 0; i < 5; ++i) { out[i] = ctx->stat[i]; if (reset) ctx->stat[i] = 0; }
   return 0;
 }
 

@@ -1219,6 +1219,7 @@ extern "C" int tph_adapt(tph_ctx* ctx, int kernel, double* sums_dev, const doubl
     if (!a) return -2;                    // the sticky error of a timed-out exchange (text set by tph_p2p_ready)
     peers = *a;
     exchange = 1;
+    ctx->stat[0] += 1;                    // the step's all-reduce, folded into k_adapt
   }
   hipLaunchKernelGGL(k_adapt, dim3(1), dim3(threads), 0, ctx->stream, kernel, (const double*)sums_dev, counts_dev, K, n_global,
                      n_dim, n_steps, n_max, sigmas_dev, state_dev, mailbox_host, mailbox_slots, partials_dev, nparts, sums_dev,

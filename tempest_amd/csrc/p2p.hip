@@ -112,6 +112,7 @@ int tph_p2p_exchange(tph_ctx* ctx, const void* src, void* dst, int64_t count, in
   tph_p2p* p = ctx->p2p;
   TPH_REQUIRE(p && p->ready, "peer-to-peer collectives are not attached");
   if (*p->err_host != 0) return p2p_fail(*p->err_host);
+  ctx->stat[0] += 1;
   switch (dtype) {
     case TPH_DT_F64: hipLaunchKernelGGL(k_p2p<double>, dim3(1), dim3(256), 0, ctx->stream, p->a, (const double*)src, (double*)dst, (int)count, op); break;
     case TPH_DT_I64: hipLaunchKernelGGL(k_p2p<long long>, dim3(1), dim3(256), 0, ctx->stream, p->a, (const long long*)src, (long long*)dst, (int)count, op); break;
@@ -421,6 +422,8 @@ extern "C" int tph_resample_put_global(tph_ctx* ctx, const int64_t* idx_dev, int
   put_args w{};
   for (int r = 0; r < ctx->world; ++r) w.win[r] = p->win[r];
   const double* mirror = tph_rows_sync(ctx);
+  ctx->stat[3] += n_local;                              // this rank's slots refilled by the shuffle ((world-1)/world of them from peers)
+  ctx->stat[4] += n_local * (int64_t)rec * 8;
   if (ctx->world > 1) {                                 // rows for OTHER ranks' slots go into their windows
     hipLaunchKernelGGL(k_put_rows, dim3((unsigned)((n_slots + 63) / 64)), dim3(256), 0, ctx->stream, w, ctx->u, ctx->x, ctx->logl,
                        ctx->cap, mirror, d, idx_dev, n_slots, n_local, tag, ctx->rank);

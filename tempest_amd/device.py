@@ -204,6 +204,12 @@ class HipContext:
     def p2p_active(self) -> bool:
         return bool(self.lib.tph_comm_p2p_active(self._ctx))
 
+    def comm_stats(self, reset=False):
+        """Traffic counters of the ctx (tph_comm_stats): dict of p2p exchanges, callback collectives / bytes, shuffled rows / bytes."""
+        out = (C.c_int64 * 5)()
+        check(self.lib.tph_comm_stats(self._ctx, out, 1 if reset else 0), "tph_comm_stats")
+        return dict(zip(("p2p_exchanges", "callback_collectives", "callback_bytes", "shuffle_rows", "shuffle_bytes"), [int(v) for v in out]))
+
     def p2p_status(self):
         check(self.lib.tph_comm_p2p_status(self._ctx), "tph_comm_p2p_status")
 
