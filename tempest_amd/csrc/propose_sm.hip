@@ -30,7 +30,8 @@
 #include "tri.h"
 
 constexpr int SM_CAP = PROP_MAX_ATTEMPTS;      // attempts 0 .. SM_CAP-1, then the current point is proposed
-constexpr int SM_CHUNK = 4;                    // particles per queue grab (small: the last chunks set the kernel's tail)
+constexpr int SM_CHUNK = 4;                    // particles per queue grab (small: the last chunks set the kernel's tail);
+                                               // the prefetch registers pb0..pb3 of k_propose_sm are one per particle of a chunk
 constexpr int SM_ROWS = 4;                     // rows per step (two Box-Muller pairs)
 
 __device__ __forceinline__ void sm_wave_sync() {
@@ -53,7 +54,7 @@ static __global__ void __launch_bounds__(256) k_sm_pad(const double* __restrict_
   }
 }
 
-template <int KERNEL>
+template <int KERNEL, bool HAS_BC>
 __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u, int64_t n, int64_t ld, int d,
                                                     const double* __restrict__ means, const double* __restrict__ Lg,
                                                     const double* __restrict__ sigmas, const uint8_t* __restrict__ bc,
@@ -107,6 +108,13 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
   int att = 0, stage = 0, won = -1, best = SM_CAP;
   bool active = false;
   double b_fac = 0.0;
+  double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0, p5 = 0.0, p6 = 0.0, p7 = 0.0;   // rows 0..7 of the lane's attempt
+  // the pool's particles, prefetched when the chunk is grabbed: lane r holds base coordinate r of each (n_dim <= 64)
+  double pb0 = 0.0, pb1 = 0.0, pb2 = 0.0, pb3 = 0.0;
+  // the chunk AFTER the current pool, requested from the queue one grab ahead (lane 0 holds the ticket): the atomic's
+  // round trip is over long before the pool runs dry
+  unsigned long long ahead = 0;
+  if (lane == 0) ahead = atomicAdd(&queue[0], 1ull);
 
 #pragma unroll 1
   for (;;) {
@@ -129,21 +137,14 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
           if (obest < SM_CAP) {
             const unsigned long long wm = __ballot(won == obest && g == gg);
             const int wl = __ffsll((long long)wm) - 1;
-            const double bw = __shfl(b_fac, wl, 64);
-            // rows 0..7 of the winning attempt are not parked (see below): from its normals, still in the winner's column,
-            // with the row's own FMA chain (lane = row)
+            // rows 0..7 of the winning attempt never left its registers (see below)
             const int rtop = d < 2 * SM_ROWS ? d : 2 * SM_ROWS;
-            if (lane < rtop) {
-              const int r = lane;
-              const double* __restrict__ Lrow = Lt + (size_t)r * stride + sm_skew(r);
-              double acc = 0.0;
-              for (int j = 0; j <= r; ++j) acc = fma(Lrow[j], zs[(size_t)j * 64 + wl], acc);
-              const double bs = bscr[(wave_id * 32 + (size_t)gg) * (size_t)dc + r];
-              double x = fma(bw, acc, bs);
-              const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
-              if (f == TPH_BC_PERIODIC) x = bc_periodic(x);
-              else if (f == TPH_BC_REFLECTIVE) x = bc_reflective(x);
-              up[(size_t)r * ld + orow] = x;
+            {
+              const double w0 = __shfl(p0, wl, 64), w1 = __shfl(p1, wl, 64), w2 = __shfl(p2, wl, 64), w3 = __shfl(p3, wl, 64);
+              const double w4 = __shfl(p4, wl, 64), w5 = __shfl(p5, wl, 64), w6 = __shfl(p6, wl, 64), w7 = __shfl(p7, wl, 64);
+              const double mine8 = lane == 0 ? w0 : lane == 1 ? w1 : lane == 2 ? w2 : lane == 3 ? w3 : lane == 4 ? w4 : lane == 5 ? w5
+                                   : lane == 6 ? w6 : w7;
+              if (lane < rtop) up[(size_t)lane * ld + orow] = mine8;
             }
             const double* __restrict__ src = vscr + (wave_id * 64 + wl) * (size_t)dc;
             for (int r = rtop + lane; r < d; r += 64)
@@ -158,28 +159,36 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
           }
           n_dec += 1ull;
         }
-        // next particle of the pool; an empty pool is refilled from the global queue (one atomic per chunk)
+        // next particle of the pool; an empty pool takes the chunk requested one grab ago and requests the next one
         if (pool_next >= pool_cnt && !exhausted) {
-          unsigned long long c = 0;
-          if (lane == 0) c = atomicAdd(&queue[0], 1ull);
-          c = __shfl(c, 0, 64);
+          const unsigned long long c = __shfl(ahead, 0, 64);
           if ((int64_t)c >= nchunks) {
             exhausted = true;
           } else {
+            if (lane == 0) ahead = atomicAdd(&queue[0], 1ull);
             pool_row = (int64_t)c * SM_CHUNK;
             pool_cnt = (int)((n - pool_row) < SM_CHUNK ? (n - pool_row) : SM_CHUNK);
             pool_next = 0;
+            // base coordinates mu_r + a (u_r - mu_r) (tpCN) / u_r (RWM) of the chunk's particles, lane = r; padding rows sit
+            // at 0.5 (always in bounds, never looked at)
+            const int r = lane < d ? lane : d - 1;
+            const int64_t last = pool_row + pool_cnt - 1;
+            const double u0 = u[(size_t)r * ld + pool_row], u1 = u[(size_t)r * ld + (pool_row + 1 <= last ? pool_row + 1 : last)];
+            const double u2 = u[(size_t)r * ld + (pool_row + 2 <= last ? pool_row + 2 : last)];
+            const double u3 = u[(size_t)r * ld + (pool_row + 3 <= last ? pool_row + 3 : last)];
+            const double mr = (KERNEL == TPH_KERNEL_TPCN) ? means[r] : 0.0;
+            pb0 = lane < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, u0 - mr, mr) : u0) : 0.5;
+            pb1 = lane < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, u1 - mr, mr) : u1) : 0.5;
+            pb2 = lane < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, u2 - mr, mr) : u2) : 0.5;
+            pb3 = lane < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, u3 - mr, mr) : u3) : 0.5;
           }
         }
         int64_t nrow = -1;
         if (pool_next < pool_cnt) {
           nrow = pool_row + pool_next;
+          const double pb = pool_next == 0 ? pb0 : pool_next == 1 ? pb1 : pool_next == 2 ? pb2 : pb3;
           ++pool_next;
-          double* __restrict__ rec = bscr + (wave_id * 32 + (size_t)gg) * (size_t)dc;
-          for (int r = lane; r < dc; r += 64) {
-            const double uj = r < d ? u[(size_t)r * ld + nrow] : 0.0;
-            rec[r] = (KERNEL == TPH_KERNEL_TPCN && r < d) ? fma(a_fac, uj - means[r], means[r]) : uj;
-          }
+          if (lane < dc) bscr[(wave_id * 32 + (size_t)gg) * (size_t)dc + lane] = pb;     // the group's record (dc <= 64)
           refilled = true;
         }
         if (g == gg) {
@@ -242,25 +251,28 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
 #endif
     if (active) {
       const double acc[SM_ROWS] = {a0, a1, a2, a3};
+      const double bs[SM_ROWS] = {b01.x, b01.y, b23.x, b23.y};
       double v[SM_ROWS];
       bool ok = true;
 #pragma unroll
-      for (int q = 0; q < SM_ROWS; ++q) {
-        const int r = r0 + q;
-        v[q] = 0.0;
-        if (r < d) {
-          const double bs = q == 0 ? b01.x : q == 1 ? b01.y : q == 2 ? b23.x : b23.y;
-          double x = fma(b_fac, acc[q], bs);
-          const uint8_t f = bc ? bc[r] : (uint8_t)TPH_BC_STRICT;
+      for (int q = 0; q < SM_ROWS; ++q) {            // padding rows of the last stage: L row zero, base 0.5 -> in bounds
+        double x = fma(b_fac, acc[q], bs[q]);
+        if (HAS_BC) {                                // periodic / reflective dimensions: a separate instantiation
+          const int r = r0 + q;
+          const uint8_t f = r < d ? bc[r] : (uint8_t)TPH_BC_STRICT;
           if (f == TPH_BC_PERIODIC) x = bc_periodic(x);
           else if (f == TPH_BC_REFLECTIVE) x = bc_reflective(x);
           else ok = ok && (x >= 0.0) && (x <= 1.0);
-          v[q] = x;
+        } else {
+          ok = ok && (x >= 0.0) && (x <= 1.0);
         }
+        v[q] = x;
       }
-      // park the rows this attempt has passed -- from the third stage on: four in five steps are first or second stages (or
-      // die), and rows 0..7 of the one attempt that wins are recomputed when the particle is decided
-      if (ok && stage >= 2) {
+      // park the rows this attempt has passed: rows 0..7 in registers (four in five steps are first or second stages, or die),
+      // later ones in the lane's record
+      if (stage == 0) { p0 = v[0]; p1 = v[1]; p2 = v[2]; p3 = v[3]; }
+      else if (stage == 1) { p4 = v[0]; p5 = v[1]; p6 = v[2]; p7 = v[3]; }
+      else if (ok) {
         *(double2*)(vrec + r0) = make_double2(v[0], v[1]);
         *(double2*)(vrec + r0 + 2) = make_double2(v[2], v[3]);
       }
@@ -446,11 +458,16 @@ static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
   // closing pass overwrites it with the form at u'
   if (pend || KERNEL == TPH_KERNEL_TPCN || maha_u)
     if (launch_maha_tile<KERNEL, 0>(ctx, u, n, ld, means, Wb, up, maha_u, tick, pend, nullptr, dof, sigmas, seed, item0, maha_up)) return -1;
-  if (lds > 64 * 1024)
-    TPH_HIP(hipFuncSetAttribute((const void*)k_propose_sm<KERNEL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_propose_sm<KERNEL>), dim3((unsigned)groups), dim3(64 * wv), lds, ctx->stream, (const double*)u, n, ld, d, means,
-                     (const double*)Lg, sigmas, bc, seed, tick, item0, up, (const double*)maha_up, ctx->sm_scr,
-                     ctx->sm_scr + (size_t)dc * (size_t)waves * 64, lgG, queue);
+#define TPH_SM(BC)                                                                                                       \
+  do {                                                                                                                   \
+    if (lds > 64 * 1024)                                                                                                 \
+      TPH_HIP(hipFuncSetAttribute((const void*)k_propose_sm<KERNEL, BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_propose_sm<KERNEL, BC>), dim3((unsigned)groups), dim3(64 * wv), lds, ctx->stream, (const double*)u, n, ld, d, \
+                       means, (const double*)Lg, sigmas, bc, seed, tick, item0, up, (const double*)maha_up, ctx->sm_scr,   \
+                       ctx->sm_scr + (size_t)dc * (size_t)waves * 64, lgG, queue);                                        \
+  } while (0)
+  if (bc) TPH_SM(true); else TPH_SM(false);
+#undef TPH_SM
   TPH_LAUNCH_CHECK();
   if (KERNEL == TPH_KERNEL_TPCN || maha_up || tick.ctl)
     if (launch_maha_tile<KERNEL, 1>(ctx, u, n, ld, means, Wb, up, maha_up, tick, nullptr, queue, dof, sigmas, seed, item0, nullptr)) return -1;

@@ -51,9 +51,37 @@ def test_config2_gauss50_65536_rwm():
     steps = np.asarray(s.state.get_history("steps")); beta = np.asarray(s.state.get_history("beta"))
     pms = steps[beta > 0].sum() * 65536
     print(f"config2: logZ={logz:.3f} (analytic {-50 * np.log(20):.3f}) iters={len(beta)} wall={wall:.1f}s pms/s={pms / wall:.3g}")
-    assert -0.5 < logz + 50 * np.log(20.0) < 3.5
+    # the algorithm's own excess at this size: +2.45 (seed 0; +2.5 at the 16 384-particle twin, +5.3 at N = 512 in device and
+    # oracle alike); window = that value +- a few seed-sigma of a 65 536-particle run
+    assert 1.5 < logz + 50 * np.log(20.0) < 3.3
     np.testing.assert_allclose(mean, 0.0, atol=0.1)
     np.testing.assert_allclose(var, np.diag(S), rtol=0.1)
+    assert pms / wall > 5e7           # 7.6e7 in round 2, 9.2e7 with the row-walker kernel (first process on a fresh box: lower)
+
+
+def test_config2_gauss50_65536_tpcn():
+    """Config 2 with the default kernel (t-preconditioned Crank-Nicolson): never more than ~17 redraw attempts per particle,
+    46 iterations as with RWM; evidence excess +1.56 at this size."""
+    import tempest_amd as tp
+    dev = torch.device("cuda", 0)
+    loglike, S = c2_target(dev)
+    t0 = time.time()
+    s = tp.Sampler(prior20, loglike, 50, n_particles=65536, vectorize=True, clustering=False, sample="tpcn",
+                   random_state=0, backend="torch", batch_prior=True)
+    s.run(n_total=4 * 65536, progress=False)
+    wall = time.time() - t0
+    logz = s.evidence()[0]
+    x, w, _ = s.posterior()
+    mean = np.average(x, weights=w, axis=0)
+    var = np.average((x - mean) ** 2, weights=w, axis=0)
+    steps = np.asarray(s.state.get_history("steps")); beta = np.asarray(s.state.get_history("beta"))
+    pms = steps[beta > 0].sum() * 65536
+    print(f"config2 tpCN: logZ={logz:.3f} (analytic {-50 * np.log(20):.3f}) iters={len(beta)} wall={wall:.1f}s pms/s={pms / wall:.3g}")
+    assert beta[-1] == 1.0 and 40 <= len(beta) <= 52
+    assert 0.8 < logz + 50 * np.log(20.0) < 2.4
+    np.testing.assert_allclose(mean, 0.0, atol=0.1)
+    np.testing.assert_allclose(var, np.diag(S), rtol=0.1)
+    assert pms / wall > 7e7
 
 
 def test_config3_mixture32_clustering():
@@ -80,8 +108,9 @@ def test_config3_mixture32_clustering():
     occ = [float(np.sum(w[(np.sign(x[:, 0]) == a) & (np.sign(x[:, 1]) == b)])) for a in (-1, 1) for b in (-1, 1)]
     print(f"config3: logZ={logz:.3f} (analytic {-d * np.log(20):.3f}) iters={len(s.state.get_history('beta'))} "
           f"wall={wall:.1f}s K={s._core.trainer.clusterer.n_clusters_} mode occupancy={np.round(occ, 3)}")
-    # the algorithm's evidence excess at default settings grows with dimension (+0.2 at d=10, ~+1 at d=32, see config 2)
-    assert -0.5 < logz + d * np.log(20.0) < 2.0
+    # the algorithm's evidence excess at default settings grows with dimension (+0.2 at d=10, ~+1 at d=32, see config 2):
+    # +0.985 at this size and seed, +0.99 at 262 144, +1.2 at the N = 1024 twin (reference ensemble -94.68 +- 0.12)
+    assert 0.4 < logz + d * np.log(20.0) < 1.7
     assert min(occ) > 0.15 and max(occ) < 0.35
 
 
@@ -220,7 +249,7 @@ def test_config3_fullsize_262144_clustering():
           f"pms/s={steps[beta > 0].sum() * n / wall:.3g} K={s._core.trainer.clusterer.n_clusters_} occupancy={np.round(occ, 3)}")
     assert wall < 60.0
     assert np.all(np.diff(beta) >= 0) and beta[-1] == 1.0
-    assert -0.5 < logz + d * np.log(20.0) < 2.0
+    assert 0.4 < logz + d * np.log(20.0) < 1.6            # +0.99 at this size (see the 65 536-particle test above)
     assert min(occ) > 0.22 and max(occ) < 0.28
     np.testing.assert_allclose(np.average(x[:, 2:], weights=w, axis=0), 0.0, atol=0.05)
     np.testing.assert_allclose(np.average(x[:, 2:] ** 2, weights=w, axis=0), 0.25, rtol=0.1)
@@ -308,3 +337,42 @@ def test_config5_shard_262144_funnel100_first_iterations():
     # the ensemble is still inside the prior box and the likelihoods are finite
     u = st.dev("u")
     assert bool(((u >= 0) & (u <= 1)).all()) and bool(torch.isfinite(st.dev("logl")).all())
+
+
+def test_config5_shard_131072_funnel100_to_beta_one():
+    """A config-5 shard run to the end: 131 072 particles of the 100-D funnel (tpCN) until beta = 1 and the stopping rule.
+    The reference's own run of the N = 4096 twin (3 seeds, 3.4 CPU-hours each) takes 31 iterations and ends with a posterior
+    mean of v = 8.55 (logZ -639.44 +- 0.09); this build's twin 31 iterations, 8.51.  A shard 32 times larger must walk the
+    same schedule -- the annealing schedule is set by ESS ratios, which do not depend on N -- and land on the same posterior."""
+    import tempest_amd as tp
+    dev = torch.device("cuda", 0)
+    d, n = 100, 131072
+    scale = torch.full((d,), 600.0, dtype=torch.float64, device=dev); scale[0] = 30.0
+    shift = torch.full((d,), -300.0, dtype=torch.float64, device=dev); shift[0] = -15.0
+
+    def prior(u):
+        return u * scale + shift
+
+    def loglike(x):
+        v = x[:, 0]
+        lv = -0.5 * (v / 3.0) ** 2 - np.log(3.0) - 0.5 * np.log(2 * np.pi)
+        lr = (-0.5 * (x[:, 1:] ** 2) * torch.exp(-v)[:, None]).sum(dim=1) - 0.5 * (d - 1) * v - 0.5 * (d - 1) * np.log(2 * np.pi)
+        return lv + lr
+    s = tp.Sampler(prior, loglike, d, n_particles=n, vectorize=True, clustering=False, random_state=0,
+                   backend="torch", batch_prior=True)
+    t0 = time.time()
+    s.run(n_total=4 * n, progress=False)
+    wall = time.time() - t0
+    logz = s.evidence()[0]
+    beta = np.asarray(s.state.get_history("beta")); steps = np.asarray(s.state.get_history("steps"))
+    x, w, _ = s.posterior()
+    mean_v = float(np.average(x[:, 0], weights=w))
+    mu, sd, runs = _ref("c5twin_funnel100_n4096")
+    ref_it = np.mean([r["iters"] for r in runs])
+    print(f"config5 shard to beta=1: logZ={logz:.3f} (twin reference {mu:.2f} +- {sd:.2f}, analytic -636.70) iters={len(beta)} "
+          f"(reference twin {ref_it:.0f}) steps={int(steps[beta > 0].sum())} mean v={mean_v:.3f} wall={wall:.1f}s "
+          f"pms/s={steps[beta > 0].sum() * n / wall:.3g}")
+    assert wall < 60.0 and beta[-1] == 1.0 and np.all(np.diff(beta) >= 0)
+    assert abs(len(beta) - ref_it) <= 3
+    assert abs(mean_v - np.mean([r["mean"][0] for r in runs])) < 0.4      # reference twin: 8.55
+    assert abs(logz - mu) < 1.5             # same estimator, larger N: the twin's value up to the N-dependence of its bias
