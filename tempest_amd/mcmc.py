@@ -239,7 +239,8 @@ class StepEngine:
         if want_blk != self.blocked:
             self.blocked = want_blk
             self.ctx.set_option(OPT_BLOCKED, 1 if want_blk else 0)
-        want_sm = (self.K == 1 and self.ctx.n_dim <= 64 and mean_attempts > (4.0 if self.staged else 6.0)
+        sm_on = float(os.environ.get("TEMPEST_AMD_SM_ON", "6.0"))
+        want_sm = (self.K == 1 and self.ctx.n_dim <= 64 and mean_attempts > (sm_on * 2.0 / 3.0 if self.staged else sm_on)
                    and os.environ.get("TEMPEST_AMD_STAGED", "1") != "0")      # debugging aid (TPH_OPT_STAGED_REDRAW)
         lanes = 0
         if want_sm:         # lanes per particle = attempts in flight: about half the expected count, 2 .. 8 (16 on small shards)

@@ -26,7 +26,7 @@ def pmc_summary(dirname, kernel_prefix="void k_propose_reg"):
 
 
 def main():
-    R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    R = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src = os.path.join(ROOT, "gpurun_out", R, "final")
     dst = os.path.join(ROOT, "profiles")
     cp = lambda a, b: shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))  # noqa: E731
@@ -47,6 +47,19 @@ def main():
             if line:
                 c2[k + tag] = json.loads(line[-1])
     json.dump(c2, open(os.path.join(dst, f"{R}_c2_runs.json"), "w"), indent=1)
+    # configs 3 and 5 (shard): kernel stats + the run lines
+    others = {}
+    for tag, stats, logs in (("c3", os.path.join("prof_c3", "c3_kernel_stats.csv"), (("", "c3.log"), ("_unprofiled", "c3_plain.log"))),
+                             ("c5_shard_131072", os.path.join("prof_c5", "c5_kernel_stats.csv"), (("", "c5.log"),))):
+        if os.path.exists(os.path.join(src, stats)):
+            cp(stats, f"{R}_{tag.split('_')[0]}_kernel_stats.csv")
+            for suffix, name in logs:
+                if os.path.exists(os.path.join(src, name)):
+                    line = [ln for ln in open(os.path.join(src, name)).read().splitlines() if ln.startswith("{")]
+                    if line:
+                        others[tag + suffix] = json.loads(line[-1])
+    if others:
+        json.dump(others, open(os.path.join(dst, f"{R}_c3_c5_runs.json"), "w"), indent=1)
     # shard-size bench lines
     for name in ("bench_131k", "bench_131k_comm"):
         cp(name + ".json", f"{R}_{name}.json")
@@ -125,11 +138,13 @@ def main():
             w["valu_instructions_per_wave64_of_particles"] = round(w["SQ_INSTS_VALU"] / waves, 1)
             w["valu_busy_us_at_2.4GHz"] = round(w["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / 2.4e3, 1)
         plain = [json.loads(ln) for ln in open(os.path.join(src, f"prop_{tag}_plain.jsonl")) if ln.startswith("{")]
-        doc["round2" if tag == "new" else "round1"] = {"pmc": per, "unprofiled_median_us": {f'{p["n"]}_{p["scenario"]}': p["median_us"] for p in plain}}
+        doc[("this_round" if tag == "new" else "previous_round") if R != "r02" else ("round2" if tag == "new" else "round1")] = {"pmc": per, "unprofiled_median_us": {f'{p["n"]}_{p["scenario"]}': p["median_us"] for p in plain}}
     json.dump(doc, open(os.path.join(dst, f"{R}_propose_pmc.json"), "w"), indent=1)
     # d > 16 proposal kernels
     rows = [json.loads(ln) for ln in open(os.path.join(src, "prop_d50.jsonl")) if ln.startswith("{")]
-    json.dump({"what": "tph_propose at d > 16: variant 3 = multi-lane kernel, 4 = blocked kernel + straggler pass", "runs": rows},
+    json.dump({"what": "tph_propose at d > 16: variant 3 = multi-lane kernel, 4 = blocked kernel + straggler pass, 5 = row-walker kernel "
+                       "(propose_sm.hip); scenario 'prior' = an ensemble from the prior with a proposal as broad as the prior (the first "
+                       "iterations of a run: tens to hundreds of redraw attempts per particle); lib = which build", "runs": rows},
               open(os.path.join(dst, f"{R}_propose_d50_d100.json"), "w"), indent=1)
     print("assembled into", dst)
 

@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=None)
     ap.add_argument("--legacy", action="store_true")
+    ap.add_argument("--older", action="store_true", help="--lib is an earlier round's library (same tph_propose signature, fewer symbols)")
     ap.add_argument("--n", type=int, default=1048576)
     ap.add_argument("--d", type=int, default=10)
     ap.add_argument("--kernel", default="tpcn")
@@ -42,7 +43,14 @@ def main():
     a = ap.parse_args()
     import torch
     from tempest_amd import _lib
-    lib = _lib.load(a.lib) if not a.legacy else C.CDLL(a.lib)
+    lib = _lib.load(a.lib) if not (a.legacy or a.older) else C.CDLL(a.lib)
+    if a.older:                           # an earlier round's library with today's tph_propose signature: bind what it exports
+        for name, (res, args) in _lib.SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                continue
+            fn.restype, fn.argtypes = res, args
     if a.legacy:
         for name, (res, args) in _lib.SIGNATURES.items():
             if name in ("tph_fit_modes", "tph_chol_inv", "tph_propose", "tph_accept"):

@@ -1,44 +1,63 @@
 #!/bin/bash
 # Regenerates the round's evidence under gpurun_out/rNN/final on the GPU box (then copied into profiles/ by
-# tools/assemble_profiles.py).  Usage: gpurun -- 'bash tools/collect_profiles.sh r02'
+# tools/assemble_profiles.py).  Usage: gpurun -- 'bash tools/collect_profiles.sh r03'
 set -e
-R=${1:-r02}
+R=${1:-r03}
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 O=gpurun_out/$R/final
 rm -rf "$O"; mkdir -p "$O"
 # 1. the bench line, plain
 python3 bench.py > "$O/bench_unprofiled.json" 2> "$O/bench_unprofiled.err"
+echo "bench done"
 # 2. the same under the kernel tracer
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -o bench -- python3 bench.py --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/bench_under_rocprof.err"
+echo "bench under rocprof done"
 # 3. reweight kernel: HBM traffic counters, separate passes
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_rw_fetch" -o f -- python3 bench.py --roofline-only > "$O/rw_fetch.json" 2> "$O/rw_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_rw_write" -o w -- python3 bench.py --roofline-only > "$O/rw_write.json" 2> "$O/rw_write.err"
-# 4. proposal kernel: instruction counters, this round's library and round 1's (scratch/oldlib, if present)
+echo "pmc K2 done"
+# 4. proposal kernel (d <= 16): instruction counters, this round's library and round 2's (scratch/oldlib, if present) on this box
 PMC="SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SMEM"
 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d "$O/pmc_prop_new" -o p -- python3 tools/bench_propose.py --scen tight,mid,wide --reps 5 > "$O/prop_new.jsonl" 2> "$O/prop_new.err"
 python3 tools/bench_propose.py --scen tight,mid,wide > "$O/prop_new_plain.jsonl" 2>> "$O/prop_new.err"
 python3 tools/bench_propose.py --scen tight,mid,wide --n 131072 >> "$O/prop_new_plain.jsonl" 2>> "$O/prop_new.err"
-if [ -f scratch/oldlib/libtempest_hip_r01.so ]; then
-  rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d "$O/pmc_prop_old" -o p -- python3 tools/bench_propose.py --legacy --lib scratch/oldlib/libtempest_hip_r01.so --scen tight,mid,wide --reps 5 > "$O/prop_old.jsonl" 2> "$O/prop_old.err"
-  python3 tools/bench_propose.py --legacy --lib scratch/oldlib/libtempest_hip_r01.so --scen tight,mid,wide > "$O/prop_old_plain.jsonl" 2>> "$O/prop_old.err"
-  python3 tools/bench_propose.py --legacy --lib scratch/oldlib/libtempest_hip_r01.so --scen tight,mid,wide --n 131072 >> "$O/prop_old_plain.jsonl" 2>> "$O/prop_old.err"
+if [ -f scratch/oldlib/libtempest_hip_r02.so ]; then
+  rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d "$O/pmc_prop_old" -o p -- python3 tools/bench_propose.py --older --lib scratch/oldlib/libtempest_hip_r02.so --scen tight,mid,wide --reps 5 > "$O/prop_old.jsonl" 2> "$O/prop_old.err"
+  python3 tools/bench_propose.py --older --lib scratch/oldlib/libtempest_hip_r02.so --scen tight,mid,wide > "$O/prop_old_plain.jsonl" 2>> "$O/prop_old.err"
+  python3 tools/bench_propose.py --older --lib scratch/oldlib/libtempest_hip_r02.so --scen tight,mid,wide --n 131072 >> "$O/prop_old_plain.jsonl" 2>> "$O/prop_old.err"
 fi
-# 5. d > 16 proposal kernels
+echo "propose d10 done"
+# 5. d > 16 proposal kernels: multi-lane (3), blocked + stragglers (4), row walker (5); "prior" = the first iterations of a run
 for k in rwm tpcn; do
+  python3 tools/bench_propose.py --d 50 --n 65536 --kernel $k --scen prior --reps 7 --variant 3 --unstaged >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+  python3 tools/bench_propose.py --d 50 --n 65536 --kernel $k --scen prior --reps 7 --variant 5 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
   python3 tools/bench_propose.py --d 50 --n 65536 --kernel $k --scen tight,mid,wide --reps 10 --variant 3 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+  python3 tools/bench_propose.py --d 50 --n 65536 --kernel $k --scen wide --reps 10 --variant 5 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
   python3 tools/bench_propose.py --d 50 --n 65536 --kernel $k --scen tight,mid --reps 10 --variant 4 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
 done
+python3 tools/bench_propose.py --d 50 --n 65536 --kernel rwm --scen prior --reps 5 --variant 3 --unstaged --sigma-scale 4 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+python3 tools/bench_propose.py --d 50 --n 65536 --kernel rwm --scen prior --reps 5 --variant 5 --sigma-scale 4 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+python3 tools/bench_propose.py --d 32 --n 262144 --kernel tpcn --scen prior --reps 5 --variant 3 --unstaged >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+python3 tools/bench_propose.py --d 32 --n 262144 --kernel tpcn --scen prior --reps 5 --variant 5 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
 python3 tools/bench_propose.py --d 100 --n 262144 --kernel tpcn --scen tight --reps 10 --variant 3 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
 python3 tools/bench_propose.py --d 100 --n 262144 --kernel tpcn --scen tight --reps 10 --variant 4 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
-# 6. config 2 end to end under the tracer
+if [ -f scratch/oldlib/libtempest_hip_r02.so ]; then      # the multi-lane kernel of round 2 on this box (before the shorter RNG chain)
+  python3 tools/bench_propose.py --older --lib scratch/oldlib/libtempest_hip_r02.so --d 50 --n 65536 --kernel rwm --scen prior --reps 7 --variant 3 --unstaged >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+  python3 tools/bench_propose.py --older --lib scratch/oldlib/libtempest_hip_r02.so --d 50 --n 65536 --kernel tpcn --scen prior --reps 7 --variant 3 --unstaged >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+fi
+echo "propose d50 done"
+# 6. configs 2, 3 and a config-5 shard end to end under the tracer
 for k in rwm tpcn; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c2_$k" -o c2 -- python3 tools/run_config.py c2 $k > "$O/c2_$k.log" 2>&1
 done
 python3 tools/run_config.py c2 rwm > "$O/c2_rwm_plain.log" 2>&1
 python3 tools/run_config.py c2 tpcn > "$O/c2_tpcn_plain.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c3" -o c3 -- python3 tools/run_config.py c3 tpcn > "$O/c3.log" 2>&1
+python3 tools/run_config.py c3 tpcn > "$O/c3_plain.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c5" -o c5 -- python3 tools/run_config.py c5 tpcn > "$O/c5.log" 2>&1
+echo "configs done"
 # 7. per-kernel roofline table
-TPH_ROOFLINE_META="$O/roof/meta.json" true
 mkdir -p "$O/roof"
 TPH_ROOFLINE_META="$O/roof/meta.json" python3 tools/roofline_table.py > "$O/roof/plain.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv -d "$O/roof/trace" -o t -- python3 tools/roofline_table.py > "$O/roof/trace.log" 2>&1
@@ -46,18 +65,13 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/roof/fetch"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/roof/write" -o w -- python3 tools/roofline_table.py > "$O/roof/write.log" 2>&1
 python3 tools/roofline_table.py --collect "$O/roof" --out "$O/roofline_table.json" > "$O/roofline_table.txt"
 rm -rf "$O/roof/trace" "$O/roof/fetch" "$O/roof/write"
+echo "roofline table done"
 # 8. config 4's 8-GPU shard size, un-sharded and through the sharded code path over RCCL at world size 1
 python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline > "$O/bench_131k.json" 2> "$O/bench_131k.err"
 TEMPEST_AMD_FORCE_COMM=1 python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline > "$O/bench_131k_comm.json" 2> "$O/bench_131k_comm.err"
-# ... and three interleaved pairs without the HIP-callback leg (single runs differ by several % on a shared box)
 for i in 1 2 3; do
   python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline --no-hip-callbacks > "$O/ab_plain$i.json" 2>> "$O/ab.err"
   TEMPEST_AMD_FORCE_COMM=1 python3 bench.py --particles 131072 --no-roofline --no-cpu-baseline --no-hip-callbacks > "$O/ab_comm$i.json" 2>> "$O/ab.err"
-done
-# 9. the up-sampling multiplicities: draw-order lookups vs sorted draws, two interleaved pairs of the bench line on this box
-for i in 1 2; do
-  TEMPEST_AMD_SORTED_DRAWS=0 python3 bench.py --no-roofline --no-cpu-baseline > "$O/sd_off$i.json" 2>> "$O/sd.err"
-  TEMPEST_AMD_SORTED_DRAWS=1 python3 bench.py --no-roofline --no-cpu-baseline > "$O/sd_on$i.json" 2>> "$O/sd.err"
 done
 # per-launch summary of the roofline kernel and the proposal kernel out of the bench trace (the raw trace is dropped below)
 python3 - "$O" <<'PY'
@@ -76,5 +90,6 @@ json.dump({"k_reweight_reduce<1, 8> on the 1.07 GB history": {"launches": len(k2
 PY
 # keep the merge small: drop the raw traces that are not summarised further
 find "$O" -name "*kernel_trace.csv" -size +8M -delete
+find "$O" -name "*counter_collection.csv" -size +20M -delete
 du -sh "$O"
 echo collected
