@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_unprofiled.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_unprofiled.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -32,12 +32,15 @@ def test_committed_bench_line_has_the_contract_fields():
     assert d["whole_run_warm"]["iterations"] == d["whole_run"]["iterations"] == d["iterations_total"]
     assert d["whole_run_warm"]["seconds"] < d["whole_run"]["seconds"]
     assert d["mutation_only"]["value"] > d["value"] and d["hip_callbacks"]["same_schedule_as_value_run"] is True
+    # round 3: the cold whole run is timed from before the Sampler's construction and says what its start-up cost
+    sb = d["whole_run"]["startup_breakdown"]
+    assert sb["wall_s_from_construction"] > 0 and "user_callbacks" in sb["threads_s"] and "device_context" in sb["threads_s"]
 
 
 def test_committed_profiles_are_self_consistent():
     """The evidence under profiles/ that the docs quote: rates follow from bytes and durations, counter traffic is the corrected
     FETCH + WRITE, the roofline kernel's counters match its algorithmic bytes, the A/B set carries its medians."""
-    t = json.load(open(os.path.join(ROOT, "profiles", "r02_roofline_table.json")))
+    t = json.load(open(os.path.join(ROOT, "profiles", "r03_roofline_table.json")))
     assert t["peak_GBs"] == 8000.0 and len(t["kernels"]) >= 18
     names = " ".join(k["kernel"] for k in t["kernels"])
     for needed in ("k_logmix_append", "k_reweight_reduce<1, 8>", "k_weights", "k_gather_rows", "k_rows_pack", "k_propose_reg", "k_accept",
@@ -51,10 +54,10 @@ def test_committed_profiles_are_self_consistent():
         assert abs(k["counter_bytes_per_launch"] - (k["FETCH_SIZE_bytes_x2"] + k["WRITE_SIZE_bytes"])) < 1.0
     k2 = next(k for k in t["kernels"] if k["kernel"].startswith("void k_reweight_reduce<1, 8>"))
     assert 0.99 < k2["traffic_over_algorithmic"] < 1.02
-    rw = json.load(open(os.path.join(ROOT, "profiles", "r02_reweight_pmc.json")))
+    rw = json.load(open(os.path.join(ROOT, "profiles", "r03_reweight_pmc.json")))
     assert rw["n_rows"] == 67108864 and 0.999 < rw["traffic_over_algorithmic"] < 1.01
     assert abs(rw["hbm_bytes_per_launch"] - (rw["hbm_read_bytes_per_launch"] + rw["hbm_write_bytes_per_launch"])) < 1.0
-    ab = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_131k_ab.json")))
+    ab = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_131k_ab.json")))
     plain = sorted(r["ms_per_step"] for r in ab["runs"] if r["run"].startswith("plain"))
     comm = sorted(r["ms_per_step"] for r in ab["runs"] if r["run"].startswith("comm"))
     assert len(plain) == 3 and len(comm) == 3 and abs(ab["median_ms_per_step"]["plain"] - plain[1]) < 1e-9
@@ -63,6 +66,17 @@ def test_committed_profiles_are_self_consistent():
     p = json.load(open(os.path.join(ROOT, "profiles", "r02_propose_pmc.json")))
     for scen in ("tight", "mid", "wide"):
         assert p["round2"]["pmc"][scen]["SQ_INSTS_VALU"] < 0.85 * p["round1"]["pmc"][scen]["SQ_INSTS_VALU"]
+    p3 = json.load(open(os.path.join(ROOT, "profiles", "r03_propose_pmc.json")))           # the shorter RNG chain, same box
+    for scen in ("tight", "mid", "wide"):
+        assert p3["this_round"]["pmc"][scen]["SQ_INSTS_VALU"] < 0.95 * p3["previous_round"]["pmc"][scen]["SQ_INSTS_VALU"]
+    # the row-walker kernel against the multi-lane kernel on the ensembles from the prior, same box
+    runs = json.load(open(os.path.join(ROOT, "profiles", "r03_propose_d50_d100.json")))["runs"]
+    med = {(r["lib"], r["kernel"], r["n"], r["d"], r["scenario"], r["variant"], round(r.get("mean_attempts_probe", 0) / 100)): r["median_us"]
+           for r in runs}
+    for kern in ("rwm", "tpcn"):
+        a = [v for k, v in med.items() if k[:6] == ("libtempest_hip.so", kern, 65536, 50, "prior", 3) and k[6] < 2]
+        b = [v for k, v in med.items() if k[:6] == ("libtempest_hip.so", kern, 65536, 50, "prior", 5) and k[6] < 2]
+        assert a and b and min(b) < 0.6 * min(a), (kern, a, b)
 
 
 def test_bench_cli_defaults():
