@@ -316,6 +316,17 @@ __device__ inline double tph_gamma_mt(const tph_rng& g, double shape, int first_
   return out;
 }
 
+// tpCN's proposal-density ratio in the Metropolis factor (mcmc.py:251-279): -A + B with A, B = -1/2 (d + nu) log(1 + m / nu) at
+// u' and u.  The lean log (both arguments are >= 1 for finite forms); a NaN / inf form goes through the library log so that
+// alpha stays NaN -> 0 as in the reference.  One definition for k_accept and the HIP-callback plugins (bit-identical paths).
+__device__ __forceinline__ double tph_tpcn_factor(double d_plus_nu, double nu, double m_u, double m_up) {
+  const double au = 1.0 + tph_div(m_u, nu), ap = 1.0 + tph_div(m_up, nu);
+  const bool plain = au < 1e300 && ap < 1e300;
+  const double B = -0.5 * d_plus_nu * (plain ? tph_log(au) : log(au));
+  const double A = -0.5 * d_plus_nu * (plain ? tph_log(ap) : log(ap));
+  return -A + B;
+}
+
 // ---- boundary conditions of the proposals (mcmc.py:326-411) and the cap of the redraw-until-in-bounds loop ----
 __device__ __forceinline__ double bc_periodic(double v) {  // numpy `v % 1.0` (npy_divmod)
   double r = fmod(v, 1.0);

@@ -1111,10 +1111,8 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accept(double beta, double* __r
     double l0 = logl[i], l1 = lp[i];
     double factor = 0.0;
     if (KERNEL == TPH_KERNEL_TPCN) {
-      double nu = dof[c];
-      double B = -0.5 * ((double)d + nu) * log(1.0 + maha_u[i] / nu);
-      double A = -0.5 * ((double)d + nu) * log(1.0 + maha_up[i] / nu);
-      factor = -A + B;
+      const double nu = dof[c];
+      factor = tph_tpcn_factor((double)d + nu, nu, maha_u[i], maha_up[i]);
     }
     double a = exp(beta * (l1 - l0) + factor);
     a = isnan(a) ? 0.0 : fmin(1.0, a);
