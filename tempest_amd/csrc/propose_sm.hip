@@ -46,6 +46,27 @@ __device__ __forceinline__ void sm_wave_sync() {
 __host__ __device__ static inline int sm_stride(int dc) { return (dc + 14 + 3) & ~3; }
 __host__ __device__ static inline int sm_skew(int r) { return 2 * ((r >> 2) & 7); }
 
+// n_dim > 64 ("deep" variant): a full-row copy of L (100-D: 93 KB) and a 100-row z tile per wave (51 KB) would leave room for
+// ONE wave.  The copy becomes a staircase -- the four rows of stage s hold len(s) = 4 (s + 1) columns rounded up to 16, zeros
+// beyond the diagonal (100-D: 50 KB) -- and the column loop masks lanes per 16-column block instead of letting shallow lanes
+// multiply zeros; the z tile keeps only the first `zl` rows in LDS (100-D: 48 rows, 24 KB per wave, four waves per CU), the rows
+// beyond live in a lane-private column of global scratch: 1 attempt in 5 gets that far at 100-D from the prior.
+// Stage s starts at smd_off(s) (16 doubles of slack per stage for the same bank skew as above), its rows are smd_rs(s) apart.
+__host__ __device__ static inline int smd_rs(int s) { return 16 * ((s >> 2) + 1); }
+__host__ __device__ static inline int smd_base(int s) { const int q = s >> 2, t = s & 3; return 64 * (q + 1) * (2 * q + t) + 16 * s; }
+__host__ __device__ static inline int smd_off(int s) { return smd_base(s) + 2 * (s & 7); }
+
+// the staircase copy of L in global memory (the workgroups copy it to LDS word for word); one workgroup
+static __global__ void __launch_bounds__(256) k_sm_pad_deep(const double* __restrict__ chol, int d, int nst, double* __restrict__ Lg) {
+  const int total = smd_base(nst);
+  for (int e = threadIdx.x; e < total; e += blockDim.x) Lg[e] = 0.0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < SM_ROWS * nst * 128; e += blockDim.x) {
+    const int r = e >> 7, j = e & 127;
+    if (r < d && j <= r) Lg[smd_off(r >> 2) + (r & 3) * smd_rs(r >> 2) + j] = chol[(size_t)r * d + j];
+  }
+}
+
 // Lg[dc][dc]: L padded with zeros above the diagonal and beyond d (the kernels below multiply, they do not branch); one workgroup
 static __global__ void __launch_bounds__(256) k_sm_pad(const double* __restrict__ chol, int d, int dc, double* __restrict__ Lg) {
   for (int e = threadIdx.x; e < dc * dc; e += blockDim.x) {
@@ -54,7 +75,7 @@ static __global__ void __launch_bounds__(256) k_sm_pad(const double* __restrict_
   }
 }
 
-template <int KERNEL, bool HAS_BC>
+template <int KERNEL, bool HAS_BC, bool DEEP>
 __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u, int64_t n, int64_t ld, int d,
                                                     const double* __restrict__ means, const double* __restrict__ Lg,
                                                     const double* __restrict__ sigmas, const uint8_t* __restrict__ bc,
@@ -62,24 +83,34 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
                                                     const double* __restrict__ bfac, double* __restrict__ vscr,
                                                     double* __restrict__ bscr, int lgG,
                                                     unsigned long long* __restrict__ queue /* [0] next chunk, [1] sum of
-                                                    attempts, [2] particles decided */) {
+                                                    attempts, [2] particles decided */,
+                                                    int zl /* DEEP: rows of z held in LDS (multiple of 16) */,
+                                                    double* __restrict__ zscr /* DEEP: the rows beyond, per wave */) {
   extern __shared__ double sm_lds[];
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int G = 1 << lgG;
   const int nst = (d + SM_ROWS - 1) / SM_ROWS, dc = SM_ROWS * nst, npairs = (d + 1) >> 1;
   const int stride = sm_stride(dc);
-  double* Lt = sm_lds;                                         // [dc][stride] (+ skew): the workgroup's copy of L
-  double* zs = Lt + (size_t)dc * stride + (size_t)wid * dc * 64;    // [dc][64] normals of this wave's attempts
-  for (int e = threadIdx.x; e < dc * dc; e += blockDim.x) {
-    const int r = e / dc, j = e - r * dc;
-    Lt[(size_t)r * stride + sm_skew(r) + j] = Lg[e];
+  const int zrows = DEEP ? zl : dc;
+  const int lt_len = DEEP ? smd_base(nst) : dc * stride;
+  double* Lt = sm_lds;                                         // [dc][stride] (+ skew), DEEP: the staircase: the workgroup's copy of L
+  double* zs = Lt + (size_t)lt_len + (size_t)wid * zrows * 64; // [zrows][64] normals of this wave's attempts
+  if (DEEP) {
+    for (int e = threadIdx.x; e < lt_len; e += blockDim.x) Lt[e] = Lg[e];
+  } else {
+    for (int e = threadIdx.x; e < dc * dc; e += blockDim.x) {
+      const int r = e / dc, j = e - r * dc;
+      Lt[(size_t)r * stride + sm_skew(r) + j] = Lg[e];
+    }
   }
-  for (int e = lane; e < dc * 64; e += 64) zs[e] = 0.0;        // stale columns are multiplied by zeros of L: they must be finite
+  for (int e = lane; e < zrows * 64; e += 64) zs[e] = 0.0;     // stale columns are multiplied by zeros of L: they must be finite
   __syncthreads();
   const uint32_t tk = tick;              // the step's RNG tick, read from the control block ONCE: inside the loop its two loads would
                                          // wait for every load in flight (vmcnt counts in order), the prefetched coordinates included
   const size_t wave_id = (size_t)blockIdx.x * (blockDim.x >> 6) + wid;
   double* __restrict__ vrec = vscr + (wave_id * 64 + lane) * (size_t)dc;      // this lane's record of passed rows
+  // DEEP: z rows zl .. of this wave's attempts, [row - zl][lane] (zeroed when allocated, only ever holds normals: finite)
+  double* __restrict__ zg = DEEP ? zscr + wave_id * (size_t)(((dc + 15) & ~15) - zl) * 64 : nullptr;
   // the groups' particles as contiguous records base[r] = mu_r + a (u_r - mu_r) (tpCN) or u_r (RWM), written when a group takes a
   // particle: a step reads four consecutive doubles of it (one 32-byte sector, shared by the group's lanes), where the
   // dimension-major u costs four scattered 64-byte sectors per lane and step -- 8 GB per launch at 65 536 x 50-D from the prior
@@ -111,6 +142,7 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
   double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0, p5 = 0.0, p6 = 0.0, p7 = 0.0;   // rows 0..7 of the lane's attempt
   // the pool's particles, prefetched when the chunk is grabbed: lane r holds base coordinate r of each (n_dim <= 64)
   double pb0 = 0.0, pb1 = 0.0, pb2 = 0.0, pb3 = 0.0;
+  double pc0 = 0.0, pc1 = 0.0, pc2 = 0.0, pc3 = 0.0;          // DEEP: coordinate 64 + lane
   // the chunk AFTER the current pool, requested from the queue one grab ahead (lane 0 holds the ticket): the atomic's
   // round trip is over long before the pool runs dry
   unsigned long long ahead = 0;
@@ -181,14 +213,27 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
             pb1 = lane < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, u1 - mr, mr) : u1) : 0.5;
             pb2 = lane < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, u2 - mr, mr) : u2) : 0.5;
             pb3 = lane < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, u3 - mr, mr) : u3) : 0.5;
+            if (DEEP) {
+              const int rh = lane + 64 < d ? lane + 64 : d - 1;
+              const double h0 = u[(size_t)rh * ld + pool_row], h1 = u[(size_t)rh * ld + (pool_row + 1 <= last ? pool_row + 1 : last)];
+              const double h2 = u[(size_t)rh * ld + (pool_row + 2 <= last ? pool_row + 2 : last)];
+              const double h3 = u[(size_t)rh * ld + (pool_row + 3 <= last ? pool_row + 3 : last)];
+              const double mh = (KERNEL == TPH_KERNEL_TPCN) ? means[rh] : 0.0;
+              pc0 = lane + 64 < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, h0 - mh, mh) : h0) : 0.5;
+              pc1 = lane + 64 < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, h1 - mh, mh) : h1) : 0.5;
+              pc2 = lane + 64 < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, h2 - mh, mh) : h2) : 0.5;
+              pc3 = lane + 64 < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, h3 - mh, mh) : h3) : 0.5;
+            }
           }
         }
         int64_t nrow = -1;
         if (pool_next < pool_cnt) {
           nrow = pool_row + pool_next;
           const double pb = pool_next == 0 ? pb0 : pool_next == 1 ? pb1 : pool_next == 2 ? pb2 : pb3;
+          const double pc = pool_next == 0 ? pc0 : pool_next == 1 ? pc1 : pool_next == 2 ? pc2 : pc3;
           ++pool_next;
-          if (lane < dc) bscr[(wave_id * 32 + (size_t)gg) * (size_t)dc + lane] = pb;     // the group's record (dc <= 64)
+          if (lane < dc) bscr[(wave_id * 32 + (size_t)gg) * (size_t)dc + lane] = pb;     // the group's record
+          if (DEEP && lane + 64 < dc) bscr[(wave_id * 32 + (size_t)gg) * (size_t)dc + 64 + lane] = pc;
           refilled = true;
         }
         if (g == gg) {
@@ -218,10 +263,13 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
       double t0, t1, t2, t3;
       gz.normal2(base_draw + (uint32_t)p0, t0, t1);
       gz.normal2(base_draw + (uint32_t)(p0 < last ? p0 + 1 : last), t2, t3);
-      zs[(size_t)(r0 + 0) * 64 + lane] = t0;
-      zs[(size_t)(r0 + 1) * 64 + lane] = t1;
-      zs[(size_t)(r0 + 2) * 64 + lane] = t2;
-      zs[(size_t)(r0 + 3) * 64 + lane] = t3;
+      if (!DEEP || r0 < zl) {
+        double* zw = zs + (size_t)r0 * 64 + lane;
+        zw[0] = t0; zw[64] = t1; zw[128] = t2; zw[192] = t3;
+      } else {
+        double* __restrict__ zw = zg + (size_t)(r0 - zl) * 64 + lane;
+        zw[0] = t0; zw[64] = t1; zw[128] = t2; zw[192] = t3;
+      }
     }
     sm_wave_sync();
     SM_PF(pf_bm);
@@ -233,15 +281,45 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(smax, o, 64); smax = other > smax ? other : smax; }
     const int jm = SM_ROWS * (__builtin_amdgcn_readfirstlane(smax) + 1);
-    const double* __restrict__ Lr = Lt + (size_t)r0 * stride + sm_skew(r0);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (DEEP) {
+      // staircase rows: a lane takes part in the 16-column blocks its rows reach (idle lanes in none)
+      const double* __restrict__ Lr = Lt + smd_off(stage);
+      const int rs = smd_rs(stage);
+      const int mylen = active ? SM_ROWS * (stage + 1) : 0;
+#pragma unroll 1
+      for (int jb = 0; jb < jm; jb += 16) {
+        if (jb < mylen) {
+          const double* __restrict__ Lb = Lr + jb;
+          double zz[16];
+          if (jb < zl) {                       // (wave-uniform) the block's 16 normals: LDS tile or the lane's global column
+            const double* zc = zs + (size_t)jb * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) zz[j] = zc[(size_t)j * 64];
+          } else {
+            const double* __restrict__ zc = zg + (size_t)(jb - zl) * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) zz[j] = zc[(size_t)j * 64];
+          }
+#pragma unroll
+          for (int j = 0; j < 16; j += 2) {
+            const double2 l0 = *(const double2*)(Lb + j), l1 = *(const double2*)(Lb + rs + j);
+            const double2 l2 = *(const double2*)(Lb + 2 * rs + j), l3 = *(const double2*)(Lb + 3 * rs + j);
+            a0 = fma(l0.x, zz[j], a0); a1 = fma(l1.x, zz[j], a1); a2 = fma(l2.x, zz[j], a2); a3 = fma(l3.x, zz[j], a3);
+            a0 = fma(l0.y, zz[j + 1], a0); a1 = fma(l1.y, zz[j + 1], a1); a2 = fma(l2.y, zz[j + 1], a2); a3 = fma(l3.y, zz[j + 1], a3);
+          }
+        }
+      }
+    } else {
+      const double* __restrict__ Lr = Lt + (size_t)r0 * stride + sm_skew(r0);
 #pragma unroll 4
-    for (int j = 0; j < jm; j += 2) {
-      const double z0 = zs[(size_t)j * 64 + lane], z1 = zs[(size_t)(j + 1) * 64 + lane];
-      const double2 l0 = *(const double2*)(Lr + j), l1 = *(const double2*)(Lr + stride + j);
-      const double2 l2 = *(const double2*)(Lr + 2 * stride + j), l3 = *(const double2*)(Lr + 3 * stride + j);
-      a0 = fma(l0.x, z0, a0); a1 = fma(l1.x, z0, a1); a2 = fma(l2.x, z0, a2); a3 = fma(l3.x, z0, a3);
-      a0 = fma(l0.y, z1, a0); a1 = fma(l1.y, z1, a1); a2 = fma(l2.y, z1, a2); a3 = fma(l3.y, z1, a3);
+      for (int j = 0; j < jm; j += 2) {
+        const double z0 = zs[(size_t)j * 64 + lane], z1 = zs[(size_t)(j + 1) * 64 + lane];
+        const double2 l0 = *(const double2*)(Lr + j), l1 = *(const double2*)(Lr + stride + j);
+        const double2 l2 = *(const double2*)(Lr + 2 * stride + j), l3 = *(const double2*)(Lr + 3 * stride + j);
+        a0 = fma(l0.x, z0, a0); a1 = fma(l1.x, z0, a1); a2 = fma(l2.x, z0, a2); a3 = fma(l3.x, z0, a3);
+        a0 = fma(l0.y, z1, a0); a1 = fma(l1.y, z1, a1); a2 = fma(l2.y, z1, a2); a3 = fma(l3.y, z1, a3);
+      }
     }
     SM_PF(pf_rows);
     int mine = INT32_MAX;             // this lane's successful attempt of the step, if any
@@ -400,12 +478,21 @@ static int launch_maha_tile(tph_ctx* ctx, double* u, int64_t n, int64_t ld, cons
 template <int KERNEL>
 static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,
                       const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
-                      double* up, double* maha_u, double* maha_up, uint8_t* pend) {
+                      double* up, double* maha_u, double* maha_up, uint8_t* pend, bool deep) {
   const int d = ctx->d;
+  TPH_REQUIRE(d <= 100, "tph_propose (row walker): n_dim=%d > 100", d);
   const int nst = (d + SM_ROWS - 1) / SM_ROWS, dc = SM_ROWS * nst, stride = sm_stride(dc);
+  const int dcp = (dc + 15) & ~15;
   const int64_t nchunks = (n + SM_CHUNK - 1) / SM_CHUNK;
   // workgroup = as many waves as fit around one LDS copy of L with a z tile each (one workgroup per CU)
-  const size_t lt_bytes = sizeof(double) * (size_t)dc * stride, z_bytes = sizeof(double) * (size_t)dc * 64;
+  // deep variant: rows of z held in LDS (TPH_OPT_SM_THRESHOLD, a multiple of 16; default 48: four waves per CU at 100-D)
+  int zl = dcp;
+  if (deep) {
+    zl = ctx->sm_thr > 0 ? ((ctx->sm_thr + 15) & ~15) : 48;
+    if (zl > dcp) zl = dcp;
+  }
+  const size_t lt_doubles = deep ? (size_t)smd_base(nst) : (size_t)dc * stride;
+  const size_t lt_bytes = sizeof(double) * lt_doubles, z_bytes = sizeof(double) * (size_t)(deep ? zl : dc) * 64;
   TPH_REQUIRE(lt_bytes + z_bytes <= 160 * 1024, "tph_propose (row walker): n_dim=%d does not fit the LDS", d);
   int wv = (int)((160 * 1024 - lt_bytes) / z_bytes);
   if (wv > 8) wv = 8;
@@ -424,7 +511,8 @@ static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
   const size_t lds = lt_bytes + (size_t)wv * z_bytes;
   // persistent buffers: blocked copies of L and L^-1 (tri.h), the queue words, the per-lane columns of passed rows
   const size_t tb8 = tri_blocked_doubles(d);
-  const size_t need_small = sizeof(double) * (tb8 + (size_t)dc * dc) + 128;
+  const size_t lg_doubles = deep ? lt_doubles : (size_t)dc * dc;
+  const size_t need_small = sizeof(double) * (tb8 + lg_doubles) + 128;
   if (ctx->sm_small_bytes < need_small) {
     TPH_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->sm_small) ctx->retired.push_back(ctx->sm_small);
@@ -432,12 +520,15 @@ static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
     TPH_HIP(hipMalloc((void**)&ctx->sm_small, need_small));
     ctx->sm_small_bytes = need_small;
   }
-  const size_t need_scr = sizeof(double) * (size_t)dc * (size_t)waves * (64 + 32);
+  // scratch: passed rows (64 lane records per wave), base records (32 per wave), deep: z rows zl.. (64 columns per wave)
+  const size_t zg_doubles = (size_t)(dcp - zl) * 64 * (size_t)waves;
+  const size_t need_scr = sizeof(double) * ((size_t)dc * (size_t)waves * (64 + 32) + zg_doubles);
   if (ctx->sm_scr_bytes < need_scr) {
     TPH_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->sm_scr) ctx->retired.push_back(ctx->sm_scr);
     ctx->sm_scr = nullptr; ctx->sm_scr_bytes = 0;
     TPH_HIP(hipMalloc((void**)&ctx->sm_scr, need_scr));
+    TPH_HIP(hipMemset(ctx->sm_scr, 0, need_scr));          // the z columns must hold finite numbers from the start
     ctx->sm_scr_bytes = need_scr;
   }
   unsigned long long* queue = (unsigned long long*)ctx->sm_small;
@@ -448,25 +539,28 @@ static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
   TPH_HIP(hipStreamIsCapturing(ctx->stream, &cap));
   const bool capturing = cap != hipStreamCaptureStatusNone;
   if (capturing || ctx->modes_epoch <= 0 || ctx->sm_epoch != ctx->modes_epoch || ctx->sm_src != (const void*)chol ||
-      ctx->sm_kernel != KERNEL) {
-    hipLaunchKernelGGL(k_sm_pad, dim3(1), dim3(256), 0, ctx->stream, chol, d, dc, Lg);
+      ctx->sm_kernel != KERNEL + (deep ? 16 : 0)) {
+    if (deep) hipLaunchKernelGGL(k_sm_pad_deep, dim3(1), dim3(256), 0, ctx->stream, chol, d, nst, Lg);
+    else hipLaunchKernelGGL(k_sm_pad, dim3(1), dim3(256), 0, ctx->stream, chol, d, dc, Lg);
     if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, winv, d, Wb);
-    ctx->sm_epoch = capturing ? -1 : ctx->modes_epoch; ctx->sm_src = (const void*)chol; ctx->sm_kernel = KERNEL;
+    ctx->sm_epoch = capturing ? -1 : ctx->modes_epoch; ctx->sm_src = (const void*)chol; ctx->sm_kernel = KERNEL + (deep ? 16 : 0);
   }
   hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)queue, 32);
   // pending moves; tpCN: the form at u (first step of a run) and every particle's step scale, parked in maha_up until the
   // closing pass overwrites it with the form at u'
   if (pend || KERNEL == TPH_KERNEL_TPCN || maha_u)
     if (launch_maha_tile<KERNEL, 0>(ctx, u, n, ld, means, Wb, up, maha_u, tick, pend, nullptr, dof, sigmas, seed, item0, maha_up)) return -1;
-#define TPH_SM(BC)                                                                                                       \
+  double* const zscr = ctx->sm_scr + (size_t)dc * (size_t)waves * (64 + 32);
+#define TPH_SM(BC, DP)                                                                                                   \
   do {                                                                                                                   \
     if (lds > 64 * 1024)                                                                                                 \
-      TPH_HIP(hipFuncSetAttribute((const void*)k_propose_sm<KERNEL, BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((k_propose_sm<KERNEL, BC>), dim3((unsigned)groups), dim3(64 * wv), lds, ctx->stream, (const double*)u, n, ld, d, \
+      TPH_HIP(hipFuncSetAttribute((const void*)k_propose_sm<KERNEL, BC, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_propose_sm<KERNEL, BC, DP>), dim3((unsigned)groups), dim3(64 * wv), lds, ctx->stream, (const double*)u, n, ld, d, \
                        means, (const double*)Lg, sigmas, bc, seed, tick, item0, up, (const double*)maha_up, ctx->sm_scr,   \
-                       ctx->sm_scr + (size_t)dc * (size_t)waves * 64, lgG, queue);                                        \
+                       ctx->sm_scr + (size_t)dc * (size_t)waves * 64, lgG, queue, zl, zscr);                              \
   } while (0)
-  if (bc) TPH_SM(true); else TPH_SM(false);
+  if (deep) { if (bc) TPH_SM(true, true); else TPH_SM(false, true); }
+  else { if (bc) TPH_SM(true, false); else TPH_SM(false, false); }
 #undef TPH_SM
   TPH_LAUNCH_CHECK();
   if (KERNEL == TPH_KERNEL_TPCN || maha_up || tick.ctl)
@@ -476,9 +570,10 @@ static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
 
 int tph_propose_sm(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                    const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
-                   const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend) {
+                   const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend, int deep) {
   const tph_stepctl tick{tick0, ctl};
+  const bool dp = deep != 0 || ctx->d > 64;
   if (kernel == TPH_KERNEL_TPCN)
-    return propose_sm<TPH_KERNEL_TPCN>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend);
-  return propose_sm<TPH_KERNEL_RWM>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend);
+    return propose_sm<TPH_KERNEL_TPCN>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend, dp);
+  return propose_sm<TPH_KERNEL_RWM>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend, dp);
 }
