@@ -61,9 +61,9 @@ int tph_ctx_destroy(tph_ctx* ctx);
 int tph_set_stream(tph_ctx* ctx, void* hip_stream);
 int tph_synchronize(tph_ctx* ctx);
 /* TPH_OPT_PROPOSE_VARIANT selects the proposal kernel: 0 = automatic (registers for n_dim <= 16, multi-lane above, blocked
- * when TPH_OPT_BLOCKED is set, stage machine when TPH_OPT_STAGED_REDRAW is), 1 = one lane per particle with LDS columns (any n_dim), 2 = one lane per particle in
+ * when TPH_OPT_BLOCKED is set, row walker when TPH_OPT_STAGED_REDRAW is), 1 = one lane per particle with LDS columns (any n_dim), 2 = one lane per particle in
  * registers (n_dim <= 16), 3 = several lanes per particle with the matrices staged in LDS, 4 = blocked + straggler pass
- * (16 < n_dim <= 100, one mode); the parity tests run every variant */
+ * (16 < n_dim <= 100, one mode), 5 = row walker (16 < n_dim <= 100, one mode); the parity tests run every variant */
 #define TPH_OPT_PROPOSE_VARIANT 0
 /* TPH_OPT_REDUCE_GRID: 0 = automatic grid of the reweight reduction, > 0 = that many blocks (experiments) */
 #define TPH_OPT_REDUCE_GRID 1
@@ -96,12 +96,13 @@ int tph_synchronize(tph_ctx* ctx);
  * kept count sizes the sort); 0 = one indexed lookup per draw in draw order; a value > 1 = that many draws as the threshold
  * instead of 2^23 (tests).  Same counts either way. */
 #define TPH_OPT_SORTED_DRAWS 8
-/* TPH_OPT_STAGED_REDRAW: 1 = 16 < n_dim <= 64, one mode, steps that are mostly REDRAWS (mcmc.py:239-249: early iterations of a
- * high-dimensional run): the stage-machine kernel (propose_sm.hip: a lane per attempt with its normals in registers, attempts
- * advance four rows at a time and stop at their first out-of-bounds coordinate, several attempts of a particle in flight, the
- * first in-bounds one in attempt order wins).  0 = those steps through the multi-lane kernel.  The host (mcmc.py: StepEngine)
- * switches on the redraw probe, like TPH_OPT_BLOCKED.  TPH_OPT_SM_LANES: log2 of the lanes per particle (0 = by size);
- * TPH_OPT_SM_THRESHOLD: a stage with fewer than value/100 x (stage + 1) lanes waits unless it is the fullest (0 = 50). */
+/* TPH_OPT_STAGED_REDRAW: 1 = 16 < n_dim <= 100, one mode, steps that are mostly REDRAWS (mcmc.py:239-249: early iterations of a
+ * high-dimensional run): the row-walker kernel (propose_sm.hip: a lane per attempt with its normals in its column of a tile,
+ * attempts advance four rows at a time and stop at their first out-of-bounds coordinate, several attempts of a particle in
+ * flight, the first in-bounds one in attempt order wins).  0 = those steps through the multi-lane kernel.  The host (mcmc.py:
+ * StepEngine) switches on the redraw probe, like TPH_OPT_BLOCKED.  TPH_OPT_SM_LANES: log2 of the lanes per particle (0 = by
+ * size); TPH_OPT_SM_THRESHOLD: rows of an attempt's normals kept in LDS, rounded up to 16 (0 = 32; the rows beyond live in
+ * global scratch -- fewer rows, more waves per CU). */
 #define TPH_OPT_STAGED_REDRAW 9
 #define TPH_OPT_SM_LANES 10
 #define TPH_OPT_SM_THRESHOLD 11

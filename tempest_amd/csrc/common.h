@@ -127,7 +127,7 @@ int tph_tri_inv(tph_ctx* ctx, const double* chol_dev, int K, double* winv_dev); 
 // propose_sm.hip: the whole proposal of a redraw-dominated step at 16 < d <= 100, one mode (pending moves, forms, u')
 int tph_propose_sm(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                    const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
-                   const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend, int deep);
+                   const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend);
 
 // --------------------------------------------------------------------------------- device helpers
 #if defined(__HIPCC__)

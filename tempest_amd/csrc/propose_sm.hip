@@ -1,4 +1,4 @@
-// Redraw-dominated proposals at 16 < d <= 64, one mode: every lane walks the rows of its own attempt.
+// Redraw-dominated proposals at 16 < d <= 100, one mode: every lane walks the rows of its own attempt.
 // Reference: tempest/mcmc.py:225-249 (tpCN), :301-312 (RWM): a walker's proposal is REDRAWN until it lies in the unit cube.
 //
 // In the first iterations of a high-dimensional run nearly every attempt leaves the cube (50-D at sigma_0: ~98 %, i.e. ~60
@@ -8,15 +8,17 @@
 // per wave-call for two normals, against ~5 per FMA).  k_propose_ml (lane groups walking their particle's attempts) spends
 // several times the pairs an ideal schedule needs: the particles of a wave diverge in their attempt counts and every round
 // draws a full group of pairs.  Here:
-//   * a LANE owns an attempt; its normals z_0..z_r live in the lane's column of an LDS tile zs[j][lane];
+//   * a LANE owns an attempt; its normals z_0..z_r live in the lane's column of a tile zs[j][lane] (first rows in LDS, the
+//     rest in global scratch: "LDS budget" below);
 //   * every step, EVERY busy lane draws the next two Box-Muller pairs of its attempt (two independent chains) and evaluates
 //     the next four rows -- whatever row it has reached: the Cholesky factor sits in LDS (one copy per workgroup, zero above
-//     the diagonal) and a lane reads ITS rows; the column loop runs to the deepest lane's row, shallower lanes multiply
-//     zeros.  An attempt stops at its first out-of-bounds coordinate and the lane starts its next attempt in the next step;
+//     the diagonal) and a lane reads ITS rows; the column loop runs in blocks of 16 to the deepest lane's row, a lane taking
+//     part in the blocks its own rows reach.  An attempt stops at its first out-of-bounds coordinate and the lane starts its
+//     next attempt in the next step;
 //   * G consecutive lanes work on ONE particle: lane g tries attempts g, g+G, g+2G, ... and the first in-bounds attempt IN
 //     ATTEMPT ORDER wins -- exactly the proposal the sequential loop returns (counter-based draws keyed by the attempt
 //     number).  Lanes whose attempt number has passed the best success so far stop at once;
-//   * particles come from a global queue in chunks of 16 (one atomic per chunk), so waves finish together;
+//   * particles come from a global queue in chunks of 4 (one atomic per chunk, requested a grab ahead), so waves finish together;
 //   * the rows an attempt has passed are parked in the lane's record of a global scratch (32 B per step) and copied to u'
 //     when the particle is decided.
 // Draws, attempt order and the arithmetic of a row (ascending-j FMA chain, v = fma(b, (L z)_r, base_r)) are those of the
@@ -39,25 +41,25 @@ __device__ __forceinline__ void sm_wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// LDS copy of L for per-lane row access.  An instruction reads, for every lane, 16 bytes of row 4 s_lane + q at the same
-// column pair: with a plain row-major layout the rows of different stages would fall on two or four bank groups.  Row r is
-// therefore stored at  r * stride + 2 * ((r / 4) mod 8) + j  with stride a multiple of 4 doubles: eight consecutive stages
-// then start on eight different 16-byte bank groups (lanes at the same stage read the same address: a broadcast).
-__host__ __device__ static inline int sm_stride(int dc) { return (dc + 14 + 3) & ~3; }
-__host__ __device__ static inline int sm_skew(int r) { return 2 * ((r >> 2) & 7); }
-
-// n_dim > 64 ("deep" variant): a full-row copy of L (100-D: 93 KB) and a 100-row z tile per wave (51 KB) would leave room for
-// ONE wave.  The copy becomes a staircase -- the four rows of stage s hold len(s) = 4 (s + 1) columns rounded up to 16, zeros
-// beyond the diagonal (100-D: 50 KB) -- and the column loop masks lanes per 16-column block instead of letting shallow lanes
-// multiply zeros; the z tile keeps only the first `zl` rows in LDS (100-D: 48 rows, 24 KB per wave, four waves per CU), the rows
-// beyond live in a lane-private column of global scratch: 1 attempt in 5 gets that far at 100-D from the prior.
-// Stage s starts at smd_off(s) (16 doubles of slack per stage for the same bank skew as above), its rows are smd_rs(s) apart.
+// LDS budget.  The kernel is latency-bound (every step is a chain of Philox, LDS and store latencies), so what matters is how many
+// waves fit a CU around the one copy of L.  A full-row copy (100-D: 93 KB) and a d-row z tile per wave (51 KB) leave room for ONE
+// wave at 100-D and five at 50-D.  Hence
+//   * the copy of L is a STAIRCASE: the four rows of stage s hold 4 (s + 1) columns rounded up to 16, zeros beyond the diagonal
+//     (100-D: 50 KB, 50-D: 16 KB), and the column loop masks lanes per 16-column block (a shallow lane skips the blocks its rows
+//     do not reach; an idle lane skips them all);
+//   * the z tile keeps only its first `zl` rows in LDS (32: 16 KB per wave -- six waves per CU at 100-D, eight at 50-D); the rows
+//     beyond live in a lane-private column of global scratch.  From the prior two attempts in three die before row 32.
+// Measured, 65 536 x 50-D RWM from the prior: 1 719 us with full rows and a 52-row tile (5 waves), 1 545 us in this form; 131 072 x
+// 100-D tpCN: 8.0 ms (zl = 32; 8.9 ms at 48, 10.4 ms at 64, 9.6 ms at 16) against 14.6 ms for k_propose_ml.
+// Stage s starts at smd_off(s): 16 doubles of slack per stage carry a skew of 2 (s mod 8) doubles, so that lanes at eight
+// consecutive stages read from eight different 16-byte bank groups (lanes at the same stage read the same address: a broadcast);
+// the rows of a stage are smd_rs(s) apart.
 __host__ __device__ static inline int smd_rs(int s) { return 16 * ((s >> 2) + 1); }
 __host__ __device__ static inline int smd_base(int s) { const int q = s >> 2, t = s & 3; return 64 * (q + 1) * (2 * q + t) + 16 * s; }
 __host__ __device__ static inline int smd_off(int s) { return smd_base(s) + 2 * (s & 7); }
 
 // the staircase copy of L in global memory (the workgroups copy it to LDS word for word); one workgroup
-static __global__ void __launch_bounds__(256) k_sm_pad_deep(const double* __restrict__ chol, int d, int nst, double* __restrict__ Lg) {
+static __global__ void __launch_bounds__(256) k_sm_stairs(const double* __restrict__ chol, int d, int nst, double* __restrict__ Lg) {
   const int total = smd_base(nst);
   for (int e = threadIdx.x; e < total; e += blockDim.x) Lg[e] = 0.0;
   __syncthreads();
@@ -67,15 +69,7 @@ static __global__ void __launch_bounds__(256) k_sm_pad_deep(const double* __rest
   }
 }
 
-// Lg[dc][dc]: L padded with zeros above the diagonal and beyond d (the kernels below multiply, they do not branch); one workgroup
-static __global__ void __launch_bounds__(256) k_sm_pad(const double* __restrict__ chol, int d, int dc, double* __restrict__ Lg) {
-  for (int e = threadIdx.x; e < dc * dc; e += blockDim.x) {
-    const int r = e / dc, j = e - r * dc;
-    Lg[e] = (r < d && j <= r) ? chol[(size_t)r * d + j] : 0.0;
-  }
-}
-
-template <int KERNEL, bool HAS_BC, bool DEEP>
+template <int KERNEL, bool HAS_BC>
 __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u, int64_t n, int64_t ld, int d,
                                                     const double* __restrict__ means, const double* __restrict__ Lg,
                                                     const double* __restrict__ sigmas, const uint8_t* __restrict__ bc,
@@ -84,33 +78,24 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
                                                     double* __restrict__ bscr, int lgG,
                                                     unsigned long long* __restrict__ queue /* [0] next chunk, [1] sum of
                                                     attempts, [2] particles decided */,
-                                                    int zl /* DEEP: rows of z held in LDS (multiple of 16) */,
-                                                    double* __restrict__ zscr /* DEEP: the rows beyond, per wave */) {
+                                                    int zl /* rows of z held in LDS (multiple of 16) */,
+                                                    double* __restrict__ zscr /* the rows beyond, per wave */) {
   extern __shared__ double sm_lds[];
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int G = 1 << lgG;
   const int nst = (d + SM_ROWS - 1) / SM_ROWS, dc = SM_ROWS * nst, npairs = (d + 1) >> 1;
-  const int stride = sm_stride(dc);
-  const int zrows = DEEP ? zl : dc;
-  const int lt_len = DEEP ? smd_base(nst) : dc * stride;
-  double* Lt = sm_lds;                                         // [dc][stride] (+ skew), DEEP: the staircase: the workgroup's copy of L
-  double* zs = Lt + (size_t)lt_len + (size_t)wid * zrows * 64; // [zrows][64] normals of this wave's attempts
-  if (DEEP) {
-    for (int e = threadIdx.x; e < lt_len; e += blockDim.x) Lt[e] = Lg[e];
-  } else {
-    for (int e = threadIdx.x; e < dc * dc; e += blockDim.x) {
-      const int r = e / dc, j = e - r * dc;
-      Lt[(size_t)r * stride + sm_skew(r) + j] = Lg[e];
-    }
-  }
-  for (int e = lane; e < zrows * 64; e += 64) zs[e] = 0.0;     // stale columns are multiplied by zeros of L: they must be finite
+  const int lt_len = smd_base(nst);
+  double* Lt = sm_lds;                                         // the workgroup's copy of L (staircase)
+  double* zs = Lt + (size_t)lt_len + (size_t)wid * zl * 64;    // [zl][64] normals of this wave's attempts, rows 0 .. zl-1
+  for (int e = threadIdx.x; e < lt_len; e += blockDim.x) Lt[e] = Lg[e];
+  for (int e = lane; e < zl * 64; e += 64) zs[e] = 0.0;        // stale entries meet zeros of L: they must be finite
   __syncthreads();
   const uint32_t tk = tick;              // the step's RNG tick, read from the control block ONCE: inside the loop its two loads would
                                          // wait for every load in flight (vmcnt counts in order), the prefetched coordinates included
   const size_t wave_id = (size_t)blockIdx.x * (blockDim.x >> 6) + wid;
   double* __restrict__ vrec = vscr + (wave_id * 64 + lane) * (size_t)dc;      // this lane's record of passed rows
-  // DEEP: z rows zl .. of this wave's attempts, [row - zl][lane] (zeroed when allocated, only ever holds normals: finite)
-  double* __restrict__ zg = DEEP ? zscr + wave_id * (size_t)(((dc + 15) & ~15) - zl) * 64 : nullptr;
+  // z rows zl .. of this wave's attempts, [row - zl][lane] (zeroed when allocated, only ever holds normals: finite)
+  double* __restrict__ zg = zscr + wave_id * (size_t)(((dc + 15) & ~15) - zl) * 64;
   // the groups' particles as contiguous records base[r] = mu_r + a (u_r - mu_r) (tpCN) or u_r (RWM), written when a group takes a
   // particle: a step reads four consecutive doubles of it (one 32-byte sector, shared by the group's lanes), where the
   // dimension-major u costs four scattered 64-byte sectors per lane and step -- 8 GB per launch at 65 536 x 50-D from the prior
@@ -142,7 +127,7 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
   double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0, p5 = 0.0, p6 = 0.0, p7 = 0.0;   // rows 0..7 of the lane's attempt
   // the pool's particles, prefetched when the chunk is grabbed: lane r holds base coordinate r of each (n_dim <= 64)
   double pb0 = 0.0, pb1 = 0.0, pb2 = 0.0, pb3 = 0.0;
-  double pc0 = 0.0, pc1 = 0.0, pc2 = 0.0, pc3 = 0.0;          // DEEP: coordinate 64 + lane
+  double pc0 = 0.0, pc1 = 0.0, pc2 = 0.0, pc3 = 0.0;          // coordinate 64 + lane (n_dim > 64)
   // the chunk AFTER the current pool, requested from the queue one grab ahead (lane 0 holds the ticket): the atomic's
   // round trip is over long before the pool runs dry
   unsigned long long ahead = 0;
@@ -213,7 +198,7 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
             pb1 = lane < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, u1 - mr, mr) : u1) : 0.5;
             pb2 = lane < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, u2 - mr, mr) : u2) : 0.5;
             pb3 = lane < d ? ((KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, u3 - mr, mr) : u3) : 0.5;
-            if (DEEP) {
+            if (d > 64) {
               const int rh = lane + 64 < d ? lane + 64 : d - 1;
               const double h0 = u[(size_t)rh * ld + pool_row], h1 = u[(size_t)rh * ld + (pool_row + 1 <= last ? pool_row + 1 : last)];
               const double h2 = u[(size_t)rh * ld + (pool_row + 2 <= last ? pool_row + 2 : last)];
@@ -233,7 +218,7 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
           const double pc = pool_next == 0 ? pc0 : pool_next == 1 ? pc1 : pool_next == 2 ? pc2 : pc3;
           ++pool_next;
           if (lane < dc) bscr[(wave_id * 32 + (size_t)gg) * (size_t)dc + lane] = pb;     // the group's record
-          if (DEEP && lane + 64 < dc) bscr[(wave_id * 32 + (size_t)gg) * (size_t)dc + 64 + lane] = pc;
+          if (lane + 64 < dc) bscr[(wave_id * 32 + (size_t)gg) * (size_t)dc + 64 + lane] = pc;
           refilled = true;
         }
         if (g == gg) {
@@ -263,7 +248,7 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
       double t0, t1, t2, t3;
       gz.normal2(base_draw + (uint32_t)p0, t0, t1);
       gz.normal2(base_draw + (uint32_t)(p0 < last ? p0 + 1 : last), t2, t3);
-      if (!DEEP || r0 < zl) {
+      if (r0 < zl) {
         double* zw = zs + (size_t)r0 * 64 + lane;
         zw[0] = t0; zw[64] = t1; zw[128] = t2; zw[192] = t3;
       } else {
@@ -274,7 +259,7 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
     sm_wave_sync();
     SM_PF(pf_bm);
 
-    // ---- L z, each lane ITS rows (LDS copy of L); the column loop runs to the deepest busy lane's row.  (Rows r0+2, r0+3 from a
+    // ---- L z, each lane ITS rows (LDS copy of L); the block loop runs to the deepest busy lane's row.  (Rows r0+2, r0+3 from a
     // padded copy in global memory instead -- two pipes for the two 16-byte loads per row and column pair -- doubled the loop's
     // time: per-lane 16-byte loads through L1 are slower than the LDS reads they were meant to relieve.)
     int smax = active ? stage : 0;
@@ -282,43 +267,31 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
     for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(smax, o, 64); smax = other > smax ? other : smax; }
     const int jm = SM_ROWS * (__builtin_amdgcn_readfirstlane(smax) + 1);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (DEEP) {
-      // staircase rows: a lane takes part in the 16-column blocks its rows reach (idle lanes in none)
-      const double* __restrict__ Lr = Lt + smd_off(stage);
-      const int rs = smd_rs(stage);
-      const int mylen = active ? SM_ROWS * (stage + 1) : 0;
+    // staircase rows: a lane takes part in the 16-column blocks its rows reach (idle lanes in none)
+    const double* __restrict__ Lr = Lt + smd_off(stage);
+    const int rs = smd_rs(stage);
+    const int mylen = active ? SM_ROWS * (stage + 1) : 0;
 #pragma unroll 1
-      for (int jb = 0; jb < jm; jb += 16) {
-        if (jb < mylen) {
-          const double* __restrict__ Lb = Lr + jb;
-          double zz[16];
-          if (jb < zl) {                       // (wave-uniform) the block's 16 normals: LDS tile or the lane's global column
-            const double* zc = zs + (size_t)jb * 64 + lane;
+    for (int jb = 0; jb < jm; jb += 16) {
+      if (jb < mylen) {
+        const double* __restrict__ Lb = Lr + jb;
+        double zz[16];
+        if (jb < zl) {                       // (wave-uniform) the block's 16 normals: LDS tile or the lane's global column
+          const double* zc = zs + (size_t)jb * 64 + lane;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) zz[j] = zc[(size_t)j * 64];
-          } else {
-            const double* __restrict__ zc = zg + (size_t)(jb - zl) * 64 + lane;
+          for (int j = 0; j < 16; ++j) zz[j] = zc[(size_t)j * 64];
+        } else {
+          const double* __restrict__ zc = zg + (size_t)(jb - zl) * 64 + lane;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) zz[j] = zc[(size_t)j * 64];
-          }
-#pragma unroll
-          for (int j = 0; j < 16; j += 2) {
-            const double2 l0 = *(const double2*)(Lb + j), l1 = *(const double2*)(Lb + rs + j);
-            const double2 l2 = *(const double2*)(Lb + 2 * rs + j), l3 = *(const double2*)(Lb + 3 * rs + j);
-            a0 = fma(l0.x, zz[j], a0); a1 = fma(l1.x, zz[j], a1); a2 = fma(l2.x, zz[j], a2); a3 = fma(l3.x, zz[j], a3);
-            a0 = fma(l0.y, zz[j + 1], a0); a1 = fma(l1.y, zz[j + 1], a1); a2 = fma(l2.y, zz[j + 1], a2); a3 = fma(l3.y, zz[j + 1], a3);
-          }
+          for (int j = 0; j < 16; ++j) zz[j] = zc[(size_t)j * 64];
         }
-      }
-    } else {
-      const double* __restrict__ Lr = Lt + (size_t)r0 * stride + sm_skew(r0);
-#pragma unroll 4
-      for (int j = 0; j < jm; j += 2) {
-        const double z0 = zs[(size_t)j * 64 + lane], z1 = zs[(size_t)(j + 1) * 64 + lane];
-        const double2 l0 = *(const double2*)(Lr + j), l1 = *(const double2*)(Lr + stride + j);
-        const double2 l2 = *(const double2*)(Lr + 2 * stride + j), l3 = *(const double2*)(Lr + 3 * stride + j);
-        a0 = fma(l0.x, z0, a0); a1 = fma(l1.x, z0, a1); a2 = fma(l2.x, z0, a2); a3 = fma(l3.x, z0, a3);
-        a0 = fma(l0.y, z1, a0); a1 = fma(l1.y, z1, a1); a2 = fma(l2.y, z1, a2); a3 = fma(l3.y, z1, a3);
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+          const double2 l0 = *(const double2*)(Lb + j), l1 = *(const double2*)(Lb + rs + j);
+          const double2 l2 = *(const double2*)(Lb + 2 * rs + j), l3 = *(const double2*)(Lb + 3 * rs + j);
+          a0 = fma(l0.x, zz[j], a0); a1 = fma(l1.x, zz[j], a1); a2 = fma(l2.x, zz[j], a2); a3 = fma(l3.x, zz[j], a3);
+          a0 = fma(l0.y, zz[j + 1], a0); a1 = fma(l1.y, zz[j + 1], a1); a2 = fma(l2.y, zz[j + 1], a2); a3 = fma(l3.y, zz[j + 1], a3);
+        }
       }
     }
     SM_PF(pf_rows);
@@ -478,21 +451,18 @@ static int launch_maha_tile(tph_ctx* ctx, double* u, int64_t n, int64_t ld, cons
 template <int KERNEL>
 static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,
                       const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
-                      double* up, double* maha_u, double* maha_up, uint8_t* pend, bool deep) {
+                      double* up, double* maha_u, double* maha_up, uint8_t* pend) {
   const int d = ctx->d;
   TPH_REQUIRE(d <= 100, "tph_propose (row walker): n_dim=%d > 100", d);
-  const int nst = (d + SM_ROWS - 1) / SM_ROWS, dc = SM_ROWS * nst, stride = sm_stride(dc);
+  const int nst = (d + SM_ROWS - 1) / SM_ROWS, dc = SM_ROWS * nst;
   const int dcp = (dc + 15) & ~15;
   const int64_t nchunks = (n + SM_CHUNK - 1) / SM_CHUNK;
   // workgroup = as many waves as fit around one LDS copy of L with a z tile each (one workgroup per CU)
-  // deep variant: rows of z held in LDS (TPH_OPT_SM_THRESHOLD, a multiple of 16; default 48: four waves per CU at 100-D)
-  int zl = dcp;
-  if (deep) {
-    zl = ctx->sm_thr > 0 ? ((ctx->sm_thr + 15) & ~15) : 48;
-    if (zl > dcp) zl = dcp;
-  }
-  const size_t lt_doubles = deep ? (size_t)smd_base(nst) : (size_t)dc * stride;
-  const size_t lt_bytes = sizeof(double) * lt_doubles, z_bytes = sizeof(double) * (size_t)(deep ? zl : dc) * 64;
+  // rows of z held in LDS (TPH_OPT_SM_THRESHOLD, a multiple of 16; default 32: see the head of the file)
+  int zl = ctx->sm_thr > 0 ? ((ctx->sm_thr + 15) & ~15) : 32;
+  if (zl > dcp) zl = dcp;
+  const size_t lt_doubles = (size_t)smd_base(nst);
+  const size_t lt_bytes = sizeof(double) * lt_doubles, z_bytes = sizeof(double) * (size_t)zl * 64;
   TPH_REQUIRE(lt_bytes + z_bytes <= 160 * 1024, "tph_propose (row walker): n_dim=%d does not fit the LDS", d);
   int wv = (int)((160 * 1024 - lt_bytes) / z_bytes);
   if (wv > 8) wv = 8;
@@ -511,8 +481,7 @@ static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
   const size_t lds = lt_bytes + (size_t)wv * z_bytes;
   // persistent buffers: blocked copies of L and L^-1 (tri.h), the queue words, the per-lane columns of passed rows
   const size_t tb8 = tri_blocked_doubles(d);
-  const size_t lg_doubles = deep ? lt_doubles : (size_t)dc * dc;
-  const size_t need_small = sizeof(double) * (tb8 + lg_doubles) + 128;
+  const size_t need_small = sizeof(double) * (tb8 + lt_doubles) + 128;
   if (ctx->sm_small_bytes < need_small) {
     TPH_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->sm_small) ctx->retired.push_back(ctx->sm_small);
@@ -520,7 +489,7 @@ static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
     TPH_HIP(hipMalloc((void**)&ctx->sm_small, need_small));
     ctx->sm_small_bytes = need_small;
   }
-  // scratch: passed rows (64 lane records per wave), base records (32 per wave), deep: z rows zl.. (64 columns per wave)
+  // scratch: passed rows (64 lane records per wave), base records (32 per wave), z rows zl.. (64 columns per wave)
   const size_t zg_doubles = (size_t)(dcp - zl) * 64 * (size_t)waves;
   const size_t need_scr = sizeof(double) * ((size_t)dc * (size_t)waves * (64 + 32) + zg_doubles);
   if (ctx->sm_scr_bytes < need_scr) {
@@ -539,11 +508,10 @@ static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
   TPH_HIP(hipStreamIsCapturing(ctx->stream, &cap));
   const bool capturing = cap != hipStreamCaptureStatusNone;
   if (capturing || ctx->modes_epoch <= 0 || ctx->sm_epoch != ctx->modes_epoch || ctx->sm_src != (const void*)chol ||
-      ctx->sm_kernel != KERNEL + (deep ? 16 : 0)) {
-    if (deep) hipLaunchKernelGGL(k_sm_pad_deep, dim3(1), dim3(256), 0, ctx->stream, chol, d, nst, Lg);
-    else hipLaunchKernelGGL(k_sm_pad, dim3(1), dim3(256), 0, ctx->stream, chol, d, dc, Lg);
+      ctx->sm_kernel != KERNEL) {
+    hipLaunchKernelGGL(k_sm_stairs, dim3(1), dim3(256), 0, ctx->stream, chol, d, nst, Lg);
     if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, winv, d, Wb);
-    ctx->sm_epoch = capturing ? -1 : ctx->modes_epoch; ctx->sm_src = (const void*)chol; ctx->sm_kernel = KERNEL + (deep ? 16 : 0);
+    ctx->sm_epoch = capturing ? -1 : ctx->modes_epoch; ctx->sm_src = (const void*)chol; ctx->sm_kernel = KERNEL;
   }
   hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)queue, 32);
   // pending moves; tpCN: the form at u (first step of a run) and every particle's step scale, parked in maha_up until the
@@ -551,16 +519,15 @@ static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
   if (pend || KERNEL == TPH_KERNEL_TPCN || maha_u)
     if (launch_maha_tile<KERNEL, 0>(ctx, u, n, ld, means, Wb, up, maha_u, tick, pend, nullptr, dof, sigmas, seed, item0, maha_up)) return -1;
   double* const zscr = ctx->sm_scr + (size_t)dc * (size_t)waves * (64 + 32);
-#define TPH_SM(BC, DP)                                                                                                   \
+#define TPH_SM(BC)                                                                                                       \
   do {                                                                                                                   \
     if (lds > 64 * 1024)                                                                                                 \
-      TPH_HIP(hipFuncSetAttribute((const void*)k_propose_sm<KERNEL, BC, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((k_propose_sm<KERNEL, BC, DP>), dim3((unsigned)groups), dim3(64 * wv), lds, ctx->stream, (const double*)u, n, ld, d, \
+      TPH_HIP(hipFuncSetAttribute((const void*)k_propose_sm<KERNEL, BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_propose_sm<KERNEL, BC>), dim3((unsigned)groups), dim3(64 * wv), lds, ctx->stream, (const double*)u, n, ld, d, \
                        means, (const double*)Lg, sigmas, bc, seed, tick, item0, up, (const double*)maha_up, ctx->sm_scr,   \
                        ctx->sm_scr + (size_t)dc * (size_t)waves * 64, lgG, queue, zl, zscr);                              \
   } while (0)
-  if (deep) { if (bc) TPH_SM(true, true); else TPH_SM(false, true); }
-  else { if (bc) TPH_SM(true, false); else TPH_SM(false, false); }
+  if (bc) TPH_SM(true); else TPH_SM(false);
 #undef TPH_SM
   TPH_LAUNCH_CHECK();
   if (KERNEL == TPH_KERNEL_TPCN || maha_up || tick.ctl)
@@ -570,10 +537,9 @@ static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
 
 int tph_propose_sm(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                    const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
-                   const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend, int deep) {
+                   const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend) {
   const tph_stepctl tick{tick0, ctl};
-  const bool dp = deep != 0 || ctx->d > 64;
   if (kernel == TPH_KERNEL_TPCN)
-    return propose_sm<TPH_KERNEL_TPCN>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend, dp);
-  return propose_sm<TPH_KERNEL_RWM>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend, dp);
+    return propose_sm<TPH_KERNEL_TPCN>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend);
+  return propose_sm<TPH_KERNEL_RWM>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend);
 }

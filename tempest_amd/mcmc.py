@@ -109,7 +109,7 @@ class StepEngine:
         self.ctl_host = torch.zeros(STEP_STATE_LEN, dtype=torch.float64).pin_memory()
         self.unstaged = False          # d > 16 proposal kernel without LDS-staged matrices (redraw-dominated steps)
         self.blocked = False           # d > 16: blocked kernel for attempt 0 + straggler pass (steps that are ~one attempt)
-        self.staged, self.sm_lanes = False, 0      # 16 < d <= 64: row-walker kernel for redraw-dominated steps, its lanes per particle (log2)
+        self.staged, self.sm_lanes = False, 0      # d > 16: row-walker kernel for redraw-dominated steps, its lanes per particle (log2)
         self.mailbox = torch.zeros(self.SLOTS, 8, dtype=torch.float64).pin_memory()   # written by tph_adapt, polled here
         self.mailbox_np = self.mailbox.numpy()
         self.use_graph, self.graph, self.graph_error = bool(use_graph), None, None
@@ -265,7 +265,7 @@ class StepEngine:
         captured with):
           * (nearly) every first attempt in bounds, one mode: attempt 0 of all particles in the blocked kernel (matrix
             operands through the scalar cache), the few others finished by the multi-lane kernel (on below 1.3, off above 2);
-          * most attempts are redraws, one mode, n_dim <= 64: the row-walker kernel (propose_sm.hip: a lane per attempt,
+          * most attempts are redraws, one mode: the row-walker kernel (propose_sm.hip: a lane per attempt,
             several attempts of a particle in flight -- as many as the attempt count makes worthwhile);
           * otherwise the multi-lane kernel, un-staged (matrices from global memory: a quarter of the LDS, four times the
             resident waves) while redraws dominate, LDS-staged once a step is about one attempt."""
@@ -278,7 +278,7 @@ class StepEngine:
             self.blocked = want_blk
             self.ctx.set_option(OPT_BLOCKED, 1 if want_blk else 0)
         sm_on = float(os.environ.get("TEMPEST_AMD_SM_ON", "6.0"))
-        want_sm = (self.K == 1 and self.ctx.n_dim <= 64 and mean_attempts > (sm_on * 2.0 / 3.0 if self.staged else sm_on)
+        want_sm = (self.K == 1 and mean_attempts > (sm_on * 2.0 / 3.0 if self.staged else sm_on)
                    and os.environ.get("TEMPEST_AMD_STAGED", "1") != "0")      # debugging aid (TPH_OPT_STAGED_REDRAW)
         lanes = 0
         if want_sm:         # lanes per particle = attempts in flight: about half the expected count, 2 .. 8 (16 on small shards)

@@ -858,12 +858,11 @@ def test_blocked_kernel_deferred_update_and_step_control(dev, kernel):
 
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
 @pytest.mark.parametrize("bc", [None, "mixed"])
-@pytest.mark.parametrize("d,lanes,walker,zl", [(19, 0, 5, 0), (33, 2, 5, 0), (50, 0, 5, 0), (50, 5, 5, 0), (64, 3, 5, 0),
-                                               # the staircase ("deep") layout of n_dim > 64, also forced below it (variant 6);
-                                               # zl = rows of z kept in LDS, the rest in the lane's global column
-                                               (50, 0, 6, 16), (37, 3, 6, 0), (72, 0, 5, 0), (100, 3, 5, 0), (100, 0, 5, 32),
-                                               (100, 2, 5, 112)])
-def test_stage_machine_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, lanes, walker, zl):
+@pytest.mark.parametrize("d,lanes,zl", [(19, 0, 0), (33, 2, 0), (50, 0, 0), (50, 5, 0), (64, 3, 0),
+                                        # zl = rows of z kept in LDS (TPH_OPT_SM_THRESHOLD; 0 = the default 32), the rest in
+                                        # the lane's column of global scratch
+                                        (50, 0, 16), (37, 3, 48), (50, 2, 64), (72, 0, 0), (100, 3, 0), (100, 0, 48), (100, 2, 112)])
+def test_stage_machine_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, lanes, zl):
     """TPH_OPT_PROPOSE_VARIANT 5 (propose_sm.hip): the redraw loop of mcmc.py:239-249 run as a stage machine -- a lane per
     attempt, several attempts of a particle in flight, eight rows at a time with early exit, the first in-bounds attempt in
     attempt order wins.  Same counter-based draws and row arithmetic as the other kernels: on an ensemble where most attempts
@@ -888,7 +887,7 @@ def test_stage_machine_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, 
     modes = _Modes(means, chol, inv, dof, dev)
     st, ft = torch.from_numpy(sigmas).to(dev), torch.from_numpy(flags).to(dev)
     got = {}
-    for variant in (walker, 3):
+    for variant in (5, 3):
         c = HipContext(d, device=0)
         c.set_option(0, variant)
         c.set_option(10, lanes)            # TPH_OPT_SM_LANES
@@ -898,7 +897,6 @@ def test_stage_machine_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, 
         c.propose(kernel, soa(u, dev), None, modes, st, ft, seed, tick, item0, up, mu_, mup, ctl=state)
         got[variant] = (aos(up), mu_.cpu().numpy(), mup.cpu().numpy(), state.cpu().numpy())
         c.close()
-    got[5] = got[walker]
     np.testing.assert_allclose(got[5][0], want_up, rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(got[5][0], got[3][0], rtol=1e-11, atol=1e-13)
     strict = np.nonzero(flags == 0)[0]
