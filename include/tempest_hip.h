@@ -74,10 +74,11 @@ int tph_synchronize(tph_ctx* ctx);
  * (a quarter of the LDS footprint, four times the resident waves: the right trade while most attempts are redraws that stop
  * after a few rows); 0 = staged (default) */
 #define TPH_OPT_ML_UNSTAGED 3
-/* TPH_OPT_BLOCKED: 1 = n_dim > 16, one mode: attempt 0 of every particle by the blocked kernel (lane = particle, matrix
- * operands through the scalar cache: the fast form of a step that is one attempt), the particles it leaves out of bounds by
- * the multi-lane kernel from attempt 1 on; 0 (default) = multi-lane kernel for everything (redraw-dominated steps).  The host
- * switches on the redraw probe, like TPH_OPT_ML_UNSTAGED. */
+/* TPH_OPT_BLOCKED: R >= 1 = n_dim > 16, one mode: attempt 0 of every particle by the blocked kernel (lane = particle, matrix
+ * operands through the scalar cache: the fast form of a step that is one attempt), then R - 1 further ROUNDS of it over the
+ * particles still out of bounds (attempt k of each, compacted lists; R <= 24), and whoever is left by the multi-lane kernel
+ * from attempt R on; 0 (default) = multi-lane kernel for everything.  The host switches on the redraw probe and sizes R from
+ * it (a few attempts per particle: ~3 x the mean), like TPH_OPT_ML_UNSTAGED. */
 #define TPH_OPT_BLOCKED 4
 /* TPH_OPT_MODES_EPOCH: v > 0 = version of the mode statistics passed to tph_propose; the blocked copies of L and L^-1 are
  * rebuilt only when it (or the chol pointer) changes.  0 (default) = rebuilt on every call. */

@@ -215,10 +215,11 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ 
                                                            const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                            int64_t item0, double* __restrict__ up,
                                                            double* __restrict__ maha_u, double* __restrict__ maha_up,
-                                                           uint8_t* __restrict__ pend, const int32_t* __restrict__ todo) {
-  // todo != NULL: straggler pass behind k_propose_blk -- only the particles it LISTED (todo[0] = count, todo[1..] = rows whose
-  // attempt 0 left the cube; a block beyond the list exits at once: 16 384 blocks scanning flags cost 69 us at 262 144 x 32-D),
-  // starting from attempt 1; everything else of the step (pending moves, attempt 0 of the others) is done already
+                                                           uint8_t* __restrict__ pend, const int32_t* __restrict__ todo,
+                                                           const int32_t* __restrict__ todo_rows, int att0) {
+  // todo != NULL: straggler pass behind k_propose_blk -- only the particles it LISTED (todo[0] = count, todo_rows[] = the rows
+  // whose attempts 0 .. att0-1 left the cube; a block beyond the list exits at once: 16 384 blocks scanning flags cost 69 us at
+  // 262 144 x 32-D), starting from attempt att0; everything else of the step (pending moves, the others' proposals) is done already
   extern __shared__ double sh[];
   constexpr int PPB = ML_THREADS / LPP;
   const int l = threadIdx.x % LPP, p = threadIdx.x / LPP;
@@ -238,7 +239,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ 
     const int64_t cnt = todo[0];
     if ((int64_t)blockIdx.x * PPB >= cnt) return;     // the whole block (uniform): nothing listed for it
     live = i < cnt;
-    i = live ? (int64_t)todo[1 + i] : n - 1;
+    i = live ? (int64_t)todo_rows[i] : n - 1;
   }
   const int64_t ii = i < n ? i : n - 1;              // dead groups shadow a particle, never store
   const int c = (STAGE == 0 && assign) ? assign[ii] : 0;
@@ -334,7 +335,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ 
   // iterations of a high-dimensional run (50-D: ~98 % of the attempts leave the unit cube) that is most of the work.  Draws,
   // attempt order and arithmetic are those of the sequential loop: the accepted proposal is bit-identical.
   const int nchunks = (d + LPP - 1) / LPP;
-  int att = todo ? 1 : 0, ch = 0, zgen = todo ? 0 : 2 * npairs;   // attempt 0: all normals are in zs already (generated above)
+  int att = todo ? att0 : 0, ch = 0, zgen = todo ? 0 : 2 * npairs;   // attempt 0: all normals are in zs already (generated above)
   bool active = !todo || live;
   while (__any(active)) {
     if (active) {
@@ -422,7 +423,8 @@ template <int KERNEL, int LPP>
 static int launch_propose_ml(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n, int64_t ld, const double* means,
                              const double* chol, const double* winv, const double* dof, const double* sigmas,
                              const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0, double* up, double* mu_,
-                             double* mup, uint8_t* pend, const int32_t* todo = nullptr) {
+                             double* mup, uint8_t* pend, const int32_t* todo = nullptr, const int32_t* todo_rows = nullptr,
+                             int att0 = 1) {
   constexpr int PPB = ML_THREADS / LPP;
   const int d = ctx->d;
   const size_t base = sizeof(double) * 3 * (size_t)PPB * (d | 1);
@@ -438,7 +440,7 @@ static int launch_propose_ml(tph_ctx* ctx, double* u, const int32_t* assign, int
       TPH_HIP(hipFuncSetAttribute((const void*)k_propose_ml<KERNEL, LPP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)lds));                                                                          \
     hipLaunchKernelGGL((k_propose_ml<KERNEL, LPP, ST>), grid, dim3(ML_THREADS), lds, ctx->stream, u, assign, n, ld, d, means, \
-                       chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend, todo);                      \
+                       chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend, todo, todo_rows, att0);     \
   } while (0)
   if (stage == 1) TPH_ML_LAUNCH(1);
   else if (stage == 2) TPH_ML_LAUNCH(2);
@@ -451,11 +453,16 @@ static int launch_propose_ml(tph_ctx* ctx, double* u, const int32_t* assign, int
 // 64 particles per workgroup, lane = particle, WV waves.  The Box-Muller pairs are dealt to the waves and land in LDS as
 // columns zs[j][lane]; L z and, for tpCN, |L^-1 (u' - mu)|^2 are the blocked triangular products of tri.h (matrix
 // element wave-uniform through the scalar cache, 8 rows per x_j read), the row chunks dealt to the waves.  Every particle
-// gets attempt 0 only -- in lockstep, which is what makes the matrix operand uniform; the particles whose attempt 0 leaves
-// the cube are flagged in `todo` and finished by k_propose_ml in straggler mode (attempt 1, 2, ... with early exit, as
-// before).  The host uses this path while the redraw probe says that most first attempts succeed (late iterations); the
-// redraw-dominated early iterations stay on k_propose_ml.  Same draws, same formulas: the proposal equals the other
-// kernels' to rounding (different summation order in the products).
+// gets attempt 0 -- in lockstep, which is what makes the matrix operand uniform; the particles whose attempt 0 leaves the cube
+// are LISTED, and the kernel runs again over the list with attempt 1, over that round's list with attempt 2, ... (R rounds,
+// TPH_OPT_BLOCKED; the lists are compact, so a round costs what its share of the particles costs: 131 072 x 100-D tpCN at 5.4
+// attempts per particle: multi-lane kernel 3.3 ms un-staged / 5.8 ms staged, one round + stragglers 2.7 ms, ten rounds 2.3 ms;
+// a round that still has work costs at least one tile's latency, 30-45 us at 100-D, so rounds pay while their list fills the chip).
+// Whoever is still listed after R rounds is finished by k_propose_ml in straggler mode (attempt R, R+1, ... with early exit).
+// The host uses this path while the redraw probe says that a step is a few attempts per particle (all but the first
+// iterations of a run); redraw-DOMINATED steps go to the row walker (propose_sm.hip), where attempts stop at their first
+// out-of-bounds row.  Same draws, same formulas: the proposal equals the other kernels' to rounding (different summation
+// order in the products).
 template <int KERNEL, int WV>
 __global__ void __launch_bounds__(64 * WV) k_propose_blk(double* __restrict__ u, int64_t n, int64_t ld, int d,
                                                          const double* __restrict__ means, const double* __restrict__ Lb,
@@ -463,7 +470,13 @@ __global__ void __launch_bounds__(64 * WV) k_propose_blk(double* __restrict__ u,
                                                          const double* __restrict__ sigmas, const uint8_t* __restrict__ bc,
                                                          uint64_t seed, tph_stepctl tick, int64_t item0, double* __restrict__ up,
                                                          double* __restrict__ maha_u, double* __restrict__ maha_up,
-                                                         uint8_t* __restrict__ pend, int32_t* __restrict__ todo) {
+                                                         uint8_t* __restrict__ pend, const int32_t* __restrict__ cnt_in,
+                                                         const int32_t* __restrict__ rows_in, int att,
+                                                         int32_t* __restrict__ cnt_out, int32_t* __restrict__ rows_out) {
+  // cnt_in == NULL: round 0, attempt 0 of every particle (and the chores of the step: pending moves, form at u, Gamma scale).
+  // cnt_in != NULL: round `att` >= 1 over the particles the round before LISTED (rows_in[0 .. *cnt_in)): attempt `att` of each,
+  // again in lockstep; the step scale b comes from where round 0 parked it (maha_up; RWM: sigma).  A round lists its own
+  // failures in rows_out / cnt_out.  Blocks beyond the list exit at once.
   extern __shared__ double sh[];
   double* zs = sh;                               // [d][64] normals, later u' - mu
   double* vs = sh + (size_t)d * 64;              // [d][64] u - mu (first step of a run), then the proposal
@@ -473,29 +486,41 @@ __global__ void __launch_bounds__(64 * WV) k_propose_blk(double* __restrict__ u,
   // the wave index as a SCALAR (readfirstlane): the row chunks a wave takes, hence the matrix addresses, are then provably
   // wave-uniform and the matrix comes through scalar loads (with threadIdx.x >> 6 the compiler emits vector loads)
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-  const bool live = i < n;
-  const int64_t ii = live ? i : n - 1;
+  int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  bool live = i < n;
+  int64_t ii = live ? i : n - 1;
+  const bool first = cnt_in == nullptr;
+  if (!first) {
+    const int64_t cnt = *cnt_in;
+    // the redraw probe from ALL first attempts (round 0's own estimate comes from its first 64 particles)
+    if (att == 1 && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl)
+      const_cast<double*>(tick.ctl)[8] = cnt < n ? (double)n / (double)(n - cnt) : 256.0;
+    if ((int64_t)blockIdx.x * 64 >= cnt) return;        // the whole block (uniform): nothing listed for it
+    live = i < cnt;
+    i = ii = (int64_t)rows_in[live ? i : 0];             // dead lanes shadow the list's first particle, never store
+  }
   const int npairs = (d + 1) >> 1;
   const double sigma = sigmas[0];
   const bool carry = KERNEL == TPH_KERNEL_TPCN && tick.carry();
   // ---- current point: resolve a pending accepted move (deferred tph_accept), rows dealt to the waves
-  const bool pd = pend && live && pend[i];
-  for (int j = wid; j < d; j += WV) {
-    double uj = u[(size_t)j * ld + ii];
-    if (pd) { uj = up[(size_t)j * ld + i]; u[(size_t)j * ld + i] = uj; }
-    if (KERNEL == TPH_KERNEL_TPCN && !carry) vs[(size_t)j * 64 + lane] = uj - means[j];
-  }
-  // ---- the normals of attempt 0, pairs dealt to the waves
+  const bool pd = first && pend && live && pend[i];
+  if (first)
+    for (int j = wid; j < d; j += WV) {
+      double uj = u[(size_t)j * ld + ii];
+      if (pd) { uj = up[(size_t)j * ld + i]; u[(size_t)j * ld + i] = uj; }
+      if (KERNEL == TPH_KERNEL_TPCN && !carry) vs[(size_t)j * 64 + lane] = uj - means[j];
+    }
+  // ---- the normals of this round's attempt, pairs dealt to the waves
   {
     tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + ii));
+    const uint32_t d0 = (uint32_t)att * (uint32_t)npairs;
     // two pairs per trip, as independent straight-line chains (the second one clamped, stored only when it exists): the
     // Box-Muller chain is latency-bound at this kernel's occupancy, like the d <= 16 kernel's
     for (int p = wid; p < npairs; p += 2 * WV) {
       const int p2 = p + WV < npairs ? p + WV : p;
       double z0, z1, y0, y1;
-      gz.normal2((uint32_t)p, z0, z1);
-      gz.normal2((uint32_t)p2, y0, y1);
+      gz.normal2(d0 + (uint32_t)p, z0, z1);
+      gz.normal2(d0 + (uint32_t)p2, y0, y1);
       zs[(size_t)(2 * p) * 64 + lane] = z0;
       if (2 * p + 1 < d) zs[(size_t)(2 * p + 1) * 64 + lane] = z1;
       if (p2 != p) {
@@ -508,7 +533,11 @@ __global__ void __launch_bounds__(64 * WV) k_propose_blk(double* __restrict__ u,
   if (pd && wid == 0) pend[i] = 0;               // every wave has read the flag
   // ---- tpCN: Mahalanobis form at u (first step of a run; afterwards carried) and the Gamma scale
   double a_fac = 1.0;
-  if (KERNEL == TPH_KERNEL_TPCN) {
+  if (KERNEL == TPH_KERNEL_TPCN && !first) {
+    if (wid == 0) bf[lane] = maha_up[ii];          // parked by round 0 (a success overwrites it with the form at u')
+    a_fac = tph_sqrt(1.0 - sigma * sigma);
+    __syncthreads();
+  } else if (KERNEL == TPH_KERNEL_TPCN) {
     if (!carry) {
       double part = 0.0;
       tri_apply(Wb, d, vs, lane, wid, WV, [&](int, double y) { part = fma(y, y, part); });
@@ -527,17 +556,19 @@ __global__ void __launch_bounds__(64 * WV) k_propose_blk(double* __restrict__ u,
       const double nu = dof[0];
       tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + ii));
       const double gam = tph_gamma_mt(gg, 0.5 * ((double)d + nu)) * tph_div(2.0, nu + m_u);
-      bf[lane] = sigma * tph_sqrt(tph_rcp(gam));
+      const double b = sigma * tph_sqrt(tph_rcp(gam));
+      bf[lane] = b;
+      if (live) maha_up[i] = b;                    // parked for the later rounds of this particle
     }
     a_fac = tph_sqrt(1.0 - sigma * sigma);
     __syncthreads();
   } else if (wid == 0) {
     bf[lane] = sigma;
-    if (live && maha_u) maha_u[i] = 0.0;
+    if (first && live && maha_u) maha_u[i] = 0.0;
   }
   if (KERNEL != TPH_KERNEL_TPCN) __syncthreads();
   const double b_fac = bf[lane];
-  // ---- rows of attempt 0: v = mu + a (u - mu) + b (L z)_r, bounds
+  // ---- rows of the attempt: v = mu + a (u - mu) + b (L z)_r, bounds
   int ok = 1;
   tri_apply(Lb, d, zs, lane, wid, WV, [&](int r, double acc) {
     const double ur = u[(size_t)r * ld + ii];
@@ -555,14 +586,14 @@ __global__ void __launch_bounds__(64 * WV) k_propose_blk(double* __restrict__ u,
   int all_ok = 1;
 #pragma unroll
   for (int w = 0; w < WV; ++w) all_ok &= s_ok[w][lane];
-  // ---- outputs of the particles whose attempt 0 is in bounds; the others are left to the straggler pass
+  // ---- outputs of the particles whose attempt is in bounds; the others are left to the next round / the straggler pass
   for (int j = wid; j < d; j += WV) {
     const double v = vs[(size_t)j * 64 + lane];
     if (live && all_ok) up[(size_t)j * ld + i] = v;
     if (KERNEL == TPH_KERNEL_TPCN) zs[(size_t)j * 64 + lane] = v - means[j];      // the normals are done with
   }
-  if (wid == 0 && live && !all_ok) todo[1 + atomicAdd(&todo[0], 1)] = (int32_t)i;     // the straggler list (order is irrelevant)
-  if (blockIdx.x == 0 && tick.ctl) {             // regime probe: mean attempts implied by this block's failures, 1 / (1 - f)
+  if (wid == 0 && live && !all_ok) rows_out[atomicAdd(cnt_out, 1)] = (int32_t)i;      // the straggler list (order is irrelevant)
+  if (first && blockIdx.x == 0 && tick.ctl) {             // regime probe: mean attempts implied by this block's failures, 1 / (1 - f)
     __syncthreads();
     if (wid == 0) {
       const unsigned long long fm = __ballot(live && !all_ok), lm = __ballot(live);
@@ -597,7 +628,10 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   // unless the caller versions its mode statistics (TPH_OPT_MODES_EPOCH > 0 and unchanged since the last call)
   const size_t tb = tri_blocked_doubles(d);
   TPH_REQUIRE(n < (1ll << 31), "tph_propose (blocked): %lld particles on one device", (long long)n);
-  const size_t need = sizeof(double) * 2 * tb + sizeof(int32_t) * ((size_t)n + 2);
+  // rounds of the blocked kernel before the straggler pass (TPH_OPT_BLOCKED = R: attempts 0 .. R-1 in lockstep)
+  constexpr int BLK_MAX_ROUNDS = 24;
+  const int rounds = ctx->blocked < 1 ? 1 : (ctx->blocked > BLK_MAX_ROUNDS ? BLK_MAX_ROUNDS : ctx->blocked);
+  const size_t need = sizeof(double) * 2 * tb + sizeof(int32_t) * (2 * (size_t)n + 32);
   if (ctx->blk_bytes < need) {
     TPH_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->blk_buf) ctx->retired.push_back(ctx->blk_buf);   // a captured step of a smaller engine may still point here
@@ -607,8 +641,9 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   }
   double* Lb = (double*)ctx->blk_buf;
   double* Wb = Lb + tb;
-  int32_t* todo = (int32_t*)(Wb + tb);               // [0] = number of stragglers of this step, [1..] their rows
-  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)todo, 1);
+  int32_t* cnts = (int32_t*)(Wb + tb);               // [k] = particles whose attempts 0..k all left the cube (k < rounds)
+  int32_t* rows[2] = {cnts + 32, cnts + 32 + n};     // their rows: round k writes rows[k & 1], round k + 1 reads it
+  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)cnts, 32);
   // A launch that is being CAPTURED into a hipGraph always records the rebuild: a replayed step never re-enters this host
   // code, so an epoch test made here would freeze the copies of the capture-time statistics while the caller refreshes the
   // fixed-address chol / winv between runs (the straggler pass and tpCN's carried form read those) -- two covariances inside
@@ -631,14 +666,16 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   do {                                                                                                                  \
     if (lds > 64 * 1024)                                                                                                \
       TPH_HIP(hipFuncSetAttribute((const void*)k_propose_blk<KERNEL, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((k_propose_blk<KERNEL, WV>), grid, dim3(64 * WV), lds, ctx->stream, u, n, ld, d, means, Lb, Wb, dof,   \
-                       sigmas, bc, seed, tick, item0, up, mu_, mup, pend, todo);                                        \
+    for (int k = 0; k < rounds; ++k)                                                                                    \
+      hipLaunchKernelGGL((k_propose_blk<KERNEL, WV>), grid, dim3(64 * WV), lds, ctx->stream, u, n, ld, d, means, Lb, Wb, dof, \
+                         sigmas, bc, seed, tick, item0, up, mu_, mup, pend, k ? cnts + (k - 1) : (const int32_t*)nullptr,  \
+                         (const int32_t*)rows[(k + 1) & 1], k, cnts + k, rows[k & 1]);                                    \
   } while (0)
   if (wv == 4) TPH_BLK_LAUNCH(4); else if (wv == 8) TPH_BLK_LAUNCH(8); else TPH_BLK_LAUNCH(16);
 #undef TPH_BLK_LAUNCH
   TPH_LAUNCH_CHECK();
-  // straggler pass: the flagged particles continue with attempt 1, 2, ... in the multi-lane kernel (un-staged: few blocks
-  // have work, and those that do are redraw-bound)
+  // straggler pass: the particles still listed continue with attempt `rounds`, ... in the multi-lane kernel (un-staged: few
+  // blocks have work, and those that do are redraw-bound)
   // as many lanes per straggler as it has Box-Muller pairs: a straggler's chain of attempts is latency-bound (few blocks
   // have any work), so the pairs of an attempt are generated in ONE round and the rows spread over more lanes
   int lpp = 4;
@@ -647,7 +684,7 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   ctx->ml_unstaged = 1;
   int rc = 0;
   switch (lpp) {
-#define TPH_ML_S(LL) case LL: rc = launch_propose_ml<KERNEL, LL>(ctx, u, nullptr, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, nullptr, todo); break;
+#define TPH_ML_S(LL) case LL: rc = launch_propose_ml<KERNEL, LL>(ctx, u, nullptr, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, nullptr, cnts + (rounds - 1), rows[(rounds - 1) & 1], rounds); break;
     TPH_ML_S(4) TPH_ML_S(8) TPH_ML_S(16) TPH_ML_S(32) TPH_ML_S(64)
 #undef TPH_ML_S
   }

@@ -108,7 +108,7 @@ class StepEngine:
         self.ctl = ctx.zeros(STEP_STATE_LEN)
         self.ctl_host = torch.zeros(STEP_STATE_LEN, dtype=torch.float64).pin_memory()
         self.unstaged = False          # d > 16 proposal kernel without LDS-staged matrices (redraw-dominated steps)
-        self.blocked = False           # d > 16: blocked kernel for attempt 0 + straggler pass (steps that are ~one attempt)
+        self.blocked = 0               # d > 16: rounds of the blocked kernel (attempts in lockstep) before the straggler pass; 0 = off
         self.staged, self.sm_lanes = False, 0      # d > 16: row-walker kernel for redraw-dominated steps, its lanes per particle (log2)
         self.mailbox = torch.zeros(self.SLOTS, 8, dtype=torch.float64).pin_memory()   # written by tph_adapt, polled here
         self.mailbox_np = self.mailbox.numpy()
@@ -155,7 +155,7 @@ class StepEngine:
             StepEngine._epoch += 1
             self.ctx.set_option(OPT_MODES_EPOCH, StepEngine._epoch)
             # the proposal regime is an option of the ctx, which engines of other shapes share: re-assert this engine's
-            self.ctx.set_option(OPT_BLOCKED, 1 if self.blocked else 0)
+            self.ctx.set_option(OPT_BLOCKED, int(self.blocked))
             self.ctx.set_option(OPT_ML_UNSTAGED, 1 if self.unstaged else 0)
             self.ctx.set_option(OPT_STAGED_REDRAW, 1 if self.staged else 0)
             self.ctx.set_option(OPT_SM_LANES, self.sm_lanes)
@@ -262,24 +262,44 @@ class StepEngine:
     def _regime(self, mean_attempts):
         """The d > 16 proposal kernels report the mean number of attempts per particle of the step, and the host picks the
         kernel for the next steps from it (launch geometry is baked into a captured graph, so a graph keeps whatever it was
-        captured with):
-          * (nearly) every first attempt in bounds, one mode: attempt 0 of all particles in the blocked kernel (matrix
-            operands through the scalar cache), the few others finished by the multi-lane kernel (on below 1.3, off above 2);
-          * most attempts are redraws, one mode: the row-walker kernel (propose_sm.hip: a lane per attempt,
-            several attempts of a particle in flight -- as many as the attempt count makes worthwhile);
-          * otherwise the multi-lane kernel, un-staged (matrices from global memory: a quarter of the LDS, four times the
-            resident waves) while redraws dominate, LDS-staged once a step is about one attempt."""
+        captured with).  One mode:
+          * a step is a few attempts per particle: the blocked kernel (attempts in lockstep, lane = particle, matrix operands
+            through the scalar cache) -- attempt 0 of everybody, further rounds over the particles still out of bounds, the
+            rest finished by the multi-lane kernel.  Its probe is the geometric estimate n / (n - first-attempt failures);
+          * most attempts are redraws: the row-walker kernel (propose_sm.hip: a lane per attempt that stops at its first
+            out-of-bounds row, several attempts of a particle in flight -- as many as the attempt count makes worthwhile).
+            Its probe is the true mean, which the hard particles near a wall pull above the geometric estimate (131 072 x
+            100-D: estimate 2.8 / true 4.7: blocked 2.2 ms, walker 3.4 ms; estimate 5.8 / true 13.6: 5.1 vs 4.2 ms) -- hence
+            the two thresholds.
+        Several modes: the multi-lane kernel, un-staged (matrices from global memory: a quarter of the LDS, four times the
+        resident waves) while redraws dominate, LDS-staged once a step is about one attempt."""
         if self.graph is not None or self.ctx.n_dim <= 16 or not mean_attempts > 0.0:
             return
         import os
         from .device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_SM_LANES, OPT_STAGED_REDRAW
-        want_blk = self.K == 1 and mean_attempts < (2.0 if self.blocked else 1.3)
-        if want_blk != self.blocked:
-            self.blocked = want_blk
-            self.ctx.set_option(OPT_BLOCKED, 1 if want_blk else 0)
-        sm_on = float(os.environ.get("TEMPEST_AMD_SM_ON", "6.0"))
-        want_sm = (self.K == 1 and mean_attempts > (sm_on * 2.0 / 3.0 if self.staged else sm_on)
-                   and os.environ.get("TEMPEST_AMD_STAGED", "1") != "0")      # debugging aid (TPH_OPT_STAGED_REDRAW)
+        walker_ok = os.environ.get("TEMPEST_AMD_STAGED", "1") != "0"      # debugging aid (TPH_OPT_STAGED_REDRAW)
+        if self.K != 1:
+            want_blk = False
+        elif self.blocked:
+            want_blk = mean_attempts < 4.5 or not walker_ok
+        elif self.staged:
+            want_blk = mean_attempts < float(os.environ.get("TEMPEST_AMD_SM_ON", "7.0"))
+        else:                          # first steps of a run (multi-lane kernel, true mean)
+            want_blk = mean_attempts < 7.0 and (walker_ok or mean_attempts < 2.0)
+        rounds = 0
+        if want_blk:
+            # A round that still has work costs at least one tile's latency (30-45 us at 100-D) however short its list: rounds
+            # pay while the list fills the chip.  Expected list after k rounds: n (1 - 1/m)^k.  Measured against one round +
+            # stragglers: 262 144 x 32-D -20 ... -26 %, 131 072 x 100-D -12 ... -17 %, 65 536 x 50-D +-0 (lists too short).
+            f, left = max(0.0, 1.0 - 1.0 / mean_attempts), float(self.n)
+            rounds = 1
+            while rounds < 24 and left * f >= 24576.0:
+                left *= f
+                rounds += 1
+        if rounds != self.blocked:
+            self.blocked = rounds
+            self.ctx.set_option(OPT_BLOCKED, rounds)
+        want_sm = self.K == 1 and not want_blk and walker_ok
         lanes = 0
         if want_sm:         # lanes per particle = attempts in flight: about half the expected count, 2 .. 8 (16 on small shards)
             lanes = 1 if mean_attempts < 8.0 else 2 if mean_attempts < 16.0 else 3 if (mean_attempts < 48.0 or self.n >= 49152) else 4

@@ -767,12 +767,14 @@ def test_volume_variation_one_call_vs_oracle(dev, d):
 
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
 @pytest.mark.parametrize("bc", [None, "mixed"])
-@pytest.mark.parametrize("d", [19, 33, 50, 65, 100])       # 4 / 8 / 8 / 16 / 16 waves per tile: 3, 5, 7, 9, 13 row chunks
-def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d):
+@pytest.mark.parametrize("d,rounds", [(19, 0), (33, 0), (50, 0), (65, 0), (100, 0),     # 4 / 8 / 8 / 16 / 16 waves per tile
+                                      (33, 2), (50, 24), (65, 3), (100, 6)])             # TPH_OPT_BLOCKED = rounds of the kernel
+def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, rounds):
     """TPH_OPT_PROPOSE_VARIANT 4: attempt 0 of every particle in the blocked kernel (lane = particle, L and L^-1 through the
-    scalar cache), the particles it leaves out of bounds finished by the multi-lane kernel from attempt 1 on.  Same draws and
-    formulas as the other kernels: the proposals and both Mahalanobis forms equal the oracle's (and the multi-lane kernel's)
-    to rounding -- on an ensemble where a good share of the first attempts fail, so that the straggler pass is exercised."""
+    scalar cache), further rounds of it (attempt 1, 2, ... of the particles still out of bounds, compacted lists), and whoever
+    is left finished by the multi-lane kernel.  Same draws and formulas as the other kernels: the proposals and both
+    Mahalanobis forms equal the oracle's (and the multi-lane kernel's) to rounding -- on an ensemble where a good share of the
+    first attempts fail, so that the later rounds and the straggler pass are exercised."""
     rs = np.random.RandomState(31 + d)
     n = 3000
     means = 0.5 + 0.05 * rs.randn(1, d)
@@ -793,9 +795,12 @@ def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d):
     for variant in (4, 3):
         c = ctx_for(d)
         c.set_option(0, variant)
+        c.set_option(4, rounds if variant == 4 else 0)
         up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
-        c.propose(kernel, soa(u, dev), None, modes, st, ft, seed, tick, item0, up, mu_, mup)
-        got[variant] = (aos(up), mu_.cpu().numpy(), mup.cpu().numpy())
+        state = c.zeros(10)
+        c.propose(kernel, soa(u, dev), None, modes, st, ft, seed, tick, item0, up, mu_, mup, ctl=state)
+        got[variant] = (aos(up), mu_.cpu().numpy(), mup.cpu().numpy(), state.cpu().numpy())
+        c.set_option(4, 0)
     first_failed = np.mean(np.any((want_up != want_up), axis=1))       # placeholder: failures are visible through the oracle below
     _ = first_failed
     np.testing.assert_allclose(got[4][0], want_up, rtol=1e-11, atol=1e-13)
@@ -808,7 +813,10 @@ def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d):
         np.testing.assert_allclose(got[4][2], got[3][2], rtol=1e-8, atol=1e-8)
     # the straggler pass really ran: some first attempts (counter-based draws of attempt 0) are out of bounds
     z0 = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, omc.bc_flags(d, list(range(d)), []), seed, tick, item0)[0]
-    assert np.mean(np.any(np.abs(z0 - want_up) > 1e-9, axis=1)) > 0.05
+    failed = np.mean(np.any(np.abs(z0 - want_up) > 1e-9, axis=1))
+    assert failed > 0.05
+    if rounds > 1 and bc is None:      # with later rounds the redraw probe counts ALL first attempts: n / (n - failures)
+        np.testing.assert_allclose(got[4][3][8], 1.0 / (1.0 - failed), rtol=1e-12)
 
 
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])

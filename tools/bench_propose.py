@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--accept", action="store_true")
     ap.add_argument("--nocarry", action="store_true")
     ap.add_argument("--wpe", type=int, default=0, help="experiment knob (TPH_OPT_REDRAW_LANES)")
+    ap.add_argument("--rounds", type=int, default=0, help="TPH_OPT_BLOCKED (rounds of the blocked kernel; use with --variant 4)")
+    ap.add_argument("--scale", type=float, default=0.0, help="overrides the scenario's spread (wide 0.29, mid 0.12, tight 0.04): dials the redraw count")
     ap.add_argument("--sigma-scale", type=float, default=1.0, help="multiplies the step size (RWM runaway: ~8)")
     ap.add_argument("--unstaged", action="store_true", help="TPH_OPT_ML_UNSTAGED = 1 (the redraw-dominated regime of d > 16)")
     ap.add_argument("--lanes", type=int, default=0, help="TPH_OPT_SM_LANES (log2 lanes per particle of the stage-machine kernel)")
@@ -78,10 +80,14 @@ def main():
         lib.tph_set_option(ctx, 10, a.lanes)
     if a.thr:
         lib.tph_set_option(ctx, 11, a.thr)
+    if a.rounds:
+        lib.tph_set_option(ctx, 4, a.rounds)
     kid = {"tpcn": 0, "rwm": 1}[a.kernel]
     rs = np.random.RandomState(0)
     for scen in a.scen.split(","):
         scale = {"wide": 0.29, "mid": 0.12, "tight": 0.04, "prior": 0.29}[scen]
+        if a.scale > 0:
+            scale = a.scale
         A = rs.randn(d, d) / np.sqrt(d)
         cov = (A @ A.T + np.eye(d)) * scale ** 2 / 2.0
         L = np.linalg.cholesky(cov)
