@@ -681,7 +681,7 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   int lpp = 4;
   while (lpp < 64 && lpp < (d + 1) / 2) lpp *= 2;
   const int keep = ctx->ml_unstaged;
-  ctx->ml_unstaged = 1;
+  ctx->ml_unstaged = 1;        // (staged, measured: 65 536 x 50-D +-0, 131 072 x 100-D +8 ... +28 %)
   int rc = 0;
   switch (lpp) {
 #define TPH_ML_S(LL) case LL: rc = launch_propose_ml<KERNEL, LL>(ctx, u, nullptr, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, nullptr, cnts + (rounds - 1), rows[(rounds - 1) & 1], rounds); break;

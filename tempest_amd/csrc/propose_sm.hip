@@ -470,12 +470,13 @@ static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
   int64_t groups = (nchunks + wv - 1) / wv;                  // never more waves than there are chunks
   if (groups > cus) groups = cus;
   const int64_t waves = groups * wv;
-  // lanes per particle (log2): enough particles per group to balance the groups of a wave; few speculative attempts when the
-  // wave has many particles
+  // lanes per particle (log2) = attempts of a particle in flight.  Measured optimum (8 waves per CU, steps of 3 ... 130 attempts
+  // per particle): 3 at 85-128 particles per wave (131 072 x 100-D, 262 144 x 32-D), 4 at 8-32 (65 536 and 16 384 x 50-D:
+  // 781 vs 825 us at 7 attempts, 989 vs 1 063 us at 23); 2 and 5 lose everywhere (1 249 / 1 133 us at 65 536 x 50-D, 7 attempts)
   int lgG = ctx->sm_lanes;
   if (lgG <= 0) {
     const double pw = (double)n / (double)waves;
-    lgG = pw >= 96.0 ? 2 : pw >= 24.0 ? 3 : 4;
+    lgG = pw >= 48.0 ? 3 : 4;
   }
   if (lgG > 6) lgG = 6;
   const size_t lds = lt_bytes + (size_t)wv * z_bytes;

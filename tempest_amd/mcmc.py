@@ -269,8 +269,9 @@ class StepEngine:
           * most attempts are redraws: the row-walker kernel (propose_sm.hip: a lane per attempt that stops at its first
             out-of-bounds row, several attempts of a particle in flight -- as many as the attempt count makes worthwhile).
             Its probe is the true mean, which the hard particles near a wall pull above the geometric estimate (131 072 x
-            100-D: estimate 2.8 / true 4.7: blocked 2.2 ms, walker 3.4 ms; estimate 5.8 / true 13.6: 5.1 vs 4.2 ms) -- hence
-            the two thresholds.
+            100-D: estimate 2.8 / true 4.7: blocked 2.2 ms, walker 3.4 ms; estimate 5.8 / true 13.6: 5.1 vs 4.2 ms; 65 536 x
+            50-D: 2.1 / 2.7: 0.47 vs 0.57 ms; 4.2 / 7.2: 0.97 vs 0.78 ms; 262 144 x 32-D: 2.3 / 2.9: 0.62 vs 1.05 ms; 5.0 / 7.9:
+            1.6 vs 1.1 ms) -- hence the two thresholds, a little higher at n_dim >= 64.
         Several modes: the multi-lane kernel, un-staged (matrices from global memory: a quarter of the LDS, four times the
         resident waves) while redraws dominate, LDS-staged once a step is about one attempt."""
         if self.graph is not None or self.ctx.n_dim <= 16 or not mean_attempts > 0.0:
@@ -280,12 +281,10 @@ class StepEngine:
         walker_ok = os.environ.get("TEMPEST_AMD_STAGED", "1") != "0"      # debugging aid (TPH_OPT_STAGED_REDRAW)
         if self.K != 1:
             want_blk = False
-        elif self.blocked:
-            want_blk = mean_attempts < 4.5 or not walker_ok
-        elif self.staged:
-            want_blk = mean_attempts < float(os.environ.get("TEMPEST_AMD_SM_ON", "7.0"))
-        else:                          # first steps of a run (multi-lane kernel, true mean)
-            want_blk = mean_attempts < 7.0 and (walker_ok or mean_attempts < 2.0)
+        elif self.blocked:             # geometric estimate
+            want_blk = mean_attempts < (4.5 if self.ctx.n_dim >= 64 else 3.5) or not walker_ok
+        else:                          # true mean (row walker, or the multi-lane kernel of a run's first steps)
+            want_blk = mean_attempts < (8.0 if self.ctx.n_dim >= 64 else 5.0) and (walker_ok or mean_attempts < 2.0)
         rounds = 0
         if want_blk:
             # A round that still has work costs at least one tile's latency (30-45 us at 100-D) however short its list: rounds
@@ -300,9 +299,7 @@ class StepEngine:
             self.blocked = rounds
             self.ctx.set_option(OPT_BLOCKED, rounds)
         want_sm = self.K == 1 and not want_blk and walker_ok
-        lanes = 0
-        if want_sm:         # lanes per particle = attempts in flight: about half the expected count, 2 .. 8 (16 on small shards)
-            lanes = 1 if mean_attempts < 8.0 else 2 if mean_attempts < 16.0 else 3 if (mean_attempts < 48.0 or self.n >= 49152) else 4
+        lanes = int(os.environ.get("TEMPEST_AMD_SM_LANES", "0"))      # 0: the library sizes the lane groups (8 or 16 lanes per particle)
         if want_sm != self.staged or lanes != self.sm_lanes:
             self.staged, self.sm_lanes = want_sm, lanes
             self.ctx.set_option(OPT_STAGED_REDRAW, 1 if want_sm else 0)
