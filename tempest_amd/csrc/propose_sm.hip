@@ -47,16 +47,16 @@ __device__ __forceinline__ void sm_wave_sync() {
 //   * the copy of L is a STAIRCASE: the four rows of stage s hold 4 (s + 1) columns rounded up to 16, zeros beyond the diagonal
 //     (100-D: 50 KB, 50-D: 16 KB), and the column loop masks lanes per 16-column block (a shallow lane skips the blocks its rows
 //     do not reach; an idle lane skips them all);
-//   * the z tile keeps only its first `zl` rows in LDS (32: 16 KB per wave -- six waves per CU at 100-D, eight at 50-D); the rows
+//   * the z tile keeps only its first `zl` rows in LDS (32: 16 KB per wave -- seven waves per CU at 100-D, eight at 50-D); the rows
 //     beyond live in a lane-private column of global scratch.  From the prior two attempts in three die before row 32.
 // Measured, 65 536 x 50-D RWM from the prior: 1 719 us with full rows and a 52-row tile (5 waves), 1 545 us in this form; 131 072 x
 // 100-D tpCN: 8.0 ms (zl = 32; 8.9 ms at 48, 10.4 ms at 64, 9.6 ms at 16) against 14.6 ms for k_propose_ml.
-// Stage s starts at smd_off(s): 16 doubles of slack per stage carry a skew of 2 (s mod 8) doubles, so that lanes at eight
-// consecutive stages read from eight different 16-byte bank groups (lanes at the same stage read the same address: a broadcast);
-// the rows of a stage are smd_rs(s) apart.
+// Stage s starts at smd_off(s): 12 doubles of slack per stage carry a skew of 2 (s mod 6) doubles, so that lanes at six
+// consecutive stages read from six different 16-byte bank groups (lanes at the same stage read the same address: a broadcast);
+// the rows of a stage are smd_rs(s) apart.  (12, not 16: at 100-D the copy then is 48 992 bytes and SEVEN 16 KB tiles fit beside it.)
 __host__ __device__ static inline int smd_rs(int s) { return 16 * ((s >> 2) + 1); }
-__host__ __device__ static inline int smd_base(int s) { const int q = s >> 2, t = s & 3; return 64 * (q + 1) * (2 * q + t) + 16 * s; }
-__host__ __device__ static inline int smd_off(int s) { return smd_base(s) + 2 * (s & 7); }
+__host__ __device__ static inline int smd_base(int s) { const int q = s >> 2, t = s & 3; return 64 * (q + 1) * (2 * q + t) + 12 * s; }
+__host__ __device__ static inline int smd_off(int s) { return smd_base(s) + 2 * (s % 6); }
 
 // the staircase copy of L in global memory (the workgroups copy it to LDS word for word); one workgroup
 static __global__ void __launch_bounds__(256) k_sm_stairs(const double* __restrict__ chol, int d, int nst, double* __restrict__ Lg) {
