@@ -50,7 +50,7 @@ def main():
     # configs 3 and 5 (shard): kernel stats + the run lines
     others = {}
     for tag, stats, logs in (("c3", os.path.join("prof_c3", "c3_kernel_stats.csv"), (("", "c3.log"), ("_unprofiled", "c3_plain.log"))),
-                             ("c5_shard_131072", os.path.join("prof_c5", "c5_kernel_stats.csv"), (("", "c5.log"),))):
+                             ("c5_shard_131072", os.path.join("prof_c5", "c5_kernel_stats.csv"), (("", "c5.log"), ("_unprofiled", "c5_plain.log")))):
         if os.path.exists(os.path.join(src, stats)):
             cp(stats, f"{R}_{tag.split('_')[0]}_kernel_stats.csv")
             for suffix, name in logs:
@@ -142,9 +142,11 @@ def main():
     json.dump(doc, open(os.path.join(dst, f"{R}_propose_pmc.json"), "w"), indent=1)
     # d > 16 proposal kernels
     rows = [json.loads(ln) for ln in open(os.path.join(src, "prop_d50.jsonl")) if ln.startswith("{")]
-    json.dump({"what": "tph_propose at d > 16: variant 3 = multi-lane kernel, 4 = blocked kernel + straggler pass, 5 = row-walker kernel "
-                       "(propose_sm.hip); scenario 'prior' = an ensemble from the prior with a proposal as broad as the prior (the first "
-                       "iterations of a run: tens to hundreds of redraw attempts per particle); lib = which build", "runs": rows},
+    json.dump({"what": "tph_propose at d > 16: variant 3 = multi-lane kernel, 4 = blocked kernel (rounds = TPH_OPT_BLOCKED) + straggler "
+                       "pass, 5 = row-walker kernel (propose_sm.hip; z_rows_lds = TPH_OPT_SM_THRESHOLD, 0 = 32); scenario 'prior' = an "
+                       "ensemble from the prior with a proposal as broad as the prior (the first iterations of a run: tens to hundreds of "
+                       "redraw attempts per particle); scale > 0 = the ensemble's spread, dialled to a few attempts per particle (the "
+                       "probe of variant 4 is the geometric estimate from the first attempts, that of 3 and 5 the true mean); lib = which build", "runs": rows},
               open(os.path.join(dst, f"{R}_propose_d50_d100.json"), "w"), indent=1)
     print("assembled into", dst)
 

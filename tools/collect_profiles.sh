@@ -42,6 +42,22 @@ python3 tools/bench_propose.py --d 32 --n 262144 --kernel tpcn --scen prior --re
 python3 tools/bench_propose.py --d 32 --n 262144 --kernel tpcn --scen prior --reps 5 --variant 5 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
 python3 tools/bench_propose.py --d 100 --n 262144 --kernel tpcn --scen tight --reps 10 --variant 3 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
 python3 tools/bench_propose.py --d 100 --n 262144 --kernel tpcn --scen tight --reps 10 --variant 4 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+# 100-D (config 5's shard): multi-lane kernel vs row walker from the prior; rows of z kept in LDS
+for sc in prior wide; do
+  python3 tools/bench_propose.py --d 100 --n 131072 --kernel tpcn --scen $sc --reps 5 --variant 3 --unstaged >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+  python3 tools/bench_propose.py --d 100 --n 131072 --kernel tpcn --scen $sc --reps 5 --variant 5 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+done
+for zl in 16 48 64; do
+  python3 tools/bench_propose.py --d 100 --n 131072 --kernel tpcn --scen prior --reps 5 --variant 5 --thr $zl >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+done
+# steps of a few attempts per particle: multi-lane kernel, blocked kernel in 1 / R rounds + stragglers, row walker (the regime table of DESIGN 3b)
+mid() {   # n d scale rounds
+  python3 tools/bench_propose.py --d $2 --n $1 --kernel tpcn --scen mid --scale $3 --reps 6 --variant 3 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+  python3 tools/bench_propose.py --d $2 --n $1 --kernel tpcn --scen mid --scale $3 --reps 6 --variant 4 --rounds 1 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+  python3 tools/bench_propose.py --d $2 --n $1 --kernel tpcn --scen mid --scale $3 --reps 6 --variant 4 --rounds $4 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+  python3 tools/bench_propose.py --d $2 --n $1 --kernel tpcn --scen mid --scale $3 --reps 6 --variant 5 >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
+}
+mid 65536 50 0.22 2; mid 65536 50 0.25 6; mid 262144 32 0.24 6; mid 262144 32 0.28 10; mid 131072 100 0.21 10; mid 131072 100 0.23 10
 if [ -f scratch/oldlib/libtempest_hip_r02.so ]; then      # the multi-lane kernel of round 2 on this box (before the shorter RNG chain)
   python3 tools/bench_propose.py --older --lib scratch/oldlib/libtempest_hip_r02.so --d 50 --n 65536 --kernel rwm --scen prior --reps 7 --variant 3 --unstaged >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
   python3 tools/bench_propose.py --older --lib scratch/oldlib/libtempest_hip_r02.so --d 50 --n 65536 --kernel tpcn --scen prior --reps 7 --variant 3 --unstaged >> "$O/prop_d50.jsonl" 2>> "$O/prop_d50.err"
@@ -56,6 +72,7 @@ python3 tools/run_config.py c2 tpcn > "$O/c2_tpcn_plain.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c3" -o c3 -- python3 tools/run_config.py c3 tpcn > "$O/c3.log" 2>&1
 python3 tools/run_config.py c3 tpcn > "$O/c3_plain.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c5" -o c5 -- python3 tools/run_config.py c5 tpcn > "$O/c5.log" 2>&1
+python3 tools/run_config.py c5 tpcn > "$O/c5_plain.log" 2>&1
 echo "configs done"
 # 7. per-kernel roofline table
 mkdir -p "$O/roof"
