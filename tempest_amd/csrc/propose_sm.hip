@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
   bool exhausted = false;
   unsigned long long n_att = 0, n_dec = 0;
 #ifdef SM_PROFILE
-  long long pf_bm = 0, pf_rows = 0, pf_refill = 0, pf_steps = 0, pf_epi = 0, pf_e1 = 0, pf_e0 = 0, pf_t = clock64();
+  long long pf_bm = 0, pf_rows = 0, pf_refill = 0, pf_steps = 0, pf_epi = 0, pf_e1 = 0, pf_e0 = 0, pf_deep = 0, pf_deep_steps = 0, pf_t = clock64();
 #define SM_PF(acc) do { const long long now_ = clock64(); acc += now_ - pf_t; pf_t = now_; } while (0)
 #else
 #define SM_PF(acc) do { } while (0)
@@ -273,6 +273,9 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
     const int mylen = active ? SM_ROWS * (stage + 1) : 0;
 #pragma unroll 1
     for (int jb = 0; jb < jm; jb += 16) {
+#ifdef SM_PROFILE
+      if (jb == zl) { SM_PF(pf_rows); ++pf_deep_steps; }          // from here on: the blocks whose z comes from global scratch -> pf_epi is reused below
+#endif
       if (jb < mylen) {
         const double* __restrict__ Lb = Lr + jb;
         double zz[16];
@@ -294,7 +297,11 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
         }
       }
     }
+#ifdef SM_PROFILE
+    if (jm > zl) SM_PF(pf_deep); else SM_PF(pf_rows);
+#else
     SM_PF(pf_rows);
+#endif
     int mine = INT32_MAX;             // this lane's successful attempt of the step, if any
 #ifdef SM_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -357,6 +364,7 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
     atomicAdd(&queue[5], (unsigned long long)pf_refill); atomicAdd(&queue[6], (unsigned long long)pf_steps);
     atomicAdd(&queue[7], (unsigned long long)pf_epi);
     atomicAdd(&queue[8], (unsigned long long)pf_e0); atomicAdd(&queue[9], (unsigned long long)pf_e1);
+    atomicAdd(&queue[10], (unsigned long long)pf_deep); atomicAdd(&queue[11], (unsigned long long)pf_deep_steps);
 #endif
   }
 }
@@ -385,8 +393,8 @@ __global__ void __launch_bounds__(64 * WV) k_maha_tile(double* __restrict__ u, i
     const_cast<double*>(tick.ctl)[8] = queue[2] ? (double)queue[1] / (double)queue[2] : 0.0;
 #ifdef SM_PROFILE
   if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0 && queue)
-    printf("SM_PROFILE attempts %llu particles %llu | wave-cycles: bm %llu rows %llu epilogue %llu (wait %llu + bounds %llu + rest) refill %llu | steps %llu\n", queue[1],
-           queue[2], queue[3], queue[4], queue[7] + queue[8] + queue[9], queue[8], queue[9], queue[5], queue[6]);
+    printf("SM_PROFILE attempts %llu particles %llu | wave-cycles: bm %llu rows(z in LDS) %llu rows(z global) %llu in %llu steps, epilogue %llu (wait %llu + bounds %llu + rest) refill %llu | steps %llu\n", queue[1],
+           queue[2], queue[3], queue[4], queue[10], queue[11], queue[7] + queue[8] + queue[9], queue[8], queue[9], queue[5], queue[6]);
 #endif
   const bool form = KERNEL == TPH_KERNEL_TPCN && (MODE == 1 || !tick.carry());
   if (MODE == 0) {
