@@ -79,3 +79,75 @@ def test_history_sized_temporaries_come_from_buckets():
     from tempest_amd.device import HipContext
     src = inspect.getsource(HipContext.empty_rows)
     assert "bit_length" in src and "3 // 4" in src
+
+
+def test_proposal_regime_rule_d_gt_16():
+    """StepEngine._regime (mcmc.py): which d > 16 proposal kernel the NEXT steps get from the redraw probe -- blocked kernel in
+    R rounds for a few attempts per particle (R from the expected length of the round's list), row walker when redraws
+    dominate, one threshold per direction (the blocked path reports the geometric estimate, the walker the true mean), the
+    multi-lane kernel for several modes; a captured graph keeps what it was captured with."""
+    from tempest_amd import mcmc
+    from tempest_amd.device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_STAGED_REDRAW
+
+    class Ctx:
+        def __init__(self, d):
+            self.n_dim, self.opts = d, {}
+
+        def set_option(self, k, v):
+            self.opts[k] = v
+
+    class Eng:
+        _regime = mcmc.StepEngine._regime
+
+        def __init__(self, d, n, K=1):
+            self.ctx, self.n, self.K, self.graph = Ctx(d), n, K, None
+            self.blocked, self.staged, self.sm_lanes, self.unstaged = 0, False, 0, False
+
+    e = Eng(50, 65536)
+    e._regime(60.0)                                   # first steps of a run from the prior: redraws dominate
+    assert e.staged and e.blocked == 0 and e.ctx.opts[OPT_STAGED_REDRAW] == 1 and e.ctx.opts.get(OPT_BLOCKED, 0) == 0
+    e._regime(6.0)                                    # the walker's probe is the TRUE mean: it keeps the step down to 5
+    assert e.staged and e.blocked == 0
+    e._regime(4.0)
+    assert not e.staged and e.blocked >= 1 and e.ctx.opts[OPT_STAGED_REDRAW] == 0
+    assert e.blocked == 4 and e.ctx.opts[OPT_BLOCKED] == 4     # expected lists 49 152, 36 864, 27 648 >= 24 576 > 20 736
+    e._regime(3.4)                                    # the blocked path's probe is the geometric estimate: stays up to 3.5
+    assert not e.staged and e.blocked >= 1
+    e._regime(3.6)
+    assert e.staged and e.blocked == 0
+    e._regime(1.0)
+    assert not e.staged and e.blocked == 1            # (nearly) every first attempt in bounds: one round
+    e.graph = object()
+    e._regime(90.0)                                   # a captured graph keeps its launch geometry
+    assert not e.staged and e.blocked == 1
+    # many particles: rounds while the expected list fills the chip, at most 24
+    big = Eng(32, 262144)
+    big._regime(2.27)
+    assert big.blocked == 5 and big.ctx.opts[OPT_BLOCKED] == 5
+    big.blocked = 1
+    big._regime(3.4)
+    assert 5 < big.blocked <= 24
+    # n_dim >= 64: the crossovers sit higher (estimate 4.5, true mean 8)
+    wide = Eng(100, 131072)
+    wide._regime(7.0)
+    assert wide.blocked >= 1 and not wide.staged
+    wide._regime(4.4)
+    assert wide.blocked >= 1
+    wide._regime(4.6)
+    assert wide.staged and wide.blocked == 0
+    wide._regime(8.5)
+    assert wide.staged
+    wide._regime(7.9)
+    assert wide.blocked >= 1 and not wide.staged
+    # several modes: neither; the multi-lane kernel, un-staged while redraws dominate (hysteresis 8 / 4)
+    k4 = Eng(32, 262144, K=4)
+    k4._regime(20.0)
+    assert k4.blocked == 0 and not k4.staged and k4.unstaged and k4.ctx.opts[OPT_ML_UNSTAGED] == 1
+    k4._regime(5.0)
+    assert k4.unstaged
+    k4._regime(3.0)
+    assert not k4.unstaged
+    # d <= 16 has one kernel
+    small = Eng(10, 1 << 20)
+    small._regime(3.0)
+    assert small.ctx.opts == {}
