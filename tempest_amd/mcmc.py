@@ -114,6 +114,7 @@ class StepEngine:
         self.mailbox_np = self.mailbox.numpy()
         self.use_graph, self.graph, self.graph_error = bool(use_graph), None, None
         self._keep, self.runs, self._own = None, 0, None
+        self._retired_graphs = []
         # Draws made ahead (tph_pregen_draws; OFF unless TEMPEST_AMD_PREGEN=1): the register proposal kernel (n_dim <= 16) spends
         # nine tenths of its time on random numbers that do not depend on the particles' positions, so those of step s + 1 can
         # be generated on a side stream while the user's callbacks of step s -- HBM-bound elementwise kernels -- occupy the main
@@ -261,8 +262,10 @@ class StepEngine:
 
     def _regime(self, mean_attempts):
         """The d > 16 proposal kernels report the mean number of attempts per particle of the step, and the host picks the
-        kernel for the next steps from it (launch geometry is baked into a captured graph, so a graph keeps whatever it was
-        captured with).  One mode:
+        kernel for the next steps from it.  A captured graph has its kernels baked in: when the rule asks for a different KERNEL
+        than the graph holds (blocked <-> walker <-> multi-lane; not for a different number of rounds), the graph is retired and
+        the step is captured again at its next launch -- an engine captured in a run's redraw-dominated first iterations would
+        otherwise walk rows for the rest of the run.  One mode:
           * a step is a few attempts per particle: the blocked kernel (attempts in lockstep, lane = particle, matrix operands
             through the scalar cache) -- attempt 0 of everybody, further rounds over the particles still out of bounds, the
             rest finished by the multi-lane kernel.  Its probe is the geometric estimate n / (n - first-attempt failures);
@@ -274,9 +277,10 @@ class StepEngine:
             1.6 vs 1.1 ms) -- hence the two thresholds, a little higher at n_dim >= 64.
         Several modes: the multi-lane kernel, un-staged (matrices from global memory: a quarter of the LDS, four times the
         resident waves) while redraws dominate, LDS-staged once a step is about one attempt."""
-        if self.graph is not None or self.ctx.n_dim <= 16 or not mean_attempts > 0.0:
+        if self.ctx.n_dim <= 16 or not mean_attempts > 0.0:
             return
         import os
+        before = (self.blocked > 0, bool(self.staged))
         from .device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_SM_LANES, OPT_STAGED_REDRAW
         walker_ok = os.environ.get("TEMPEST_AMD_STAGED", "1") != "0"      # debugging aid (TPH_OPT_STAGED_REDRAW)
         if self.K != 1:
@@ -285,6 +289,8 @@ class StepEngine:
             want_blk = mean_attempts < (4.5 if self.ctx.n_dim >= 64 else 3.5) or not walker_ok
         else:                          # true mean (row walker, or the multi-lane kernel of a run's first steps)
             want_blk = mean_attempts < (8.0 if self.ctx.n_dim >= 64 else 5.0) and (walker_ok or mean_attempts < 2.0)
+        if self.graph is not None and (want_blk, self.K == 1 and not want_blk and walker_ok) == before:
+            return                     # same kernel: the graph stays (its rounds and lane groups too)
         rounds = 0
         if want_blk:
             # A round that still has work costs at least one tile's latency (30-45 us at 100-D) however short its list: rounds
@@ -305,9 +311,13 @@ class StepEngine:
             self.ctx.set_option(OPT_STAGED_REDRAW, 1 if want_sm else 0)
             self.ctx.set_option(OPT_SM_LANES, lanes)
         want = mean_attempts > (4.0 if self.unstaged else 8.0)      # hysteresis
-        if want != self.unstaged:
+        if want != self.unstaged and self.graph is None:
             self.unstaged = want
             self.ctx.set_option(OPT_ML_UNSTAGED, 1 if want else 0)
+        if self.graph is not None and (self.blocked > 0, bool(self.staged)) != before:
+            # retired, not destroyed: its last replay may still be in flight (and its pool holds the callbacks' outputs)
+            self._retired_graphs.append((self.graph, self._keep))
+            self.graph, self._keep = None, None
 
     def _capture(self):
         """Stream capture of one step (torch.cuda.CUDAGraph without torch.cuda.graph's empty_cache(), which would hand

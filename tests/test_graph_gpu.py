@@ -288,3 +288,28 @@ def test_step_control_block_semantics():
     ctx.adapt("tpcn", sums, counts, K, n, 1, 1, sg, state, mailbox=mailbox)
     ctx.synchronize()
     assert torch.equal(state, frozen) and torch.equal(sg, sg_frozen)
+
+
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+def test_graph_is_captured_again_when_the_redraw_regime_changes_the_proposal_kernel(kernel):
+    """d > 16 from the prior: the first iterations are redraw-dominated (row walker), the later ones one attempt per particle
+    (blocked kernel).  A graph captured early is retired when the regime rule asks for the other kernel and the step is
+    captured again -- the run ends on the blocked kernel, and equals the step-by-step run (same rule, same probe values)."""
+    import tempest_amd as tp
+    d = 40
+
+    def gauss(x):
+        return -0.5 * (x ** 2).sum(dim=1)
+    runs = []
+    for graph in (False, True):
+        s = tp.Sampler(prior20, gauss, d, n_particles=1024, vectorize=True, clustering=False, random_state=3, sample=kernel,
+                       graph=graph)
+        s.run(n_total=4096, progress=False)
+        runs.append((s.evidence()[0], _history(s), s))
+    eng = list(runs[1][2]._core.mutator._engines.values())
+    assert eng and all(e.graph is not None for e in eng)
+    assert any(e._retired_graphs for e in eng), "the regime never changed the kernel under a captured graph"
+    assert all(e.blocked >= 1 and not e.staged for e in eng)            # the run ends in the one-attempt regime
+    assert abs(runs[0][0] - runs[1][0]) < 1e-9
+    np.testing.assert_array_equal(runs[0][1]["steps"], runs[1][1]["steps"])
+    np.testing.assert_allclose(runs[0][1]["logz"], runs[1][1]["logz"], rtol=0, atol=1e-9)

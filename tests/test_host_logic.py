@@ -85,7 +85,8 @@ def test_proposal_regime_rule_d_gt_16():
     """StepEngine._regime (mcmc.py): which d > 16 proposal kernel the NEXT steps get from the redraw probe -- blocked kernel in
     R rounds for a few attempts per particle (R from the expected length of the round's list), row walker when redraws
     dominate, one threshold per direction (the blocked path reports the geometric estimate, the walker the true mean), the
-    multi-lane kernel for several modes; a captured graph keeps what it was captured with."""
+    multi-lane kernel for several modes; a captured graph keeps what it was captured with until the rule asks for another
+    kernel."""
     from tempest_amd import mcmc
     from tempest_amd.device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_STAGED_REDRAW
 
@@ -102,6 +103,7 @@ def test_proposal_regime_rule_d_gt_16():
         def __init__(self, d, n, K=1):
             self.ctx, self.n, self.K, self.graph = Ctx(d), n, K, None
             self.blocked, self.staged, self.sm_lanes, self.unstaged = 0, False, 0, False
+            self._retired_graphs, self._keep = [], None
 
     e = Eng(50, 65536)
     e._regime(60.0)                                   # first steps of a run from the prior: redraws dominate
@@ -117,9 +119,14 @@ def test_proposal_regime_rule_d_gt_16():
     assert e.staged and e.blocked == 0
     e._regime(1.0)
     assert not e.staged and e.blocked == 1            # (nearly) every first attempt in bounds: one round
-    e.graph = object()
-    e._regime(90.0)                                   # a captured graph keeps its launch geometry
-    assert not e.staged and e.blocked == 1
+    g = e.graph = object()
+    e._regime(1.3)                                    # a captured graph keeps its kernel, rounds included ...
+    assert e.graph is g and not e.staged and e.blocked == 1 and not e._retired_graphs
+    e._regime(90.0)                                   # ... until the rule asks for ANOTHER kernel: retired, captured again later
+    assert e.graph is None and e.staged and e.blocked == 0 and e._retired_graphs[0][0] is g
+    e.graph = g
+    e._regime(60.0)
+    assert e.graph is g and len(e._retired_graphs) == 1
     # many particles: rounds while the expected list fills the chip, at most 24
     big = Eng(32, 262144)
     big._regime(2.27)
