@@ -1105,3 +1105,35 @@ def test_fit_mvstud_drop_in_against_the_reference_outputs(dev):
         np.testing.assert_allclose(Sig, wSig, rtol=1e-9, atol=1e-16)
         np.linalg.cholesky(Sig)                                  # positive definite, as the reference guarantees
     np.testing.assert_array_equal(fit_mvstud(cases[2])[1], fit_mvstud(cases[2])[1])      # reproducible
+
+
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+@pytest.mark.parametrize("d", [17, 97])
+def test_stage_machine_odd_sizes_vs_multilane(dev, kernel, d):
+    """The row walker at the edges of its index arithmetic: a dimension just above 16 and one just below 100 (neither a
+    multiple of 4 nor of 16), ensembles smaller than a queue chunk, of exactly one tile, of one more; every (lanes per
+    particle, rows of z in LDS) the options allow at these sizes.  Same proposals as the multi-lane kernel to rounding."""
+    from tempest_amd.device import HipContext
+    rs = np.random.RandomState(7 * d)
+    means = 0.5 + 0.05 * rs.randn(1, d)
+    A = rs.randn(d, d) / np.sqrt(d)
+    covs = ((A @ A.T + np.eye(d)) * (0.25 ** 2 / 2.0))[None]
+    _, chol, inv = ps.mode_statistics(means, covs)
+    modes = _Modes(means, chol, inv, np.array([5.0]), dev)
+    st = torch.from_numpy(np.array([2.38 / np.sqrt(d)])).to(dev)
+    for n, lanes, zl in ((1, 0, 0), (3, 6, 16), (5, 1, 0), (64, 0, 48), (65, 3, 0), (257, 4, 112)):
+        u = rs.rand(n, d)
+        got = {}
+        for variant in (5, 3):
+            c = HipContext(d, device=0)
+            c.set_option(0, variant)
+            c.set_option(10, lanes)
+            c.set_option(11, zl)
+            up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+            c.propose(kernel, soa(u, dev), None, modes, st, None, 4242, 9, 123456789, up, mu_, mup)
+            got[variant] = (aos(up), mup.cpu().numpy())
+            c.close()
+        np.testing.assert_allclose(got[5][0], got[3][0], rtol=1e-11, atol=1e-13, err_msg=f"n={n}")
+        assert np.all((got[5][0] >= 0) & (got[5][0] <= 1))
+        if kernel == "tpcn":
+            np.testing.assert_allclose(got[5][1], got[3][1], rtol=1e-8, atol=1e-8)
