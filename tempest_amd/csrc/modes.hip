@@ -1099,12 +1099,18 @@ __global__ void __launch_bounds__(256) k_med_finish(const long long* __restrict_
 // One block per mode.  LinAlgError <=> a non-positive (or NaN) pivot; then the reference adds
 // max(1e-6, 1e-6*|trace|) to the diagonal and retries (student.py:75-79, modes.py:111-119).
 // inv = L^-T L^-1 with W = L^-1 in scratch.
+// The factor (and, up to 96-D, its inverse) are built in LDS: every element of L is read O(d) times by serial chains -- thread 0's
+// pivot sum, each thread's column of the triangular solve -- and from global memory each of those reads was a trip to L2 (350 us
+// for one 50 x 50 matrix, 1.6 ms at 100-D).  Same operations in the same order: the results are those of the global-memory form.
 __global__ void __launch_bounds__(256) k_chol_inv(double* __restrict__ covs, int d, double* __restrict__ chols,
-                                                  double* __restrict__ invs, double* __restrict__ work) {
+                                                  double* __restrict__ invs, double* __restrict__ work, int w_lds) {
+  extern __shared__ double cl[];
   double* A = covs + (size_t)blockIdx.x * d * d;
-  double* L = chols + (size_t)blockIdx.x * d * d;
+  double* Lg = chols + (size_t)blockIdx.x * d * d;
   double* Ainv = invs + (size_t)blockIdx.x * d * d;
-  double* W = work + (size_t)blockIdx.x * d * d;
+  double* Wg = work + (size_t)blockIdx.x * d * d;
+  double* L = cl;
+  double* W = w_lds ? cl + (size_t)d * d : Wg;
   __shared__ int fail;
   __shared__ double piv;
   for (int round = 0; round < 3; ++round) {
@@ -1139,6 +1145,7 @@ __global__ void __launch_bounds__(256) k_chol_inv(double* __restrict__ covs, int
     }
   }
   __syncthreads();
+  for (int e = threadIdx.x; e < d * d; e += blockDim.x) Lg[e] = L[e];
   for (int c = threadIdx.x; c < d; c += blockDim.x) {  // column c of W solves L y = e_c
     for (int i = 0; i < d; ++i) {
       if (i < c) { W[i * d + c] = 0.0; continue; }
@@ -1148,6 +1155,8 @@ __global__ void __launch_bounds__(256) k_chol_inv(double* __restrict__ covs, int
     }
   }
   __syncthreads();
+  if (w_lds)
+    for (int e = threadIdx.x; e < d * d; e += blockDim.x) Wg[e] = W[e];
   for (int e = threadIdx.x; e < d * d; e += blockDim.x) {
     int i = e / d, j = e % d;
     int m = i > j ? i : j;
@@ -1165,7 +1174,12 @@ extern "C" int tph_chol_inv(tph_ctx* ctx, double* covs_dev, int K, double* chol_
     if (tph_scratch_reserve(ctx, need)) return -1;
     work = (double*)ctx->scratch;
   }
-  hipLaunchKernelGGL(k_chol_inv, dim3(K), dim3(256), 0, ctx->stream, covs_dev, ctx->d, chol_dev, inv_dev, work);
+  const int d_ = ctx->d;
+  const int w_lds = 2 * sizeof(double) * (size_t)d_ * d_ <= 150 * 1024 ? 1 : 0;
+  const size_t lds = sizeof(double) * (size_t)d_ * d_ * (w_lds ? 2 : 1);
+  if (lds > 64 * 1024)
+    TPH_HIP(hipFuncSetAttribute((const void*)k_chol_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_chol_inv, dim3(K), dim3(256), lds, ctx->stream, covs_dev, ctx->d, chol_dev, inv_dev, work, w_lds);
   TPH_LAUNCH_CHECK();
   return 0;
 }
@@ -1746,8 +1760,13 @@ extern "C" int tph_cv_sum(tph_ctx* ctx, const double* w_dev, int64_t n, const do
 // diagonally pivoted Cholesky of the covariance; the rank is the number of pivots above d * eps * trace (for a positive
 // semi-definite matrix s_max <= trace, and the pivots of the pivoted factorisation bound the trailing singular values), i.e.
 // the same verdict on the degenerate ensembles the rule exists for.  Rank-deficient: cov += 1e-6 trace I as the reference.
-__global__ void __launch_bounds__(256) k_vv_prepare(double* __restrict__ cov, int d, double* __restrict__ work, double* __restrict__ L,
-                                                    double* __restrict__ W, double* __restrict__ flag) {
+// (the working copy, the factor and -- up to 96-D -- its inverse live in LDS, as in k_chol_inv: same operations, same order)
+__global__ void __launch_bounds__(256) k_vv_prepare(double* __restrict__ cov, int d, double* __restrict__ Lg,
+                                                    double* __restrict__ Wg, double* __restrict__ flag, int w_lds) {
+  extern __shared__ double vl[];
+  double* work = vl;                    // pivoted phase: the working copy; afterwards the same words hold L
+  double* L = vl;
+  double* W = w_lds ? vl + (size_t)d * d : Wg;
   __shared__ double s_val[256];
   __shared__ int s_idx[256];
   __shared__ int s_rank, s_fail;
@@ -1836,6 +1855,10 @@ __global__ void __launch_bounds__(256) k_vv_prepare(double* __restrict__ cov, in
     }
   else
     for (int e = tid; e < d * d; e += 256) W[e] = 0.0;
+  __syncthreads();
+  for (int e = tid; e < d * d; e += 256) Lg[e] = L[e];
+  if (w_lds)
+    for (int e = tid; e < d * d; e += 256) Wg[e] = W[e];
   if (tid == 0) { flag[0] = (double)s_fail; flag[1] = (double)s_rank; }
 }
 
@@ -1946,8 +1969,7 @@ extern "C" int tph_volume_variation(tph_ctx* ctx, const double* w_dev, int64_t n
   double* ssum = s0 + 3;
   double* mean = s0 + 8;
   double* cov = mean + d;
-  double* work = cov + mat;
-  double* L = work + mat;
+  double* L = cov + 2 * mat;            // (cov + mat: free -- the pivoted factorisation's working copy lives in LDS)
   double* W = L + mat;
   double* Wb = W + mat;
   double* mom = Wb + tri_blocked_doubles(d);
@@ -1997,7 +2019,11 @@ extern "C" int tph_volume_variation(tph_ctx* ctx, const double* w_dev, int64_t n
     if (centre_dev) TPH_HIP(hipMemcpyAsync(centre_dev, mean, sizeof(double) * d, hipMemcpyDeviceToDevice, ctx->stream));
   }
   // ---- d x d work on the device, blocked layout of L^-1
-  hipLaunchKernelGGL(k_vv_prepare, dim3(1), dim3(256), 0, ctx->stream, cov, d, work, L, W, flag);
+  const int w_lds = 2 * sizeof(double) * (size_t)d * d <= 150 * 1024 ? 1 : 0;
+  const size_t lds_vv = sizeof(double) * (size_t)d * d * (w_lds ? 2 : 1);
+  if (lds_vv > 64 * 1024)
+    TPH_HIP(hipFuncSetAttribute((const void*)k_vv_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_vv));
+  hipLaunchKernelGGL(k_vv_prepare, dim3(1), dim3(256), lds_vv, ctx->stream, cov, d, L, W, flag, w_lds);
   hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, W, d, Wb);
   // ---- the statistic
   const int64_t ntiles = (n + 63) / 64;
