@@ -53,7 +53,24 @@ __global__ void __launch_bounds__(GMM_THREADS) k_gmm_estep(const double* __restr
       for (int r0 = 0; r0 < d; r0 += 8) {
         double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (r0 + 8 <= d) {
-          for (int j = 0; j < d; ++j) {
+          // four columns per trip: their 4 x 64 B of matrix come as back-to-back scalar loads behind ONE wait (a scalar load
+          // waited for alone costs its full latency per 8 FMAs -- tri.h); same order of the FMAs in every accumulator
+          int j = 0;
+          for (; j + 4 <= d; j += 4) {
+            double t[4][8], xc[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const double* __restrict__ Pj = P + (size_t)(j + a) * d + r0;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) t[a][q] = Pj[q];
+              xc[a] = xs[(j + a) * GMM_THREADS] - mu[j + a];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+              for (int q = 0; q < 8; ++q) acc[q] = fma(t[a][q], xc[a], acc[q]);
+          }
+          for (; j < d; ++j) {
             const double xc = xs[j * GMM_THREADS] - mu[j];
             const double* __restrict__ Pj = P + (size_t)j * d + r0;
 #pragma unroll
