@@ -179,13 +179,22 @@ PARITY_CASES = {
 }
 
 
+# d > 16: the proposal kernel of a step follows the redraw probe of the RANK's own shard (blocked kernel in rounds / row walker,
+# lane groups and rounds sized by the shard), and those kernels agree to rounding, not bit for bit: a sharded run is the same
+# sampler statistically -- same schedule within an iteration, evidence within the seed-to-seed spread
+LOOSE_CASES = {
+    "tpcn_d24": dict(sample="tpcn", resample="mult", clustering=False, n_dim=24, target="gauss", n=2048, n_total=4096),
+    "rwm_d24": dict(sample="rwm", resample="syst", clustering=False, n_dim=24, target="gauss", n=2048, n_total=4096),
+}
+
+
 def parity_run(name, device=0):
     """One seeded run of PARITY_CASES[name] on the current process group (or none): the quantities every world size
     must agree on."""
     import numpy as np
     import torch
     import tempest_amd as tp
-    c = PARITY_CASES[name]
+    c = PARITY_CASES[name] if name in PARITY_CASES else LOOSE_CASES[name]
     d = c["n_dim"]
     dev = torch.device("cuda", device)
     mean = torch.linspace(-2, 2, d, dtype=torch.float64, device=dev)
@@ -359,7 +368,8 @@ def parity_gpu_worker(rank, world, port, out_dir):
     import torch.distributed as dist
     _init(rank, world, port)
     only = os.environ.get("TEMPEST_AMD_TEST_CASES")
-    out = {name: parity_run(name) for name in PARITY_CASES if not only or name in only.split(",")}
+    cases = LOOSE_CASES if os.environ.get("TEMPEST_AMD_TEST_LOOSE") == "1" else PARITY_CASES
+    out = {name: parity_run(name) for name in cases if not only or name in only.split(",")}
     json.dump(out, open(os.path.join(out_dir, f"parity{rank}.json"), "w"))
     dist.barrier()
     dist.destroy_process_group()

@@ -125,3 +125,27 @@ def test_world2_is_the_same_sampler_as_world1(tmp_path):
               "world2 - world1", two["logz"] - one["logz"])
     if "tpcn_cluster" in PARITY_CASES:
         assert max(r0["tpcn_cluster"]["K"]) > 1         # the clustered case really exercised K > 1
+
+
+@pytest.mark.gpu
+def test_world2_at_n_dim_above_16_is_the_same_sampler_statistically(tmp_path, monkeypatch):
+    """n_dim > 16 under a communicator: every rank picks the proposal kernel of its shard's steps from its own redraw probe
+    (blocked kernel in rounds, row walker), kernels that agree to rounding -- so two ranks reproduce the one-GPU run
+    statistically: both ranks hold the same global results bit for bit, the schedule has the same length to within an
+    iteration and the evidence agrees within the seed-to-seed spread (0.15 at these sizes), for tpCN and RWM."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    from tests._dist_workers import LOOSE_CASES, parity_gpu_worker, parity_run
+    monkeypatch.setenv("TEMPEST_AMD_TEST_LOOSE", "1")
+    _spawn(parity_gpu_worker, 2, tmp_path)
+    r0 = json.load(open(tmp_path / "parity0.json"))
+    r1 = json.load(open(tmp_path / "parity1.json"))
+    assert r0 == r1
+    for name in LOOSE_CASES:
+        one, two = parity_run(name), r0[name]
+        assert abs(len(two["beta"]) - len(one["beta"])) <= 1, name
+        assert two["beta"][-1] == 1.0 and one["beta"][-1] == 1.0
+        assert abs(two["logz"] - one["logz"]) < 0.5, (name, two["logz"], one["logz"])
+        assert two["post_n"] == one["post_n"], name
+        print(name, "iterations", len(one["beta"]), len(two["beta"]), "logz", one["logz"], two["logz"])
