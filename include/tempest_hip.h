@@ -403,6 +403,18 @@ int tph_gmm_estep(tph_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, cons
                   int label, int K, const double* params_dev, int mode, double eps, const double* shift_dev,
                   const double* scale_dev, double* wr_dev, int32_t* label_out_dev, double* stats_dev);
 
+/* Device-paced EM for covariance_type "full" (cluster.py:104-133,174-304): the loop's state lives in ONE device block of
+ * tph_gmm_em_state_doubles(n_dim, K) doubles -- control words [0..15] = {iteration, done flag, lower bound, n_iter, the last
+ * E-step's three sums, ...}, the M-step's moments, the packed E-step parameters, and the weights / means / covariances those
+ * parameters were formed from (offsets: 16 + K(1+d) + K d + K d^2 + K(2+d+d^2), then K, K d, K d^2).  tph_gmm_em_begin: the
+ * fit's first M-step from the initial responsibilities in wr_dev (K x n) and a fresh control block.  tph_gmm_em_run ENQUEUES
+ * `iters` iterations (parameters incl. precisions and log-determinants by a kernel; E-step; convergence test on the device;
+ * M-step); passes behind a raised done flag are no-ops.  The host reads the control words once per call. */
+int64_t tph_gmm_em_state_doubles(int n_dim, int K);
+int tph_gmm_em_begin(tph_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int K, const double* wr_dev, double* state_dev);
+int tph_gmm_em_run(tph_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, const double* sw_dev, const int32_t* labels_dev,
+                   int label, int K, double* wr_dev, double* state_dev, double reg_covar, double tol, int max_iter, int iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,9 @@ SIGNATURES = {
     "tph_x_weighted_sums": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr, ptr]),
     "tph_x_weighted_cov": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr, ptr]),
     "tph_gmm_estep": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr, c_int, c_int, ptr, c_int, c_dbl, ptr, ptr, ptr, ptr, ptr]),
+    "tph_gmm_em_state_doubles": (c_i64, [c_int, c_int]),
+    "tph_gmm_em_begin": (c_int, [ptr, ptr, c_i64, c_i64, c_int, ptr, ptr]),
+    "tph_gmm_em_run": (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr, c_int, c_int, ptr, ptr, c_dbl, c_dbl, c_int, c_int]),
     "tph_cv_sum": (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr]),
     "tph_volume_variation": (c_int, [ptr, ptr, c_i64, ptr, ptr]),
     "tph_comm_attach": (c_int, [ptr, c_int, c_int, ptr, c_i64, ptr, ptr, ptr]),

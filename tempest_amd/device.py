@@ -494,6 +494,24 @@ class HipContext:
                                      _ptr(label_out, torch.int32) if label_out is not None else None, _ptr(stats)),
               "tph_gmm_estep")
 
+    def gmm_em_state(self, K):
+        """A zeroed state block of the device-paced EM (tph_gmm_em_*) and the offsets of its parts."""
+        d = self.n_dim
+        total = int(self.lib.tph_gmm_em_state_doubles(d, int(K)))
+        off = {"ctl": 0}
+        o = 16 + K * (1 + d) + K * d + K * d * d + K * (2 + d + d * d)
+        off["weights"], off["means"], off["covs"] = o, o + K, o + K + K * d
+        assert off["covs"] + K * d * d == total
+        return self.zeros(total), off
+
+    def gmm_em_begin(self, x, K, wr, state):
+        check(self.lib.tph_gmm_em_begin(self._ctx, _ptr(x), x.shape[1], x.shape[1], int(K), _ptr(wr), _ptr(state)), "tph_gmm_em_begin")
+
+    def gmm_em_run(self, x, sw, labels, label, K, wr, state, reg, tol, max_iter, iters):
+        check(self.lib.tph_gmm_em_run(self._ctx, _ptr(x), x.shape[1], x.shape[1], _ptr(sw),
+                                      _ptr(labels, torch.int32) if labels is not None else None, int(label), int(K), _ptr(wr),
+                                      _ptr(state), float(reg), float(tol), int(max_iter), int(iters)), "tph_gmm_em_run")
+
     # ------------------------------------------------------------------------ volume variation
     def weighted_moments(self, w):
         d = self.n_dim
