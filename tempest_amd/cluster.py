@@ -160,19 +160,22 @@ class GaussianMixture:
             ctx.gmm_estep(ws.X, swc, ws.labels, label, ws.to_dev(p), K, 0, eps=0.0, wr=ws.wr, stats=ws.stats)
             if self.covariance_type == "full" and ws.M <= 16384:
                 # Small working sets: device-paced loop (tph_gmm_em_*).  Parameters (incl. the d x d inverses), convergence test
-                # and M-step stay on the device and the host reads 16 control words per BATCH of six iterations: with the host in
+                # and M-step stay on the device and the host reads 16 control words per BATCH of iterations: with the host in
                 # every iteration an iteration cost 0.3 ms whatever the size -- 3.1 of the 3.7 s of a 1 000-particle run (10 500
                 # iterations in 1 200 fits).  Large working sets keep the loop below: there an iteration is a millisecond of
                 # kernels, the round trips are hidden behind them, and iterations enqueued past convergence would be the cost
                 # (measured at 262 144 rows: 1.85 -> 2.1 s).
                 state, off = ctx.gmm_em_state(K)
                 ctx.gmm_em_begin(ws.X, K, ws.wr, state)
-                batch = 6
+                # a single Gaussian is at its fixed point after the first M-step (the test passes at iteration 2: three passes);
+                # two components take 9 ... 27 iterations (10th ... 90th percentile of the 1 000-particle run's 470 such fits)
+                batch = 3 if K == 1 else 12
                 while True:
                     ctx.gmm_em_run(ws.X, swc, ws.labels, label, K, ws.wr, state, self.reg_covar, self.tol, self.max_iter, batch)
                     ctl = state[:16].cpu().numpy()
                     if ctl[1] != 0.0:
                         break
+                    batch = 3 if K == 1 else 6
                 tail = state[off["weights"]:].cpu().numpy()
                 weights = tail[:K].copy()
                 means = tail[K:K + K * d].reshape(K, d).copy()
