@@ -172,11 +172,12 @@ class GaussianMixture:
                 batch = 3 if K == 1 else 12
                 while True:
                     ctx.gmm_em_run(ws.X, swc, ws.labels, label, K, ws.wr, state, self.reg_covar, self.tol, self.max_iter, batch)
-                    ctl = state[:16].cpu().numpy()
+                    host = state.cpu().numpy()            # the whole block (a few KB): one copy per batch, the last one is the result
+                    ctl = host[:16]
                     if ctl[1] != 0.0:
                         break
                     batch = 3 if K == 1 else 6
-                tail = state[off["weights"]:].cpu().numpy()
+                tail = host[off["weights"]:]
                 weights = tail[:K].copy()
                 means = tail[K:K + K * d].reshape(K, d).copy()
                 covs = tail[K + K * d:].reshape(K, d, d).copy()
