@@ -871,8 +871,8 @@ def test_blocked_kernel_deferred_update_and_step_control(dev, kernel):
                                         # the lane's column of global scratch
                                         (50, 0, 16), (37, 3, 48), (50, 2, 64), (72, 0, 0), (100, 3, 0), (100, 0, 48), (100, 2, 112)])
 def test_stage_machine_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, lanes, zl):
-    """TPH_OPT_PROPOSE_VARIANT 5 (propose_sm.hip): the redraw loop of mcmc.py:239-249 run as a stage machine -- a lane per
-    attempt, several attempts of a particle in flight, eight rows at a time with early exit, the first in-bounds attempt in
+    """TPH_OPT_PROPOSE_VARIANT 5 (propose_sm.hip, the row walker): the redraw loop of mcmc.py:239-249 with a lane per
+    attempt, several attempts of a particle in flight, four rows at a time with early exit, the first in-bounds attempt in
     attempt order wins.  Same counter-based draws and row arithmetic as the other kernels: on an ensemble where most attempts
     leave the cube (tens of attempts per particle, some particles at the 256-attempt cap) the proposals and both
     Mahalanobis forms equal the oracle's sequential loop and the multi-lane kernel to rounding."""
