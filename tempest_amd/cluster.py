@@ -73,6 +73,8 @@ class GaussianMixture:
     E-step kernel takes full precision matrices, the M-step reduces the weighted scatter matrices to the stored form).  Host-array `fit`/`predict`/`bic`
     mirror the reference's interface; the hierarchical model drives `_fit_ws` on a shared working set."""
 
+    device_paced_max_rows = 16384      # working sets up to this size run the EM loop device-paced (tph_gmm_em_*), see _fit_ws
+
     def __init__(self, n_components=1, covariance_type="full", max_iter=1000, n_init=1, tol=1e-3, reg_covar=1e-6,
                  random_state=None):
         if covariance_type not in ("full", "tied", "diag", "spherical"):
@@ -158,7 +160,7 @@ class GaussianMixture:
             p = _pack_params(np.zeros(K), means, np.tile(np.eye(d), (K, 1, 1)), 0.0)
             p[:, -1] = -d * LOG2PI
             ctx.gmm_estep(ws.X, swc, ws.labels, label, ws.to_dev(p), K, 0, eps=0.0, wr=ws.wr, stats=ws.stats)
-            if self.covariance_type == "full" and ws.M <= 16384:
+            if self.covariance_type == "full" and ws.M <= self.device_paced_max_rows:
                 # Small working sets: device-paced loop (tph_gmm_em_*).  Parameters (incl. the d x d inverses), convergence test
                 # and M-step stay on the device and the host reads 16 control words per BATCH of iterations: with the host in
                 # every iteration an iteration cost 0.3 ms whatever the size -- 3.1 of the 3.7 s of a 1 000-particle run (10 500
