@@ -126,7 +126,7 @@ def reweight_roofline(device, n_rows, other_rows=(2_621_440, 10_485_760)):
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(avg_ms, 5), "history_rows": n_rows,
             "measured_peak": {"read_GBs": round(read_gbs, 1), "copy_GBs": round(copy_gbs, 1),
-                              "what": "16-B non-temporal streaming read / copy kernels of the library (tph_membw_time) over the "
+                              "what": "16-B non-temporal streaming read / copy kernels of the library (tph_bench_membw_time) over the "
                                       "same 1.07 GB in this process"},
             "frac_of_measured": round(achieved / read_gbs, 4), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
             "fp64_vector_tflops_measured": round(fp64, 2),

@@ -63,7 +63,8 @@ int tph_synchronize(tph_ctx* ctx);
 /* TPH_OPT_PROPOSE_VARIANT selects the proposal kernel: 0 = automatic (registers for n_dim <= 16, multi-lane above, blocked
  * when TPH_OPT_BLOCKED is set, row walker when TPH_OPT_STAGED_REDRAW is), 1 = one lane per particle with LDS columns (any n_dim), 2 = one lane per particle in
  * registers (n_dim <= 16), 3 = several lanes per particle with the matrices staged in LDS, 4 = blocked + straggler pass
- * (16 < n_dim <= 100, one mode), 5 = row walker (16 < n_dim <= 100, one mode); the parity tests run every variant */
+ * (16 < n_dim <= 100, one mode), 5 = row walker (16 < n_dim <= 100, one mode), 6 = screened batches (16 < n_dim <= 112, one
+ * mode); the parity tests run every variant */
 #define TPH_OPT_PROPOSE_VARIANT 0
 /* TPH_OPT_REDUCE_GRID: 0 = automatic grid of the reweight reduction, > 0 = that many blocks (experiments) */
 #define TPH_OPT_REDUCE_GRID 1
@@ -107,6 +108,17 @@ int tph_synchronize(tph_ctx* ctx);
 #define TPH_OPT_STAGED_REDRAW 9
 #define TPH_OPT_SM_LANES 10
 #define TPH_OPT_SM_THRESHOLD 11
+/* TPH_OPT_SCREEN: 1 (default) = the redraw-dominated steps of TPH_OPT_STAGED_REDRAW run as SCREENED BATCHES (propose_mf.hip,
+ * 16 < n_dim <= 112): a wave holds 64 attempts as columns of 16 x 16 tiles and walks them in lockstep through panels of 16
+ * rows on the matrix cores (FP16 copy of L, FP32 Box-Muller pairs from the same Philox blocks); an attempt is dropped only
+ * when a coordinate is out of bounds by more than a rigorous bound of the low-precision error, every attempt that is not
+ * dropped is evaluated in FP64 by the arithmetic of the other kernels, and the first of those in bounds, in attempt order, is
+ * the proposal -- the proposal of the sequential loop of mcmc.py:239-249, equal to the row walker's bit for bit.  0 = the FP64
+ * row walker.  TPH_OPT_MF_LANES: log2 of the attempts a particle keeps in flight (2..6; 0 = by size).  TPH_OPT_MF_AUDIT: 1 =
+ * every dropped attempt is ALSO evaluated in FP64 and contradictions are counted (tph_bench_mf_counters word 3; tests). */
+#define TPH_OPT_SCREEN 12
+#define TPH_OPT_MF_LANES 13
+#define TPH_OPT_MF_AUDIT 14
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- multi-GPU: one process per GPU --------------------------------------
@@ -181,14 +193,6 @@ int tph_history_load(tph_ctx* ctx, const double* u_host, const double* x_host, c
  * With a communicator attached both return the GLOBAL triples (all-gather of the ranks' triples + device-side merge). */
 int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int nb, double* out_dev /*[nb][3]*/);
 int tph_reweight_eval(tph_ctx* ctx, const double* betas_host, int nb, double* out_host /*[nb][3]*/);
-/* measurement aid: average duration (ms, HIP events on the ctx stream) of `reps` back-to-back launches of the
- * reduction kernel alone for nb trial betas */
-int tph_reweight_time(tph_ctx* ctx, double beta, int nb, int reps, double* avg_ms_host);
-/* measurement aids: the box's own ceilings, timed in the same process (HIP events on the ctx stream).  tph_membw_time:
- * average duration of a streaming READ (mode 0: n_doubles * 8 bytes per launch, the reduction's access pattern) or COPY
- * (mode 1: 2 * n_doubles * 8 bytes) over freshly allocated buffers; tph_fp64_time: sustained FP64 vector-FMA rate (TFLOP/s). */
-int tph_membw_time(tph_ctx* ctx, int mode, int64_t n_doubles, int reps, double* avg_ms_host);
-int tph_fp64_time(tph_ctx* ctx, int reps, double* tflops_host);
 /* normalised weights w_s = e^{beta l_s - C_s - vmax}/s1 for all N_h particles (reweight.py:106,328) */
 int tph_weights(tph_ctx* ctx, double beta, double vmax, double s1, double* w_dev);
 /* unnormalised log-weights beta*l - C + log(n_h_global)  (state_manager.py:473) */
@@ -414,6 +418,21 @@ int64_t tph_gmm_em_state_doubles(int n_dim, int K);
 int tph_gmm_em_begin(tph_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int K, const double* wr_dev, double* state_dev);
 int tph_gmm_em_run(tph_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, const double* sw_dev, const int32_t* labels_dev,
                    int label, int K, double* wr_dev, double* state_dev, double reg_covar, double tol, int max_iter, int iters);
+
+/* ---- measurement aids (tph_bench_*): used by bench.py, tools/ and the tests; NOT part of the drop-in surface ------------
+ * tph_bench_reweight_time: average duration (ms, HIP events on the ctx stream) of `reps` back-to-back launches of the
+ * reweight reduction kernel alone for nb trial betas.  tph_bench_membw_time: the box's own ceiling, timed in the same
+ * process -- a streaming READ (mode 0: n_doubles * 8 bytes per launch, the reduction's access pattern) or COPY (mode 1:
+ * 2 * n_doubles * 8 bytes) over freshly allocated buffers.  tph_bench_fp64_time: sustained FP64 vector-FMA rate (TFLOP/s).
+ * tph_bench_mf_normals: max |z~ - z| of the screened kernel's FP32 Box-Muller pair against the FP64 pair of the same
+ * Philox blocks over n_blocks blocks starting at block `first` (edge = 1: hand-made blocks at the ends of u1 and around the
+ * switch of the logarithm); out = (max error, max |z|, blocks).  tph_bench_mf_counters: the counters of the last screened
+ * launch: next chunk, sum of attempts, particles, audit contradictions, FP64 verifications, attempts screened, pair jobs. */
+int tph_bench_reweight_time(tph_ctx* ctx, double beta, int nb, int reps, double* avg_ms_host);
+int tph_bench_membw_time(tph_ctx* ctx, int mode, int64_t n_doubles, int reps, double* avg_ms_host);
+int tph_bench_fp64_time(tph_ctx* ctx, int reps, double* tflops_host);
+int tph_bench_mf_normals(tph_ctx* ctx, uint64_t seed, uint64_t first, uint64_t n_blocks, int edge, double* out3_host);
+int tph_bench_mf_counters(tph_ctx* ctx, unsigned long long* out7_host);
 
 #ifdef __cplusplus
 }

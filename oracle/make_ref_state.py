@@ -13,6 +13,8 @@ REFERENCE write its own files:
                                             of the reference package -- code, not data, and not loadable without it)
   tests/golden/ref_state_small.npz          what the reference computes from that state: flat history arrays,
                                             compute_logw_and_logz(1.0), the iteration table
+  tests/golden/ref_state_small_posterior.npz   (--posterior-only) what the reference's posterior() returns on that state
+                                            (core.py:187-242): trimmed and untrimmed, with logw, and a second trim setting
 Both .state files contain only dicts, lists, floats and NumPy arrays.
 """
 import os
@@ -22,7 +24,7 @@ import numpy as np
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
-def main():
+def main(posterior_only=False):
     import dill
     import tempest as tp
     d, n = 3, 64
@@ -45,6 +47,18 @@ def main():
     for _ in range(7):
         s.sample()
     st = s.state
+    if posterior_only:
+        # the same seeded run again: it must be the state the committed fixtures hold, then the reference's own posterior()
+        old = np.load(os.path.join(OUT, "ref_state_small.npz"))
+        assert np.array_equal(old["u"], st.get_history("u", flat=True)) and np.array_equal(old["logl"], st.get_history("logl", flat=True))
+        out = {}
+        for tag, kw in (("trim", dict(trim_importance_weights=True)), ("full", dict(trim_importance_weights=False)),
+                        ("trim90", dict(trim_importance_weights=True, ess_trim=0.9, bins_trim=50))):
+            x, w, logl, logw = s.posterior(return_logw=True, **kw)
+            out.update({f"x_{tag}": x, f"w_{tag}": w, f"logl_{tag}": logl, f"logw_{tag}": logw})
+        np.savez(os.path.join(OUT, "ref_state_small_posterior.npz"), **out)
+        print("wrote ref_state_small_posterior.npz", {k: v.shape for k, v in out.items()})
+        return
     path = os.path.join(OUT, "ref_state_small.state")
     st.save_state(path)
     dd = st.to_dict()
@@ -71,4 +85,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+    main(posterior_only="--posterior-only" in sys.argv)

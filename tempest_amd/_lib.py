@@ -35,9 +35,11 @@ SIGNATURES = {
     "tph_history_load": (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, ptr, ptr, ptr, ptr]),
     "tph_reweight_partials": (c_int, [ptr, ptr, c_int, ptr]),
     "tph_reweight_eval": (c_int, [ptr, ptr, c_int, ptr]),
-    "tph_reweight_time": (c_int, [ptr, c_dbl, c_int, c_int, ptr]),
-    "tph_membw_time": (c_int, [ptr, c_int, c_i64, c_int, ptr]),
-    "tph_fp64_time": (c_int, [ptr, c_int, ptr]),
+    "tph_bench_reweight_time": (c_int, [ptr, c_dbl, c_int, c_int, ptr]),
+    "tph_bench_membw_time": (c_int, [ptr, c_int, c_i64, c_int, ptr]),
+    "tph_bench_fp64_time": (c_int, [ptr, c_int, ptr]),
+    "tph_bench_mf_normals": (c_int, [ptr, c_u64, c_u64, c_u64, c_int, ptr]),
+    "tph_bench_mf_counters": (c_int, [ptr, ptr]),
     "tph_weights": (c_int, [ptr, c_dbl, c_dbl, c_dbl, ptr]),
     "tph_logw": (c_int, [ptr, c_dbl, c_i64, ptr]),
     "tph_sum_sq_max": (c_int, [ptr, ptr, c_i64, ptr]),

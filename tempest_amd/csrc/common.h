@@ -89,6 +89,12 @@ struct tph_ctx {
   size_t sm_scr_bytes = 0;
   int sm_epoch = -1, sm_kernel = -1;
   const void* sm_src = nullptr;
+  // screened-batch proposal kernel (propose_mf.hip): TPH_OPT_SCREEN / _MF_LANES / _MF_AUDIT and its persistent buffer
+  int screen = 1, mf_lanes = 0, mf_audit = 0;
+  void* mf_buf = nullptr;           // queue words | blocked L^-1 | FP16 pack of L + row error tables | transposed FP64 L
+  size_t mf_bytes = 0;
+  int mf_epoch = -1, mf_kernel = -1;
+  const void* mf_src = nullptr;
   std::vector<void*> retired;       // outgrown buffers a captured hipGraph of an earlier step may still address: freed with the ctx
   double* vv_buf = nullptr;         // small persistent buffers of tph_volume_variation (moments, factors, blocked L^-1)
   size_t vv_bytes = 0;
@@ -126,6 +132,10 @@ const double* tph_rows_sync(tph_ctx* ctx);          // resample.hip: mirror up t
 int tph_tri_inv(tph_ctx* ctx, const double* chol_dev, int K, double* winv_dev);   // modes.hip
 // propose_sm.hip: the whole proposal of a redraw-dominated step at 16 < d <= 100, one mode (pending moves, forms, u')
 int tph_propose_sm(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
+                   const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
+                   const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend);
+// propose_mf.hip: the same step with the attempts screened on the matrix cores and only the survivors evaluated in FP64
+int tph_propose_mf(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                    const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
                    const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend);
 

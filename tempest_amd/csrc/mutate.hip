@@ -1001,6 +1001,12 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
   }
   const int variant = ctx->propose_variant;   // 0 auto | 1 one-lane LDS | 2 one-lane registers (d<=16) | 3 multi-lane | 4 blocked
   const bool use_reg = (variant == 2 || variant == 0) && ctx->d <= 16;
+  // redraw-dominated steps: attempts screened on the matrix cores, survivors in FP64 (propose_mf.hip; TPH_OPT_SCREEN, default)
+  // or every attempt walked row by row in FP64 (propose_sm.hip)
+  if (!use_reg && ctx->d > 16 && ctx->d <= 112 && !assign_dev && K == 1 &&
+      (variant == 6 || (variant == 0 && ctx->staged && !ctx->blocked && ctx->screen)))
+    return tph_propose_mf(ctx, kernel, u_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick0, ctl_dev,
+                          item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev);
   if (!use_reg && ctx->d > 16 && ctx->d <= 100 && !assign_dev && K == 1 &&
       (variant == 5 || (variant == 0 && ctx->staged && !ctx->blocked)))
     return tph_propose_sm(ctx, kernel, u_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick0, ctl_dev,

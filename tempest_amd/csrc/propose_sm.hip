@@ -369,92 +369,7 @@ __global__ void __launch_bounds__(512) k_propose_sm(const double* __restrict__ u
   }
 }
 
-// ---- Mahalanobis forms of a tile of 64 particles, |L^-1 (v - mu)|^2 through the blocked product of tri.h, and the chores
-// around the stage-machine kernel.  MODE 0 (before it): resolve the deferred Metropolis moves (u <- u' where pending); tpCN:
-// the form at u -> maha_u on the first step of a run (afterwards it is carried), then the Gamma draw and the step scale
-// b = sigma sqrt(s) of every particle -> bfac_out (mcmc.py:228-236; one draw per particle and step, reused by its redraws).
-// MODE 1 (after it): the form at u' -> maha_up (tpCN; 0 for RWM), and the step's mean attempts per particle -> state[8]
-// (regime probe for the host).
-template <int KERNEL, int WV, int MODE>
-__global__ void __launch_bounds__(64 * WV) k_maha_tile(double* __restrict__ u, int64_t n, int64_t ld, int d,
-                                                       const double* __restrict__ means, const double* __restrict__ Wb,
-                                                       double* __restrict__ up, double* __restrict__ maha, tph_stepctl tick,
-                                                       uint8_t* __restrict__ pend, const unsigned long long* __restrict__ queue,
-                                                       const double* __restrict__ dof, const double* __restrict__ sigmas,
-                                                       uint64_t seed, int64_t item0, double* __restrict__ bfac_out) {
-  extern __shared__ double sh[];
-  double* xs = sh;                                 // [d][64]
-  double* sc = sh + (size_t)d * 64;                // [WV][64]
-  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-  const bool live = i < n;
-  const int64_t ii = live ? i : n - 1;
-  if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl && queue)
-    const_cast<double*>(tick.ctl)[8] = queue[2] ? (double)queue[1] / (double)queue[2] : 0.0;
-#ifdef SM_PROFILE
-  if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0 && queue)
-    printf("SM_PROFILE attempts %llu particles %llu | wave-cycles: bm %llu rows(z in LDS) %llu rows(z global) %llu in %llu steps, epilogue %llu (wait %llu + bounds %llu + rest) refill %llu | steps %llu\n", queue[1],
-           queue[2], queue[3], queue[4], queue[10], queue[11], queue[7] + queue[8] + queue[9], queue[8], queue[9], queue[5], queue[6]);
-#endif
-  const bool form = KERNEL == TPH_KERNEL_TPCN && (MODE == 1 || !tick.carry());
-  if (MODE == 0) {
-    const bool pd = pend && live && pend[i];
-    for (int j = wid; j < d; j += WV) {
-      double uj = u[(size_t)j * ld + ii];
-      if (pd) { uj = up[(size_t)j * ld + i]; u[(size_t)j * ld + i] = uj; }
-      if (form) xs[(size_t)j * 64 + lane] = uj - means[j];
-    }
-    __syncthreads();
-    if (pd && wid == 0) pend[i] = 0;
-  } else if (form) {
-    for (int j = wid; j < d; j += WV) xs[(size_t)j * 64 + lane] = up[(size_t)j * ld + ii] - means[j];
-    __syncthreads();
-  }
-  if (KERNEL != TPH_KERNEL_TPCN) {
-    if (maha && wid == 0 && live) maha[i] = 0.0;
-    return;
-  }
-  double m = 0.0;
-  if (form) {
-    double part = 0.0;
-    tri_apply(Wb, d, xs, lane, wid, WV, [&](int, double y) { part = fma(y, y, part); });
-    sc[(size_t)wid * 64 + lane] = part;
-    __syncthreads();
-    if (wid == 0) {
-      for (int w = 0; w < WV; ++w) m += sc[(size_t)w * 64 + lane];
-      if (live) maha[i] = m;
-    }
-  } else if (wid == 0) {
-    m = maha[ii];
-  }
-  if (MODE == 0 && wid == 0 && live) {
-    const double nu = dof[0], sigma = sigmas[0];
-    tph_rng gr(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
-    const double gam = tph_gamma_mt(gr, 0.5 * ((double)d + nu)) * tph_div(2.0, nu + m);
-    bfac_out[i] = sigma * tph_sqrt(tph_rcp(gam));
-  }
-}
-
-template <int KERNEL, int MODE>
-static int launch_maha_tile(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* Wb, double* up,
-                            double* maha, tph_stepctl tick, uint8_t* pend, const unsigned long long* queue, const double* dof,
-                            const double* sigmas, uint64_t seed, int64_t item0, double* bfac_out) {
-  const int d = ctx->d;
-  const int wv = d <= 32 ? 4 : d <= 64 ? 8 : 16;
-  const size_t lds = sizeof(double) * ((size_t)d * 64 + (size_t)wv * 64);
-  const dim3 grid((unsigned)((n + 63) / 64));
-#define TPH_MT(WV)                                                                                                       \
-  do {                                                                                                                   \
-    if (lds > 64 * 1024)                                                                                                 \
-      TPH_HIP(hipFuncSetAttribute((const void*)k_maha_tile<KERNEL, WV, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((k_maha_tile<KERNEL, WV, MODE>), grid, dim3(64 * WV), lds, ctx->stream, u, n, ld, d, means, Wb, up, maha, \
-                       tick, pend, queue, dof, sigmas, seed, item0, bfac_out);                                           \
-  } while (0)
-  if (wv == 4) TPH_MT(4); else if (wv == 8) TPH_MT(8); else TPH_MT(16);
-#undef TPH_MT
-  TPH_LAUNCH_CHECK();
-  return 0;
-}
+#include "maha_tile.h"
 
 template <int KERNEL>
 static int propose_sm(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,

@@ -310,9 +310,9 @@ extern "C" int tph_reweight_eval(tph_ctx* ctx, const double* betas_host, int nb,
 
 // HIP-event timing of the streaming reduction alone (no finalize, no host work between launches):
 // what bench.py reports as the kernel's average launch duration.
-extern "C" int tph_reweight_time(tph_ctx* ctx, double beta, int nb, int reps, double* avg_ms_host) {
-  TPH_REQUIRE(ctx && avg_ms_host && reps > 0, "tph_reweight_time: bad argument");
-  TPH_REQUIRE(nb >= 1 && nb <= TPH_MAX_NB && ctx->size > 0, "tph_reweight_time: bad nb / empty history");
+extern "C" int tph_bench_reweight_time(tph_ctx* ctx, double beta, int nb, int reps, double* avg_ms_host) {
+  TPH_REQUIRE(ctx && avg_ms_host && reps > 0, "tph_bench_reweight_time: bad argument");
+  TPH_REQUIRE(nb >= 1 && nb <= TPH_MAX_NB && ctx->size > 0, "tph_bench_reweight_time: bad nb / empty history");
   tph_betas bt;
   for (int i = 0; i < TPH_MAX_NB; ++i) bt.b[i] = beta * (1.0 - 0.01 * i);
   int grid = reduce_grid(ctx, ctx->size);
@@ -368,12 +368,12 @@ __global__ void __launch_bounds__(TPH_RED_THREADS) k_membw(const double* __restr
   }
   if (MODE == 0 && acc == 1.2345e300) sink[0] = acc;     // never true: keeps the loads alive
 }
-extern "C" int tph_membw_time(tph_ctx* ctx, int mode, int64_t n_doubles, int reps, double* avg_ms_host) {
-  TPH_REQUIRE(ctx && avg_ms_host && reps > 0 && n_doubles >= 1024 && (mode == 0 || mode == 1), "tph_membw_time: bad argument");
+extern "C" int tph_bench_membw_time(tph_ctx* ctx, int mode, int64_t n_doubles, int reps, double* avg_ms_host) {
+  TPH_REQUIRE(ctx && avg_ms_host && reps > 0 && n_doubles >= 1024 && (mode == 0 || mode == 1), "tph_bench_membw_time: bad argument");
   const size_t bytes = sizeof(double) * (size_t)n_doubles;
   double *a = nullptr, *b = nullptr;
   TPH_HIP(hipMalloc((void**)&a, bytes));
-  if (mode == 1 && hipMalloc((void**)&b, bytes) != hipSuccess) { (void)hipFree(a); TPH_REQUIRE(false, "tph_membw_time: out of memory"); }
+  if (mode == 1 && hipMalloc((void**)&b, bytes) != hipSuccess) { (void)hipFree(a); TPH_REQUIRE(false, "tph_bench_membw_time: out of memory"); }
   TPH_HIP(hipMemsetAsync(a, 0, bytes, ctx->stream));
   const int grid = tph_grid_for(n_doubles, TPH_RED_THREADS, 16, 1024);
   hipEvent_t e0, e1;
@@ -410,8 +410,8 @@ __global__ void __launch_bounds__(256) k_fp64_probe(double* __restrict__ out, do
   }
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
 }
-extern "C" int tph_fp64_time(tph_ctx* ctx, int reps, double* tflops_host) {
-  TPH_REQUIRE(ctx && tflops_host && reps > 0, "tph_fp64_time: bad argument");
+extern "C" int tph_bench_fp64_time(tph_ctx* ctx, int reps, double* tflops_host) {
+  TPH_REQUIRE(ctx && tflops_host && reps > 0, "tph_bench_fp64_time: bad argument");
   const int blocks = ctx->n_simd;                 // 4 waves per SIMD
   const int iters = 256;
   if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)blocks * 256)) return -1;

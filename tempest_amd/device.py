@@ -25,6 +25,9 @@ OPT_SORTED_DRAWS = 8           # TPH_OPT_SORTED_DRAWS
 OPT_STAGED_REDRAW = 9          # TPH_OPT_STAGED_REDRAW
 OPT_SM_LANES = 10              # TPH_OPT_SM_LANES
 OPT_SM_THRESHOLD = 11          # TPH_OPT_SM_THRESHOLD
+OPT_SCREEN = 12                # TPH_OPT_SCREEN
+OPT_MF_LANES = 13              # TPH_OPT_MF_LANES
+OPT_MF_AUDIT = 14              # TPH_OPT_MF_AUDIT
 BC_STRICT, BC_PERIODIC, BC_REFLECTIVE = 0, 1, 2
 
 TAG_PRIOR, TAG_NORMAL, TAG_GAMMA, TAG_ACCEPT, TAG_RESAMPLE, TAG_UPSAMPLE, TAG_REPAIR, TAG_SYST = 1, 2, 3, 4, 5, 6, 7, 8
@@ -181,7 +184,7 @@ class HipContext:
     def reweight_time(self, beta=0.37, nb=1, reps=20):
         """Average launch duration (ms) of the reduction kernel, HIP events on the ctx stream."""
         out = C.c_double(0.0)
-        check(self.lib.tph_reweight_time(self._ctx, float(beta), int(nb), int(reps), C.byref(out)), "tph_reweight_time")
+        check(self.lib.tph_bench_reweight_time(self._ctx, float(beta), int(nb), int(reps), C.byref(out)), "tph_bench_reweight_time")
         return out.value
 
     # ------------------------------------------------------------------ small collectives inside the library
@@ -238,13 +241,25 @@ class HipContext:
     def membw_time(self, mode, n_doubles, reps=20):
         """Average launch duration (ms) of the streaming read (mode 0) / copy (mode 1) ceiling kernel."""
         out = C.c_double(0.0)
-        check(self.lib.tph_membw_time(self._ctx, int(mode), int(n_doubles), int(reps), C.byref(out)), "tph_membw_time")
+        check(self.lib.tph_bench_membw_time(self._ctx, int(mode), int(n_doubles), int(reps), C.byref(out)), "tph_bench_membw_time")
         return out.value
 
     def fp64_tflops(self, reps=10):
         out = C.c_double(0.0)
-        check(self.lib.tph_fp64_time(self._ctx, int(reps), C.byref(out)), "tph_fp64_time")
+        check(self.lib.tph_bench_fp64_time(self._ctx, int(reps), C.byref(out)), "tph_bench_fp64_time")
         return out.value
+
+    def mf_normals_error(self, seed, first, n_blocks, edge=False):
+        """(max |z~ - z|, max |z|, blocks) of the screened kernel's FP32 Box-Muller pair against the FP64 pair."""
+        out = (C.c_double * 3)()
+        check(self.lib.tph_bench_mf_normals(self._ctx, int(seed), int(first), int(n_blocks), int(bool(edge)), out), "tph_bench_mf_normals")
+        return out[0], out[1], out[2]
+
+    def mf_counters(self):
+        """Counters of the last screened proposal launch: dict(attempts, particles, contradictions, verified, screened, pair_jobs)."""
+        out = (C.c_ulonglong * 7)()
+        check(self.lib.tph_bench_mf_counters(self._ctx, out), "tph_bench_mf_counters")
+        return dict(attempts=out[1], particles=out[2], contradictions=out[3], verified=out[4], screened=out[5], pair_jobs=out[6])
 
     def weights(self, beta, vmax, s1, out=None):
         if out is None:

@@ -239,6 +239,40 @@ def test_reference_written_state_file_loads_and_resumes(tmp_path, fname):
     assert len(back["_history"]["u"]) == s.state.get_history_length() and back["_history"]["u"][0].shape == (n, d)
 
 
+def test_posterior_composition_equals_the_reference_on_its_own_state():
+    """tempest/core.py:187-242 end to end: on the state file the reference wrote, `posterior()` returns what the reference's own
+    `posterior()` returned for it (tests/golden/ref_state_small_posterior.npz, generated by `oracle/make_ref_state.py
+    --posterior-only`): the kept-row set exactly (rows compared through their bit-identical x and logl), the renormalised
+    weights and logw to rtol 1e-10 -- with the default trim, without trimming, and with another (ess, bins) setting."""
+    import os
+    import tempest_amd as tp
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(G, "ref_state_small.npz"))
+    want = np.load(os.path.join(G, "ref_state_small_posterior.npz"))
+    d, n = int(g["n_dim"]), int(g["n_particles"])
+    mean = torch.tensor(g["mean"], dtype=torch.float64, device="cuda:0")
+
+    def like(x):
+        return -0.5 * ((x - mean) ** 2).sum(dim=1) - 0.5 * d * float(np.log(2 * np.pi))
+    s = tp.Sampler(prior20, like, d, n_particles=n, vectorize=True, clustering=False, random_state=7)
+    s.load_state(os.path.join(G, "ref_state_small.state"))
+    for tag, kw in (("trim", dict(trim_importance_weights=True)), ("full", dict(trim_importance_weights=False)),
+                    ("trim90", dict(trim_importance_weights=True, ess_trim=0.9, bins_trim=50))):
+        x, w, logl, logw = s.posterior(return_logw=True, **kw)
+        assert x.shape == want[f"x_{tag}"].shape, (tag, x.shape)
+        np.testing.assert_array_equal(x, want[f"x_{tag}"])                 # the same rows, in the same (history) order
+        np.testing.assert_array_equal(logl, want[f"logl_{tag}"])
+        np.testing.assert_allclose(w, want[f"w_{tag}"], rtol=1e-10, atol=0)
+        np.testing.assert_allclose(logw, want[f"logw_{tag}"], rtol=1e-10, atol=1e-10)
+        assert abs(w.sum() - 1.0) < 1e-12
+    assert want["x_trim"].shape[0] < want["x_full"].shape[0]              # the trim does drop rows on this state
+    # resample=True: equally weighted rows drawn from the kept set (the draw is this library's own stream)
+    x, w, logl = s.posterior(resample=True)
+    assert x.shape == want["x_trim"].shape and np.allclose(w, 1.0 / len(w))
+    kept = {tuple(r) for r in want["x_trim"]}
+    assert all(tuple(r) in kept for r in x)
+
+
 # ----------------------------------------------------------------------------------------------- likelihood blobs
 def _blob_of(x):
     """What the test likelihood attaches to a point: a deterministic function of x, so `blobs == f(x)` row by row says that
