@@ -138,6 +138,11 @@ int tph_propose_sm(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, c
 int tph_propose_mf(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                    const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
                    const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend);
+// the same over a device-side list of particles (count + rows), from attempt att0: the straggler pass behind the blocked kernel
+int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
+                        const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
+                        const double* ctl, int64_t item0, double* up, double* maha_up, const int32_t* todo_cnt, const int32_t* todo_rows,
+                        int att0);
 
 // --------------------------------------------------------------------------------- device helpers
 #if defined(__HIPCC__)

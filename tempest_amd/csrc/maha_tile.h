@@ -17,14 +17,23 @@ __global__ void __launch_bounds__(64 * WV) k_maha_tile(double* __restrict__ u, i
                                                        double* __restrict__ up, double* __restrict__ maha, tph_stepctl tick,
                                                        uint8_t* __restrict__ pend, const unsigned long long* __restrict__ queue,
                                                        const double* __restrict__ dof, const double* __restrict__ sigmas,
-                                                       uint64_t seed, int64_t item0, double* __restrict__ bfac_out) {
+                                                       uint64_t seed, int64_t item0, double* __restrict__ bfac_out,
+                                                       const int32_t* __restrict__ todo_cnt, const int32_t* __restrict__ todo_rows) {
+  // todo_cnt != NULL: only the particles LISTED in todo_rows[0 .. *todo_cnt) (the closing pass behind a screened launch over
+  // the blocked kernel's failures); a block beyond the list exits at once
   extern __shared__ double sh[];
   double* xs = sh;                                 // [d][64]
   double* sc = sh + (size_t)d * 64;                // [WV][64]
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-  const bool live = i < n;
-  const int64_t ii = live ? i : n - 1;
+  int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  bool live = i < n;
+  if (todo_cnt) {
+    const int64_t cnt = *todo_cnt;
+    if ((int64_t)blockIdx.x * 64 >= cnt) return;          // the whole block (uniform)
+    live = i < cnt;
+    i = (int64_t)todo_rows[live ? i : 0];
+  }
+  const int64_t ii = live ? i : (todo_cnt ? i : n - 1);
   if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl && queue)
     const_cast<double*>(tick.ctl)[8] = queue[2] ? (double)queue[1] / (double)queue[2] : 0.0;
 #ifdef SM_PROFILE
@@ -74,7 +83,8 @@ __global__ void __launch_bounds__(64 * WV) k_maha_tile(double* __restrict__ u, i
 template <int KERNEL, int MODE>
 static int launch_maha_tile(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* Wb, double* up,
                             double* maha, tph_stepctl tick, uint8_t* pend, const unsigned long long* queue, const double* dof,
-                            const double* sigmas, uint64_t seed, int64_t item0, double* bfac_out) {
+                            const double* sigmas, uint64_t seed, int64_t item0, double* bfac_out, const int32_t* todo_cnt = nullptr,
+                            const int32_t* todo_rows = nullptr) {
   const int d = ctx->d;
   const int wv = d <= 32 ? 4 : d <= 64 ? 8 : 16;
   const size_t lds = sizeof(double) * ((size_t)d * 64 + (size_t)wv * 64);
@@ -84,7 +94,7 @@ static int launch_maha_tile(tph_ctx* ctx, double* u, int64_t n, int64_t ld, cons
     if (lds > 64 * 1024)                                                                                                 \
       TPH_HIP(hipFuncSetAttribute((const void*)k_maha_tile<KERNEL, WV, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((k_maha_tile<KERNEL, WV, MODE>), grid, dim3(64 * WV), lds, ctx->stream, u, n, ld, d, means, Wb, up, maha, \
-                       tick, pend, queue, dof, sigmas, seed, item0, bfac_out);                                           \
+                       tick, pend, queue, dof, sigmas, seed, item0, bfac_out, todo_cnt, todo_rows);                      \
   } while (0)
   if (wv == 4) TPH_MT(4); else if (wv == 8) TPH_MT(8); else TPH_MT(16);
 #undef TPH_MT

@@ -674,8 +674,14 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   if (wv == 4) TPH_BLK_LAUNCH(4); else if (wv == 8) TPH_BLK_LAUNCH(8); else TPH_BLK_LAUNCH(16);
 #undef TPH_BLK_LAUNCH
   TPH_LAUNCH_CHECK();
-  // straggler pass: the particles still listed continue with attempt `rounds`, ... in the multi-lane kernel (un-staged: few
-  // blocks have work, and those that do are redraw-bound)
+  // straggler pass: the particles still listed continue with attempt `rounds`, ...  Screened windows over the list
+  // (propose_mf.hip, TPH_OPT_SCREEN: 8 attempts of a straggler in flight, the first in bounds in attempt order wins; a
+  // launch over a short list costs its workgroups' table loads, where the multi-lane kernel's straggler pass cost the chain
+  // of its hardest particle's attempts: config 5's shard 357 us per launch, config 2 47-56 us) -- or, with the screen off or
+  // beyond its range, the multi-lane kernel
+  if (ctx->screen && d <= 112)
+    return tph_propose_mf_list(ctx, KERNEL, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick.tick, tick.ctl, item0, up, mup,
+                               cnts + (rounds - 1), rows[(rounds - 1) & 1], rounds);
   // as many lanes per straggler as it has Box-Muller pairs: a straggler's chain of attempts is latency-bound (few blocks
   // have any work), so the pairs of an attempt are generated in ONE round and the rows spread over more lanes
   int lpp = 4;

@@ -38,6 +38,7 @@
 
 constexpr int MF_CAP = PROP_MAX_ATTEMPTS;      // attempts 0 .. MF_CAP-1, then the current point is proposed
 constexpr int MF_CHUNK = 4;                    // particles per queue grab
+constexpr int MF_DIRECT = 2;                   // list mode: attempts of a straggler evaluated in FP64 before any window is screened
 constexpr int MF_WAVES = 8;                    // waves per workgroup (they share the LDS copy of the packed factor)
 // the transposed FP64 factor of the verification, LT: rows 0..63 as T0[j][r] (j < min(d, 64), 64 rows per column, zeros above
 // the diagonal), rows 64..d-1 as T1[j][r - 64] (j < d, d - 64 rows per column): lane = row reads column j without conflicts
@@ -174,8 +175,24 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
                                                              const double* __restrict__ LT, const double* __restrict__ sigmas,
                                                              const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                              int64_t item0, double* __restrict__ up, const double* __restrict__ bfac,
-                                                             int lgG, unsigned long long* __restrict__ queue, int audit) {
+                                                             int lgG, unsigned long long* __restrict__ queue, int audit,
+                                                             const int32_t* __restrict__ todo_cnt, const int32_t* __restrict__ todo_rows,
+                                                             int att0) {
+  // todo_cnt != NULL: only the particles LISTED in todo_rows[0 .. *todo_cnt) (those the blocked kernel's rounds left out of
+  // bounds), from attempt att0 on; workgroups beyond the list exit before they load anything
   extern __shared__ __attribute__((aligned(16))) unsigned char mf_lds[];
+  int chunk = MF_CHUNK;
+  if (todo_cnt) {
+    // a short list is SPREAD: one straggler per wave while there are waves (its windows are a chain of latencies, and nothing
+    // else would use the other waves), with 16 attempts in flight instead of 8
+    n = *todo_cnt;
+    const int64_t waves = (int64_t)gridDim.x * MF_WAVES;
+    const int64_t ppw = (n + waves - 1) / waves;
+    chunk = ppw < 1 ? 1 : (ppw > MF_CHUNK ? MF_CHUNK : (int)ppw);
+    if ((int64_t)blockIdx.x * (MF_WAVES * chunk) >= n) return;
+    const int lg = ppw <= 1 ? 4 : 3;
+    lgG = lg > lgG ? lg : lgG;
+  }
   constexpr int DPAD = 16 * NP, NBLK = NP * (NP + 1) / 2;
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int G = 1 << lgG, NPW = 64 >> lgG;
@@ -214,10 +231,11 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
   const uint32_t tk = tick;
   const double sigma = sigmas[0];
   const double a_fac = (KERNEL == TPH_KERNEL_TPCN) ? tph_sqrt(1.0 - sigma * sigma) : 1.0;
-  const int64_t nchunks = (n + MF_CHUNK - 1) / MF_CHUNK;
+  const int64_t nchunks = (n + chunk - 1) / chunk;
   const unsigned long long wmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
   // particle slots: lane e < NPW holds slot e
   int ps_row = -1, ps_a0 = 0;
+  bool ps_fresh = false;              // list mode: the particle has not had its direct tries yet (see (B))
   float ps_bs = 0.0f;
   int64_t pool_row = 0;
   int pool_next = 0, pool_cnt = 0;
@@ -303,13 +321,13 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
           const unsigned long long c = __shfl(ahead, 0, 64);
           if ((int64_t)c >= nchunks) { exhausted = true; break; }
           if (lane == 0) ahead = atomicAdd(&queue[0], 1ull);
-          pool_row = (int64_t)c * MF_CHUNK;
-          pool_cnt = (int)((n - pool_row) < MF_CHUNK ? (n - pool_row) : MF_CHUNK);
+          pool_row = (int64_t)c * chunk;
+          pool_cnt = (int)((n - pool_row) < chunk ? (n - pool_row) : chunk);
           pool_next = 0;
         }
         const int e = __ffsll((long long)need) - 1;
         need &= need - 1ull;
-        if (lane == e) { ps_row = (int)(pool_row + pool_next); ps_a0 = 0; }
+        if (lane == e) { ps_row = todo_rows ? todo_rows[pool_row + pool_next] : (int)(pool_row + pool_next); ps_a0 = att0; ps_fresh = todo_cnt != nullptr; }
         ++pool_next;
         fresh |= 1ull << e;
       }
@@ -352,8 +370,13 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
     coltab[lane] = make_int2(my_row, my_att);
     colb[lane] = __shfl(ps_bs, my_ps, 64);
     colzm[lane] = 0u;
-    unsigned long long alive = __ballot(my_row >= 0 && my_att < MF_CAP);
-    n_scr += (unsigned long long)__popcll(alive);
+    // List mode, a straggler's first pass: its next MF_DIRECT attempts go STRAIGHT to the FP64 evaluation, no screen.  Late in a
+    // run the blocked kernel's failures mostly succeed at their next attempt, and a screened window (every panel of every live
+    // column, a chain of LDS round trips per panel) costs several times the one evaluation that settles them.
+    const bool direct = todo_cnt != nullptr && __ballot(lane < NPW && ps_row >= 0 && ps_fresh) != 0ull;
+    const bool my_fresh = __shfl((int)ps_fresh, my_ps, 64) != 0;
+    unsigned long long alive = __ballot(my_row >= 0 && my_att < MF_CAP && (!direct || (my_fresh && (lane & (G - 1)) < MF_DIRECT)));
+    if (!direct) n_scr += (unsigned long long)__popcll(alive);
     mf_wave_sync();
     float bs[4];
 #pragma unroll
@@ -364,7 +387,7 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
     mf_h4 Z[4][NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      if (alive != 0ull) {
+      if (alive != 0ull && !direct) {
         // live (column, pair) jobs -> FP16 normals in the bounce buffer
         const int A = __popcll(alive);
         if ((alive >> lane) & 1ull) list[__popcll(alive & ((1ull << lane) - 1ull))] = (uint8_t)lane;
@@ -461,7 +484,10 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
       }
     }
     MF_PF(4);
-    if (lane < NPW && ps_row >= 0) ps_a0 += G;
+    if (lane < NPW && ps_row >= 0) {
+      if (!direct) ps_a0 += G;
+      else if (ps_fresh) { ps_a0 += MF_DIRECT; ps_fresh = false; }
+    }
     {
       unsigned long long capped = __ballot(lane < NPW && ps_row >= 0 && ps_a0 >= MF_CAP);
 #pragma unroll 1
@@ -497,19 +523,12 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
   }
 }
 
+// persistent buffers of the screened kernel (queue words | blocked L^-1 (tri.h, tpCN forms) | screening pack | transposed FP64
+// factor), rebuilt when the caller's mode statistics change
+struct mf_bufs { unsigned long long* queue; double* Wb; unsigned char* pack; double* LT; };
 template <int KERNEL>
-static int propose_mf(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,
-                      const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
-                      double* up, double* maha_u, double* maha_up, uint8_t* pend) {
-  const int d = ctx->d;
-  TPH_REQUIRE(d > 16 && d <= MF_MAX_DIM, "tph_propose (screened batches): n_dim=%d outside 17..%d", d, MF_MAX_DIM);
-  TPH_REQUIRE(n < (1ll << 31), "tph_propose (screened batches): %lld particles on one device", (long long)n);
-  const int np = mf_panels(d), dpad = 16 * np;
-  const int64_t nchunks = (n + MF_CHUNK - 1) / MF_CHUNK;
-  // attempts of a particle in flight (log2; TPH_OPT_MF_LANES, 0 = by size as in the row walker: 8 when a wave gets >= 48 particles)
-  const int cus = ctx->n_simd / 4;
-  int lgG = ctx->mf_lanes;
-  // persistent buffers: queue words | blocked L^-1 (tri.h, tpCN forms) | screening pack | transposed FP64 factor
+static int mf_prepare(tph_ctx* ctx, const double* chol, const double* winv, mf_bufs* b) {
+  const int d = ctx->d, np = mf_panels(d);
   const size_t tb8 = tri_blocked_doubles(d);
   const size_t off_wb = 128, off_pack = off_wb + sizeof(double) * tb8;
   const size_t off_lt = (off_pack + mf_pack_bytes(np) + 255) & ~(size_t)255;
@@ -521,49 +540,54 @@ static int propose_mf(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
     TPH_HIP(hipMalloc((void**)&ctx->mf_buf, need));
     ctx->mf_bytes = need;
   }
-  unsigned long long* queue = (unsigned long long*)ctx->mf_buf;
-  double* Wb = (double*)((char*)ctx->mf_buf + off_wb);
-  unsigned char* pack = (unsigned char*)ctx->mf_buf + off_pack;
-  double* LT = (double*)((char*)ctx->mf_buf + off_lt);
+  b->queue = (unsigned long long*)ctx->mf_buf;
+  b->Wb = (double*)((char*)ctx->mf_buf + off_wb);
+  b->pack = (unsigned char*)ctx->mf_buf + off_pack;
+  b->LT = (double*)((char*)ctx->mf_buf + off_lt);
   // a launch being captured into a hipGraph records the rebuild (a replayed step never re-enters this host code)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   TPH_HIP(hipStreamIsCapturing(ctx->stream, &cap));
   const bool capturing = cap != hipStreamCaptureStatusNone;
   if (capturing || ctx->modes_epoch <= 0 || ctx->mf_epoch != ctx->modes_epoch || ctx->mf_src != (const void*)chol ||
       ctx->mf_kernel != KERNEL) {
-    hipLaunchKernelGGL(k_mf_pack, dim3(1), dim3(256), 0, ctx->stream, chol, d, np, pack, LT);
-    if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, winv, d, Wb);
+    hipLaunchKernelGGL(k_mf_pack, dim3(1), dim3(256), 0, ctx->stream, chol, d, np, b->pack, b->LT);
+    if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, winv, d, b->Wb);
     ctx->mf_epoch = capturing ? -1 : ctx->modes_epoch; ctx->mf_src = (const void*)chol; ctx->mf_kernel = KERNEL;
   }
-  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)queue, 32);
-  // pending moves; tpCN: the form at u (first step of a run) and every particle's step scale, parked in maha_up until the
-  // closing pass overwrites it with the form at u'
-  if (pend || KERNEL == TPH_KERNEL_TPCN || maha_u)
-    if (launch_maha_tile<KERNEL, 0>(ctx, u, n, ld, means, Wb, up, maha_u, tick, pend, nullptr, dof, sigmas, seed, item0, maha_up)) return -1;
-  // workgroups: as many as fit a CU (LDS), never more waves than there are chunks
+  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)b->queue, 32);
+  return 0;
+}
+
+// the screened kernel over n particles (todo_cnt == NULL) or over a device-side list of at most n (from attempt att0)
+template <int KERNEL>
+static int mf_launch(tph_ctx* ctx, const mf_bufs& b, const double* u, int64_t n, int64_t ld, const double* means, const double* sigmas,
+                     const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0, double* up, const double* bfac,
+                     const int32_t* todo_cnt, const int32_t* todo_rows, int att0) {
+  const int d = ctx->d, np = mf_panels(d), dpad = 16 * np;
+  const int64_t nchunks = (n + MF_CHUNK - 1) / MF_CHUNK;
+  const int cus = ctx->n_simd / 4;
+  // workgroups: one per CU (8 waves of up to 256 VGPRs -- the FP16 normals of all panels stay in registers -- around one LDS
+  // copy of the packed factor and of the FP64 factor; compiled for four waves per SIMD the normals of the earlier panels spill
+  // to scratch: 3.5 against 3.3 ms at 131 072 x 100-D from the prior), never more waves than there are chunks
   int64_t groups = (nchunks + MF_WAVES - 1) / MF_WAVES;
-  if (lgG <= 0) {
-    const int64_t g2 = groups > 2 * (int64_t)cus ? 2 * (int64_t)cus : groups;
-    lgG = (double)n / (double)(g2 * MF_WAVES) >= 48.0 ? 3 : 4;
-  }
+  if (groups > cus) groups = cus;
+  // attempts of a particle in flight (log2; TPH_OPT_MF_LANES, 0 = by size as in the row walker: 8 when a wave gets >= 48 particles)
+  int lgG = ctx->mf_lanes;
+  if (lgG <= 0) lgG = (double)n / (double)(groups * MF_WAVES) >= 48.0 ? 3 : 4;
+  if (todo_cnt && ctx->mf_lanes <= 0) lgG = 3;
   if (lgG < 3) lgG = 3;
   if (lgG > 6) lgG = 6;
   const int npw = 64 >> lgG;
   const size_t lds = mf_shared_bytes(np, d) + (size_t)MF_WAVES * mf_wave_bytes(npw, dpad);
   TPH_REQUIRE(lds <= 160 * 1024, "tph_propose (screened batches): n_dim=%d needs %zu B of LDS", d, lds);
-  // one workgroup per CU: 8 waves of up to 256 VGPRs (the FP16 normals of all panels stay in registers) around one LDS copy of
-  // the packed factor and of the FP64 factor.  (Compiled for four waves per SIMD the normals of the earlier panels spill to
-  // scratch: 3.5 against 3.3 ms at 131 072 x 100-D from the prior.)
-  const int per_cu = 1;
-  if (groups > (int64_t)per_cu * cus) groups = (int64_t)per_cu * cus;
   const int audit = ctx->mf_audit;
 #define TPH_MF(BC, NPV)                                                                                                  \
   do {                                                                                                                   \
     if (lds > 64 * 1024)                                                                                                 \
       TPH_HIP(hipFuncSetAttribute((const void*)k_propose_mf<KERNEL, BC, NPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((k_propose_mf<KERNEL, BC, NPV>), dim3((unsigned)groups), dim3(64 * MF_WAVES), lds, ctx->stream,    \
-                       (const double*)u, n, ld, d, means, (const unsigned char*)pack, (const double*)LT, sigmas, bc, seed, \
-                       tick, item0, up, (const double*)maha_up, lgG, queue, audit);                                      \
+                       u, n, ld, d, means, (const unsigned char*)b.pack, (const double*)b.LT, sigmas, bc, seed,           \
+                       tick, item0, up, bfac, lgG, b.queue, audit, todo_cnt, todo_rows, att0);                           \
   } while (0)
 #define TPH_MF_NP(NPV) do { if (bc) TPH_MF(true, NPV); else TPH_MF(false, NPV); } while (0)
   switch (np) {
@@ -577,9 +601,52 @@ static int propose_mf(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
 #undef TPH_MF_NP
 #undef TPH_MF
   TPH_LAUNCH_CHECK();
-  if (KERNEL == TPH_KERNEL_TPCN || maha_up || tick.ctl)
-    if (launch_maha_tile<KERNEL, 1>(ctx, u, n, ld, means, Wb, up, maha_up, tick, nullptr, queue, dof, sigmas, seed, item0, nullptr)) return -1;
   return 0;
+}
+
+template <int KERNEL>
+static int propose_mf(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,
+                      const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
+                      double* up, double* maha_u, double* maha_up, uint8_t* pend) {
+  const int d = ctx->d;
+  TPH_REQUIRE(d > 16 && d <= MF_MAX_DIM, "tph_propose (screened batches): n_dim=%d outside 17..%d", d, MF_MAX_DIM);
+  TPH_REQUIRE(n < (1ll << 31), "tph_propose (screened batches): %lld particles on one device", (long long)n);
+  mf_bufs b;
+  if (mf_prepare<KERNEL>(ctx, chol, winv, &b)) return -1;
+  // pending moves; tpCN: the form at u (first step of a run) and every particle's step scale, parked in maha_up until the
+  // closing pass overwrites it with the form at u'
+  if (pend || KERNEL == TPH_KERNEL_TPCN || maha_u)
+    if (launch_maha_tile<KERNEL, 0>(ctx, u, n, ld, means, b.Wb, up, maha_u, tick, pend, nullptr, dof, sigmas, seed, item0, maha_up)) return -1;
+  if (mf_launch<KERNEL>(ctx, b, u, n, ld, means, sigmas, bc, seed, tick, item0, up, maha_up, nullptr, nullptr, 0)) return -1;
+  if (KERNEL == TPH_KERNEL_TPCN || maha_up || tick.ctl)
+    if (launch_maha_tile<KERNEL, 1>(ctx, u, n, ld, means, b.Wb, up, maha_up, tick, nullptr, b.queue, dof, sigmas, seed, item0, nullptr)) return -1;
+  return 0;
+}
+
+// The straggler pass behind the blocked kernel's rounds (mutate.hip: launch_propose_blk): the particles it LISTED continue from
+// attempt att0 here -- screened windows, first in-bounds attempt in attempt order -- and, for tpCN, get the form at u'.  The
+// chores of the step (pending moves, form at u, step scale parked in maha_up) were done by the blocked kernel's first round.
+template <int KERNEL>
+static int propose_mf_list(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,
+                           const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
+                           double* up, double* maha_up, const int32_t* todo_cnt, const int32_t* todo_rows, int att0) {
+  mf_bufs b;
+  if (mf_prepare<KERNEL>(ctx, chol, winv, &b)) return -1;
+  if (mf_launch<KERNEL>(ctx, b, u, n, ld, means, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0)) return -1;
+  if (KERNEL == TPH_KERNEL_TPCN || maha_up)
+    if (launch_maha_tile<KERNEL, 1>(ctx, u, n, ld, means, b.Wb, up, maha_up, tick, nullptr, nullptr, dof, sigmas, seed, item0, nullptr,
+                                    todo_cnt, todo_rows)) return -1;
+  return 0;
+}
+
+int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
+                        const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
+                        const double* ctl, int64_t item0, double* up, double* maha_up, const int32_t* todo_cnt, const int32_t* todo_rows,
+                        int att0) {
+  const tph_stepctl tick{tick0, ctl};
+  if (kernel == TPH_KERNEL_TPCN)
+    return propose_mf_list<TPH_KERNEL_TPCN>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0);
+  return propose_mf_list<TPH_KERNEL_RWM>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0);
 }
 
 int tph_propose_mf(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,

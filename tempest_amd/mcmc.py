@@ -281,14 +281,22 @@ class StepEngine:
             return
         import os
         before = (self.blocked > 0, bool(self.staged))
-        from .device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_SM_LANES, OPT_STAGED_REDRAW
+        from .device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_SCREEN, OPT_SM_LANES, OPT_STAGED_REDRAW
         walker_ok = os.environ.get("TEMPEST_AMD_STAGED", "1") != "0"      # debugging aid (TPH_OPT_STAGED_REDRAW)
+        nd = self.ctx.n_dim
+        screened = os.environ.get("TEMPEST_AMD_SCREEN", "1") != "0" and nd <= 112      # TPH_OPT_SCREEN (debugging aid)
+        if screened:
+            # crossovers of tools/regime_sweep.py (profiles/r04_regime_sweep.jsonl): blocked rounds + straggler pass against the
+            # screened batches, whose time is flat in the attempt count up to ~10 attempts per particle
+            up_est, down_true = (2.2, 2.2) if nd >= 64 else ((2.8, 3.6) if nd > 32 else (6.5, 9.0))
+        else:
+            up_est, down_true = (4.5, 8.0) if nd >= 64 else (3.5, 5.0)
         if self.K != 1:
             want_blk = False
         elif self.blocked:             # geometric estimate
-            want_blk = mean_attempts < (4.5 if self.ctx.n_dim >= 64 else 3.5) or not walker_ok
-        else:                          # true mean (row walker, or the multi-lane kernel of a run's first steps)
-            want_blk = mean_attempts < (8.0 if self.ctx.n_dim >= 64 else 5.0) and (walker_ok or mean_attempts < 2.0)
+            want_blk = mean_attempts < up_est or not walker_ok
+        else:                          # true mean (screened batches / row walker, or the multi-lane kernel of a run's first steps)
+            want_blk = mean_attempts < down_true and (walker_ok or mean_attempts < 2.0)
         if self.graph is not None and (want_blk, self.K == 1 and not want_blk and walker_ok) == before:
             return                     # same kernel: the graph stays (its rounds and lane groups too)
         rounds = 0
@@ -298,7 +306,13 @@ class StepEngine:
             # stragglers: 262 144 x 32-D -20 ... -26 %, 131 072 x 100-D -12 ... -17 %, 65 536 x 50-D +-0 (lists too short).
             f, left = max(0.0, 1.0 - 1.0 / mean_attempts), float(self.n)
             rounds = 1
-            while rounds < 24 and left * f >= 24576.0:
+            if screened:
+                # the straggler pass is a screened launch over the list: it settles a short list in one launch's latency, a long
+                # one at ~8 us per straggler and wave -- rounds pay while the expected list is more than a few hundred particles
+                cap, floor = (6 if nd >= 64 else 8), 256.0
+            else:
+                cap, floor = 24, 24576.0
+            while rounds < cap and left * f >= floor:
                 left *= f
                 rounds += 1
         if rounds != self.blocked:
@@ -310,6 +324,7 @@ class StepEngine:
             self.staged, self.sm_lanes = want_sm, lanes
             self.ctx.set_option(OPT_STAGED_REDRAW, 1 if want_sm else 0)
             self.ctx.set_option(OPT_SM_LANES, lanes)
+            self.ctx.set_option(OPT_SCREEN, 1 if screened else 0)
         want = mean_attempts > (4.0 if self.unstaged else 8.0)      # hysteresis
         if want != self.unstaged and self.graph is None:
             self.unstaged = want

@@ -81,14 +81,16 @@ def test_history_sized_temporaries_come_from_buckets():
     assert "bit_length" in src and "3 // 4" in src
 
 
-def test_proposal_regime_rule_d_gt_16():
-    """StepEngine._regime (mcmc.py): which d > 16 proposal kernel the NEXT steps get from the redraw probe -- blocked kernel in
+def test_proposal_regime_rule_d_gt_16(monkeypatch):
+    """(With the screen off, TEMPEST_AMD_SCREEN=0: the FP64 row walker's crossovers; the screened rule: next test.)
+    StepEngine._regime (mcmc.py): which d > 16 proposal kernel the NEXT steps get from the redraw probe -- blocked kernel in
     R rounds for a few attempts per particle (R from the expected length of the round's list), row walker when redraws
     dominate, one threshold per direction (the blocked path reports the geometric estimate, the walker the true mean), the
     multi-lane kernel for several modes; a captured graph keeps what it was captured with until the rule asks for another
     kernel."""
     from tempest_amd import mcmc
-    from tempest_amd.device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_STAGED_REDRAW
+    from tempest_amd.device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_SCREEN, OPT_STAGED_REDRAW
+    monkeypatch.setenv("TEMPEST_AMD_SCREEN", "0")
 
     class Ctx:
         def __init__(self, d):
@@ -158,3 +160,27 @@ def test_proposal_regime_rule_d_gt_16():
     small = Eng(10, 1 << 20)
     small._regime(3.0)
     assert small.ctx.opts == {}
+    monkeypatch.setenv("TEMPEST_AMD_SCREEN", "1")
+    # ---- with the screened batches (default): their time is flat in the attempt count, so the crossovers sit lower at high
+    # n_dim and higher at 32-D (tools/regime_sweep.py), and the blocked kernel runs more, shorter rounds (the straggler pass is
+    # a screened launch over the list)
+    s100 = Eng(100, 131072)
+    s100._regime(60.0)
+    assert s100.staged and s100.blocked == 0 and s100.ctx.opts[OPT_SCREEN] == 1
+    s100._regime(2.3)
+    assert s100.staged
+    s100._regime(2.1)                                 # true mean below 2.2: blocked rounds
+    assert not s100.staged and 1 <= s100.blocked <= 6
+    s100._regime(2.1)                                 # now the geometric estimate: stays up to 2.2
+    assert not s100.staged
+    s100._regime(2.3)
+    assert s100.staged and s100.blocked == 0
+    s32 = Eng(32, 262144)
+    s32._regime(12.0)
+    assert s32.staged
+    s32._regime(8.0)                                  # 32-D: the screened batches only win above ~9 attempts per particle
+    assert not s32.staged and s32.blocked == 8
+    s32._regime(1.05)                                 # lists 12 483, 594, 28: three rounds
+    assert s32.blocked == 3
+    s32._regime(6.6)
+    assert s32.staged

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--thr", type=int, default=0, help="TPH_OPT_SM_THRESHOLD")
     ap.add_argument("--mflanes", type=int, default=0, help="TPH_OPT_MF_LANES (log2 attempts in flight per particle, screened kernel: --variant 6)")
     ap.add_argument("--audit", action="store_true", help="TPH_OPT_MF_AUDIT = 1")
+    ap.add_argument("--noscreen", action="store_true", help="TPH_OPT_SCREEN = 0 (FP64 row walker / multi-lane straggler pass)")
     ap.add_argument("--pending", type=float, default=0.0,
                     help="fraction of particles with a pending accepted move to resolve (deferred tph_accept), per launch")
     a = ap.parse_args()
@@ -88,6 +89,8 @@ def main():
         lib.tph_set_option(ctx, 13, a.mflanes)
     if a.audit:
         lib.tph_set_option(ctx, 14, 1)
+    if a.noscreen:
+        lib.tph_set_option(ctx, 12, 0)
     kid = {"tpcn": 0, "rwm": 1}[a.kernel]
     rs = np.random.RandomState(0)
     for scen in a.scen.split(","):
@@ -152,7 +155,7 @@ def main():
                "min_us": round(float(np.min(ts)), 2), "first_attempt_in_bounds": inb, "mean_attempts_probe": float(ctl[8].item()), "fell_back_to_current": same,
                "algorithmic_bytes": (16 * d + 4 + 16) * n,
                "GBps_algorithmic": round((16 * d + 20) * n / np.median(ts) / 1e3, 1)}
-        if a.variant == 6:
+        if a.variant == 6 or (a.variant == 4 and not a.noscreen):
             cnt = (C.c_ulonglong * 7)()
             assert lib.tph_bench_mf_counters(ctx, cnt) == 0
             out["mf"] = dict(attempts=cnt[1], particles=cnt[2], contradictions=cnt[3], verified=cnt[4], screened=cnt[5], pair_jobs=cnt[6],
