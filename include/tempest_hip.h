@@ -119,6 +119,10 @@ int tph_synchronize(tph_ctx* ctx);
 #define TPH_OPT_SCREEN 12
 #define TPH_OPT_MF_LANES 13
 #define TPH_OPT_MF_AUDIT 14
+/* TPH_OPT_BLK_MFMA: 1 (default) = the rounds of the blocked path (TPH_OPT_BLOCKED, 16 < n_dim <= 112) run on the FP64 matrix
+ * cores (propose_blkm.hip: a wave per 16 particles, L z and |L^-1 (u' - mu)|^2 as v_mfma_f64_16x16x4_f64 tiles, the normals
+ * generated straight into the operand layout); 0 = lane = particle with the matrix through the scalar cache (k_propose_blk). */
+#define TPH_OPT_BLK_MFMA 15
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- multi-GPU: one process per GPU --------------------------------------

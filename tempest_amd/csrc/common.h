@@ -95,6 +95,12 @@ struct tph_ctx {
   size_t mf_bytes = 0;
   int mf_epoch = -1, mf_kernel = -1;
   const void* mf_src = nullptr;
+  // matrix-core round kernel of the blocked path (propose_blkm.hip): TPH_OPT_BLK_MFMA and its blocked copies of L and L^-1
+  int blk_mfma = 1;
+  void* bm_buf = nullptr;
+  size_t bm_bytes = 0;
+  int bm_epoch = -1, bm_kernel = -1;
+  const void* bm_src = nullptr;
   std::vector<void*> retired;       // outgrown buffers a captured hipGraph of an earlier step may still address: freed with the ctx
   double* vv_buf = nullptr;         // small persistent buffers of tph_volume_variation (moments, factors, blocked L^-1)
   size_t vv_bytes = 0;
@@ -138,6 +144,11 @@ int tph_propose_sm(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, c
 int tph_propose_mf(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                    const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
                    const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend);
+// propose_blkm.hip: one round of the blocked path with both triangular products on the FP64 matrix cores
+int tph_blkm_round(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
+                   const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
+                   const double* ctl, int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, const int32_t* cnt_in,
+                   const int32_t* rows_in, int att, int32_t* cnt_out, int32_t* rows_out);
 // the same over a device-side list of particles (count + rows), from attempt att0: the straggler pass behind the blocked kernel
 int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                         const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,

@@ -160,7 +160,7 @@ extern "C" int tph_ctx_destroy(tph_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   tph_p2p_release(ctx);
   void* bufs[] = {ctx->u, ctx->x, ctx->logl, ctx->cmix, ctx->table_dev, ctx->partials, ctx->small_dev, ctx->scratch, ctx->winv,
-                  ctx->blk_table, ctx->vv_buf, ctx->blk_buf, ctx->rows, ctx->sm_small, ctx->sm_scr, ctx->mf_buf};
+                  ctx->blk_table, ctx->vv_buf, ctx->blk_buf, ctx->rows, ctx->sm_small, ctx->sm_scr, ctx->mf_buf, ctx->bm_buf};
   for (void* b : bufs) (void)hipFree(b);
   for (void* b : ctx->retired) (void)hipFree(b);
   (void)hipHostFree(ctx->pinned);
@@ -250,6 +250,7 @@ extern "C" int tph_set_option(tph_ctx* ctx, int option, int value) {
     case TPH_OPT_SCREEN: ctx->screen = value ? 1 : 0; break;
     case TPH_OPT_MF_LANES: ctx->mf_lanes = value; break;
     case TPH_OPT_MF_AUDIT: ctx->mf_audit = value ? 1 : 0; break;
+    case TPH_OPT_BLK_MFMA: ctx->blk_mfma = value ? 1 : 0; break;
     default: TPH_REQUIRE(false, "tph_set_option: unknown option %d", option);
   }
   return 0;

@@ -648,6 +648,13 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   // code, so an epoch test made here would freeze the copies of the capture-time statistics while the caller refreshes the
   // fixed-address chol / winv between runs (the straggler pass and tpCN's carried form read those) -- two covariances inside
   // one Metropolis ratio.  The copies made under capture are not trusted by later eager calls either.
+  const bool mfma = ctx->blk_mfma && d <= 112;      // TPH_OPT_BLK_MFMA: the rounds on the FP64 matrix cores (propose_blkm.hip)
+  if (mfma) {
+    for (int k = 0; k < rounds; ++k)
+      if (tph_blkm_round(ctx, KERNEL, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick.tick, tick.ctl, item0, up, mu_, mup, pend,
+                         k ? cnts + (k - 1) : (const int32_t*)nullptr, (const int32_t*)rows[(k + 1) & 1], k, cnts + k, rows[k & 1]))
+        return -1;
+  } else {
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   TPH_HIP(hipStreamIsCapturing(ctx->stream, &cap));
   const bool capturing = cap != hipStreamCaptureStatusNone;
@@ -674,6 +681,7 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   if (wv == 4) TPH_BLK_LAUNCH(4); else if (wv == 8) TPH_BLK_LAUNCH(8); else TPH_BLK_LAUNCH(16);
 #undef TPH_BLK_LAUNCH
   TPH_LAUNCH_CHECK();
+  }
   // straggler pass: the particles still listed continue with attempt `rounds`, ...  Screened windows over the list
   // (propose_mf.hip, TPH_OPT_SCREEN: 8 attempts of a straggler in flight, the first in bounds in attempt order wins; a
   // launch over a short list costs its workgroups' table loads, where the multi-lane kernel's straggler pass cost the chain
@@ -1017,7 +1025,7 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
       (variant == 5 || (variant == 0 && ctx->staged && !ctx->blocked)))
     return tph_propose_sm(ctx, kernel, u_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick0, ctl_dev,
                           item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev);
-  if (!use_reg && ctx->d > 16 && ctx->d <= 100 && !assign_dev && K == 1 && (variant == 4 || (variant == 0 && ctx->blocked))) {
+  if (!use_reg && ctx->d > 16 && ctx->d <= (ctx->blk_mfma ? 112 : 100) && !assign_dev && K == 1 && (variant == 4 || (variant == 0 && ctx->blocked))) {
     if (kernel == TPH_KERNEL_TPCN)
       return launch_propose_blk<TPH_KERNEL_TPCN>(ctx, u_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed,
                                                  tick, item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev);

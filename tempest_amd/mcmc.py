@@ -288,7 +288,7 @@ class StepEngine:
         if screened:
             # crossovers of tools/regime_sweep.py (profiles/r04_regime_sweep.jsonl): blocked rounds + straggler pass against the
             # screened batches, whose time is flat in the attempt count up to ~10 attempts per particle
-            up_est, down_true = (2.2, 2.2) if nd >= 64 else ((2.8, 3.6) if nd > 32 else (6.5, 9.0))
+            up_est, down_true = (3.0, 5.0) if nd >= 64 else ((2.9, 4.3) if nd > 32 else (8.0, 13.0))
         else:
             up_est, down_true = (4.5, 8.0) if nd >= 64 else (3.5, 5.0)
         if self.K != 1:
@@ -309,7 +309,7 @@ class StepEngine:
             if screened:
                 # the straggler pass is a screened launch over the list: it settles a short list in one launch's latency, a long
                 # one at ~8 us per straggler and wave -- rounds pay while the expected list is more than a few hundred particles
-                cap, floor = (6 if nd >= 64 else 8), 256.0
+                cap, floor = (6 if nd >= 64 else (8 if nd > 32 else 12)), 64.0
             else:
                 cap, floor = 24, 24576.0
             while rounds < cap and left * f >= floor:

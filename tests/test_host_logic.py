@@ -167,20 +167,20 @@ def test_proposal_regime_rule_d_gt_16(monkeypatch):
     s100 = Eng(100, 131072)
     s100._regime(60.0)
     assert s100.staged and s100.blocked == 0 and s100.ctx.opts[OPT_SCREEN] == 1
-    s100._regime(2.3)
+    s100._regime(5.1)
     assert s100.staged
-    s100._regime(2.1)                                 # true mean below 2.2: blocked rounds
+    s100._regime(4.9)                                 # true mean below 5: blocked rounds
     assert not s100.staged and 1 <= s100.blocked <= 6
-    s100._regime(2.1)                                 # now the geometric estimate: stays up to 2.2
-    assert not s100.staged
-    s100._regime(2.3)
+    s100._regime(2.9)                                 # now the geometric estimate: stays up to 3
+    assert not s100.staged and s100.blocked == 6
+    s100._regime(3.1)
     assert s100.staged and s100.blocked == 0
     s32 = Eng(32, 262144)
-    s32._regime(12.0)
+    s32._regime(14.0)
     assert s32.staged
-    s32._regime(8.0)                                  # 32-D: the screened batches only win above ~9 attempts per particle
-    assert not s32.staged and s32.blocked == 8
+    s32._regime(12.0)                                 # 32-D: the screened batches only win above ~13 attempts per particle
+    assert not s32.staged and s32.blocked == 12
     s32._regime(1.05)                                 # lists 12 483, 594, 28: three rounds
     assert s32.blocked == 3
-    s32._regime(6.6)
+    s32._regime(8.1)
     assert s32.staged

@@ -768,13 +768,17 @@ def test_volume_variation_one_call_vs_oracle(dev, d):
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
 @pytest.mark.parametrize("bc", [None, "mixed"])
 @pytest.mark.parametrize("d,rounds", [(19, 0), (33, 0), (50, 0), (65, 0), (100, 0),     # 4 / 8 / 8 / 16 / 16 waves per tile
-                                      (33, 2), (50, 24), (65, 3), (100, 6)])             # TPH_OPT_BLOCKED = rounds of the kernel
-def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, rounds):
-    """TPH_OPT_PROPOSE_VARIANT 4: attempt 0 of every particle in the blocked kernel (lane = particle, L and L^-1 through the
-    scalar cache), further rounds of it (attempt 1, 2, ... of the particles still out of bounds, compacted lists), and whoever
+                                      (33, 2), (50, 24), (65, 3), (100, 6), (112, 2), (17, 3)])   # TPH_OPT_BLOCKED = rounds of the kernel
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, rounds, mfma):
+    """TPH_OPT_PROPOSE_VARIANT 4: attempt 0 of every particle in the blocked kernel -- on the FP64 matrix cores (mfma = 1,
+    propose_blkm.hip: a wave per 16 particles, both triangular products as v_mfma_f64_16x16x4 tiles) or with lane = particle
+    and L and L^-1 through the scalar cache (mfma = 0, TPH_OPT_BLK_MFMA) --, further rounds of it (attempt 1, 2, ... of the particles still out of bounds, compacted lists), and whoever
     is left finished by the multi-lane kernel.  Same draws and formulas as the other kernels: the proposals and both
     Mahalanobis forms equal the oracle's (and the multi-lane kernel's) to rounding -- on an ensemble where a good share of the
     first attempts fail, so that the later rounds and the straggler pass are exercised."""
+    if mfma == 0 and d > 100:
+        pytest.skip("the scalar-cache kernel serves n_dim <= 100")
     rs = np.random.RandomState(31 + d)
     n = 3000
     means = 0.5 + 0.05 * rs.randn(1, d)
@@ -796,11 +800,13 @@ def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, rou
         c = ctx_for(d)
         c.set_option(0, variant)
         c.set_option(4, rounds if variant == 4 else 0)
+        c.set_option(15, mfma)                 # TPH_OPT_BLK_MFMA
         up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
         state = c.zeros(10)
         c.propose(kernel, soa(u, dev), None, modes, st, ft, seed, tick, item0, up, mu_, mup, ctl=state)
         got[variant] = (aos(up), mu_.cpu().numpy(), mup.cpu().numpy(), state.cpu().numpy())
         c.set_option(4, 0)
+        c.set_option(15, 1)
     first_failed = np.mean(np.any((want_up != want_up), axis=1))       # placeholder: failures are visible through the oracle below
     _ = first_failed
     np.testing.assert_allclose(got[4][0], want_up, rtol=1e-11, atol=1e-13)
@@ -820,9 +826,10 @@ def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, rou
 
 
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
-def test_blocked_kernel_deferred_update_and_step_control(dev, kernel):
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_blocked_kernel_deferred_update_and_step_control(dev, kernel, mfma):
     """The blocked path inside a chain: deferred Metropolis update (pending mask) and the carried Mahalanobis form give the
-    same chain, bit for bit, as the multi-lane... no: as the blocked path with the in-place update."""
+    same chain, bit for bit, as the blocked path with the in-place update (matrix-core and scalar-cache round kernels)."""
     rs = np.random.RandomState(5)
     d, n = 50, 4000
     means = 0.5 + 0.02 * rs.randn(1, d)
@@ -834,6 +841,7 @@ def test_blocked_kernel_deferred_update_and_step_control(dev, kernel):
     u0 = np.clip(means[0] + 0.05 * rs.randn(n, d), 0.002, 0.998)
     c = ctx_for(d)
     c.set_option(0, 4)
+    c.set_option(15, mfma)
 
     def like(up):
         x = 20 * up - 10

@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--mflanes", type=int, default=0, help="TPH_OPT_MF_LANES (log2 attempts in flight per particle, screened kernel: --variant 6)")
     ap.add_argument("--audit", action="store_true", help="TPH_OPT_MF_AUDIT = 1")
     ap.add_argument("--noscreen", action="store_true", help="TPH_OPT_SCREEN = 0 (FP64 row walker / multi-lane straggler pass)")
+    ap.add_argument("--nomfma", action="store_true", help="TPH_OPT_BLK_MFMA = 0 (blocked rounds through the scalar cache)")
+    ap.add_argument("--epoch", type=int, default=0, help="TPH_OPT_MODES_EPOCH (> 0: the packed copies of the factors are built once)")
     ap.add_argument("--pending", type=float, default=0.0,
                     help="fraction of particles with a pending accepted move to resolve (deferred tph_accept), per launch")
     a = ap.parse_args()
@@ -91,6 +93,10 @@ def main():
         lib.tph_set_option(ctx, 14, 1)
     if a.noscreen:
         lib.tph_set_option(ctx, 12, 0)
+    if a.nomfma:
+        lib.tph_set_option(ctx, 15, 0)
+    if a.epoch:
+        lib.tph_set_option(ctx, 5, a.epoch)
     kid = {"tpcn": 0, "rwm": 1}[a.kernel]
     rs = np.random.RandomState(0)
     for scen in a.scen.split(","):
