@@ -99,8 +99,12 @@ struct tph_ctx {
   int blk_mfma = 1;
   void* bm_buf = nullptr;
   size_t bm_bytes = 0;
-  int bm_epoch = -1, bm_kernel = -1;
+  int bm_epoch = -1, bm_kernel = -1, bm_K = 0;
   const void* bm_src = nullptr;
+  void* mt_buf = nullptr;           // several modes: tile table, particle order, per-mode failure lists of the rounds
+  size_t mt_bytes = 0;
+  const void* mt_assign = nullptr;
+  int64_t mt_n = 0;
   std::vector<void*> retired;       // outgrown buffers a captured hipGraph of an earlier step may still address: freed with the ctx
   double* vv_buf = nullptr;         // small persistent buffers of tph_volume_variation (moments, factors, blocked L^-1)
   size_t vv_bytes = 0;
@@ -149,6 +153,11 @@ int tph_blkm_round(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, c
                    const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
                    const double* ctl, int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, const int32_t* cnt_in,
                    const int32_t* rows_in, int att, int32_t* cnt_out, int32_t* rows_out);
+// several modes: every round over mode-pure tiles; the particles still out of bounds are left in one list for the caller
+int tph_blkm_multi(tph_ctx* ctx, int kernel, double* u, const int32_t* assign, int64_t n, int64_t ld, int K, const double* means,
+                   const double* chol, const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed,
+                   uint32_t tick0, const double* ctl, int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, int rounds,
+                   const int32_t** todo_cnt, const int32_t** todo_rows);
 // the same over a device-side list of particles (count + rows), from attempt att0: the straggler pass behind the blocked kernel
 int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                         const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,

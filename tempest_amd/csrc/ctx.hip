@@ -160,7 +160,7 @@ extern "C" int tph_ctx_destroy(tph_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   tph_p2p_release(ctx);
   void* bufs[] = {ctx->u, ctx->x, ctx->logl, ctx->cmix, ctx->table_dev, ctx->partials, ctx->small_dev, ctx->scratch, ctx->winv,
-                  ctx->blk_table, ctx->vv_buf, ctx->blk_buf, ctx->rows, ctx->sm_small, ctx->sm_scr, ctx->mf_buf, ctx->bm_buf};
+                  ctx->blk_table, ctx->vv_buf, ctx->blk_buf, ctx->rows, ctx->sm_small, ctx->sm_scr, ctx->mf_buf, ctx->bm_buf, ctx->mt_buf};
   for (void* b : bufs) (void)hipFree(b);
   for (void* b : ctx->retired) (void)hipFree(b);
   (void)hipHostFree(ctx->pinned);

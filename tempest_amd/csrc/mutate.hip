@@ -1032,6 +1032,40 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
     return launch_propose_blk<TPH_KERNEL_RWM>(ctx, u_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed,
                                               tick, item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev);
   }
+  // several modes, a step of a few attempts per particle: the rounds of the blocked path over mode-pure tiles of 16 particles
+  // (propose_blkm.hip), then the multi-lane kernel over the particles still out of bounds (it reads its particle's mode)
+  if (!use_reg && ctx->d > 16 && ctx->d <= 112 && assign_dev && K > 1 && K <= 64 && ctx->blk_mfma &&
+      (variant == 4 || (variant == 0 && ctx->blocked))) {
+    const int rounds = ctx->blocked < 1 ? 1 : ctx->blocked;
+    const int32_t *todo_cnt = nullptr, *todo_rows = nullptr;
+    if (tph_blkm_multi(ctx, kernel, u_dev, assign_dev, n, ld, K, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick0,
+                       ctl_dev, item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev, rounds, &todo_cnt, &todo_rows))
+      return -1;
+    int lpp = 4;
+    while (lpp < 64 && lpp < (ctx->d + 1) / 2) lpp *= 2;
+    const int keep = ctx->ml_unstaged;
+    ctx->ml_unstaged = 1;
+    int rc = 0;
+    const int att0 = rounds > 24 ? 24 : rounds;
+    switch (lpp) {
+#define TPH_ML_M(LL)                                                                                                     \
+  case LL:                                                                                                               \
+    rc = kernel == TPH_KERNEL_TPCN                                                                                       \
+             ? launch_propose_ml<TPH_KERNEL_TPCN, LL>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev,   \
+                                                      bc_dev, seed, tick, item0, uprime_dev, maha_u_dev, maha_up_dev, nullptr, todo_cnt,  \
+                                                      todo_rows, att0)                                                                      \
+             : launch_propose_ml<TPH_KERNEL_RWM, LL>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev,    \
+                                                     bc_dev, seed, tick, item0, uprime_dev, maha_u_dev, maha_up_dev, nullptr, todo_cnt,   \
+                                                     todo_rows, att0);                                                                      \
+    break;
+      TPH_ML_M(4) TPH_ML_M(8) TPH_ML_M(16) TPH_ML_M(32) TPH_ML_M(64)
+#undef TPH_ML_M
+    }
+    ctx->ml_unstaged = keep;
+    if (rc) return rc;
+    TPH_LAUNCH_CHECK();
+    return 0;
+  }
   if (!use_reg && (variant == 3 || variant == 0) && ctx->d <= 8 * 64) {
     // lanes per particle: the fewest with <= 8 rows per lane, so that as many particles as possible share one
     // block's staged matrices (the draws are dealt round-robin over the lanes in as many passes as needed)

@@ -29,8 +29,10 @@ __host__ __device__ static inline int bm_blk(int p, int s) { return 2 * p * (p +
 
 // Tb[blk(p, s)][lane] = T[16p + (lane & 15)][col(s, lane >> 4)], zero outside the lower triangle / beyond d.
 // perm = 1: col(s, k) = 8 (s >> 1) + 2k + (s & 1) (the Box-Muller layout of L z); perm = 0: col = 4s + k (natural: L^-1 x)
-static __global__ void __launch_bounds__(256) k_blkm_pack(const double* __restrict__ T, int d, int np, int perm, double* __restrict__ Tb) {
+static __global__ void __launch_bounds__(256) k_blkm_pack(const double* __restrict__ T_all, int d, int np, int perm, double* __restrict__ Tb_all) {
   const int total = bm_blocks(np) * 64;
+  const double* __restrict__ T = T_all + (size_t)blockIdx.x * d * d;           // one workgroup per mode
+  double* __restrict__ Tb = Tb_all + (size_t)blockIdx.x * total;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     const int b = e >> 6, lane = e & 63;
     int p = 0;
@@ -41,39 +43,156 @@ static __global__ void __launch_bounds__(256) k_blkm_pack(const double* __restri
   }
 }
 
-template <int KERNEL, int NP, bool HAS_BC>
-__global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, int64_t n, int64_t ld, int d, const double* __restrict__ means,
-                                                      const double* __restrict__ Lm, const double* __restrict__ Wm,
+
+// ---- several modes: tiles of 16 particles of ONE mode ------------------------------------------------------------------
+// The matrix operand of a tile is its mode's factor, so a tile must not mix modes.  Once per set of mode statistics (the
+// assignments are fixed during an iteration's MCMC steps) the particles are grouped by mode: order[] lists the rows mode by
+// mode, and a tile table cuts every mode's stretch into tiles {mode, start in order[], particles, start of the mode}.  The
+// failure lists of the rounds are kept PER MODE too (mode m owns the stretch [mstart_m, mstart_m + n_m) of the list arrays,
+// its counter is cnt[m]), so that the tiles of a later round are again pure: tile (m, j) takes entries 16j .. 16j+15 of mode
+// m's list.  Layout of the ctx-owned block (int32): hdr[4] = {tiles, K, -, -} | mstart[64] | mcount[64] | cursor[64] |
+// tiles[][4] | order[n].
+constexpr int BM_KMAX = 64;
+__host__ __device__ static inline size_t bm_mt_words(int64_t n, int K) { return 4 + 3 * BM_KMAX + 4 * (size_t)((n + 15) / 16 + K + 1) + (size_t)n; }
+
+static __global__ void __launch_bounds__(256) k_mt_count(const int32_t* __restrict__ assign, int64_t n, int K, int32_t* __restrict__ mt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = i < n ? assign[i] : -1;
+  int32_t* mcount = mt + 4 + BM_KMAX;
+  for (int m = 0; m < K; ++m) {
+    const unsigned long long b = __ballot(a == m);
+    if (b && (threadIdx.x & 63) == 0) atomicAdd(&mcount[m], __popcll(b));
+  }
+}
+static __global__ void __launch_bounds__(256) k_mt_layout(int64_t n, int K, int32_t* __restrict__ mt) {
+  __shared__ int s_start[BM_KMAX + 1], s_toff[BM_KMAX + 1];
+  int32_t* mstart = mt + 4;
+  const int32_t* mcount = mt + 4 + BM_KMAX;
+  int32_t* tiles = mt + 4 + 3 * BM_KMAX;
+  if (threadIdx.x == 0) {
+    int st = 0, to = 0;
+    for (int m = 0; m < K; ++m) {
+      s_start[m] = st; s_toff[m] = to;
+      mstart[m] = st;
+      st += mcount[m];
+      to += (mcount[m] + 15) / 16;
+    }
+    s_start[K] = st; s_toff[K] = to;
+    mt[0] = to; mt[1] = K;
+  }
+  __syncthreads();
+  const int ntiles = s_toff[K];
+  for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+    int m = 0;
+    while (s_toff[m + 1] <= t) ++m;
+    const int j = t - s_toff[m], nm = s_start[m + 1] - s_start[m];
+    tiles[4 * t] = m;
+    tiles[4 * t + 1] = s_start[m] + 16 * j;
+    tiles[4 * t + 2] = nm - 16 * j < 16 ? nm - 16 * j : 16;
+    tiles[4 * t + 3] = s_start[m];
+  }
+}
+static __global__ void __launch_bounds__(256) k_mt_scatter(const int32_t* __restrict__ assign, int64_t n, int K, int32_t* __restrict__ mt,
+                                                           int64_t tiles_max) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int a = i < n ? assign[i] : -1;
+  const int32_t* mstart = mt + 4;
+  int32_t* cursor = mt + 4 + 2 * BM_KMAX;
+  int32_t* order = mt + 4 + 3 * BM_KMAX + 4 * tiles_max;
+  for (int m = 0; m < K; ++m) {
+    const unsigned long long b = __ballot(a == m);
+    if (!b) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&cursor[m], __popcll(b));
+    base = __shfl(base, 0, 64);
+    if (a == m) order[mstart[m] + base + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)i;
+  }
+}
+// the modes' failure lists of the last round, strung together for the straggler pass: rows_cat[0 .. *cnt_cat)
+static __global__ void __launch_bounds__(256) k_mt_concat(const int32_t* __restrict__ mt, const int32_t* __restrict__ cnt_in,
+                                                          const int32_t* __restrict__ rows_in, int32_t* __restrict__ cnt_cat,
+                                                          int32_t* __restrict__ rows_cat) {
+  __shared__ int s_base;
+  const int m = blockIdx.x, c = cnt_in[m], st = mt[4 + m];
+  if (threadIdx.x == 0) s_base = c ? atomicAdd(cnt_cat, c) : 0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < c; e += blockDim.x) rows_cat[s_base + e] = rows_in[st + e];
+}
+
+template <int KERNEL, int NP, bool HAS_BC, bool MULTI>
+__global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, int64_t n, int64_t ld, int d, const double* __restrict__ means_all,
+                                                      const double* __restrict__ Lm_all, const double* __restrict__ Wm_all,
                                                       const double* __restrict__ dof, const double* __restrict__ sigmas,
                                                       const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick, int64_t item0,
                                                       double* __restrict__ up, double* __restrict__ maha_u, double* __restrict__ maha_up,
                                                       uint8_t* __restrict__ pend, const int32_t* __restrict__ cnt_in,
                                                       const int32_t* __restrict__ rows_in, int att, int32_t* __restrict__ cnt_out,
-                                                      int32_t* __restrict__ rows_out) {
+                                                      int32_t* __restrict__ rows_out, const int32_t* __restrict__ mt, int64_t tiles_max) {
   // cnt_in == NULL: round 0, attempt 0 of every particle and the chores of the step (pending moves, form at u, Gamma scale);
-  // cnt_in != NULL: attempt `att` of the particles listed by the round before; the step scale comes from where round 0 parked it
+  // cnt_in != NULL: attempt `att` of the particles listed by the round before; the step scale comes from where round 0 parked it.
+  // MULTI: several modes -- the wave's tile, its mode and the mode's stretch of the lists come from the tile table mt (above).
   constexpr int NS = 4 * NP;
-  __shared__ int s_fail[4];
+  __shared__ int s_fail[4], s_mode[4];
   __shared__ int s_base;
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int k = lane >> 4, nn = lane & 15;
   const bool first = cnt_in == nullptr;
-  int64_t slot = ((int64_t)blockIdx.x * 4 + wid) * 16 + nn;
-  int64_t total = n;
-  if (!first) {
-    total = *cnt_in;
-    if (att == 1 && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl)      // the redraw probe from ALL first attempts
-      const_cast<double*>(tick.ctl)[8] = total < n ? (double)n / (double)(n - total) : 256.0;
-    if ((int64_t)blockIdx.x * 64 >= total) return;                        // the whole block (uniform): nothing listed for it
+  const int64_t T = (int64_t)blockIdx.x * 4 + wid;
+  int mode = 0, lbase = 0;                // the wave's mode; where its mode's stretch of the list arrays starts
+  bool live;
+  int64_t i;
+  if (!MULTI) {
+    const int64_t slot = T * 16 + nn;
+    int64_t total = n;
+    if (!first) {
+      total = *cnt_in;
+      if (att == 1 && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl)      // the redraw probe from ALL first attempts
+        const_cast<double*>(tick.ctl)[8] = total < n ? (double)n / (double)(n - total) : 256.0;
+      if ((int64_t)blockIdx.x * 64 >= total) return;                        // the whole block (uniform): nothing listed for it
+    }
+    live = slot < total;
+    i = first ? (live ? slot : n - 1) : (int64_t)rows_in[live ? slot : 0];  // dead columns shadow a particle, never store
+  } else {
+    const int ntiles = mt[0];
+    const int32_t* tiles = mt + 4 + 3 * BM_KMAX;
+    const int32_t* order = tiles + 4 * tiles_max;
+    const bool valid = T < ntiles;
+    const int t4 = valid ? 4 * (int)T : 0;
+    mode = tiles[t4];
+    lbase = tiles[t4 + 3];
+    const int start = tiles[t4 + 1], count = tiles[t4 + 2];
+    if (first) {
+      live = valid && nn < count;
+      i = order[start + (live ? nn : 0)];
+    } else {
+      const int j16 = start - lbase, cm = cnt_in[mode];
+      live = valid && j16 + nn < cm;
+      i = live ? (int64_t)rows_in[lbase + j16 + nn] : (int64_t)order[start];
+      if (att == 1 && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl) {
+        int64_t total = 0;
+        for (int m = 0; m < mt[1]; ++m) total += cnt_in[m];
+        const_cast<double*>(tick.ctl)[8] = total < n ? (double)n / (double)(n - total) : 256.0;
+      }
+    }
   }
-  // (a wave beyond the list inside the last block runs along on a shadow particle: the block meets at two barriers below)
-  const bool live = slot < total;
-  const int64_t i = first ? (live ? slot : n - 1) : (int64_t)rows_in[live ? slot : 0];     // dead columns shadow a particle, never store
+  const bool wave_on = __ballot(live) != 0ull;     // a wave without particles skips the arithmetic and only meets the barriers
+  if (!first) {                                   // (uniform) blocks whose four tiles are all beyond their lists
+    if (lane == 0) s_fail[wid] = wave_on;
+    __syncthreads();
+    if (!(s_fail[0] | s_fail[1] | s_fail[2] | s_fail[3])) return;
+    __syncthreads();
+  }
+  const double* __restrict__ means = means_all + (size_t)mode * d;
+  const double* __restrict__ Lm = Lm_all + (size_t)mode * bm_blocks(NP) * 64;
+  const double* __restrict__ Wm = Wm_all + (size_t)mode * bm_blocks(NP) * 64;
   const int npairs = (d + 1) >> 1;
-  const double sigma = sigmas[0];
+  const double sigma = sigmas[mode];
   const bool carry = KERNEL == TPH_KERNEL_TPCN && tick.carry();
   const double a_fac = (KERNEL == TPH_KERNEL_TPCN) ? tph_sqrt(1.0 - sigma * sigma) : 1.0;
   double X[NS];                                  // the B operands: normals (permuted steps), then rows of the proposal (natural steps)
+  bool all_ok = false;
+  unsigned int okc = 0u;
 
   // sum over the rows of |T x|^2 for the tile (x in X as natural-step operands): every lane ends with ITS column's value
   auto form = [&](const double* __restrict__ Tb) -> double {
@@ -91,113 +210,130 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
     return part;
   };
 
-  // ---- round 0: pending accepted move (deferred tph_accept), form at u (first step of a run; afterwards carried), Gamma scale
-  double b_fac = sigma;
-  if (first) {
-    const bool pd = pend && live && pend[i];
-    if (pd || (KERNEL == TPH_KERNEL_TPCN && !carry)) {
+  if (wave_on) {
+    // ---- round 0: pending accepted move (deferred tph_accept), form at u (first step of a run; afterwards carried), Gamma scale
+    double b_fac = sigma;
+    if (first) {
+      const bool pd = pend && live && pend[i];
+      if (pd || (KERNEL == TPH_KERNEL_TPCN && !carry)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const int r = 4 * s + k;
+          double uj = 0.0;
+          if (r < d) {
+            uj = u[(size_t)r * ld + i];
+            if (pd) { uj = up[(size_t)r * ld + i]; u[(size_t)r * ld + i] = uj; }
+            uj -= (KERNEL == TPH_KERNEL_TPCN) ? means[r] : 0.0;
+          }
+          X[s] = uj;
+        }
+      }
+      if (KERNEL == TPH_KERNEL_TPCN) {
+        double m_u;
+        if (carry) {
+          m_u = maha_u[i];
+        } else {
+          m_u = form(Wm);
+          if (live && k == 0 && maha_u) maha_u[i] = m_u;
+        }
+        const double nu = dof[mode];
+        tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
+        const double gam = tph_gamma_mt(gg, 0.5 * ((double)d + nu)) * tph_div(2.0, nu + m_u);
+        b_fac = sigma * tph_sqrt(tph_rcp(gam));
+        if (live && k == 0) maha_up[i] = b_fac;        // parked for the later rounds of this particle
+      } else if (live && k == 0 && maha_u) {
+        maha_u[i] = 0.0;
+      }
+      // (the four lanes of a column read the flag in the same instruction of one wave: the store is behind their loads)
+      if (pd && k == 0) pend[i] = 0;
+    } else if (KERNEL == TPH_KERNEL_TPCN) {
+      b_fac = maha_up[i];
+    }
+
+    // ---- the normals of this round's attempt: lane (k, n) draws pairs k, k + 4, ... of particle n = its operands of steps 2c, 2c + 1
+    {
+      tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
+      const uint32_t d0 = (uint32_t)att * (uint32_t)npairs;
+#pragma unroll
+      for (int c = 0; c < NS / 2; ++c) {
+        const int q = k + 4 * c;
+        double z0 = 0.0, z1 = 0.0;
+        if (q < npairs) gz.normal2(d0 + (uint32_t)q, z0, z1);
+        X[2 * c] = z0;
+        X[2 * c + 1] = z1;             // (row 2q + 1 == d for odd d: its column of L is zero)
+      }
+    }
+    // ---- rows of the attempt, last panel first: v = fma(b, (L z)_r, mu_r + a (u_r - mu_r)), bounds; results in place
+    bool ok = true;
+#pragma unroll
+    for (int p = NP - 1; p >= 0; --p) {
+      bm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4 * p + 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lm[(size_t)bm_blk(p, s) * 64 + lane], X[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 16 * p + k + 4 * q;
+        double v = 0.0;
+        if (r < d) {
+          const double ur = u[(size_t)r * ld + i];
+          const double mr = (KERNEL == TPH_KERNEL_TPCN) ? means[r] : 0.0;
+          const double base = (KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, ur - mr, mr) : ur;
+          v = fma(b_fac, acc[q], base);
+          const uint8_t f = HAS_BC ? bc[r] : (uint8_t)TPH_BC_STRICT;
+          if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
+          else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
+          else ok = ok && (v >= 0.0) && (v <= 1.0);
+        }
+        X[4 * p + q] = v;
+      }
+    }
+    // a column is in bounds when its four lanes are
+    const unsigned long long okb = __ballot(ok);
+    okc = (unsigned int)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48)) & 0xFFFFu;
+    all_ok = (okc >> nn) & 1u;
+    // ---- outputs of the particles whose attempt is in bounds; the others are listed for the next round / the straggler pass
+    if (live && all_ok) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const int r = 4 * s + k;
-        double uj = 0.0;
-        if (r < d) {
-          uj = u[(size_t)r * ld + i];
-          if (pd) { uj = up[(size_t)r * ld + i]; u[(size_t)r * ld + i] = uj; }
-          uj -= (KERNEL == TPH_KERNEL_TPCN) ? means[r] : 0.0;
-        }
-        X[s] = uj;
+        if (r < d) up[(size_t)r * ld + i] = X[s];
       }
-    }
-    if (KERNEL == TPH_KERNEL_TPCN) {
-      double m_u;
-      if (carry) {
-        m_u = maha_u[i];
-      } else {
-        m_u = form(Wm);
-        if (live && k == 0 && maha_u) maha_u[i] = m_u;
-      }
-      const double nu = dof[0];
-      tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
-      const double gam = tph_gamma_mt(gg, 0.5 * ((double)d + nu)) * tph_div(2.0, nu + m_u);
-      b_fac = sigma * tph_sqrt(tph_rcp(gam));
-      if (live && k == 0) maha_up[i] = b_fac;        // parked for the later rounds of this particle
-    } else if (live && k == 0 && maha_u) {
-      maha_u[i] = 0.0;
-    }
-    // every lane of a column has read the flag (four lanes, one wave: the store below is ordered behind their loads by the
-    // s_waitcnt of the loads' first use above)
-    if (pd && k == 0) pend[i] = 0;
-  } else if (KERNEL == TPH_KERNEL_TPCN) {
-    b_fac = maha_up[i];
-  }
-
-  // ---- the normals of this round's attempt: lane (k, n) draws pairs k, k + 4, ... of particle n = its operands of steps 2c, 2c + 1
-  {
-    tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
-    const uint32_t d0 = (uint32_t)att * (uint32_t)npairs;
-#pragma unroll
-    for (int c = 0; c < NS / 2; ++c) {
-      const int q = k + 4 * c;
-      double z0 = 0.0, z1 = 0.0;
-      if (q < npairs) gz.normal2(d0 + (uint32_t)q, z0, z1);
-      X[2 * c] = z0;
-      X[2 * c + 1] = z1;             // (row 2q + 1 == d for odd d: its column of L is zero)
-    }
-  }
-  // ---- rows of the attempt, last panel first: v = fma(b, (L z)_r, mu_r + a (u_r - mu_r)), bounds; results in place
-  bool ok = true;
-#pragma unroll
-  for (int p = NP - 1; p >= 0; --p) {
-    bm_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s = 0; s < 4 * p + 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lm[(size_t)bm_blk(p, s) * 64 + lane], X[s], acc, 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = 16 * p + k + 4 * q;
-      double v = 0.0;
-      if (r < d) {
-        const double ur = u[(size_t)r * ld + i];
-        const double mr = (KERNEL == TPH_KERNEL_TPCN) ? means[r] : 0.0;
-        const double base = (KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, ur - mr, mr) : ur;
-        v = fma(b_fac, acc[q], base);
-        const uint8_t f = HAS_BC ? bc[r] : (uint8_t)TPH_BC_STRICT;
-        if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
-        else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
-        else ok = ok && (v >= 0.0) && (v <= 1.0);
-      }
-      X[4 * p + q] = v;
-    }
-  }
-  // a column is in bounds when its four lanes are
-  const unsigned long long okb = __ballot(ok);
-  const unsigned int okc = (unsigned int)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48)) & 0xFFFFu;
-  const bool all_ok = (okc >> nn) & 1u;
-  // ---- outputs of the particles whose attempt is in bounds; the others are listed for the next round / the straggler pass
-  if (live && all_ok) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int r = 4 * s + k;
-      if (r < d) up[(size_t)r * ld + i] = X[s];
     }
   }
   {
-    // the block's failures take ONE slot range of the list (an atomic per wave -- 16 384 of them on one address at 262 144
-    // particles -- cost 110 us of a 195 us launch with a fifth of the first attempts out of bounds)
+    // the block's failures take ONE slot range of their mode's list (an atomic per wave -- 16 384 of them on one address at
+    // 262 144 particles -- cost 110 us of a 195 us launch with a fifth of the first attempts out of bounds); a block whose
+    // four tiles belong to different modes (at most K - 1 of them) falls back to one atomic per wave
     const unsigned long long failb = __ballot(live && !all_ok && k == 0);
     const int nf = __popcll(failb);
-    if (lane == 0) s_fail[wid] = nf | (__popcll(__ballot(live && k == 0)) << 8);
+    if (lane == 0) { s_fail[wid] = nf | (__popcll(__ballot(live && k == 0)) << 8); s_mode[wid] = mode; }
     __syncthreads();
-    int before = 0, nfail = 0, nlive = 0;
+    int before = 0, nfail = 0, nlive = 0, m0 = mode;
+    bool same = true;
+    if (MULTI) {                                         // the mode of the block's failures (tiles without failures do not count)
+#pragma unroll
+      for (int w = 3; w >= 0; --w) if (s_fail[w] & 255) m0 = s_mode[w];
+    }
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const int f = s_fail[w] & 255;
       before += w < wid ? f : 0;
       nfail += f;
       nlive += s_fail[w] >> 8;
+      same = same && (!MULTI || f == 0 || s_mode[w] == m0);
     }
-    if (threadIdx.x == 0 && nfail) s_base = atomicAdd(cnt_out, nfail);
-    __syncthreads();
-    if (live && !all_ok && k == 0) rows_out[s_base + before + __popcll(failb & ((1ull << lane) - 1ull))] = (int32_t)i;
+    int slot0;
+    if (same) {
+      if (threadIdx.x == 0 && nfail) s_base = atomicAdd(cnt_out + m0, nfail);
+      __syncthreads();
+      slot0 = s_base + before;
+    } else {
+      __syncthreads();
+      int b0 = 0;
+      if (lane == 0 && nf) b0 = atomicAdd(cnt_out + mode, nf);
+      slot0 = __shfl(b0, 0, 64);
+    }
+    if (live && !all_ok && k == 0) rows_out[lbase + slot0 + __popcll(failb & ((1ull << lane) - 1ull))] = (int32_t)i;
     if (first && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl) {      // regime probe: mean attempts implied by this block's failures, 1 / (1 - f)
       const double f = (double)nfail / fmax(1.0, (double)nlive);
       const_cast<double*>(tick.ctl)[8] = f < 0.99 ? 1.0 / (1.0 - f) : 100.0;
@@ -217,17 +353,14 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
   }
 }
 
-// One round of the matrix-core blocked kernel on the ctx stream (mutate.hip drives the rounds).  The blocked copies of L (permuted
-// steps) and L^-1 (natural steps) live in a ctx-owned buffer, rebuilt when the caller's mode statistics change (and always under
-// stream capture: a replayed step never re-enters this host code).
+// One round of the matrix-core blocked kernel on the ctx stream (mutate.hip drives the rounds of the one-mode path; several
+// modes: tph_blkm_propose_multi below).  The blocked copies of L (permuted steps) and L^-1 (natural steps) of every mode live in
+// a ctx-owned buffer, rebuilt when the caller's mode statistics change (and always under stream capture: a replayed step never
+// re-enters this host code).
 template <int KERNEL>
-static int blkm_round(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,
-                      const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
-                      double* up, double* mu_, double* mup, uint8_t* pend, const int32_t* cnt_in, const int32_t* rows_in, int att,
-                      int32_t* cnt_out, int32_t* rows_out) {
+static int blkm_pack(tph_ctx* ctx, int K, const double* chol, const double* winv, double** Lm, double** Wm) {
   const int d = ctx->d, np = bm_panels(d);
-  TPH_REQUIRE(d > 16 && d <= 112, "tph_propose (blocked, matrix cores): n_dim=%d outside 17..112", d);
-  const size_t one = sizeof(double) * (size_t)bm_blocks(np) * 64;
+  const size_t one = sizeof(double) * (size_t)bm_blocks(np) * 64 * (size_t)K;
   if (ctx->bm_bytes < 2 * one) {
     TPH_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->bm_buf) ctx->retired.push_back(ctx->bm_buf);
@@ -235,22 +368,36 @@ static int blkm_round(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
     TPH_HIP(hipMalloc((void**)&ctx->bm_buf, 2 * one));
     ctx->bm_bytes = 2 * one;
   }
-  double* Lm = (double*)ctx->bm_buf;
-  double* Wm = Lm + (size_t)bm_blocks(np) * 64;
-  if (att == 0) {
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    TPH_HIP(hipStreamIsCapturing(ctx->stream, &cap));
-    const bool capturing = cap != hipStreamCaptureStatusNone;
-    if (capturing || ctx->modes_epoch <= 0 || ctx->bm_epoch != ctx->modes_epoch || ctx->bm_src != (const void*)chol || ctx->bm_kernel != KERNEL) {
-      hipLaunchKernelGGL(k_blkm_pack, dim3(1), dim3(256), 0, ctx->stream, chol, d, np, 1, Lm);
-      if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_blkm_pack, dim3(1), dim3(256), 0, ctx->stream, winv, d, np, 0, Wm);
-      ctx->bm_epoch = capturing ? -1 : ctx->modes_epoch; ctx->bm_src = (const void*)chol; ctx->bm_kernel = KERNEL;
-    }
+  *Lm = (double*)ctx->bm_buf;
+  *Wm = *Lm + (size_t)bm_blocks(np) * 64 * (size_t)K;
+  return 0;
+}
+template <int KERNEL>
+static int blkm_refresh(tph_ctx* ctx, int K, const double* chol, const double* winv, double* Lm, double* Wm, bool* rebuilt) {
+  const int d = ctx->d, np = bm_panels(d);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  TPH_HIP(hipStreamIsCapturing(ctx->stream, &cap));
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  *rebuilt = capturing || ctx->modes_epoch <= 0 || ctx->bm_epoch != ctx->modes_epoch || ctx->bm_src != (const void*)chol ||
+             ctx->bm_kernel != KERNEL || ctx->bm_K != K;
+  if (*rebuilt) {
+    hipLaunchKernelGGL(k_blkm_pack, dim3(K), dim3(256), 0, ctx->stream, chol, d, np, 1, Lm);
+    if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_blkm_pack, dim3(K), dim3(256), 0, ctx->stream, winv, d, np, 0, Wm);
+    ctx->bm_epoch = capturing ? -1 : ctx->modes_epoch; ctx->bm_src = (const void*)chol; ctx->bm_kernel = KERNEL; ctx->bm_K = K;
   }
-  const dim3 grid((unsigned)((n + 63) / 64));
+  return 0;
+}
+
+template <int KERNEL, bool MULTI>
+static int blkm_launch(tph_ctx* ctx, int64_t blocks, double* u, int64_t n, int64_t ld, const double* means, const double* Lm, const double* Wm,
+                       const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
+                       double* up, double* mu_, double* mup, uint8_t* pend, const int32_t* cnt_in, const int32_t* rows_in, int att,
+                       int32_t* cnt_out, int32_t* rows_out, const int32_t* mt, int64_t tiles_max) {
+  const int d = ctx->d, np = bm_panels(d);
+  const dim3 grid((unsigned)blocks);
 #define TPH_BM(NPV, BC)                                                                                                  \
-  hipLaunchKernelGGL((k_propose_blkm<KERNEL, NPV, BC>), grid, dim3(256), 0, ctx->stream, u, n, ld, d, means, (const double*)Lm, \
-                     (const double*)Wm, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend, cnt_in, rows_in, att, cnt_out, rows_out)
+  hipLaunchKernelGGL((k_propose_blkm<KERNEL, NPV, BC, MULTI>), grid, dim3(256), 0, ctx->stream, u, n, ld, d, means, Lm, Wm, dof, sigmas, \
+                     bc, seed, tick, item0, up, mu_, mup, pend, cnt_in, rows_in, att, cnt_out, rows_out, mt, tiles_max)
 #define TPH_BM_NP(NPV) do { if (bc) TPH_BM(NPV, true); else TPH_BM(NPV, false); } while (0)
   switch (np) {
     case 2: TPH_BM_NP(2); break;
@@ -266,6 +413,23 @@ static int blkm_round(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
   return 0;
 }
 
+template <int KERNEL>
+static int blkm_round(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,
+                      const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
+                      double* up, double* mu_, double* mup, uint8_t* pend, const int32_t* cnt_in, const int32_t* rows_in, int att,
+                      int32_t* cnt_out, int32_t* rows_out) {
+  const int d = ctx->d;
+  TPH_REQUIRE(d > 16 && d <= 112, "tph_propose (blocked, matrix cores): n_dim=%d outside 17..112", d);
+  double *Lm, *Wm;
+  if (blkm_pack<KERNEL>(ctx, 1, chol, winv, &Lm, &Wm)) return -1;
+  if (att == 0) {
+    bool rebuilt;
+    if (blkm_refresh<KERNEL>(ctx, 1, chol, winv, Lm, Wm, &rebuilt)) return -1;
+  }
+  return blkm_launch<KERNEL, false>(ctx, (n + 63) / 64, u, n, ld, means, Lm, Wm, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend,
+                                    cnt_in, rows_in, att, cnt_out, rows_out, nullptr, 0);
+}
+
 int tph_blkm_round(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                    const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
                    const double* ctl, int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, const int32_t* cnt_in,
@@ -276,4 +440,72 @@ int tph_blkm_round(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, c
                                        rows_in, att, cnt_out, rows_out);
   return blkm_round<TPH_KERNEL_RWM>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend, cnt_in,
                                     rows_in, att, cnt_out, rows_out);
+}
+
+// Several modes: all `rounds` rounds of the blocked path over mode-pure tiles; whoever is still out of bounds afterwards is left
+// in ONE list (*todo_cnt entries of todo_rows, both device pointers into ctx-owned memory) for the caller's straggler pass.
+template <int KERNEL>
+static int blkm_multi(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n, int64_t ld, int K, const double* means, const double* chol,
+                      const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick,
+                      int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, int rounds, const int32_t** todo_cnt,
+                      const int32_t** todo_rows) {
+  const int d = ctx->d;
+  TPH_REQUIRE(d > 16 && d <= 112 && K >= 1 && K <= BM_KMAX, "tph_propose (blocked, several modes): n_dim=%d / K=%d out of range", d, K);
+  TPH_REQUIRE(n < (1ll << 31), "tph_propose (blocked): %lld particles on one device", (long long)n);
+  double *Lm, *Wm;
+  if (blkm_pack<KERNEL>(ctx, K, chol, winv, &Lm, &Wm)) return -1;
+  bool rebuilt;
+  if (blkm_refresh<KERNEL>(ctx, K, chol, winv, Lm, Wm, &rebuilt)) return -1;
+  // tile table + order | counters of the rounds [rounds + 1][K] | the two list arrays | the concatenated list
+  const int64_t tiles_max = (n + 15) / 16 + K + 1;
+  const size_t mtw = bm_mt_words(n, K), cntw = (size_t)(24 + 2) * BM_KMAX;
+  const size_t need = sizeof(int32_t) * (mtw + cntw + 3 * (size_t)n + 64);
+  if (ctx->mt_bytes < need) {
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->mt_buf) ctx->retired.push_back(ctx->mt_buf);
+    ctx->mt_buf = nullptr; ctx->mt_bytes = 0;
+    TPH_HIP(hipMalloc((void**)&ctx->mt_buf, need));
+    ctx->mt_bytes = need;
+    rebuilt = true;
+  }
+  int32_t* mt = (int32_t*)ctx->mt_buf;
+  int32_t* cnts = mt + mtw;
+  int32_t* rows[2] = {cnts + cntw, cnts + cntw + n};
+  int32_t* rows_cat = cnts + cntw + 2 * n;
+  if (rebuilt || ctx->mt_assign != (const void*)assign || ctx->mt_n != n) {      // (the assignments are fixed while the statistics are)
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)mt, 4 + 3 * BM_KMAX);
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_mt_count, dim3(gb), dim3(256), 0, ctx->stream, assign, n, K, mt);
+    hipLaunchKernelGGL(k_mt_layout, dim3(1), dim3(256), 0, ctx->stream, n, K, mt);
+    hipLaunchKernelGGL(k_mt_scatter, dim3(gb), dim3(256), 0, ctx->stream, assign, n, K, mt, tiles_max);
+    ctx->mt_assign = (const void*)assign; ctx->mt_n = n;
+  }
+  if (rounds < 1) rounds = 1;
+  if (rounds > 24) rounds = 24;
+  hipLaunchKernelGGL(k_zero_words, dim3(4), dim3(64), 0, ctx->stream, (unsigned int*)cnts, (int)cntw);
+  const int64_t blocks = (tiles_max + 3) / 4;
+  for (int k = 0; k < rounds; ++k)
+    if (blkm_launch<KERNEL, true>(ctx, blocks, u, n, ld, means, Lm, Wm, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend,
+                                  k ? cnts + (size_t)(k - 1) * BM_KMAX : (const int32_t*)nullptr, (const int32_t*)rows[(k + 1) & 1], k,
+                                  cnts + (size_t)k * BM_KMAX, rows[k & 1], mt, tiles_max))
+      return -1;
+  int32_t* cnt_cat = cnts + (size_t)25 * BM_KMAX;
+  hipLaunchKernelGGL(k_mt_concat, dim3(K), dim3(256), 0, ctx->stream, (const int32_t*)mt, (const int32_t*)(cnts + (size_t)(rounds - 1) * BM_KMAX),
+                     (const int32_t*)rows[(rounds - 1) & 1], cnt_cat, rows_cat);
+  TPH_LAUNCH_CHECK();
+  *todo_cnt = cnt_cat;
+  *todo_rows = rows_cat;
+  return 0;
+}
+
+int tph_blkm_multi(tph_ctx* ctx, int kernel, double* u, const int32_t* assign, int64_t n, int64_t ld, int K, const double* means,
+                   const double* chol, const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed,
+                   uint32_t tick0, const double* ctl, int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, int rounds,
+                   const int32_t** todo_cnt, const int32_t** todo_rows) {
+  const tph_stepctl tick{tick0, ctl};
+  if (kernel == TPH_KERNEL_TPCN)
+    return blkm_multi<TPH_KERNEL_TPCN>(ctx, u, assign, n, ld, K, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend,
+                                       rounds, todo_cnt, todo_rows);
+  return blkm_multi<TPH_KERNEL_RWM>(ctx, u, assign, n, ld, K, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend,
+                                    rounds, todo_cnt, todo_rows);
 }

@@ -292,7 +292,10 @@ class StepEngine:
         else:
             up_est, down_true = (4.5, 8.0) if nd >= 64 else (3.5, 5.0)
         if self.K != 1:
-            want_blk = False
+            # several modes: the matrix-core rounds over mode-pure tiles while a step is a few attempts per particle (propose_blkm.hip,
+            # up to 64 modes; what they leave goes to the multi-lane kernel); redraw-dominated steps: the multi-lane kernel alone
+            multi_ok = screened and self.K <= 64 and os.environ.get("TEMPEST_AMD_BLK_MFMA", "1") != "0"
+            want_blk = multi_ok and mean_attempts < (8.0 if self.blocked else 13.0)
         elif self.blocked:             # geometric estimate
             want_blk = mean_attempts < up_est or not walker_ok
         else:                          # true mean (screened batches / row walker, or the multi-lane kernel of a run's first steps)

@@ -249,6 +249,10 @@ def test_config3_fullsize_262144_clustering():
           f"pms/s={steps[beta > 0].sum() * n / wall:.3g} K={s._core.trainer.clusterer.n_clusters_} occupancy={np.round(occ, 3)}")
     assert wall < 60.0
     assert np.all(np.diff(beta) >= 0) and beta[-1] == 1.0
+    # K: the reference's split search does not split large clean multi-mode sets (tests/golden/ref_hgm_scale.json: K = 1 at
+    # 100 000 rows, improvement -6 315 against a threshold of 6 459; its twin at N = 1024 ends with K = 1 or 2:
+    # ref_cluster_counts.json); the device search makes the same decisions (test_split_decisions_on_growing_sets_...)
+    assert s._core.trainer.clusterer.n_clusters_ in (1, 2)
     assert 0.4 < logz + d * np.log(20.0) < 1.6            # +0.99 at this size (see the 65 536-particle test above)
     assert min(occ) > 0.22 and max(occ) < 0.28
     np.testing.assert_allclose(np.average(x[:, 2:], weights=w, axis=0), 0.0, atol=0.05)

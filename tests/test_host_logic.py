@@ -184,3 +184,13 @@ def test_proposal_regime_rule_d_gt_16(monkeypatch):
     assert s32.blocked == 3
     s32._regime(8.1)
     assert s32.staged
+    # several modes: the matrix-core rounds over mode-pure tiles below ~8 estimated attempts, the multi-lane kernel above
+    m4 = Eng(32, 262144, K=4)
+    m4._regime(20.0)
+    assert m4.blocked == 0 and not m4.staged and m4.unstaged
+    m4._regime(12.0)
+    assert m4.blocked == 12 and not m4.staged
+    m4._regime(1.2)
+    assert 3 <= m4.blocked <= 6 and not m4.staged
+    m4._regime(8.5)
+    assert m4.blocked == 0 and not m4.staged

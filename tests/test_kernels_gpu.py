@@ -826,6 +826,59 @@ def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, rou
 
 
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+@pytest.mark.parametrize("bc", [None, "mixed"])
+@pytest.mark.parametrize("d,K,rounds,n", [(19, 3, 1, 3000), (32, 4, 3, 2999), (50, 2, 2, 1000), (100, 3, 4, 700), (33, 5, 24, 530)])
+def test_blocked_rounds_with_several_modes_vs_oracle_and_multilane(dev, kernel, bc, d, K, rounds, n):
+    """K > 1 at n_dim > 16 on the fast path (tempest/mcmc.py:225-249 applies per-cluster mu / L / Sigma^-1 at any dimension):
+    the particles are grouped by mode into tiles of 16, every tile runs the matrix-core round kernel with ITS mode's factors,
+    the failure lists of the rounds are kept per mode, and the particles still out of bounds go to the multi-lane kernel.
+    Modes of very different sizes (one of them EMPTY, one smaller than a tile), an ensemble that is not a multiple of 16, a
+    good share of first attempts out of bounds: proposals and both Mahalanobis forms equal the oracle's to rounding."""
+    rs = np.random.RandomState(77 + d + K)
+    means = 0.5 + 0.08 * rs.randn(K, d)
+    covs = np.empty((K, d, d))
+    for k in range(K):
+        A = rs.randn(d, d) * ((0.03 + 0.02 * k) / np.sqrt(d))
+        covs[k] = A @ A.T + (1e-4 + 5e-5 * k) * np.eye(d)
+    _, chol, inv = ps.mode_statistics(means, covs)
+    dof = np.array([8.0, 1e6, 3.0, 25.0, 12.0][:K])
+    sigmas = (np.array([0.6, 0.9, 0.4, 0.7, 0.5][:K])) * (2.38 / np.sqrt(d) if kernel == "rwm" else 1.0)
+    probs = np.array([0.55, 0.0, 0.44, 0.01, 0.3][:K])          # mode 1 is empty; mode 3 (K >= 4) holds a handful of particles
+    probs = probs / probs.sum()
+    assign = rs.choice(K, size=n, p=probs).astype(np.int32)
+    u = np.clip(means[assign] + 0.1 * rs.randn(n, d), 0.002, 0.998)
+    u[: n // 3, rs.randint(d)] = 0.001                           # a third of the ensemble sits on a wall
+    flags = omc.bc_flags(d, [1], [min(4, d - 1)]) if bc else omc.bc_flags(d)
+    seed, tick, item0 = 4711, 9, 2_500_000_000
+    want_up, want_mu, want_mup = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, flags, seed, tick, item0)
+    modes = _Modes(means, chol, inv, dof, dev)
+    st, ft = torch.from_numpy(sigmas).to(dev), torch.from_numpy(flags).to(dev)
+    at = torch.from_numpy(assign).to(dev)
+    got = {}
+    for variant in (4, 3):
+        c = ctx_for(d)
+        c.set_option(0, variant)
+        c.set_option(4, rounds if variant == 4 else 0)
+        up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+        state = c.zeros(10)
+        c.propose(kernel, soa(u, dev), at, modes, st, ft, seed, tick, item0, up, mu_, mup, ctl=state)
+        got[variant] = (aos(up), mu_.cpu().numpy(), mup.cpu().numpy(), state.cpu().numpy())
+        c.close()
+    np.testing.assert_allclose(got[4][0], want_up, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(got[4][0], got[3][0], rtol=1e-11, atol=1e-13)
+    strict = np.nonzero(flags == 0)[0]
+    assert np.all((got[4][0][:, strict] >= 0) & (got[4][0][:, strict] <= 1))
+    if kernel == "tpcn":
+        np.testing.assert_allclose(got[4][1], want_mu, rtol=1e-9)
+        np.testing.assert_allclose(got[4][2], want_mup, rtol=1e-8, atol=1e-8)
+    z0 = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, omc.bc_flags(d, list(range(d)), []), seed, tick, item0)[0]
+    failed = np.mean(np.any(np.abs(z0 - want_up) > 1e-9, axis=1))
+    assert failed > 0.03
+    if rounds > 1 and bc is None:      # with later rounds the redraw probe counts ALL first attempts: n / (n - failures)
+        np.testing.assert_allclose(got[4][3][8], 1.0 / (1.0 - failed), rtol=1e-12)
+
+
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
 @pytest.mark.parametrize("mfma", [1, 0])
 def test_blocked_kernel_deferred_update_and_step_control(dev, kernel, mfma):
     """The blocked path inside a chain: deferred Metropolis update (pending mask) and the carried Mahalanobis form give the

@@ -1,5 +1,7 @@
 """One BASELINE.json configuration end to end on one GPU (used under rocprofv3 for profiles/): `run_config.py c2|c3|c5 rwm|tpcn`
-(c5: a 131 072-particle shard of config 5's 100-D funnel)."""
+(c5: a 131 072-particle shard of config 5's 100-D funnel; sep / sep1: the separable 32-D four-mode twin of config 3 that the
+reference's BIC search does split (oracle/make_ref_cluster_counts.py), 262 144 particles, with clustering -- K grows to 4 --
+and without -- K = 1 --; TEMPEST_AMD_RUN_PARTICLES overrides the particle count)."""
 import sys
 import time
 
@@ -13,8 +15,46 @@ def main():
     import tempest_amd as tp
     which, kernel = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "tpcn")
     dev = torch.device("cuda", 0)
-    assert which in ("c2", "c3", "c5")
-    if which == "c3":       # 32-D four-mode Gaussian mixture, 262 144 particles, clustering (BASELINE config 3)
+    assert which in ("c2", "c3", "c5", "sep", "sep1")
+    ks, phase = [], {}
+    if which in ("sep", "sep1"):
+        d, n = 32, int(__import__("os").environ.get("TEMPEST_AMD_RUN_PARTICLES", "262144"))
+        mus = torch.zeros(4, d, dtype=torch.float64, device=dev)
+        for k, (a, b) in enumerate([(-6, -6), (-6, 6), (6, -6), (6, 6)]):
+            mus[k, 0], mus[k, 1] = a, b
+        const = float(-np.log(4.0) - 0.5 * d * np.log(2 * np.pi * 0.09))
+
+        def loglike(x):
+            q = ((x[:, None, :] - mus[None]) ** 2).sum(dim=2)
+            return torch.logsumexp(-0.5 * q / 0.09, dim=1) + const
+        s = tp.Sampler(lambda u: 20 * u - 10, loglike, d, vectorize=True, n_particles=n, clustering=which == "sep", random_state=0,
+                       sample=kernel, backend="torch", batch_prior=True,
+                       split_threshold=float(__import__("os").environ.get("TEMPEST_AMD_RUN_SPLIT", "1.0")))
+        # TEMPEST_AMD_RUN_MAX_POINTS: the clustering working set is thinned to that many rows (the documented `max_points` of the
+        # device clustering, default 262 144): at a few thousand rows the split search does find the four modes, which is how a
+        # K = 4 run at 262 144 particles is produced for the timing of the several-modes proposal path
+        mp = __import__("os").environ.get("TEMPEST_AMD_RUN_MAX_POINTS")
+        if mp and s._core.trainer.clusterer is not None:
+            s._core.trainer.clusterer.max_points = int(mp)
+        from tempest_amd.steps import mutate as mu_, train as tr
+        orig_t, orig_m = tr.Trainer.run, mu_.Mutator.run
+
+        def trun(self, w):
+            t = time.perf_counter()
+            ms = orig_t(self, w)
+            torch.cuda.synchronize()
+            phase["train"] = phase.get("train", 0.0) + time.perf_counter() - t
+            ks.append(int(ms.K))
+            return ms
+
+        def mrun(self, ms):
+            t = time.perf_counter()
+            r = orig_m(self, ms)
+            torch.cuda.synchronize()
+            phase["mutate"] = phase.get("mutate", 0.0) + time.perf_counter() - t
+            return r
+        tr.Trainer.run, mu_.Mutator.run = trun, mrun
+    elif which == "c3":       # 32-D four-mode Gaussian mixture, 262 144 particles, clustering (BASELINE config 3)
         d, n = 32, 262144
         mus = torch.zeros(4, d, dtype=torch.float64, device=dev)
         for k, (a, b) in enumerate([(-4, -4), (-4, 4), (4, -4), (4, 4)]):
@@ -53,7 +93,8 @@ def main():
     steps = np.asarray(s.state.get_history("steps")); beta = np.asarray(s.state.get_history("beta"))
     print(f'{{"config": "{which}", "kernel": "{kernel}", "n_dim": {d}, "n_particles": {n}, "logz": {s.evidence()[0]}, '
           f'"analytic_logz": {-d * np.log(20.0) if which != "c5" else -np.log(30.0) - 99 * np.log(600.0)}, "iterations": {len(beta)}, "mcmc_steps": {int(steps[beta > 0].sum())}, '
-          f'"wall_s": {wall}, "pms_per_s": {steps[beta > 0].sum() * n / wall}}}')
+          f'"wall_s": {wall}, "pms_per_s": {steps[beta > 0].sum() * n / wall}'
+          + (f', "K": {ks}, "phase_s": {{"train": {phase.get("train", 0.0):.3f}, "mutate": {phase.get("mutate", 0.0):.3f}}}' if ks else "") + "}")
 
 
 if __name__ == "__main__":
