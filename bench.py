@@ -110,16 +110,20 @@ def reweight_roofline(device, n_rows, other_rows=(2_621_440, 10_485_760)):
     ctx.close()
     torch.cuda.empty_cache()
     traffic, traffic_source = None, None
-    for name in ("r02_reweight_pmc.json", "r01_reweight_pmc.json"):
-        pmc = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(pmc) or traffic is not None:
-            continue
+    import glob
+    import re
+    # counter traffic of this kernel on this history: the NEWEST round's profiled run (profiles/rNN_reweight_pmc.json)
+    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reweight_pmc.json")),
+                      key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)), reverse=True):
+        if traffic is not None:
+            break
+        name = os.path.basename(pmc)
         try:
             rec = json.load(open(pmc))
             if rec.get("n_rows") == n_rows:
                 traffic = rec.get("hbm_bytes_per_launch")
                 traffic_source = ("profiles/" + name + ": rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of "
-                                  "this kernel on this history in an earlier profiled run, NOT counters of this run")
+                                  "this kernel on this history in that round's profiled run, NOT counters of this run")
         except Exception:
             traffic = None
     return {"bound": "hbm", "kernel": "k_reweight_reduce<1, 8>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -133,7 +137,7 @@ def reweight_roofline(device, n_rows, other_rows=(2_621_440, 10_485_760)):
             "other_points": points, "check_ess": float(s1 * s1 / s2)}
 
 
-def cpu_baseline(budget_s=20.0):
+def cpu_baseline(budget_s=10.0):
     """Oracle (NumPy port of the reference algorithm) on the host: 10-D Rosenbrock, N=4096, as many PS
     iterations as fit the time budget (at least the 3 warm-up + 2 annealing ones)."""
     from oracle.sampler import OracleSampler

@@ -306,16 +306,6 @@ int tph_propose(tph_ctx* ctx, int kernel, double* u_dev /* in; with pending_dev 
                 uint8_t* pending_dev /* NULL, or the mask written by the previous step's deferred tph_accept: particles with
                                         pending[i] != 0 first take uprime[i] (that step's accepted proposal) as their current
                                         point -- u is updated in place, the flag cleared -- and then propose from it */);
-/* The random numbers of a proposal launch do not depend on the particles' positions: tph_pregen_draws writes attempt 0's
- * normals (zpre_dev: [n_dim][ld]) and, for tpCN, the Gamma variates (gpre_dev: [n]) of the launch with this (seed, tick,
- * item0, ctl) on `hip_stream` (NULL: the ctx stream) -- e.g. beside the user's likelihood kernels of the step before --
- * and tph_propose_use_pregen makes the NEXT tph_propose call read them instead of generating them (n_dim <= 16; redraw
- * attempts 1, 2, ... are still generated in the kernel).  Same counters and functions: bit-identical proposals.  The caller
- * orders the two streams (the buffers must be complete before tph_propose runs and untouched until it has). */
-int tph_pregen_draws(tph_ctx* ctx, int kernel, int64_t n, int64_t ld, const int32_t* assign_dev, const double* dof_dev,
-                     uint64_t seed, uint32_t tick, int64_t item0, const double* ctl_dev, double* zpre_dev, double* gpre_dev,
-                     void* hip_stream);
-int tph_propose_use_pregen(tph_ctx* ctx, const double* zpre_dev, const double* gpre_dev);
 /* Metropolis step (mcmc.py:163-177 with the factor of :251-279): masked overwrite of u,x,logl and
  * per-rank sums  sums_dev = (n_accepted, sum alpha_0 .. sum alpha_{K-1}).  x_dev and xprime_dev may both be NULL: x is
  * then not maintained during the run (it is a function of u: the caller re-evaluates prior_transform once at the end, which

@@ -55,8 +55,6 @@ SIGNATURES = {
     "tph_inf_repair_src": (c_int, [ptr, ptr, ptr, ptr, c_i64, c_i64, c_u64, c_u32, c_i64, ptr, ptr]),
     "tph_propose": (c_int, [ptr, c_int, ptr, ptr, c_i64, c_i64, c_int, ptr, ptr, ptr, ptr, ptr, ptr,
                             c_u64, c_u32, c_i64, ptr, ptr, ptr, ptr, ptr]),
-    "tph_pregen_draws": (c_int, [ptr, c_int, c_i64, c_i64, ptr, ptr, c_u64, c_u32, c_i64, ptr, ptr, ptr, ptr]),
-    "tph_propose_use_pregen": (c_int, [ptr, ptr, ptr]),
     "tph_accept": (c_int, [ptr, c_int, c_dbl, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i64, c_i64,
                            c_int, ptr, c_u64, c_u32, c_i64, ptr, ptr, ptr, ptr]),
     "tph_adapt": (c_int, [ptr, c_int, ptr, ptr, c_int, c_dbl, c_int, c_int, c_int, ptr, ptr, ptr, c_int, ptr, c_i64]),

@@ -120,7 +120,6 @@ struct tph_ctx {
   int blk_table_cap = 0, blk_T = 0;
   int64_t blk_rows = 0;
   tph_p2p* p2p = nullptr;           // small-message collectives over peer-mapped memory (tph_comm_p2p_attach), or NULL
-  const double *zpre = nullptr, *gpre = nullptr;     // tph_propose_use_pregen: draws of the NEXT tph_propose launch, made ahead
   int64_t stat[5] = {0, 0, 0, 0, 0};   // tph_comm_stats: p2p exchanges, callback collectives, callback bytes, rows put, bytes put
   bool comm_active() const { return comm_allreduce != nullptr; }
 };

@@ -745,10 +745,7 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(double* __restrict__ u,
                                                          const double* __restrict__ dof, const double* __restrict__ sigmas,
                                                          const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick,
                                                          int64_t item0, double* __restrict__ up, double* __restrict__ maha_u,
-                                                         double* __restrict__ maha_up, int tiles, uint8_t* __restrict__ pend,
-                                                         const double* __restrict__ zpre, const double* __restrict__ gpre) {
-  // zpre / gpre: the normals of attempt 0 ([D][ld]) and the Gamma variates of this launch, generated ahead of it by
-  // tph_pregen_draws (same counters, same functions: the same doubles) -- or NULL: generated here
+                                                         double* __restrict__ maha_up, int tiles, uint8_t* __restrict__ pend) {
   constexpr int NPW = 64 * REG_MAX_TILES;
   __shared__ double s_bfac[NPW];
   __shared__ int s_list[2][NPW];
@@ -764,10 +761,7 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(double* __restrict__ u,
     const double* __restrict__ L = chol + (size_t)c * D * D;
     bool ok = true;
     if (att < PROP_MAX_ATTEMPTS) {
-      if (zpre != nullptr && att == 0) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) z[j] = zpre[(size_t)j * ld + i];
-      } else {
+      {
       // the normals of this attempt: a ROLLED loop over the Box-Muller pairs writing a private array (dynamic index ->
       // scratch memory, 8 B per value and lane, L1/L2-resident): one Philox / log / sincospi body with ~30 live
       // registers instead of ceil(D/2) interleaved copies
@@ -881,7 +875,7 @@ __global__ void __launch_bounds__(64, WPE) k_propose_reg(double* __restrict__ u,
         }
         const double nu = dof[c];
         tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
-        const double g0 = gpre ? gpre[i] : tph_gamma_mt(gg, 0.5 * ((double)D + nu));
+        const double g0 = tph_gamma_mt(gg, 0.5 * ((double)D + nu));
         const double gam = g0 * tph_div(2.0, nu + m_u);
         b_fac = sigma * tph_sqrt(tph_rcp(gam));
       } else if (maha_u) {
@@ -948,7 +942,6 @@ static void launch_propose_reg(tph_ctx* ctx, double* u, const int32_t* assign, i
                                const double* means, const double* chol, const double* winv, const double* dof,
                                const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
                                double* up, double* mu_, double* mup, uint8_t* pend) {
-  const double* zpre = ctx->zpre; const double* gpre = ctx->gpre;      // tph_propose_use_pregen: this launch only
   // one resident batch: waves = min(tiles, 4 per SIMD x SIMDs), tiles of a wave = ceil(tiles / waves) <= REG_MAX_TILES
   // (TPH_OPT_REDRAW_LANES = t > 0 forces t tiles per wave: experiments)
   constexpr int WPE = 4;
@@ -961,7 +954,7 @@ static void launch_propose_reg(tph_ctx* ctx, double* u, const int32_t* assign, i
   waves = (ntiles + tiles - 1) / tiles;
 #define TPH_REG_LAUNCH(ONE, BC)                                                                                         \
   hipLaunchKernelGGL((k_propose_reg<KERNEL, D, ONE, WPE, BC>), dim3((unsigned)waves), dim3(64), 0, ctx->stream, u, assign, n, ld, \
-                     means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, tiles, pend, zpre, gpre)
+                     means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, tiles, pend)
   // The instantiation with the Box-Muller pairs as independent, interleaved chains (template argument 2): wherever it stays
   // within 128 VGPRs -- RWM at every n_dim, tpCN up to n_dim = 11 -- it keeps four waves per SIMD AND fills their issue slots
   // (1 048 576 x 10-D: 82.8 -> 71.3 us with every first attempt in bounds, 197 -> 157 us with half of them out); above that
@@ -969,7 +962,7 @@ static void launch_propose_reg(tph_ctx* ctx, double* u, const int32_t* assign, i
   constexpr bool ilp_fits = KERNEL == TPH_KERNEL_RWM || D <= 11;
   if (assign == nullptr && !bc && ctx->redraw_lanes == 0 && (ilp_fits || waves <= 2 * (int64_t)ctx->n_simd)) {
     hipLaunchKernelGGL((k_propose_reg<KERNEL, D, true, 2, false>), dim3((unsigned)waves), dim3(64), 0, ctx->stream, u, assign, n, ld,
-                       means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, tiles, pend, zpre, gpre);
+                       means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, tiles, pend);
   } else if (assign == nullptr) { if (bc) TPH_REG_LAUNCH(true, true); else TPH_REG_LAUNCH(true, false); }
   else { if (bc) TPH_REG_LAUNCH(false, true); else TPH_REG_LAUNCH(false, false); }
 #undef TPH_REG_LAUNCH
@@ -1087,7 +1080,6 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
     TPH_LAUNCH_CHECK();
     return 0;
   }
-  if (!use_reg) { ctx->zpre = nullptr; ctx->gpre = nullptr; }      // pre-generated draws serve the register kernel only
   if (use_reg) {
     switch (ctx->d) {
       TPH_PROPOSE_CASE(1) TPH_PROPOSE_CASE(2) TPH_PROPOSE_CASE(3) TPH_PROPOSE_CASE(4) TPH_PROPOSE_CASE(5)
@@ -1095,7 +1087,6 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
       TPH_PROPOSE_CASE(11) TPH_PROPOSE_CASE(12) TPH_PROPOSE_CASE(13) TPH_PROPOSE_CASE(14) TPH_PROPOSE_CASE(15)
       TPH_PROPOSE_CASE(16)
     }
-    ctx->zpre = nullptr; ctx->gpre = nullptr;
     TPH_LAUNCH_CHECK();
     return 0;
   }
@@ -1119,64 +1110,6 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
   return 0;
 }
 
-// ---- draws of a proposal launch, generated AHEAD of it ------------------------------------------------------------------
-// Nine tenths of the register proposal kernel are its random numbers (section 3a of DESIGN.md), and none of them depends on
-// where the particles are: attempt 0's normals and the Gamma variate of a launch are functions of (seed, tick, particle).
-// This kernel writes them for the NEXT step's launch -- on a stream of the caller's choice, i.e. beside the user's
-// likelihood kernels of the current step, which are bound by HBM and leave the vector units idle -- and tph_propose, told
-// so by tph_propose_use_pregen, reads them instead of generating them (redraw attempts 1, 2, ... stay in the kernel).
-// Same counters, same functions: the same doubles, hence the same chain.
-template <int D>
-__global__ void __launch_bounds__(64) k_pregen(int64_t n, int64_t ld, const int32_t* __restrict__ assign,
-                                               const double* __restrict__ dof, int tpcn, uint64_t seed, tph_stepctl tick,
-                                               int64_t item0, double* __restrict__ zpre, double* __restrict__ gpre) {
-  // a THIN persistent grid (the launch is sized to ~one wave per SIMD): it shares the chip with the user's kernels, which
-  // must keep nearly all of the wave slots -- a full-size grid beside them cost more on the main stream than it saved
-  constexpr int NP = (D + 1) / 2;
-  const uint32_t tk = tick;
-  for (int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 64) {
-    tph_rng gz(seed, tk, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
-    double z[2 * NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) gz.normal2((uint32_t)p, z[2 * p], z[2 * p + 1]);
-#pragma unroll
-    for (int j = 0; j < D; ++j) zpre[(size_t)j * ld + i] = z[j];
-    if (tpcn) {
-      const int c = assign ? assign[i] : 0;
-      tph_rng gg(seed, tk, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
-      gpre[i] = tph_gamma_mt(gg, 0.5 * ((double)D + dof[c]));
-    }
-  }
-}
-
-extern "C" int tph_pregen_draws(tph_ctx* ctx, int kernel, int64_t n, int64_t ld, const int32_t* assign_dev, const double* dof_dev,
-                                uint64_t seed, uint32_t tick0, int64_t item0, const double* ctl_dev, double* zpre_dev,
-                                double* gpre_dev, void* hip_stream) {
-  TPH_REQUIRE(ctx && zpre_dev && n > 0 && ld >= n, "tph_pregen_draws: bad argument");
-  TPH_REQUIRE(ctx->d <= 16, "tph_pregen_draws: serves the register proposal kernel (n_dim <= 16), n_dim is %d", ctx->d);
-  TPH_REQUIRE(kernel == TPH_KERNEL_RWM || (gpre_dev && dof_dev), "tph_pregen_draws: tpCN needs dof_dev and gpre_dev");
-  const tph_stepctl tick{tick0, ctl_dev};
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-  int64_t waves = (n + 63) / 64;
-  int per_simd = 1;
-  if (const char* env = getenv("TEMPEST_AMD_PREGEN_WAVES")) per_simd = atoi(env) > 0 ? atoi(env) : 1;
-  if (waves > (int64_t)per_simd * ctx->n_simd) waves = (int64_t)per_simd * ctx->n_simd;
-  const dim3 grid((unsigned)waves);
-  const int tpcn = kernel == TPH_KERNEL_TPCN ? 1 : 0;
-  switch (ctx->d) {
-#define TPH_PG(DD) case DD: hipLaunchKernelGGL(k_pregen<DD>, grid, dim3(64), 0, st, n, ld, assign_dev, dof_dev, tpcn, seed, tick, item0, zpre_dev, gpre_dev); break;
-    TPH_PG(1) TPH_PG(2) TPH_PG(3) TPH_PG(4) TPH_PG(5) TPH_PG(6) TPH_PG(7) TPH_PG(8) TPH_PG(9) TPH_PG(10) TPH_PG(11) TPH_PG(12)
-    TPH_PG(13) TPH_PG(14) TPH_PG(15) TPH_PG(16)
-#undef TPH_PG
-  }
-  TPH_LAUNCH_CHECK();
-  return 0;
-}
-extern "C" int tph_propose_use_pregen(tph_ctx* ctx, const double* zpre_dev, const double* gpre_dev) {
-  TPH_REQUIRE(ctx, "tph_propose_use_pregen: ctx is NULL");
-  ctx->zpre = zpre_dev; ctx->gpre = gpre_dev;
-  return 0;
-}
 
 // ------------------------------------------------------------------------------------------ accept
 constexpr int ACC_THREADS = 256;

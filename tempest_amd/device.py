@@ -403,16 +403,6 @@ class HipContext:
                                    _ptr(ctl) if ctl is not None else None,
                                    _ptr(pending, torch.uint8) if pending is not None else None), "tph_propose")
 
-    def pregen_draws(self, kernel, n, assign, dof, seed, tick, item0, ctl, zpre, gpre, stream=None):
-        """Attempt 0's normals and the Gamma variates of the proposal launch with this tick, on `stream` (tph_pregen_draws)."""
-        check(self.lib.tph_pregen_draws(self._ctx, KERNEL_ID[kernel], n, zpre.shape[1],
-                                        _ptr(assign, torch.int32) if assign is not None else None, _ptr(dof), seed, tick, item0,
-                                        _ptr(ctl) if ctl is not None else None, _ptr(zpre), _ptr(gpre) if gpre is not None else None,
-                                        C.c_void_p(stream.cuda_stream) if stream is not None else None), "tph_pregen_draws")
-
-    def use_pregen(self, zpre, gpre):
-        check(self.lib.tph_propose_use_pregen(self._ctx, _ptr(zpre), _ptr(gpre) if gpre is not None else None), "tph_propose_use_pregen")
-
     def accept(self, kernel, beta, u, x, logl, uprime, xprime, loglprime, maha_u, maha_up, assign, K, dof, seed,
                tick, item0, sums, ctl=None, partials=None, pending=None):
         n = u.shape[1]

@@ -115,22 +115,6 @@ class StepEngine:
         self.use_graph, self.graph, self.graph_error = bool(use_graph), None, None
         self._keep, self.runs, self._own = None, 0, None
         self._retired_graphs = []
-        # Draws made ahead (tph_pregen_draws; OFF unless TEMPEST_AMD_PREGEN=1): the register proposal kernel (n_dim <= 16) spends
-        # nine tenths of its time on random numbers that do not depend on the particles' positions, so those of step s + 1 can
-        # be generated on a side stream while the user's callbacks of step s -- HBM-bound elementwise kernels -- occupy the main
-        # stream.  Bit-identical, and measured SLOWER on MI355X: at 1 048 576 x 10-D the iteration went from 30.2 to 33.8-35.7 ms
-        # (2.67e9 -> 2.25-2.38e9 pms/s) with a full-size grid as with a thin persistent one (1, 2, 4 waves per SIMD): the step is a
-        # chain of ~14 dependent kernels, and a second queue beside it delays every link (wave slots, cross-stream events) by
-        # more than the 37 us the proposal kernel gets shorter.  Kept as an opt-in for hardware where that balance differs.
-        import os
-        self.pregen = (not use_graph and plugin is None and d <= 16 and n * d >= (1 << 19)
-                       and os.environ.get("TEMPEST_AMD_PREGEN", "0") == "1")
-        self.zpre = self.gpre = self.side = self.pre_ready = None
-        self.pre_valid = False
-        if self.pregen:
-            self.zpre = ctx.empty(d, n)
-            self.gpre = ctx.empty(n) if kernel == "tpcn" else None
-            self.side = torch.cuda.Stream(device=ctx.device)
 
     def load(self, u, x, logl, assign, modes, beta, tick_base, sigma_init, counts):
         """Start a run: active set, proposal modes and the step-control block.  A graph needs fixed addresses, so
@@ -160,8 +144,6 @@ class StepEngine:
             self.ctx.set_option(OPT_ML_UNSTAGED, 1 if self.unstaged else 0)
             self.ctx.set_option(OPT_STAGED_REDRAW, 1 if self.staged else 0)
             self.ctx.set_option(OPT_SM_LANES, self.sm_lanes)
-        self.pre_valid = False                  # a new run has a new tick base: its first step draws in the kernel
-        self._enq, self._tick_base = 0, int(tick_base)
         self.sigmas.fill_(sigma_init)
         self.pending.zero_()
         self.counts.copy_(counts)
@@ -183,28 +165,8 @@ class StepEngine:
                              self.seed, 1, 2, self.item0, self.ctl, self.partials)
             self._adapt(fold=True)
             return None, None
-        if self.pregen and self.pre_valid:
-            import torch
-            torch.cuda.current_stream(ctx.device).wait_event(self.pre_ready)
-            ctx.use_pregen(self.zpre, self.gpre)
         ctx.propose(self.kernel, self.u, self.assign, self.modes, self.sigmas, self.bc, self.seed, 1, self.item0,
                     self.up, self.maha_u, self.maha_up, ctl=self.ctl, pending=self.pending)
-        if self.pregen:
-            # the draws of the NEXT step, once this proposal has read the buffers, beside this step's callbacks.  Its tick is
-            # passed by VALUE (1 + base + 2 x steps enqueued: what the device forms from the control block for that launch):
-            # the side stream may run behind tph_adapt, which advances the block's step counter
-            import torch
-            main = torch.cuda.current_stream(ctx.device)
-            ev = torch.cuda.Event()
-            ev.record(main)
-            self.side.wait_event(ev)
-            self._enq += 1
-            tick_next = (1 + self._tick_base + 2 * self._enq) & 0xFFFFFFFF
-            ctx.pregen_draws(self.kernel, self.n, self.assign, self.modes.dof_dev, self.seed, tick_next, self.item0, None, self.zpre,
-                             self.gpre, stream=self.side)
-            self.pre_ready = torch.cuda.Event()
-            self.pre_ready.record(self.side)
-            self.pre_valid = True
         # the block partials of the Metropolis kernel are summed inside tph_adapt (one launch less per step), which on a
         # sharded run also exchanges the sums with the peers (tph_comm_p2p_*); without that exchange the host all-reduces
         # the column sums between the two launches

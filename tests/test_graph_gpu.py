@@ -150,34 +150,6 @@ def test_d_gt_16_proposal_paths_replayed_from_a_graph_equal_eager_launches(kerne
     c.close()
 
 
-@pytest.mark.parametrize("kernel,K", [("tpcn", 1), ("rwm", 1), ("tpcn", 2)])
-def test_draws_generated_ahead_on_a_side_stream_change_no_bit(kernel, K, monkeypatch):
-    """Large shards, n_dim <= 16: the normals of attempt 0 and the Gamma variates of step s + 1 are generated on a side
-    stream while the callbacks of step s run (tph_pregen_draws), and the proposal kernel reads them.  Same counters, same
-    functions -- the run is the run without it, bit for bit (TEMPEST_AMD_PREGEN=0), with one mode and with two clusters."""
-    import tempest_amd as tp
-    d, n = 8, 131072                    # n * d = 2^20 > 2^19: step-by-step engine with the side stream
-
-    def like(x):
-        if K == 1:
-            return rosen(x)
-        return bimodal(x)
-    runs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("TEMPEST_AMD_PREGEN", flag)
-        s = tp.Sampler(prior20, like, d, n_particles=n, vectorize=True, clustering=(K > 1), random_state=4, sample=kernel)
-        for _ in range(7):
-            s.sample(return_state=False)
-        eng = list(s._core.mutator._engines.values())
-        assert eng and all(e.graph is None and e.pregen == (flag == "1") for e in eng)
-        runs.append((s.state.get_current("logz"), s.state.get_current("u"), s.state.get_current("logl"), _history(s)))
-    assert runs[0][0] == runs[1][0]
-    np.testing.assert_array_equal(runs[0][1], runs[1][1])
-    np.testing.assert_array_equal(runs[0][2], runs[1][2])
-    for k in runs[0][3]:
-        np.testing.assert_array_equal(runs[0][3][k], runs[1][3][k], err_msg=k)
-
-
 def test_uncapturable_callback_falls_back():
     """A likelihood that synchronises with the host cannot be stream-captured: the engine warns once and keeps launching
     step by step, with the same numbers."""
