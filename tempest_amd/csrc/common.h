@@ -97,6 +97,7 @@ struct tph_ctx {
   const void* mf_src = nullptr;
   // matrix-core round kernel of the blocked path (propose_blkm.hip): TPH_OPT_BLK_MFMA and its blocked copies of L and L^-1
   int blk_mfma = 1;
+  int blk_tries = 0;                // TPH_OPT_BLK_TRIES: attempts a round of the matrix-core kernel gives its failing columns in place (0 = by n_dim)
   void* bm_buf = nullptr;
   size_t bm_bytes = 0;
   int bm_epoch = -1, bm_kernel = -1, bm_K = 0;
@@ -148,6 +149,7 @@ int tph_propose_mf(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, c
                    const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
                    const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend);
 // propose_blkm.hip: one round of the blocked path with both triangular products on the FP64 matrix cores
+int tph_blkm_tries(const tph_ctx* ctx);      // attempts per round of the matrix-core kernel (TPH_OPT_BLK_TRIES resolved)
 int tph_blkm_round(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                    const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
                    const double* ctl, int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, const int32_t* cnt_in,

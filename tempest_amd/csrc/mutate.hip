@@ -649,11 +649,14 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   // fixed-address chol / winv between runs (the straggler pass and tpCN's carried form read those) -- two covariances inside
   // one Metropolis ratio.  The copies made under capture are not trusted by later eager calls either.
   const bool mfma = ctx->blk_mfma && d <= 112;      // TPH_OPT_BLK_MFMA: the rounds on the FP64 matrix cores (propose_blkm.hip)
+  int att_next = rounds;                            // the straggler pass starts here
   if (mfma) {
+    const int tries = tph_blkm_tries(ctx);      // TPH_OPT_BLK_TRIES: attempts per round, in place
     for (int k = 0; k < rounds; ++k)
       if (tph_blkm_round(ctx, KERNEL, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick.tick, tick.ctl, item0, up, mu_, mup, pend,
-                         k ? cnts + (k - 1) : (const int32_t*)nullptr, (const int32_t*)rows[(k + 1) & 1], k, cnts + k, rows[k & 1]))
+                         k ? cnts + (k - 1) : (const int32_t*)nullptr, (const int32_t*)rows[(k + 1) & 1], k * tries, cnts + k, rows[k & 1]))
         return -1;
+    att_next = rounds * tries;
   } else {
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   TPH_HIP(hipStreamIsCapturing(ctx->stream, &cap));
@@ -689,7 +692,7 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   // beyond its range, the multi-lane kernel
   if (ctx->screen && d <= 112)
     return tph_propose_mf_list(ctx, KERNEL, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick.tick, tick.ctl, item0, up, mup,
-                               cnts + (rounds - 1), rows[(rounds - 1) & 1], rounds);
+                               cnts + (rounds - 1), rows[(rounds - 1) & 1], att_next);
   // as many lanes per straggler as it has Box-Muller pairs: a straggler's chain of attempts is latency-bound (few blocks
   // have any work), so the pairs of an attempt are generated in ONE round and the rows spread over more lanes
   int lpp = 4;
@@ -698,7 +701,7 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   ctx->ml_unstaged = 1;        // (staged, measured: 65 536 x 50-D +-0, 131 072 x 100-D +8 ... +28 %)
   int rc = 0;
   switch (lpp) {
-#define TPH_ML_S(LL) case LL: rc = launch_propose_ml<KERNEL, LL>(ctx, u, nullptr, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, nullptr, cnts + (rounds - 1), rows[(rounds - 1) & 1], rounds); break;
+#define TPH_ML_S(LL) case LL: rc = launch_propose_ml<KERNEL, LL>(ctx, u, nullptr, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, nullptr, cnts + (rounds - 1), rows[(rounds - 1) & 1], att_next); break;
     TPH_ML_S(4) TPH_ML_S(8) TPH_ML_S(16) TPH_ML_S(32) TPH_ML_S(64)
 #undef TPH_ML_S
   }
@@ -1039,7 +1042,7 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
     const int keep = ctx->ml_unstaged;
     ctx->ml_unstaged = 1;
     int rc = 0;
-    const int att0 = rounds > 24 ? 24 : rounds;
+    const int att0 = (rounds > 24 ? 24 : rounds) * tph_blkm_tries(ctx);
     switch (lpp) {
 #define TPH_ML_M(LL)                                                                                                     \
   case LL:                                                                                                               \

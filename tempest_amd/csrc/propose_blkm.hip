@@ -23,6 +23,13 @@
 
 typedef double bm_d4 __attribute__((ext_vector_type(4)));
 
+// the redraw probe of the blocked path: mean attempts per particle implied by the share fs of the particles whose first `tries`
+// attempts all left the cube -- per-attempt failure rate f = fs^(1/tries), geometric mean 1 / (1 - f) (capped like the redraw loop)
+__device__ __forceinline__ double bm_probe(double fs, int tries) {
+  const double f = tries > 1 ? pow(fs, 1.0 / (double)tries) : fs;
+  return f < 1.0 - 1.0 / 256.0 ? 1.0 / (1.0 - f) : 256.0;
+}
+
 __host__ __device__ static inline int bm_panels(int d) { return (d + 15) / 16; }
 __host__ __device__ static inline int bm_blocks(int np) { return 2 * np * (np + 1); }       // sum over p of 4p + 4
 __host__ __device__ static inline int bm_blk(int p, int s) { return 2 * p * (p + 1) + s; }
@@ -120,7 +127,7 @@ static __global__ void __launch_bounds__(256) k_mt_concat(const int32_t* __restr
   for (int e = threadIdx.x; e < c; e += blockDim.x) rows_cat[s_base + e] = rows_in[st + e];
 }
 
-template <int KERNEL, int NP, bool HAS_BC, bool MULTI>
+template <int KERNEL, int NP, bool HAS_BC, bool MULTI, int MAXT>
 __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, int64_t n, int64_t ld, int d, const double* __restrict__ means_all,
                                                       const double* __restrict__ Lm_all, const double* __restrict__ Wm_all,
                                                       const double* __restrict__ dof, const double* __restrict__ sigmas,
@@ -128,7 +135,7 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
                                                       double* __restrict__ up, double* __restrict__ maha_u, double* __restrict__ maha_up,
                                                       uint8_t* __restrict__ pend, const int32_t* __restrict__ cnt_in,
                                                       const int32_t* __restrict__ rows_in, int att, int32_t* __restrict__ cnt_out,
-                                                      int32_t* __restrict__ rows_out, const int32_t* __restrict__ mt, int64_t tiles_max) {
+                                                      int32_t* __restrict__ rows_out, const int32_t* __restrict__ mt, int64_t tiles_max, int tries) {
   // cnt_in == NULL: round 0, attempt 0 of every particle and the chores of the step (pending moves, form at u, Gamma scale);
   // cnt_in != NULL: attempt `att` of the particles listed by the round before; the step scale comes from where round 0 parked it.
   // MULTI: several modes -- the wave's tile, its mode and the mode's stretch of the lists come from the tile table mt (above).
@@ -147,8 +154,8 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
     int64_t total = n;
     if (!first) {
       total = *cnt_in;
-      if (att == 1 && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl)      // the redraw probe from ALL first attempts
-        const_cast<double*>(tick.ctl)[8] = total < n ? (double)n / (double)(n - total) : 256.0;
+      if (att == tries && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl)      // the redraw probe from ALL particles' first `tries` attempts
+        const_cast<double*>(tick.ctl)[8] = bm_probe((double)total / (double)n, tries);
       if ((int64_t)blockIdx.x * 64 >= total) return;                        // the whole block (uniform): nothing listed for it
     }
     live = slot < total;
@@ -169,10 +176,10 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
       const int j16 = start - lbase, cm = cnt_in[mode];
       live = valid && j16 + nn < cm;
       i = live ? (int64_t)rows_in[lbase + j16 + nn] : (int64_t)order[start];
-      if (att == 1 && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl) {
+      if (att == tries && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl) {
         int64_t total = 0;
         for (int m = 0; m < mt[1]; ++m) total += cnt_in[m];
-        const_cast<double*>(tick.ctl)[8] = total < n ? (double)n / (double)(n - total) : 256.0;
+        const_cast<double*>(tick.ctl)[8] = bm_probe((double)total / (double)n, tries);
       }
     }
   }
@@ -192,7 +199,6 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
   const double a_fac = (KERNEL == TPH_KERNEL_TPCN) ? tph_sqrt(1.0 - sigma * sigma) : 1.0;
   double X[NS];                                  // the B operands: normals (permuted steps), then rows of the proposal (natural steps)
   bool all_ok = false;
-  unsigned int okc = 0u;
 
   // sum over the rows of |T x|^2 for the tile (x in X as natural-step operands): every lane ends with ITS column's value
   auto form = [&](const double* __restrict__ Tb) -> double {
@@ -250,55 +256,87 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
       b_fac = maha_up[i];
     }
 
-    // ---- the normals of this round's attempt: lane (k, n) draws pairs k, k + 4, ... of particle n = its operands of steps 2c, 2c + 1
-    {
-      tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
-      const uint32_t d0 = (uint32_t)att * (uint32_t)npairs;
+    // ---- the round's attempts att, att + 1, ... att + tries - 1: every column still out of bounds gets the next one IN PLACE (a
+    // tile with one failing column pays a whole pass for it, but late in a run that is a fifth of the tiles for one more pass --
+    // against a list launch, a closing pass and their launch latencies for a handful of particles: config 2, 35-70 us per step)
+    // (Written out, not looped: inside a loop the compiler keeps every address of the matrix blocks and of the current point
+    // live across the body -- 256 VGPRs, one wave per SIMD, 705 against 198 us at 131 072 x 100-D -- where the straight-line form
+    // needs 125.)
+    bool pending = live;                               // this lane's column still has no in-bounds attempt
+    const bool want_form = KERNEL == TPH_KERNEL_TPCN;
+    auto attempt = [&](const int t) {
+      // the normals of the attempt: lane (k, n) draws pairs k, k + 4, ... of particle n = its operands of steps 2c, 2c + 1
+      {
+        tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
+        const uint32_t d0 = (uint32_t)(att + t) * (uint32_t)npairs;
 #pragma unroll
-      for (int c = 0; c < NS / 2; ++c) {
-        const int q = k + 4 * c;
-        double z0 = 0.0, z1 = 0.0;
-        if (q < npairs) gz.normal2(d0 + (uint32_t)q, z0, z1);
-        X[2 * c] = z0;
-        X[2 * c + 1] = z1;             // (row 2q + 1 == d for odd d: its column of L is zero)
-      }
-    }
-    // ---- rows of the attempt, last panel first: v = fma(b, (L z)_r, mu_r + a (u_r - mu_r)), bounds; results in place
-    bool ok = true;
-#pragma unroll
-    for (int p = NP - 1; p >= 0; --p) {
-      bm_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 4 * p + 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lm[(size_t)bm_blk(p, s) * 64 + lane], X[s], acc, 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r = 16 * p + k + 4 * q;
-        double v = 0.0;
-        if (r < d) {
-          const double ur = u[(size_t)r * ld + i];
-          const double mr = (KERNEL == TPH_KERNEL_TPCN) ? means[r] : 0.0;
-          const double base = (KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, ur - mr, mr) : ur;
-          v = fma(b_fac, acc[q], base);
-          const uint8_t f = HAS_BC ? bc[r] : (uint8_t)TPH_BC_STRICT;
-          if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
-          else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
-          else ok = ok && (v >= 0.0) && (v <= 1.0);
+        for (int c = 0; c < NS / 2; ++c) {
+          const int q = k + 4 * c;
+          double z0 = 0.0, z1 = 0.0;
+          if (pending && q < npairs) gz.normal2(d0 + (uint32_t)q, z0, z1);
+          X[2 * c] = z0;
+          X[2 * c + 1] = z1;             // (row 2q + 1 == d for odd d: its column of L is zero)
         }
-        X[4 * p + q] = v;
       }
-    }
-    // a column is in bounds when its four lanes are
-    const unsigned long long okb = __ballot(ok);
-    okc = (unsigned int)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48)) & 0xFFFFu;
-    all_ok = (okc >> nn) & 1u;
-    // ---- outputs of the particles whose attempt is in bounds; the others are listed for the next round / the straggler pass
-    if (live && all_ok) {
+      // rows of the attempt, last panel first: v = fma(b, (L z)_r, mu_r + a (u_r - mu_r)), bounds; results in place.  (The
+      // matrix blocks, the current point and the mean are the SAME loads in every attempt: behind an opaque offset each attempt
+      // loads them where it uses them -- otherwise the values of the first attempt are kept for the next, 224 + 112 VGPRs.)
+      const double* __restrict__ Lq = tph_opaque(Lm);
+      const double* __restrict__ uq = tph_opaque((const double*)u);
+      const double* __restrict__ mq = tph_opaque(means);
+      bool ok = true;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const int r = 4 * s + k;
-        if (r < d) up[(size_t)r * ld + i] = X[s];
+      for (int p = NP - 1; p >= 0; --p) {
+        bm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4 * p + 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lq[(size_t)bm_blk(p, s) * 64 + lane], X[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 16 * p + k + 4 * q;
+          double v = 0.0;
+          if (r < d) {
+            const double ur = uq[(size_t)r * ld + i];
+            const double mr = (KERNEL == TPH_KERNEL_TPCN) ? mq[r] : 0.0;
+            const double base = (KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, ur - mr, mr) : ur;
+            v = fma(b_fac, acc[q], base);
+            const uint8_t f = HAS_BC ? bc[r] : (uint8_t)TPH_BC_STRICT;
+            if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
+            else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
+            else ok = ok && (v >= 0.0) && (v <= 1.0);
+          }
+          X[4 * p + q] = v;
+        }
       }
-    }
+      // a column is in bounds when its four lanes are
+      const unsigned long long okb = __ballot(ok);
+      const unsigned int okt = (unsigned int)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48)) & 0xFFFFu;
+      const bool now_ok = pending && ((okt >> nn) & 1u);
+      // outputs of the columns whose attempt is in bounds
+      if (now_ok) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const int r = 4 * s + k;
+          if (r < d) up[(size_t)r * ld + i] = X[s];
+        }
+      }
+      if (want_form) {
+        if (__ballot(now_ok) != 0ull) {               // (wave-uniform) some column needs its form |L^-1 (u' - mu)|^2
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            const int r = 4 * s + k;
+            X[s] = r < d ? X[s] - mq[r] : 0.0;
+          }
+          const double m_up = form(tph_opaque(Wm));
+          if (now_ok && k == 0) maha_up[i] = m_up;
+        }
+      } else if (now_ok && k == 0 && maha_up) {
+        maha_up[i] = 0.0;
+      }
+      if (now_ok) { pending = false; all_ok = true; }
+    };
+    attempt(0);
+    if (MAXT > 1 && tries > 1 && __ballot(pending) != 0ull) attempt(1);
+    if (MAXT > 2 && tries > 2 && __ballot(pending) != 0ull) attempt(2);
   }
   {
     // the block's failures take ONE slot range of their mode's list (an atomic per wave -- 16 384 of them on one address at
@@ -335,23 +373,14 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
     }
     if (live && !all_ok && k == 0) rows_out[lbase + slot0 + __popcll(failb & ((1ull << lane) - 1ull))] = (int32_t)i;
     if (first && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl) {      // regime probe: mean attempts implied by this block's failures, 1 / (1 - f)
-      const double f = (double)nfail / fmax(1.0, (double)nlive);
-      const_cast<double*>(tick.ctl)[8] = f < 0.99 ? 1.0 / (1.0 - f) : 100.0;
+      const_cast<double*>(tick.ctl)[8] = bm_probe((double)nfail / fmax(1.0, (double)nlive), tries);
     }
-  }
-  if (KERNEL == TPH_KERNEL_TPCN) {
-    if (okc == 0u) return;                          // (wave-uniform) no column needs its form
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int r = 4 * s + k;
-      X[s] = r < d ? X[s] - means[r] : 0.0;
-    }
-    const double m_up = form(Wm);
-    if (live && all_ok && k == 0) maha_up[i] = m_up;
-  } else if (live && all_ok && k == 0 && maha_up) {
-    maha_up[i] = 0.0;
   }
 }
+
+// TPH_OPT_BLK_TRIES (0 = by dimension: a retry in place costs a whole tile pass, which pays below n_dim 64 -- regime sweep:
+// 65 536 x 50-D 71 -> 62 us, 262 144 x 32-D 99 -> 79 us at one attempt per particle; 131 072 x 100-D 479 -> 598 us at 1.13)
+static inline int bm_tries(const tph_ctx* ctx) { return ctx->blk_tries > 0 ? (ctx->blk_tries > 3 ? 3 : ctx->blk_tries) : (ctx->d >= 64 ? 1 : 2); }
 
 // One round of the matrix-core blocked kernel on the ctx stream (mutate.hip drives the rounds of the one-mode path; several
 // modes: tph_blkm_propose_multi below).  The blocked copies of L (permuted steps) and L^-1 (natural steps) of every mode live in
@@ -394,11 +423,17 @@ static int blkm_launch(tph_ctx* ctx, int64_t blocks, double* u, int64_t n, int64
                        double* up, double* mu_, double* mup, uint8_t* pend, const int32_t* cnt_in, const int32_t* rows_in, int att,
                        int32_t* cnt_out, int32_t* rows_out, const int32_t* mt, int64_t tiles_max) {
   const int d = ctx->d, np = bm_panels(d);
+  const int tries = bm_tries(ctx);
   const dim3 grid((unsigned)blocks);
-#define TPH_BM(NPV, BC)                                                                                                  \
-  hipLaunchKernelGGL((k_propose_blkm<KERNEL, NPV, BC, MULTI>), grid, dim3(256), 0, ctx->stream, u, n, ld, d, means, Lm, Wm, dof, sigmas, \
-                     bc, seed, tick, item0, up, mu_, mup, pend, cnt_in, rows_in, att, cnt_out, rows_out, mt, tiles_max)
-#define TPH_BM_NP(NPV) do { if (bc) TPH_BM(NPV, true); else TPH_BM(NPV, false); } while (0)
+#define TPH_BM(NPV, BC, MT)                                                                                              \
+  hipLaunchKernelGGL((k_propose_blkm<KERNEL, NPV, BC, MULTI, MT>), grid, dim3(256), 0, ctx->stream, u, n, ld, d, means, Lm, Wm, dof, \
+                     sigmas, bc, seed, tick, item0, up, mu_, mup, pend, cnt_in, rows_in, att, cnt_out, rows_out, mt, tiles_max, tries)
+  // (the one-attempt instantiation keeps four waves per SIMD at n_dim = 100: 198 against 247 us at 131 072 particles)
+#define TPH_BM_NP(NPV)                                                                                                   \
+  do {                                                                                                                   \
+    if (tries > 1) { if (bc) TPH_BM(NPV, true, 3); else TPH_BM(NPV, false, 3); }                                         \
+    else { if (bc) TPH_BM(NPV, true, 1); else TPH_BM(NPV, false, 1); }                                                   \
+  } while (0)
   switch (np) {
     case 2: TPH_BM_NP(2); break;
     case 3: TPH_BM_NP(3); break;
@@ -422,13 +457,15 @@ static int blkm_round(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
   TPH_REQUIRE(d > 16 && d <= 112, "tph_propose (blocked, matrix cores): n_dim=%d outside 17..112", d);
   double *Lm, *Wm;
   if (blkm_pack<KERNEL>(ctx, 1, chol, winv, &Lm, &Wm)) return -1;
-  if (att == 0) {
+  if (cnt_in == nullptr) {
     bool rebuilt;
     if (blkm_refresh<KERNEL>(ctx, 1, chol, winv, Lm, Wm, &rebuilt)) return -1;
   }
   return blkm_launch<KERNEL, false>(ctx, (n + 63) / 64, u, n, ld, means, Lm, Wm, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend,
                                     cnt_in, rows_in, att, cnt_out, rows_out, nullptr, 0);
 }
+
+int tph_blkm_tries(const tph_ctx* ctx) { return bm_tries(ctx); }
 
 int tph_blkm_round(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                    const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
@@ -486,8 +523,8 @@ static int blkm_multi(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n,
   const int64_t blocks = (tiles_max + 3) / 4;
   for (int k = 0; k < rounds; ++k)
     if (blkm_launch<KERNEL, true>(ctx, blocks, u, n, ld, means, Lm, Wm, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend,
-                                  k ? cnts + (size_t)(k - 1) * BM_KMAX : (const int32_t*)nullptr, (const int32_t*)rows[(k + 1) & 1], k,
-                                  cnts + (size_t)k * BM_KMAX, rows[k & 1], mt, tiles_max))
+                                  k ? cnts + (size_t)(k - 1) * BM_KMAX : (const int32_t*)nullptr, (const int32_t*)rows[(k + 1) & 1],
+                                  k * bm_tries(ctx), cnts + (size_t)k * BM_KMAX, rows[k & 1], mt, tiles_max))
       return -1;
   int32_t* cnt_cat = cnts + (size_t)25 * BM_KMAX;
   hipLaunchKernelGGL(k_mt_concat, dim3(K), dim3(256), 0, ctx->stream, (const int32_t*)mt, (const int32_t*)(cnts + (size_t)(rounds - 1) * BM_KMAX),

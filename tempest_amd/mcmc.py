@@ -277,8 +277,10 @@ class StepEngine:
                 cap, floor = (6 if nd >= 64 else (8 if nd > 32 else 12)), 64.0
             else:
                 cap, floor = 24, 24576.0
-            while rounds < cap and left * f >= floor:
-                left *= f
+            # (a matrix-core round gives its failing columns `tries` attempts in place: TPH_OPT_BLK_TRIES, 1 at n_dim >= 64, 2 below)
+            f_round = f ** (1 if (nd >= 64 or not screened) else 2)
+            while rounds < cap and left * f_round >= floor:
+                left *= f_round
                 rounds += 1
         if rounds != self.blocked:
             self.blocked = rounds

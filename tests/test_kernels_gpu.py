@@ -769,8 +769,8 @@ def test_volume_variation_one_call_vs_oracle(dev, d):
 @pytest.mark.parametrize("bc", [None, "mixed"])
 @pytest.mark.parametrize("d,rounds", [(19, 0), (33, 0), (50, 0), (65, 0), (100, 0),     # 4 / 8 / 8 / 16 / 16 waves per tile
                                       (33, 2), (50, 24), (65, 3), (100, 6), (112, 2), (17, 3)])   # TPH_OPT_BLOCKED = rounds of the kernel
-@pytest.mark.parametrize("mfma", [1, 0])
-def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, rounds, mfma):
+@pytest.mark.parametrize("mfma,tries", [(1, 1), (1, 3), (0, 1)])
+def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, rounds, mfma, tries):
     """TPH_OPT_PROPOSE_VARIANT 4: attempt 0 of every particle in the blocked kernel -- on the FP64 matrix cores (mfma = 1,
     propose_blkm.hip: a wave per 16 particles, both triangular products as v_mfma_f64_16x16x4 tiles) or with lane = particle
     and L and L^-1 through the scalar cache (mfma = 0, TPH_OPT_BLK_MFMA) --, further rounds of it (attempt 1, 2, ... of the particles still out of bounds, compacted lists), and whoever
@@ -801,6 +801,7 @@ def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, rou
         c.set_option(0, variant)
         c.set_option(4, rounds if variant == 4 else 0)
         c.set_option(15, mfma)                 # TPH_OPT_BLK_MFMA
+        c.set_option(16, tries)                # TPH_OPT_BLK_TRIES: attempts per round, in place (matrix-core kernel)
         up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
         state = c.zeros(10)
         c.propose(kernel, soa(u, dev), None, modes, st, ft, seed, tick, item0, up, mu_, mup, ctl=state)
@@ -821,8 +822,10 @@ def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, rou
     z0 = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, omc.bc_flags(d, list(range(d)), []), seed, tick, item0)[0]
     failed = np.mean(np.any(np.abs(z0 - want_up) > 1e-9, axis=1))
     assert failed > 0.05
-    if rounds > 1 and bc is None:      # with later rounds the redraw probe counts ALL first attempts: n / (n - failures)
+    if rounds > 1 and bc is None and tries == 1:      # with later rounds the redraw probe counts ALL first attempts: n / (n - failures)
         np.testing.assert_allclose(got[4][3][8], 1.0 / (1.0 - failed), rtol=1e-12)
+    if rounds > 1 and bc is None and tries > 1:       # ... of the particles whose first `tries` attempts all failed: f = fs^(1/tries)
+        assert 1.0 < got[4][3][8] < 2.0 / (1.0 - failed)
 
 
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
@@ -859,6 +862,7 @@ def test_blocked_rounds_with_several_modes_vs_oracle_and_multilane(dev, kernel, 
         c = ctx_for(d)
         c.set_option(0, variant)
         c.set_option(4, rounds if variant == 4 else 0)
+        c.set_option(16, 1 if d in (19, 50) else 2)      # TPH_OPT_BLK_TRIES
         up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
         state = c.zeros(10)
         c.propose(kernel, soa(u, dev), at, modes, st, ft, seed, tick, item0, up, mu_, mup, ctl=state)
@@ -874,7 +878,7 @@ def test_blocked_rounds_with_several_modes_vs_oracle_and_multilane(dev, kernel, 
     z0 = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, omc.bc_flags(d, list(range(d)), []), seed, tick, item0)[0]
     failed = np.mean(np.any(np.abs(z0 - want_up) > 1e-9, axis=1))
     assert failed > 0.03
-    if rounds > 1 and bc is None:      # with later rounds the redraw probe counts ALL first attempts: n / (n - failures)
+    if rounds > 1 and bc is None and d in (19, 50):      # one attempt per round: the redraw probe is n / (n - first-attempt failures)
         np.testing.assert_allclose(got[4][3][8], 1.0 / (1.0 - failed), rtol=1e-12)
 
 

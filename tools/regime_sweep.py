@@ -24,7 +24,8 @@ def main():
     ap.add_argument("--kernel", default="tpcn")
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--scales", default="0.10,0.16,0.19,0.21,0.23,0.25,0.27,0.29")
-    ap.add_argument("--rounds", default="1,2,3,4,6,8,12,16")
+    ap.add_argument("--rounds", default="1,2,3,4,6,8,12")
+    ap.add_argument("--tries", default="1,2,3", help="TPH_OPT_BLK_TRIES values (attempts per round, in place)")
     a = ap.parse_args()
     import torch
     from tempest_amd import _lib
@@ -58,10 +59,11 @@ def main():
                                      p(up), p(mu_), p(mup), p(ctl) if carry else None, None)
                 assert rc == 0, lib.tph_last_error()
 
-            def timed(variant, rounds=0, lanes=0):
+            def timed(variant, rounds=0, lanes=0, tries=1):
                 lib.tph_set_option(ctx, 0, variant)
                 lib.tph_set_option(ctx, 4, rounds)
                 lib.tph_set_option(ctx, 13, lanes)
+                lib.tph_set_option(ctx, 16, tries)
                 ctl[0] = 0.0
                 launch(1, False)
                 ctl[0] = 1.0
@@ -76,10 +78,12 @@ def main():
                     ts.append(e0.elapsed_time(e1) * 1e3)
                 return round(float(np.median(ts)), 1), float(ctl[8].item())
             out = {"n": n, "d": d, "kernel": a.kernel, "scale": scale, "blocked_us": {}, "screened_us": {}}
-            for R in (int(v) for v in a.rounds.split(",")):
-                tm, probe = timed(4, R)
-                out["blocked_us"][R] = tm
-                out["estimate"] = round(probe, 3)
+            for tries in (int(v) for v in a.tries.split(",")):
+                for R in (int(v) for v in a.rounds.split(",")):
+                    tm, probe = timed(4, R, tries=tries)
+                    out["blocked_us"][f"{tries}x{R}"] = tm
+                    if tries == 1:
+                        out["estimate"] = round(probe, 3)
             for lanes in (3, 4):
                 tm, probe = timed(6, 0, lanes)
                 out["screened_us"][1 << lanes] = tm
