@@ -416,6 +416,16 @@ int tph_gmm_em_begin(tph_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, i
 int tph_gmm_em_run(tph_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, const double* sw_dev, const int32_t* labels_dev,
                    int label, int K, double* wr_dev, double* state_dev, double reg_covar, double tol, int max_iter, int iters);
 
+/* ---- Student-t EM (opt-in extension: tempest/student.py:40-57, 96-102; the reference's own loop returns its start values,
+ * SURVEY F5 -- that estimator is tph_fit_modes) ------------------------------------------------------------------------
+ * Rows carry int32 multiplicities (counts) and an optional label filter; delta_i = (x_i - mu)^T Sigma^-1 (x_i - mu) per row.
+ * tph_student_sums: for nb <= 16 trial nu: out[b] = (sum_i c_i log w_i, sum_i c_i w_i), w_i = (nu_b + d) / (nu_b + delta_i)
+ * (the data-dependent terms of the digamma equation).  tph_student_weights: v_i = c_i (nu + d) / (nu + delta_i). */
+int tph_student_sums(tph_ctx* ctx, const double* delta_dev, const int32_t* counts_dev, const int32_t* labels_dev, int label, int64_t n,
+                     const double* nus_host, int nb, double* out_host /*[nb][2]*/);
+int tph_student_weights(tph_ctx* ctx, const double* delta_dev, const int32_t* counts_dev, const int32_t* labels_dev, int label, int64_t n,
+                        double nu, double* v_dev);
+
 /* ---- measurement aids (tph_bench_*): used by bench.py, tools/ and the tests; NOT part of the drop-in surface ------------
  * tph_bench_reweight_time: average duration (ms, HIP events on the ctx stream) of `reps` back-to-back launches of the
  * reweight reduction kernel alone for nb trial betas.  tph_bench_membw_time: the box's own ceiling, timed in the same

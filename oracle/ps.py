@@ -441,3 +441,49 @@ def inf_repair(logl, choice_uniforms):
         src[infm] = fin[pick]
     with np.errstate(divide="ignore"):
         return src, float(np.log(fin.size / n))
+
+
+def fit_mvstud_em(data, counts=None, tolerance=1e-6, max_iter=100, nu_hi=1e6, nu_lo=1e-2):
+    """The EM of tempest/student.py:66-116 WITH a working degrees-of-freedom update (opt-in extension).
+
+    The reference evaluates the digamma equation (student.py:40-57) at nu = 1e300, where it rounds to a value >= 0 for any
+    data: nu becomes inf on the first pass and the start values are returned (`fit_mvstud_effective` above).  Here the loop
+    is the reference's line by line -- start values (:60-64), ridge on a failed Cholesky (:73-77), delta_i (:79-87), nu from
+    the root of func0 (:40-57), Sigma = sum_i w_i diff_i diff_i^T / n about the OLD mean (:96-98), mu = sum w x / sum w
+    (:100-102), stop on |nu - last_nu| <= tolerance -- with ONE change: the root is bracketed on [nu_lo, nu_hi] = [1e-2, 1e6]
+    (func0(nu_hi) >= 0 -> nu = inf: the Gaussian limit; func0(nu_lo) <= 0 -> nu_lo).  `counts`: integer multiplicities of the
+    rows (the x4 up-sampling of modes.py:196-201 as counts); n = sum of the counts.  PARITY UNPINNED by the reference (its
+    own loop never iterates): this restatement is the checker of the device version."""
+    from scipy import optimize, special
+    X = np.asarray(data, dtype=np.float64)
+    n_rows, dim = X.shape
+    c = np.ones(n_rows) if counts is None else np.asarray(counts, dtype=np.float64)
+    n = c.sum()
+    mu, Sigma, _ = fit_mvstud_effective(np.repeat(X, c.astype(int), axis=0)) if counts is not None else fit_mvstud_effective(X)
+    nu, last_nu, it = 20.0, 0.0, 0
+
+    def ridge(S):
+        try:
+            np.linalg.cholesky(S)
+            return S
+        except np.linalg.LinAlgError:
+            return S + np.eye(dim) * max(1e-6, 1e-6 * abs(np.trace(S)))
+    while abs(last_nu - nu) > tolerance and it < max_iter:
+        it += 1
+        Sigma = ridge(Sigma)
+        diffs = X - mu
+        delta = np.sum(diffs * np.linalg.solve(Sigma, diffs.T).T, axis=1)
+
+        def func0(v):
+            w = (v + dim) / (v + delta)
+            return (-special.psi(v / 2) + np.log(v / 2) + np.sum(c * np.log(w)) / n - np.sum(c * w) / n + 1
+                    + special.psi((v + dim) / 2) - np.log((v + dim) / 2))
+        last_nu = nu
+        if func0(nu_hi) >= 0:
+            return mu, Sigma, np.inf, it
+        nu = nu_lo if func0(nu_lo) <= 0 else optimize.brentq(func0, nu_lo, nu_hi, xtol=1e-12, rtol=1e-13)
+        w = c * (nu + dim) / (nu + delta)
+        Sigma = (diffs * w[:, None]).T @ diffs / n
+        mu = (w[:, None] * X).sum(axis=0) / w.sum()
+    return mu, ridge(Sigma), nu, it
+

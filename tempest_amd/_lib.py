@@ -38,6 +38,8 @@ SIGNATURES = {
     "tph_bench_reweight_time": (c_int, [ptr, c_dbl, c_int, c_int, ptr]),
     "tph_bench_membw_time": (c_int, [ptr, c_int, c_i64, c_int, ptr]),
     "tph_bench_fp64_time": (c_int, [ptr, c_int, ptr]),
+    "tph_student_sums": (c_int, [ptr, ptr, ptr, ptr, c_int, c_i64, ptr, c_int, ptr]),
+    "tph_student_weights": (c_int, [ptr, ptr, ptr, ptr, c_int, c_i64, c_dbl, ptr]),
     "tph_bench_mf_normals": (c_int, [ptr, c_u64, c_u64, c_u64, c_int, ptr]),
     "tph_bench_mf_counters": (c_int, [ptr, ptr]),
     "tph_weights": (c_int, [ptr, c_dbl, c_dbl, c_dbl, ptr]),

@@ -24,7 +24,7 @@ _FIELDS = (
     "pool", "clustering", "normalize", "cluster_every", "split_threshold", "n_max_clusters", "sample",
     "n_steps", "n_max_steps", "resample", "output_dir", "output_label", "random_state",
 )
-_GPU_FIELDS = ("device", "backend", "batch_prior", "graph")
+_GPU_FIELDS = ("device", "backend", "batch_prior", "graph", "student_em")
 
 
 class SamplerConfig:
@@ -63,6 +63,7 @@ class SamplerConfig:
         backend: str = "auto",
         batch_prior: Optional[bool] = None,
         graph: Optional[bool] = None,
+        student_em: bool = False,
     ):
         put = lambda k, v: object.__setattr__(self, k, v)  # noqa: E731
         local = locals()
@@ -148,6 +149,8 @@ class SamplerConfig:
             bad.append(f"output_label must be str or None, got {type(self.output_label)}")
         if self.graph is not None and not isinstance(self.graph, bool):
             bad.append(f"graph must be bool or None, got {self.graph!r}")
+        if not isinstance(self.student_em, bool):
+            bad.append(f"student_em must be bool, got {self.student_em!r}")
         if self.backend not in ("auto", "torch", "numpy"):
             bad.append(f"backend must be 'auto', 'torch' or 'numpy', got {self.backend!r}")
 

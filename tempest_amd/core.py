@@ -180,7 +180,7 @@ class SamplerCore:
                 normalize=config.normalize)
         self.trainer = Trainer(state=state, pbar=None, clusterer=clusterer, cluster_every=config.cluster_every,
                                clustering=config.clustering, TRIM_ESS=TRIM_ESS, TRIM_BINS=TRIM_BINS,
-                               DOF_FALLBACK=DOF_FALLBACK, rng=self.rng)
+                               DOF_FALLBACK=DOF_FALLBACK, rng=self.rng, student_em=config.student_em)
         self.resampler = Resampler(state=state, n_particles=self.n_local, resample=config.resample,
                                    clusterer=clusterer, clustering=config.clustering,
                                    have_blobs=config.blobs_dtype is not None, rng=self.rng)

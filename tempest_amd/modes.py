@@ -75,7 +75,8 @@ class ModeStatistics:
 
     # ------------------------------------------------------------------------------- fitting
     @classmethod
-    def _fit(cls, ctx, w_dev, n, labels_dev, K, seed, tick, dof_fallback, resample_factor, kept_count=None, comm=None):
+    def _fit(cls, ctx, w_dev, n, labels_dev, K, seed, tick, dof_fallback, resample_factor, kept_count=None, comm=None,
+             student_em=False):
         """Shared device path: multinomial x`resample_factor` up-sampling as multiplicities
         (modes.py:196-201 / 269-274), then median + covariance + chol/inv (student.py effective form).
         With a communicator (`comm` active: w_dev, labels_dev cover this rank's shard of the history) the label sizes,
@@ -109,7 +110,31 @@ class ModeStatistics:
                                                      n_draw_max=resample_factor * nk)
         means, covs, chol, inv, winv = ctx.fit_modes(counts, labels_dev, K, n, global_=sharded)
         dof = torch.full((K,), float(dof_fallback), dtype=torch.float64, device=ctx.device)   # nu = inf -> fallback (F5)
-        return cls(None, None, None, _dev=(ctx, means, covs, chol, inv, dof, winv))
+        ms = cls(None, None, None, _dev=(ctx, means, covs, chol, inv, dof, winv))
+        return ms._student_em(counts, labels_dev, n, dof_fallback, comm=comm) if student_em else ms
+
+    def _student_em(self, counts, labels_dev, n, dof_fallback, comm=None):
+        """Opt-in extension (Sampler(student_em=True)): every mode's (mu, Sigma, nu) refined by the Student-t EM of
+        tempest/student.py:66-116 with a working degrees-of-freedom update, from the default estimator as the start, over the
+        up-sampled rows (counts = multiplicities) of the history on the device; nu = inf keeps dof_fallback."""
+        import torch
+        from .device import KEY_U
+        from .student import em_on_device
+        if comm is not None and comm.active:
+            raise NotImplementedError("student_em=True is not available on a sharded run")
+        ctx = self._ctx
+        ptr, ld = ctx.history_ptr(KEY_U)
+        means, covs = self.means_dev.cpu().numpy().copy(), self.covs_dev.cpu().numpy().copy()
+        dof = np.full(self.K, float(dof_fallback))
+        for k in range(self.K):
+            mu, Sigma, nu, _ = em_on_device(ctx, ptr, ld, n, counts, labels_dev if self.K > 1 else None, k, means[k], covs[k])
+            means[k], covs[k] = mu, Sigma
+            if np.isfinite(nu):
+                dof[k] = nu
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)  # noqa: E731
+        covs_dev = to(covs)
+        chol, inv, winv = ctx.chol_inv(covs_dev)
+        return ModeStatistics(None, None, None, _dev=(ctx, to(means), covs_dev, chol, inv, to(dof), winv))
 
     @classmethod
     def from_particles(cls, u, weights, labels, dof_fallback: float = DOF_FALLBACK, resample_factor: int = 4,

@@ -46,6 +46,7 @@ class Sampler:
         batch_prior: Optional[bool] = None,
         graph: Optional[bool] = None,
         distributed: Optional[bool] = None,
+        student_em: bool = False,
     ):
         """GPU additions (keyword-only):
         device      -- GPU index (default: current torch device; LOCAL_RANK under torchrun).
@@ -59,6 +60,9 @@ class Sampler:
                        callback that cannot be captured falls back with a warning).  False: launch every step's
                        kernels one by one.  None (default): graph when the shard is small enough for the step to be
                        launch-bound (n_particles_per_gpu * n_dim <= 2^19).
+        student_em  -- True: every proposal mode's (mu, Sigma, nu) comes from the Student-t EM of tempest/student.py:66-116 with a
+                       working degrees-of-freedom update, started from the default estimator (an EXTENSION: the reference's
+                       own loop returns its start values with nu = inf -> dof_fallback; see tempest_amd/student.py).  One GPU only.
         distributed -- shard the particles over the ranks of the initialised torch.distributed group
                        (default: yes if a group is initialised); n_particles is the GLOBAL count."""
         wrapped = FunctionWrapper(log_likelihood, log_likelihood_args, log_likelihood_kwargs) \
@@ -71,7 +75,7 @@ class Sampler:
             cluster_every=cluster_every, split_threshold=split_threshold, n_max_clusters=n_max_clusters,
             sample=sample, n_steps=n_steps, n_max_steps=n_max_steps, resample=resample, output_dir=output_dir,
             output_label=output_label, random_state=random_state, device=device, backend=backend,
-            batch_prior=batch_prior, graph=graph)
+            batch_prior=batch_prior, graph=graph, student_em=student_em)
         comm = None
         if distributed is not False:
             from .comm import Comm

@@ -13,7 +13,7 @@ from .resample import _as_device_weights
 
 class Trainer:
     def __init__(self, state, pbar=None, clusterer=None, cluster_every: int = 1, clustering: bool = True,
-                 TRIM_ESS: float = 512, TRIM_BINS: int = 10, DOF_FALLBACK: float = 1.0, rng=None):
+                 TRIM_ESS: float = 512, TRIM_BINS: int = 10, DOF_FALLBACK: float = 1.0, rng=None, student_em: bool = False):
         self.state = state
         self.pbar = pbar
         self.clusterer = clusterer
@@ -22,6 +22,7 @@ class Trainer:
         self.TRIM_ESS = TRIM_ESS
         self.TRIM_BINS = TRIM_BINS
         self.DOF_FALLBACK = DOF_FALLBACK
+        self.student_em = bool(student_em)      # opt-in extension: working Student-t EM per mode (tempest_amd/student.py)
         self.rng = rng
 
     def _rng(self):
@@ -57,7 +58,7 @@ class Trainer:
             tick = rng.next()
             for _ in range(K - 1):
                 rng.next()
-            ms = ModeStatistics._fit(ctx, wt, n_h, labels, K, rng.seed, tick, self.DOF_FALLBACK, 4, comm=st.comm)
+            ms = ModeStatistics._fit(ctx, wt, n_h, labels, K, rng.seed, tick, self.DOF_FALLBACK, 4, comm=st.comm, student_em=self.student_em)
         else:
             cdf = ctx.cdf_global(w, thr[0:1])
             counts = ctx.multinomial_counts_global(cdf, rng.seed, rng.next(), kept_count=thr[2:3], factor=4,
@@ -65,6 +66,8 @@ class Trainer:
             means, covs, chol, inv, winv = ctx.fit_modes(counts, None, 1, n_h, global_=True)
             dof = torch.full((1,), float(self.DOF_FALLBACK), dtype=torch.float64, device=ctx.device)
             ms = ModeStatistics(None, None, None, _dev=(ctx, means, covs, chol, inv, dof, winv))
+            if self.student_em:
+                ms = ms._student_em(counts, None, n_h, self.DOF_FALLBACK, comm=st.comm)
         if self.pbar is not None:
             self.pbar.update_stats(dict(K=ms.K))
         return ms

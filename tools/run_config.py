@@ -67,7 +67,7 @@ def main():
         s = tp.Sampler(lambda u: 20 * u - 10, loglike, d, vectorize=True, n_particles=n, clustering=True, random_state=0,
                        sample=kernel, backend="torch", batch_prior=True)
     elif which == "c5":     # 100-D Neal funnel, a 131 072-particle shard of BASELINE config 5's 2 097 152
-        d, n = 100, 131072
+        d, n = 100, int(__import__("os").environ.get("TEMPEST_AMD_RUN_PARTICLES", "131072"))
         scale = torch.full((d,), 600.0, dtype=torch.float64, device=dev); scale[0] = 30.0
         shift = torch.full((d,), -300.0, dtype=torch.float64, device=dev); shift[0] = -15.0
 
