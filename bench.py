@@ -343,6 +343,15 @@ def main():
                                       "note": "untimed tail of the run (after the K timed iterations), one device "
                                               "synchronisation after every phase; mutate = time inside Mutator.run incl. the "
                                               "user's callbacks"}
+        if use_dist and comm_block is not None and len(tail_steps):
+            # where an iteration's time goes on EVERY rank (the tail's per-phase split, ms per iteration): a phase whose time does
+            # not shrink with the shard -- replicated work, a slow exchange -- shows here, rank by rank
+            keys = list(core.timing)
+            mine = torch.tensor([core.timing[k] * 1e3 / len(tail_steps) for k in keys], dtype=torch.float64,
+                                device="cpu" if rehearsal else dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            comm_block["phase_ms_per_iteration_by_rank"] = {k: [round(float(t[i].item()), 3) for t in allr] for i, k in enumerate(keys)}
         all_steps = np.asarray(s.state._scalars["steps"]); all_beta = np.asarray(s.state._scalars["beta"])
         extra["whole_run"] = {"value": float(np.sum(all_steps[all_beta > 0])) * n_global / t_run, "unit": "particle-mutation-steps/s",
                               "seconds": t_run, "iterations": int(len(all_beta)),
