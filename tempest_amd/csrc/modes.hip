@@ -393,16 +393,27 @@ __global__ void __launch_bounds__(256) k_wsum(const double* __restrict__ hu, int
   const int col = blockIdx.y;
   const double* src = col ? hu + (size_t)(col - 1) * cap : nullptr;
   double s = 0.0, mn = DBL_MAX, mx = -DBL_MAX;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (labels && labels[i] != label) continue;
-    double w = (double)wt[i];
-    if (col) {
-      double v = src[i];
-      s += w * v;
-      if (w > 0.0) { mn = fmin(mn, v); mx = fmax(mx, v); }
-    } else {
-      s += w;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // four rows in flight per lane (the loads of a trip are issued before the first use); accumulated in row order, as one by one
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+    double w[4], v[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = i0 + k * stride;
+      ok[k] = i < n && (!labels || labels[i] == label);
+      w[k] = ok[k] ? (double)wt[i] : 0.0;
+      v[k] = (ok[k] && col) ? src[i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!ok[k]) continue;
+      if (col) {
+        s += w[k] * v[k];
+        if (w[k] > 0.0) { mn = fmin(mn, v[k]); mx = fmax(mx, v[k]); }
+      } else {
+        s += w[k];
+      }
     }
   }
   __shared__ double sh[4];
@@ -759,17 +770,27 @@ __global__ void __launch_bounds__(256) k_wcov_small(const double* __restrict__ h
 #pragma unroll
   for (int j = 0; j < D; ++j) m[j] = mean[j];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    double w = (!labels || labels[i] == label) ? (double)wt[i] : 0.0;
-    double xc[D];
+  // two rows in flight per lane (2 D loads issued before the first use); accumulated in row order, as one by one
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 2 * stride) {
+    double w[2], xc[2][D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) xc[j] = hu[(size_t)j * cap + i] - m[j];
-    int k = 0;
+    for (int r = 0; r < 2; ++r) {
+      const int64_t i = i0 + r * stride;
+      const bool in = i < n;
+      w[r] = (in && (!labels || labels[i] == label)) ? (double)wt[i] : 0.0;
 #pragma unroll
-    for (int a = 0; a < D; ++a) {
-      const double wa = w * xc[a];
+      for (int j = 0; j < D; ++j) xc[r][j] = (in ? hu[(size_t)j * cap + i] : m[j]) - m[j];
+    }
 #pragma unroll
-      for (int b = 0; b <= a; ++b) acc[k++] += wa * xc[b];
+    for (int r = 0; r < 2; ++r) {
+      if (r == 1 && i0 + stride >= n) break;
+      int k = 0;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        const double wa = w[r] * xc[r][a];
+#pragma unroll
+        for (int b = 0; b <= a; ++b) acc[k++] += wa * xc[r][b];
+      }
     }
   }
   __shared__ double sh[4];
@@ -780,6 +801,10 @@ __global__ void __launch_bounds__(256) k_wcov_small(const double* __restrict__ h
     if (threadIdx.x == 0) mine[k] = t;
   }
 }
+
+// grid of the register kernel: at 168 VGPRs three of its blocks fit a CU, and a grid past the 768 resident ones only adds
+// rounds of (start-up latency + 55 block reductions) -- measured on a 3.3 M-row working set: 2048 blocks 143 us
+static inline int wcov_small_blocks(int nblk) { return nblk < 768 ? nblk : 768; }
 
 template <typename WT>
 static bool launch_wcov_small(tph_ctx* ctx, const double* src, int64_t src_ld, const WT* wt, const int32_t* labels, int label,
@@ -878,11 +903,12 @@ static int moments_launch_cov(tph_ctx* ctx, const void* wt, bool wt_is_int, cons
   TPH_REQUIRE(npl <= COV_NPT * 256, "covariance kernel supports n_dim <= 100 (got %d)", d);
   if (d <= 12) {
     // register kernel: block partials [nblk][npl] (no row slices)
-    bool ok = wt_is_int ? launch_wcov_small<int32_t>(ctx, src, src_ld, (const int32_t*)wt, labels, label, n, mean_dev, partials, nblk)
-                        : launch_wcov_small<double>(ctx, src, src_ld, (const double*)wt, labels, label, n, mean_dev, partials, nblk);
+    const int nb = wcov_small_blocks(nblk);
+    bool ok = wt_is_int ? launch_wcov_small<int32_t>(ctx, src, src_ld, (const int32_t*)wt, labels, label, n, mean_dev, partials, nb)
+                        : launch_wcov_small<double>(ctx, src, src_ld, (const double*)wt, labels, label, n, mean_dev, partials, nb);
     TPH_REQUIRE(ok, "covariance: no register kernel for n_dim=%d", d);
     double* csum1 = partials + (size_t)nblk * npl;
-    hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, partials, nblk, npl, csum1);
+    hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, partials, nb, npl, csum1);
     hipLaunchKernelGGL(k_cov_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum1, sums_dev, d, student, cov_dev);
     TPH_LAUNCH_CHECK();
     return 0;
@@ -946,12 +972,22 @@ __global__ void __launch_bounds__(256) k_med_hist1(const double* __restrict__ hu
   __syncthreads();
   const double* src = hu + (size_t)j * cap;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    int c = cnt[i];
-    if (c == 0 || (labels && labels[i] != label)) continue;
-    int d1, d2;
-    med_digits(src[i], lo, scale, d1, d2);
-    atomicAdd(&h[d1], (unsigned int)c);
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {     // four rows in flight per lane
+    int c[4];
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = i0 + k * stride;
+      c[k] = (i < n && (!labels || labels[i] == label)) ? cnt[i] : 0;
+      v[k] = i < n ? src[i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c[k] == 0) continue;
+      int d1, d2;
+      med_digits(v[k], lo, scale, d1, d2);
+      atomicAdd(&h[d1], (unsigned int)c[k]);
+    }
   }
   __syncthreads();
   unsigned int* g = hist1 + (size_t)j * MED_BINS;
@@ -1015,13 +1051,23 @@ __global__ void __launch_bounds__(256) k_med_hist2(const double* __restrict__ hu
   const int b0 = (int)sel[((size_t)j * 2 + 0) * 4], b1 = (int)sel[((size_t)j * 2 + 1) * 4];
   const double* src = hu + (size_t)j * cap;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    int c = cnt[i];
-    if (c == 0 || (labels && labels[i] != label)) continue;
-    int d1, d2;
-    med_digits(src[i], lo, scale, d1, d2);
-    if (d1 == b0) atomicAdd(&h[d2], (unsigned int)c);
-    if (d1 == b1) atomicAdd(&h[MED_BINS + d2], (unsigned int)c);
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {     // four rows in flight per lane
+    int c[4];
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = i0 + k * stride;
+      c[k] = (i < n && (!labels || labels[i] == label)) ? cnt[i] : 0;
+      v[k] = i < n ? src[i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c[k] == 0) continue;
+      int d1, d2;
+      med_digits(v[k], lo, scale, d1, d2);
+      if (d1 == b0) atomicAdd(&h[d2], (unsigned int)c[k]);
+      if (d1 == b1) atomicAdd(&h[MED_BINS + d2], (unsigned int)c[k]);
+    }
   }
   __syncthreads();
   unsigned int* g = hist2 + (size_t)j * 2 * MED_BINS;
@@ -1041,19 +1087,30 @@ __global__ void __launch_bounds__(256) k_med_collect(const double* __restrict__ 
   const int a0 = (int)s0[0], a1 = (int)s0[1], c0 = (int)s1[0], c1 = (int)s1[1];
   const double* src = hu + (size_t)j * cap;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    int c = cnt[i];
-    if (c == 0 || (labels && labels[i] != label)) continue;
-    double v = src[i];
-    int d1, d2;
-    med_digits(v, lo, scale, d1, d2);
-    if (d1 == a0 && d2 == a1) {
-      int slot = atomicAdd(&fill[j * 2 + 0], 1);
-      if (slot < MED_CAP) { vals[((size_t)j * 2 + 0) * MED_CAP + slot] = v; cnts[((size_t)j * 2 + 0) * MED_CAP + slot] = c; }
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {     // four rows in flight per lane
+    int cs[4];
+    double vs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = i0 + k * stride;
+      cs[k] = (i < n && (!labels || labels[i] == label)) ? cnt[i] : 0;
+      vs[k] = i < n ? src[i] : 0.0;
     }
-    if (d1 == c0 && d2 == c1) {
-      int slot = atomicAdd(&fill[j * 2 + 1], 1);
-      if (slot < MED_CAP) { vals[((size_t)j * 2 + 1) * MED_CAP + slot] = v; cnts[((size_t)j * 2 + 1) * MED_CAP + slot] = c; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = cs[k];
+      if (c == 0) continue;
+      const double v = vs[k];
+      int d1, d2;
+      med_digits(v, lo, scale, d1, d2);
+      if (d1 == a0 && d2 == a1) {
+        int slot = atomicAdd(&fill[j * 2 + 0], 1);
+        if (slot < MED_CAP) { vals[((size_t)j * 2 + 0) * MED_CAP + slot] = v; cnts[((size_t)j * 2 + 0) * MED_CAP + slot] = c; }
+      }
+      if (d1 == c0 && d2 == c1) {
+        int slot = atomicAdd(&fill[j * 2 + 1], 1);
+        if (slot < MED_CAP) { vals[((size_t)j * 2 + 1) * MED_CAP + slot] = v; cnts[((size_t)j * 2 + 1) * MED_CAP + slot] = c; }
+      }
     }
   }
 }
@@ -1269,7 +1326,14 @@ __global__ void __launch_bounds__(256) k_nz_scatter(const double* __restrict__ u
       const int64_t pos = out + woff + below;
       cc[pos] = cnt;
       if (lc) lc[pos] = labels[i];
-      for (int j = 0; j < d; ++j) uc[(size_t)j * ldc + pos] = u[(size_t)j * cap + i];
+      for (int j0 = 0; j0 < d; j0 += 8) {        // eight coordinates in flight per kept row
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = j0 + k < d ? u[(size_t)(j0 + k) * cap + i] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (j0 + k < d) uc[(size_t)(j0 + k) * ldc + pos] = v[k];
+      }
     }
     out += tot;
     __syncthreads();
@@ -1538,9 +1602,10 @@ extern "C" int tph_fit_modes_global(tph_ctx* ctx, const int32_t* counts_dev, con
       const int S = cov_slices(npl);
       TPH_REQUIRE(npl <= COV_NPT * 256, "covariance kernel supports n_dim <= 100 (got %d)", d);
       if (d <= 12) {
-        bool ok = launch_wcov_small<int32_t>(ctx, src, src_ld, counts_dev, lab, k, n, mean, part, nblk);
+        const int nb = wcov_small_blocks(nblk);
+        bool ok = launch_wcov_small<int32_t>(ctx, src, src_ld, counts_dev, lab, k, n, mean, part, nb);
         TPH_REQUIRE(ok, "covariance: no register kernel for n_dim=%d", d);
-        hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk, npl, csum);
+        hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nb, npl, csum);
       } else {
         int rpb = S;
         if (launch_wcov<int32_t>(ctx, src, src_ld, counts_dev, lab, k, n, mean, part, nblk, &rpb)) return -1;

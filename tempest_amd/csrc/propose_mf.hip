@@ -270,16 +270,24 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
     mf_wave_sync();
     double acc0 = 0.0, acc1 = 0.0;
     const int jm = d < 64 ? d : 64;
-    {
+    if (d > 64) {
+      // rows lane and lane + 64 side by side: two independent chains of fused multiply-adds, each in column order as everywhere
+      // else (lanes without a second row walk the last one's and drop the sum)
+      const int r1n = d - 64;
+      const double* l0 = LTs + lane;
+      const double* l1 = LTs + jm * 64 + (lane < r1n ? lane : r1n - 1);
+#pragma unroll 8
+      for (int j = 0; j < 64; ++j) {
+        const double z = zv[j];
+        acc0 = fma(l0[j * 64], z, acc0);
+        acc1 = fma(l1[j * r1n], z, acc1);
+      }
+#pragma unroll 4
+      for (int j = 64; j < d; ++j) acc1 = fma(l1[j * r1n], zv[j], acc1);
+    } else {
       const double* l0 = LTs + lane;
 #pragma unroll 8
       for (int j = 0; j < jm; ++j) acc0 = fma(l0[j * 64], zv[j], acc0);
-    }
-    if (d > 64 && lane < d - 64) {
-      const int r1n = d - 64;
-      const double* l1 = LTs + jm * 64 + lane;
-#pragma unroll 8
-      for (int j = 0; j < d; ++j) acc1 = fma(l1[j * r1n], zv[j], acc1);
     }
     bool ok = true;
     double x0 = 0.0, x1 = 0.0;

@@ -136,12 +136,9 @@ __global__ void __launch_bounds__(tph_scan::THREADS) k_seg_tile_sums(const doubl
   using namespace tph_scan;
   const double thr = MODE == MASKED ? thr_dev[0] : 0.0;
   const int64_t t = blockIdx.x / tpb, j = blockIdx.x % tpb;
-  const int64_t lim = (t + 1) * rows;
-  const int64_t base = t * rows + j * TILE + (int64_t)threadIdx.x * ITEMS;
-  double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k)
-    if (base + k < lim) s += load<MODE>(w, base + k, thr);
+  double x[ITEMS];
+  load_tile<MODE>(w, t * rows + j * TILE, (t + 1) * rows, thr, x);
+  double s = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
   __shared__ double sh[THREADS / 64];
   s = tph_block_sum(s, sh);
   if (threadIdx.x == 0) tiles[blockIdx.x] = s;
@@ -198,32 +195,13 @@ __global__ void __launch_bounds__(tph_scan::THREADS) k_seg_apply(const double* _
   using namespace tph_scan;
   const double thr = MODE == MASKED ? thr_dev[0] : 0.0;
   const int64_t t = blockIdx.x / tpb, j = blockIdx.x % tpb;
-  const int64_t lim = (t + 1) * rows;
-  const int64_t base = t * rows + j * TILE + (int64_t)threadIdx.x * ITEMS;
-  double v[ITEMS];
-  double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    s += base + k < lim ? load<MODE>(w, base + k, thr) : 0.0;
-    v[k] = s;
-  }
+  const int64_t lim = (t + 1) * rows, base = t * rows + j * TILE;
+  double x[ITEMS];
+  load_tile<MODE>(w, base, lim, thr, x);
   __shared__ double wsum[THREADS / 64];
-  const double inc = wave_incl(s);
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (lane == 63) wsum[wid] = inc;
-  __syncthreads();
-  double off = tiles[blockIdx.x];
-  for (int k = 0; k < wid; ++k) off += wsum[k];
-  const double prev = __shfl_up(inc, 1, 64);
-  if (lane > 0) off += prev;
+  scan_tile(x, tiles[blockIdx.x], wsum);
   const double lo = table[t], hi = table[T + t];
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k)
-    if (base + k < lim) {
-      double c = fmin(fmax(off + v[k], lo), hi);
-      if (base + k == lim - 1) c = hi;
-      out[base + k] = c;
-    }
+  store_tile(out, base, lim, x, [=](double v, int64_t p) { return p == lim - 1 ? hi : fmin(fmax(v, lo), hi); });
 }
 
 extern "C" int tph_cdf_global(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev, double* cdf_dev,
@@ -448,9 +426,20 @@ __global__ void __launch_bounds__(256) k_gather_rows(const double* __restrict__ 
   extern __shared__ double tile[];
   const int rec = 2 * d + 1, pitch = rec + 1;
   const int64_t i0 = (int64_t)blockIdx.x * ROWS_TILE;
-  for (int e = threadIdx.x; e < ROWS_TILE * rec; e += 256) {
-    const int r = e / rec, c = e - r * rec;
-    if (i0 + r < n_out) tile[r * pitch + c] = rows[(size_t)idx[i0 + r] * rec + c];
+  for (int e0 = threadIdx.x; e0 < ROWS_TILE * rec; e0 += 4 * 256) {      // four indexed loads in flight per lane
+    double v[4];
+    int at[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = e0 + k * 256;
+      const int r = e / rec, c = e - r * rec;
+      const bool in = e < ROWS_TILE * rec && i0 + r < n_out;
+      at[k] = in ? r * pitch + c : -1;
+      v[k] = in ? rows[(size_t)idx[i0 + r] * rec + c] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (at[k] >= 0) tile[at[k]] = v[k];
   }
   __syncthreads();
   for (int e = threadIdx.x; e < ROWS_TILE * rec; e += 256) {

@@ -163,6 +163,24 @@ def test_cdf(dev, n):
     np.testing.assert_allclose(cdfm, np.cumsum(np.where(w >= 1.0, w, 0.0)), rtol=1e-12, atol=1e-300)
 
 
+@pytest.mark.parametrize("off_in,off_out", [(1, 0), (0, 1), (1, 1), (3, 2)])
+def test_cdf_unaligned_views(dev, off_in, off_out):
+    """Weights and cdf at addresses that are 8- but not 16-byte aligned (views into larger arrays): the scan's two-values-per-lane
+    loads and stores fall back to single ones; same values as the aligned call, bit for bit, and nothing written outside."""
+    rs = np.random.RandomState(2)
+    n = 5 * 2048 + 77
+    w = np.exp(rs.randn(n))
+    c = ctx_for(1)
+    aligned = c.cdf(torch.from_numpy(w).to(dev)).cpu().numpy()
+    buf = torch.zeros(n + 8, dtype=torch.float64, device=dev)
+    buf[off_in:off_in + n] = torch.from_numpy(w).to(dev)
+    out = torch.full((n + 8,), -7.0, dtype=torch.float64, device=dev)
+    c.cdf(buf[off_in:off_in + n], out=out[off_out:off_out + n])
+    o = out.cpu().numpy()
+    np.testing.assert_array_equal(o[off_out:off_out + n], aligned)
+    assert np.all(o[:off_out] == -7.0) and np.all(o[off_out + n:] == -7.0)
+
+
 def test_cdf_wide_dynamic_range(dev):
     """Importance weights span tens of orders of magnitude: the scan must keep the small prefix in front of a
     dominant weight (no `inclusive - own` cancellation) and stay monotone."""
