@@ -352,6 +352,58 @@ __device__ inline double tph_gamma_mt(const tph_rng& g, double shape, int first_
   return out;
 }
 
+// The scalar part of the step's adaptation -- per-cluster mean alpha (mcmc.py:180-186), sigma update (:281-288 / :320-323),
+// adaptive step count and stopping rule (:104-140, 192-194, with the `sigmas[:n_nonempty]` weighting quirk), returned statistics
+// (:196-197) -- by ONE thread, on `sigmas[K]` and the step-control block `state` (tempest_hip.h), which may be device memory
+// (k_adapt) or a workgroup's own copy (the persistent step kernel of the HIP-callback plugins: every workgroup adapts for
+// itself from the same sums, with the same arithmetic).  `mailbox` (or NULL): the step's record into pinned host memory.
+__device__ inline void tph_adapt_scalar(int kernel, const double* __restrict__ sums, const double* __restrict__ counts, int K,
+                                        double n_global, int d, int n_steps, int n_max, double* __restrict__ sigmas,
+                                        double* __restrict__ state, double* __restrict__ mailbox, int slots) {
+  const int iteration = (int)state[0] + 1;
+  const double sigma_0 = 2.38 / sqrt((double)d);
+  const double rate = 1.0 / (double)(iteration + 1);
+  double alpha_tot = 0.0;
+  for (int c = 0; c < K; ++c) {
+    alpha_tot += sums[1 + c];
+    if (counts[c] > 0.0) {
+      double mean_accept = sums[1 + c] / counts[c];
+      double s = sigmas[c] + rate * (mean_accept - 0.234);
+      if (kernel == TPH_KERNEL_TPCN) s = fmin(fmax(s, 0.0), fmin(sigma_0, 0.99));
+      sigmas[c] = s;
+    }
+  }
+  const double acc = sums[0] / n_global;
+  // weighted average of sigmas[:n_nonempty] with the non-empty cluster sizes (mcmc.py:107-117)
+  double wsum = 0.0, wsig = 0.0, smean = 0.0;
+  int q = 0;
+  for (int c = 0; c < K; ++c) {
+    smean += sigmas[c];
+    if (counts[c] > 0.0) { wsig += sigmas[q] * counts[c]; wsum += counts[c]; ++q; }
+  }
+  const double weighted_sigma = wsig / wsum;
+  const double n_min = (double)n_steps * d;
+  double ratio = sigma_0 / fmax(1e-6, weighted_sigma);
+  double n_adapt = (double)n_steps * d * (0.234 / fmax(0.01, acc)) * (ratio * ratio);
+  double n_final = fmin(fmax(n_min, n_adapt), (double)n_max * d);
+  long long n_int = (long long)n_final;  // int() truncation
+  state[0] = (double)iteration;
+  state[1] = (iteration >= n_int) ? 1.0 : 0.0;
+  state[2] = acc;
+  state[3] = alpha_tot / n_global;
+  state[4] = (smean / K) / sigma_0;
+  state[5] = (double)n_int;
+  if (mailbox) {
+    // the step's record straight into pinned host memory: the host polls the sequence field instead of putting a
+    // device-to-host copy (and its cross-engine barrier) between two steps of the stream
+    double* rec = mailbox + (size_t)(iteration % slots) * 8;
+    for (int j = 0; j < 6; ++j) rec[j] = state[j];
+    rec[6] = state[8];                                   // mean redraw attempts seen by the d > 16 proposal kernel (0: not reported)
+    __threadfence_system();
+    __hip_atomic_store(rec + 7, (double)iteration, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // tpCN's proposal-density ratio in the Metropolis factor (mcmc.py:251-279): -A + B with A, B = -1/2 (d + nu) log(1 + m / nu) at
 // u' and u.  The lean log (both arguments are >= 1 for finite forms); a NaN / inf form goes through the library log so that
 // alpha stays NaN -> 0 as in the reference.  One definition for k_accept and the HIP-callback plugins (bit-identical paths).

@@ -1249,48 +1249,7 @@ __global__ void __launch_bounds__(1024) k_adapt(int kernel, const double* __rest
     sums = sums_out;
   }
   if (threadIdx.x != 0) return;
-  const int iteration = (int)state[0] + 1;
-  const double sigma_0 = 2.38 / sqrt((double)d);
-  const double rate = 1.0 / (double)(iteration + 1);
-  double alpha_tot = 0.0;
-  for (int c = 0; c < K; ++c) {
-    alpha_tot += sums[1 + c];
-    if (counts[c] > 0.0) {
-      double mean_accept = sums[1 + c] / counts[c];
-      double s = sigmas[c] + rate * (mean_accept - 0.234);
-      if (kernel == TPH_KERNEL_TPCN) s = fmin(fmax(s, 0.0), fmin(sigma_0, 0.99));
-      sigmas[c] = s;
-    }
-  }
-  const double acc = sums[0] / n_global;
-  // weighted average of sigmas[:n_nonempty] with the non-empty cluster sizes (mcmc.py:107-117)
-  double wsum = 0.0, wsig = 0.0, smean = 0.0;
-  int q = 0;
-  for (int c = 0; c < K; ++c) {
-    smean += sigmas[c];
-    if (counts[c] > 0.0) { wsig += sigmas[q] * counts[c]; wsum += counts[c]; ++q; }
-  }
-  const double weighted_sigma = wsig / wsum;
-  const double n_min = (double)n_steps * d;
-  double ratio = sigma_0 / fmax(1e-6, weighted_sigma);
-  double n_adapt = (double)n_steps * d * (0.234 / fmax(0.01, acc)) * (ratio * ratio);
-  double n_final = fmin(fmax(n_min, n_adapt), (double)n_max * d);
-  long long n_int = (long long)n_final;  // int() truncation
-  state[0] = (double)iteration;
-  state[1] = (iteration >= n_int) ? 1.0 : 0.0;
-  state[2] = acc;
-  state[3] = alpha_tot / n_global;
-  state[4] = (smean / K) / sigma_0;
-  state[5] = (double)n_int;
-  if (mailbox) {
-    // the step's record straight into pinned host memory: the host polls the sequence field instead of putting a
-    // device-to-host copy (and its cross-engine barrier) between two steps of the stream
-    double* rec = mailbox + (size_t)(iteration % slots) * 8;
-    for (int j = 0; j < 6; ++j) rec[j] = state[j];
-    rec[6] = state[8];                                   // mean redraw attempts seen by the d > 16 proposal kernel (0: not reported)
-    __threadfence_system();
-    __hip_atomic_store(rec + 7, (double)iteration, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  tph_adapt_scalar(kernel, sums, counts, K, n_global, d, n_steps, n_max, sigmas, state, mailbox, slots);
 }
 
 extern "C" int tph_adapt(tph_ctx* ctx, int kernel, double* sums_dev, const double* counts_dev, int K, double n_global,

@@ -108,7 +108,8 @@ def build_plugin(source: str, n_dim: int, verbose: bool = False) -> Path:
 class HipCallbacks:
     """prior_transform + log_likelihood as HIP device functions (see the module docstring)."""
 
-    def __init__(self, source: str, n_dim: int, fused: bool = True, verbose: bool = False, whole_step: bool = True):
+    def __init__(self, source: str, n_dim: int, fused: bool = True, verbose: bool = False, whole_step: bool = True,
+                 persistent: bool = False):
         if not isinstance(n_dim, int) or n_dim <= 0:
             raise ValueError(f"n_dim must be a positive int, got {n_dim!r}")
         for fn in ("prior_transform", "log_likelihood"):
@@ -116,6 +117,14 @@ class HipCallbacks:
                 raise ValueError(f"HipCallbacks source must define __device__ {fn}(...)")
         self.n_dim, self.source, self.fused = n_dim, source, bool(fused)
         self.whole_step = whole_step           # False: proposal and evaluate+accept as two kernels; "always": at any size
+        # A whole run of steps in ONE cooperative launch (tphu_run) where the whole-step kernel applies.  OFF by default: measured
+        # at 131 072 particles (profiles/r04_persistent_run.json) a step costs 32.5 us inside that launch against 30.0 us step by
+        # step under the captured hipGraph -- 23.0 us whole-step kernel + 6.8 us tph_adapt + 0.4 us between them; the grid
+        # barrier plus every workgroup's own sum of the tile partials cost more than the adaptation launch they replace.
+        # TEMPEST_AMD_PERSISTENT=1/0 overrides the argument.
+        env = os.environ.get("TEMPEST_AMD_PERSISTENT")
+        self.persistent = bool(persistent) if env is None else env != "0"
+        self.run_groups = 0                    # > 0 limits the workgroups of that launch (tests: several tiles per workgroup)
         self.path = build_plugin(source, n_dim, verbose)
         import torch  # noqa: F401  (its HIP runtime must be the one in the process, as for libtempest_hip)
         lib = C.CDLL(str(self.path))
@@ -128,7 +137,9 @@ class HipCallbacks:
                                     C.c_uint64, C.c_uint32, i64, ptr, ptr, ptr, ptr]
         lib.tphu_step.argtypes = [ptr, C.c_int, C.c_double, ptr, ptr, ptr, i64, i64, ptr, ptr, ptr, ptr, ptr, ptr, C.c_uint64,
                                   C.c_uint32, C.c_uint32, i64, ptr, ptr, C.c_int]
-        for f in (lib.tphu_prior, lib.tphu_like, lib.tphu_accept, lib.tphu_step):
+        lib.tphu_run.argtypes = [ptr, C.c_int, ptr, ptr, ptr, i64, i64, ptr, ptr, ptr, ptr, ptr, ptr, C.c_uint64, C.c_uint32, C.c_uint32,
+                                 i64, ptr, ptr, ptr, ptr, C.c_double, C.c_int, C.c_int, ptr, C.c_int, C.c_int, C.c_int, C.c_int]
+        for f in (lib.tphu_prior, lib.tphu_like, lib.tphu_accept, lib.tphu_step, lib.tphu_run):
             f.restype = C.c_int
         if lib.tphu_n_dim() != n_dim:
             raise TempestHipError(f"plugin {self.path} was built for n_dim={lib.tphu_n_dim()}")
@@ -208,6 +219,38 @@ class HipCallbacks:
         and the longer kernel only lowers its occupancy."""
         return (self.fused and self.whole_step and self.n_dim <= 16 and K == 1 and not has_assign
                 and (self.whole_step == "always" or n <= 512 * 1024))
+
+    def can_run(self, K, has_assign, n) -> bool:
+        """A whole run of steps (the loop of mcmc.py:142-208) in ONE cooperative launch: where the whole-step kernel applies
+        (one process; the caller checks that), unless a launch was refused before (no cooperative launch on the device)."""
+        return bool(self.persistent) and self.can_fuse_step(K, has_assign, n)
+
+    def run(self, kernel_id, u, logl, maha_u, modes, sigmas, bc, seed, tick_propose, tick_accept, item0, ctl, partials2, barrier,
+            counts, n_global, n_steps, n_max, mailbox, slots, max_steps, redraw_lanes=0) -> bool:
+        """tphu_run: steps until the stopping rule of `ctl` fires, adaptation included, in one launch (partials2: 2 x tiles x 2
+        doubles; barrier: 4 int32 words; mailbox: (slots + 1) x 8 pinned doubles, the last row takes the final record).  False:
+        the device refused the launch -- nothing ran, step the usual way."""
+        n = u.shape[1]
+        tiles = (n + 255) // 256
+        if partials2.numel() < 4 * tiles or barrier.numel() < 4 or mailbox.numel() < 8 * (slots + 1):
+            raise TempestHipError("HipCallbacks.run: buffers too small")
+        for t in (u, logl, maha_u):
+            if not (t.is_cuda and t.is_contiguous()):
+                raise TempestHipError("HipCallbacks.run: expected contiguous device tensors")
+        p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        winv = getattr(modes, "winv_dev", None)
+        if winv is None:
+            import torch
+            winv = torch.linalg.inv(modes.chol_dev)
+        rc = self.lib.tphu_run(self._stream(u), int(kernel_id), p(u), p(logl), p(maha_u), n, n, p(modes.means_dev), p(modes.chol_dev),
+                               p(winv), p(modes.dof_dev), p(sigmas), p(bc), int(seed), int(tick_propose), int(tick_accept), int(item0),
+                               p(ctl), p(partials2), p(barrier), p(counts), float(n_global), int(n_steps), int(n_max), p(mailbox),
+                               int(slots), int(max_steps), int(redraw_lanes), int(self.run_groups))
+        if rc == -3:
+            self.persistent = False
+            return False
+        self._check(rc, "tphu_run")
+        return True
 
     def step(self, kernel_id, u, logl, maha_u, modes, sigmas, bc, seed, tick_propose, tick_accept, item0, ctl, partials,
              redraw_lanes=0):

@@ -110,8 +110,11 @@ class StepEngine:
         self.unstaged = False          # d > 16 proposal kernel without LDS-staged matrices (redraw-dominated steps)
         self.blocked = 0               # d > 16: rounds of the blocked kernel (attempts in lockstep) before the straggler pass; 0 = off
         self.staged, self.sm_lanes = False, 0      # d > 16: row-walker kernel for redraw-dominated steps, its lanes per particle (log2)
-        self.mailbox = torch.zeros(self.SLOTS, 8, dtype=torch.float64).pin_memory()   # written by tph_adapt, polled here
+        # written by tph_adapt, polled here: the ring of step records and, behind it, the last record of a run made in ONE launch
+        self._mail_all = torch.zeros(self.SLOTS + 1, 8, dtype=torch.float64).pin_memory()
+        self.mailbox = self._mail_all[:self.SLOTS]
         self.mailbox_np = self.mailbox.numpy()
+        self._run_bufs = None
         self.use_graph, self.graph, self.graph_error = bool(use_graph), None, None
         self._keep, self.runs, self._own = None, 0, None
         self._retired_graphs = []
@@ -190,6 +193,57 @@ class StepEngine:
     def _adapt(self, fold=False):
         self.ctx.adapt(self.kernel, self.sums, self.counts, self.K, self.n_global, self.n_steps, self.n_max,
                        self.sigmas, self.ctl, mailbox=self.mailbox, partials=self.partials if fold else None, n=self.n)
+
+    def can_run_all(self):
+        """The whole run in one launch (HipCallbacks.run: every step, adaptation and stopping rule inside one cooperative kernel)?"""
+        return (self.plugin is not None and not self.comm_active
+                and self.plugin.can_run(self.K, self.assign is not None, self.n))
+
+    def run_all(self):
+        """Launch the run loaded by load() as ONE kernel and wait for its last step's record; None if the device refused the
+        launch (nothing ran: step as usual)."""
+        import torch
+        from .device import KERNEL_ID
+        if self._run_bufs is None:
+            tiles = (self.n + 255) // 256
+            self._run_bufs = (self.ctx.empty(4 * tiles), torch.zeros(4, dtype=torch.int32, device=self.ctx.device))
+        partials2, barrier = self._run_bufs
+        last = self._mail_all.numpy()[self.SLOTS]
+        last[7] = -1.0
+        d = self.ctx.n_dim
+        if not self.plugin.run(KERNEL_ID[self.kernel], self.u, self.logl, self.maha_u, self.modes, self.sigmas, self.bc, self.seed,
+                               1, 2, self.item0, self.ctl, partials2, barrier, self.counts, self.n_global, self.n_steps,
+                               self.n_max, self._mail_all, self.SLOTS, self.n_max * d + 1):
+            return None
+        self._poll(last, None, "the run")
+        if last[1] == 0.0:
+            from ._lib import TempestHipError
+            raise TempestHipError("MCMC run in one launch ended without its stopping rule having fired")
+        return last[:6].copy()
+
+    def _poll(self, rec, step, what, timeout=None):
+        """Spin on a pinned record until its sequence field shows `step` (None: any step); errors as in wait_record."""
+        import os
+        import time
+        import torch
+        if timeout is None:
+            env = os.environ.get("TEMPEST_AMD_STEP_TIMEOUT")
+            timeout = float(env) if env else None
+        arrived = (lambda: rec[7] >= 0.0) if step is None else (lambda: rec[7] == step)
+        spins, t0 = 0, None
+        while not arrived():
+            spins += 1
+            if spins & 0x3FFF == 0:
+                now = time.monotonic()
+                t0 = t0 or now
+                if now - t0 > 0.05:
+                    time.sleep(0)
+                if now - t0 > 2.0 and torch.cuda.current_stream(self.ctx.device).query() and not arrived():
+                    from ._lib import TempestHipError
+                    raise TempestHipError(f"{what}: the stream is idle and the device never delivered the record")
+                if timeout is not None and now - t0 > timeout:
+                    from ._lib import TempestHipError
+                    raise TempestHipError(f"{what}: no record from the device after {timeout} s")
 
     def wait_record(self, step, timeout=None):
         """State record (tph_adapt's state[0..5]) of step `step`, polled from the pinned mailbox.  The wait ends with an
@@ -483,8 +537,16 @@ class DeviceMCMC:
         eng.load(u, x, logl, assign, self.modes, self.beta, tick_base, sig0, counts)
         n_min = self.n_steps * d
         it, st = 0, None
-        eng.step(self.comm)
-        while True:
+        if eng.can_run_all():
+            st = eng.run_all()                # every step of the run in one launch (None: refused, nothing ran)
+            if st is not None:
+                it = int(st[0])
+                if self.pbar is not None and self.verbose:
+                    self.pbar.update_stats({"calls": self.pbar.info.get("calls", 0) + it * n_global, "acc": st[3],
+                                            "steps": it, "eff": st[4]})
+        if st is None:
+            eng.step(self.comm)
+        while st is None or st[1] == 0.0:
             it += 1                           # step `it` is enqueued
             eng.step(self.comm)               # one step ahead of the read; a no-op on the device if the rule has fired
             if it < n_min:

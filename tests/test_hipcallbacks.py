@@ -40,9 +40,9 @@ def test_plugin_builds_and_exports_abi():
     assert path.exists() and build_plugin(SRC, 4) == path              # cached by content hash
     assert build_plugin(SRC, 6) != path                                # n_dim is part of the key
     lib = ctypes.CDLL(str(path))
-    for sym in ("tphu_last_error", "tphu_n_dim", "tphu_abi", "tphu_prior", "tphu_like", "tphu_accept", "tphu_step"):
+    for sym in ("tphu_last_error", "tphu_n_dim", "tphu_abi", "tphu_prior", "tphu_like", "tphu_accept", "tphu_step", "tphu_run"):
         assert hasattr(lib, sym), sym
-    assert lib.tphu_n_dim() == 4 and lib.tphu_abi() == 2
+    assert lib.tphu_n_dim() == 4 and lib.tphu_abi() == 3
 
 
 @needs_hipcc
@@ -144,6 +144,55 @@ def test_whole_step_kernel_equals_two_kernel_step(kernel, bcs):
     np.testing.assert_array_equal(out[0][1], out[1][1])
     np.testing.assert_array_equal(out[0][2], out[1][2])
     np.testing.assert_array_equal(out[0][3], out[1][3])
+
+
+@pytest.mark.gpu
+@needs_hipcc
+@pytest.mark.parametrize("kernel,bcs,n,groups", [("tpcn", None, 700, 0), ("rwm", None, 700, 0), ("tpcn", ([0], [2]), 700, 0),
+                                                 ("tpcn", None, 5000, 3), ("rwm", None, 2049, 2)])
+def test_run_in_one_launch_equals_step_by_step(kernel, bcs, n, groups):
+    """tphu_run (every step of a mutation run, adaptation and stopping rule included, in ONE cooperative launch) == the same steps
+    launched one by one (tphu_step + tph_adapt): whole sampler runs bit-identical -- evidence, steps per iteration, acceptance,
+    posterior -- also with several 256-particle tiles per workgroup (`run_groups`) and with a ragged last tile."""
+    import tempest_amd as tp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = 4
+    out = []
+    for persistent in (True, False):
+        cb = tp.HipCallbacks(SRC, d, persistent=persistent)
+        cb.run_groups = groups
+        kw = dict(periodic=bcs[0], reflective=bcs[1]) if bcs else {}
+        s = tp.Sampler(cb.prior_transform, cb.log_likelihood, d, n_particles=n, vectorize=True, clustering=False,
+                       random_state=9, sample=kernel, graph=False, **kw)
+        s.run(n_total=3 * n, progress=False)
+        assert cb.persistent == persistent                      # (the device did not refuse the cooperative launch)
+        out.append((s.evidence()[0], np.asarray(s.state.get_history("steps")), s.posterior()[0],
+                    np.asarray(s.state.get_history("acceptance")), np.asarray(s.state.get_history("efficiency"))))
+    assert out[0][0] == out[1][0]
+    for k in (1, 2, 3, 4):
+        np.testing.assert_array_equal(out[0][k], out[1][k])
+
+
+@pytest.mark.gpu
+@needs_hipcc
+def test_run_in_one_launch_sums_partials_like_the_wide_adapt_kernel():
+    """Above 1024 tiles tph_adapt sums the tile partials with 1024 threads; the one-launch run reproduces that order with its 256
+    (four strided chains per thread, sixteen wave sums): 300 000 particles, same steps and acceptance bit for bit."""
+    import tempest_amd as tp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d, n = 4, 300_000
+    out = []
+    for persistent in (True, False):
+        cb = tp.HipCallbacks(SRC, d, persistent=persistent)
+        s = tp.Sampler(cb.prior_transform, cb.log_likelihood, d, n_particles=n, vectorize=True, clustering=False,
+                       random_state=3, graph=False)
+        s.run(n_total=n, progress=False)
+        out.append((s.evidence()[0], np.asarray(s.state.get_history("steps")), np.asarray(s.state.get_history("acceptance"))))
+    assert out[0][0] == out[1][0]
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
 
 
 @pytest.mark.gpu
