@@ -26,7 +26,7 @@ def pmc_summary(dirname, kernel_prefix="void k_propose_reg"):
 
 
 def main():
-    R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    R = sys.argv[1] if len(sys.argv) > 1 else "r04"
     src = os.path.join(ROOT, "gpurun_out", R, "final")
     dst = os.path.join(ROOT, "profiles")
     cp = lambda a, b: shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))  # noqa: E731
@@ -45,7 +45,9 @@ def main():
         for tag, name in (("", f"c2_{k}.log"), ("_unprofiled", f"c2_{k}_plain.log")):
             line = [ln for ln in open(os.path.join(src, name)).read().splitlines() if ln.startswith("{")]
             if line:
-                c2[k + tag] = json.loads(line[-1])
+                c2[k + tag] = json.loads(line[0])            # first run of the process ...
+                if len(line) > 1:
+                    c2[k + tag + "_second_run_in_process"] = json.loads(line[-1])
     json.dump(c2, open(os.path.join(dst, f"{R}_c2_runs.json"), "w"), indent=1)
     # configs 3 and 5 (shard): kernel stats + the run lines
     others = {}
@@ -57,7 +59,14 @@ def main():
                 if os.path.exists(os.path.join(src, name)):
                     line = [ln for ln in open(os.path.join(src, name)).read().splitlines() if ln.startswith("{")]
                     if line:
-                        others[tag + suffix] = json.loads(line[-1])
+                        others[tag + suffix] = json.loads(line[0])
+                        if len(line) > 1:
+                            others[tag + suffix + "_second_run_in_process"] = json.loads(line[-1])
+    for tag, name in (("c5_shard_262144", "c5_262144.log"), ("sep32_262144_K_grows_to_4", "sep_k4.log"), ("sep32_262144_K_1", "sep_k1.log")):
+        if os.path.exists(os.path.join(src, name)):
+            line = [ln for ln in open(os.path.join(src, name)).read().splitlines() if ln.startswith("{")]
+            if line:
+                others[tag] = json.loads(line[-1])
     if others:
         json.dump(others, open(os.path.join(dst, f"{R}_c3_c5_runs.json"), "w"), indent=1)
     # shard-size bench lines
@@ -146,7 +155,9 @@ def main():
                        "pass, 5 = row-walker kernel (propose_sm.hip; z_rows_lds = TPH_OPT_SM_THRESHOLD, 0 = 32); scenario 'prior' = an "
                        "ensemble from the prior with a proposal as broad as the prior (the first iterations of a run: tens to hundreds of "
                        "redraw attempts per particle); scale > 0 = the ensemble's spread, dialled to a few attempts per particle (the "
-                       "probe of variant 4 is the geometric estimate from the first attempts, that of 3 and 5 the true mean); lib = which build", "runs": rows},
+                       "probe of variant 4 is the geometric estimate from the first attempts, that of 3, 5 and 6 the true mean); 6 = screened batches "
+                       "(propose_mf.hip; `mf` = its counters: attempts, FP64 verifications, contradictions); variant 4 runs its rounds on the "
+                       "FP64 matrix cores and its stragglers through the screened kernel unless the line says nomfma / noscreen; lib = which build", "runs": rows},
               open(os.path.join(dst, f"{R}_propose_d50_d100.json"), "w"), indent=1)
     print("assembled into", dst)
 

@@ -157,7 +157,7 @@ def main():
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
         out = {"what": "tph_propose", "lib": os.path.basename(a.lib or "libtempest_hip.so"), "kernel": a.kernel, "n": n, "d": d,
-               "scenario": scen, "variant": a.variant, "rounds": a.rounds, "scale": a.scale, "lanes": a.lanes, "z_rows_lds": a.thr, "unstaged": bool(a.unstaged), "carry": not a.nocarry, "pending_fraction": a.pending, "median_us": round(float(np.median(ts)), 2),
+               "scenario": scen, "variant": a.variant, "rounds": a.rounds, "scale": a.scale, "lanes": a.lanes, "z_rows_lds": a.thr, "unstaged": bool(a.unstaged), "nomfma": bool(a.nomfma), "noscreen": bool(a.noscreen), "audit": bool(a.audit), "carry": not a.nocarry, "pending_fraction": a.pending, "median_us": round(float(np.median(ts)), 2),
                "min_us": round(float(np.min(ts)), 2), "first_attempt_in_bounds": inb, "mean_attempts_probe": float(ctl[8].item()), "fell_back_to_current": same,
                "algorithmic_bytes": (16 * d + 4 + 16) * n,
                "GBps_algorithmic": round((16 * d + 20) * n / np.median(ts) / 1e3, 1)}
