@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the round's evidence under gpurun_out/rNN/final on the GPU box (then copied into profiles/ by
-# tools/assemble_profiles.py).  Usage: gpurun -- 'bash tools/collect_profiles.sh r03'
+# tools/assemble_profiles.py).  Usage: gpurun -- 'bash tools/collect_profiles.sh r04 [A|B]'  (A: sections 1-5, B: sections 6-8)
 set -e
 R=${1:-r04}
 cd "$GRAFT_REPO_ROOT"
