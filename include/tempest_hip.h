@@ -123,9 +123,14 @@ int tph_synchronize(tph_ctx* ctx);
  * cores (propose_blkm.hip: a wave per 16 particles, L z and |L^-1 (u' - mu)|^2 as v_mfma_f64_16x16x4_f64 tiles, the normals
  * generated straight into the operand layout); 0 = lane = particle with the matrix through the scalar cache (k_propose_blk). */
 #define TPH_OPT_BLK_MFMA 15
-/* TPH_OPT_BLK_TRIES: t (1..3; 0 = default: 1 at n_dim >= 64, 2 below) = a round of the matrix-core kernel evaluates up to t consecutive attempts of its failing
+/* TPH_OPT_BLK_TRIES: t (1..3; 0 = default: 2 up to n_dim 32, 1 above) = a round of the matrix-core kernel evaluates up to t consecutive attempts of its failing
  * columns in place (round k: attempts k t .. k t + t - 1) before a particle is listed for the next round / the straggler pass */
 #define TPH_OPT_BLK_TRIES 16
+/* TPH_OPT_BLK_FAN: 1 (default) = a round of the matrix-core kernel over a LIST gives every listed particle G consecutive
+ * attempts side by side (G = the largest power of two <= 16 with G x list <= n_particles / 2; the first in bounds in attempt order
+ * is the proposal), with the screened kernel as the straggler pass (TPH_OPT_SCREEN); 0 = one attempt per particle and try;
+ * 2 / 3 = the fanned-out list may fill all / a quarter of the ensemble's columns (experiments). */
+#define TPH_OPT_BLK_FAN 17
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- multi-GPU: one process per GPU --------------------------------------

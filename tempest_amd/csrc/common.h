@@ -98,6 +98,7 @@ struct tph_ctx {
   // matrix-core round kernel of the blocked path (propose_blkm.hip): TPH_OPT_BLK_MFMA and its blocked copies of L and L^-1
   int blk_mfma = 1;
   int blk_tries = 0;                // TPH_OPT_BLK_TRIES: attempts a round of the matrix-core kernel gives its failing columns in place (0 = by n_dim)
+  int blk_fan = 1;                  // TPH_OPT_BLK_FAN: list rounds give a straggler up to 16 attempts side by side (1 = default)
   void* bm_buf = nullptr;
   size_t bm_bytes = 0;
   int bm_epoch = -1, bm_kernel = -1, bm_K = 0;
@@ -153,7 +154,7 @@ int tph_blkm_tries(const tph_ctx* ctx);      // attempts per round of the matrix
 int tph_blkm_round(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                    const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
                    const double* ctl, int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, const int32_t* cnt_in,
-                   const int32_t* rows_in, int att, int32_t* cnt_out, int32_t* rows_out);
+                   const int32_t* rows_in, int att, int32_t* cnt_out, int32_t* rows_out, const int32_t* att_in, int32_t* att_out);
 // several modes: every round over mode-pure tiles; the particles still out of bounds are left in one list for the caller
 int tph_blkm_multi(tph_ctx* ctx, int kernel, double* u, const int32_t* assign, int64_t n, int64_t ld, int K, const double* means,
                    const double* chol, const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed,
@@ -163,7 +164,7 @@ int tph_blkm_multi(tph_ctx* ctx, int kernel, double* u, const int32_t* assign, i
 int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                         const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
                         const double* ctl, int64_t item0, double* up, double* maha_up, const int32_t* todo_cnt, const int32_t* todo_rows,
-                        int att0);
+                        int att0, const int32_t* att0_dev = nullptr);      // att0_dev: the first attempt read from the device instead
 
 // --------------------------------------------------------------------------------- device helpers
 #if defined(__HIPCC__)

@@ -252,6 +252,7 @@ extern "C" int tph_set_option(tph_ctx* ctx, int option, int value) {
     case TPH_OPT_MF_AUDIT: ctx->mf_audit = value ? 1 : 0; break;
     case TPH_OPT_BLK_MFMA: ctx->blk_mfma = value ? 1 : 0; break;
     case TPH_OPT_BLK_TRIES: ctx->blk_tries = value < 0 ? 0 : (value > 3 ? 3 : value); break;
+    case TPH_OPT_BLK_FAN: ctx->blk_fan = value < 0 ? 0 : (value > 3 ? 3 : value); break;
     default: TPH_REQUIRE(false, "tph_set_option: unknown option %d", option);
   }
   return 0;

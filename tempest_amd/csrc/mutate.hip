@@ -631,7 +631,7 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   // rounds of the blocked kernel before the straggler pass (TPH_OPT_BLOCKED = R: attempts 0 .. R-1 in lockstep)
   constexpr int BLK_MAX_ROUNDS = 24;
   const int rounds = ctx->blocked < 1 ? 1 : (ctx->blocked > BLK_MAX_ROUNDS ? BLK_MAX_ROUNDS : ctx->blocked);
-  const size_t need = sizeof(double) * 2 * tb + sizeof(int32_t) * (2 * (size_t)n + 32);
+  const size_t need = sizeof(double) * 2 * tb + sizeof(int32_t) * (2 * (size_t)n + 64);
   if (ctx->blk_bytes < need) {
     TPH_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->blk_buf) ctx->retired.push_back(ctx->blk_buf);   // a captured step of a smaller engine may still point here
@@ -642,19 +642,24 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   double* Lb = (double*)ctx->blk_buf;
   double* Wb = Lb + tb;
   int32_t* cnts = (int32_t*)(Wb + tb);               // [k] = particles whose attempts 0..k all left the cube (k < rounds)
-  int32_t* rows[2] = {cnts + 32, cnts + 32 + n};     // their rows: round k writes rows[k & 1], round k + 1 reads it
-  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)cnts, 32);
+  int32_t* atts = cnts + 32;                         // [k] = the first attempt the particles listed by round k have not tried yet
+  int32_t* rows[2] = {cnts + 64, cnts + 64 + n};     // their rows: round k writes rows[k & 1], round k + 1 reads it
+  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)cnts, 64);
   // A launch that is being CAPTURED into a hipGraph always records the rebuild: a replayed step never re-enters this host
   // code, so an epoch test made here would freeze the copies of the capture-time statistics while the caller refreshes the
   // fixed-address chol / winv between runs (the straggler pass and tpCN's carried form read those) -- two covariances inside
   // one Metropolis ratio.  The copies made under capture are not trusted by later eager calls either.
   const bool mfma = ctx->blk_mfma && d <= 112;      // TPH_OPT_BLK_MFMA: the rounds on the FP64 matrix cores (propose_blkm.hip)
   int att_next = rounds;                            // the straggler pass starts here
+  // the list rounds give a straggler several attempts side by side (propose_blkm.hip: fan-out) when the screened kernel finishes
+  // the list: it reads the attempt to go on from on the device (the multi-lane straggler pass takes it by value)
+  const bool fan = mfma && ctx->screen && ctx->blk_fan;
   if (mfma) {
     const int tries = tph_blkm_tries(ctx);      // TPH_OPT_BLK_TRIES: attempts per round, in place
     for (int k = 0; k < rounds; ++k)
       if (tph_blkm_round(ctx, KERNEL, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick.tick, tick.ctl, item0, up, mu_, mup, pend,
-                         k ? cnts + (k - 1) : (const int32_t*)nullptr, (const int32_t*)rows[(k + 1) & 1], k * tries, cnts + k, rows[k & 1]))
+                         k ? cnts + (k - 1) : (const int32_t*)nullptr, (const int32_t*)rows[(k + 1) & 1], k * tries, cnts + k, rows[k & 1],
+                         (fan && k) ? atts + (k - 1) : (const int32_t*)nullptr, fan ? atts + k : (int32_t*)nullptr))
         return -1;
     att_next = rounds * tries;
   } else {
@@ -692,7 +697,7 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   // beyond its range, the multi-lane kernel
   if (ctx->screen && d <= 112)
     return tph_propose_mf_list(ctx, KERNEL, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick.tick, tick.ctl, item0, up, mup,
-                               cnts + (rounds - 1), rows[(rounds - 1) & 1], att_next);
+                               cnts + (rounds - 1), rows[(rounds - 1) & 1], att_next, fan ? atts + (rounds - 1) : (const int32_t*)nullptr);
   // as many lanes per straggler as it has Box-Muller pairs: a straggler's chain of attempts is latency-bound (few blocks
   // have any work), so the pairs of an attempt are generated in ONE round and the rows spread over more lanes
   int lpp = 4;

@@ -135,7 +135,8 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
                                                       double* __restrict__ up, double* __restrict__ maha_u, double* __restrict__ maha_up,
                                                       uint8_t* __restrict__ pend, const int32_t* __restrict__ cnt_in,
                                                       const int32_t* __restrict__ rows_in, int att, int32_t* __restrict__ cnt_out,
-                                                      int32_t* __restrict__ rows_out, const int32_t* __restrict__ mt, int64_t tiles_max, int tries) {
+                                                      int32_t* __restrict__ rows_out, const int32_t* __restrict__ mt, int64_t tiles_max, int tries,
+                                                      const int32_t* __restrict__ att_in, int32_t* __restrict__ att_out, int fan_div) {
   // cnt_in == NULL: round 0, attempt 0 of every particle and the chores of the step (pending moves, form at u, Gamma scale);
   // cnt_in != NULL: attempt `att` of the particles listed by the round before; the step scale comes from where round 0 parked it.
   // MULTI: several modes -- the wave's tile, its mode and the mode's stretch of the lists come from the tile table mt (above).
@@ -149,17 +150,33 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
   int mode = 0, lbase = 0;                // the wave's mode; where its mode's stretch of the list arrays starts
   bool live;
   int64_t i;
+  // FAN-OUT (one mode, att_out given): a listed particle gets G consecutive columns of a tile -- its next G attempts side by side,
+  // the first in bounds in attempt order wins -- with G the largest power of two (<= 16) that keeps the fanned-out list within a
+  // fraction 1 / fan_div of the ensemble's columns.  A round over a short list costs one tile's chain of latencies whatever it holds; spent on G attempts
+  // per particle instead of one it empties the list G times as fast (config 2 mid-run: 4-6 rounds -> 2).  The attempt the NEXT
+  // round starts from travels through att_out / att_in (the width is chosen on the device, from the list's length).
+  int G = 1, lgG = 0, att_base = att;
   if (!MULTI) {
     const int64_t slot = T * 16 + nn;
     int64_t total = n;
     if (!first) {
       total = *cnt_in;
-      if (att == tries && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl)      // the redraw probe from ALL particles' first `tries` attempts
-        const_cast<double*>(tick.ctl)[8] = bm_probe((double)total / (double)n, tries);
+      if (att_out) {
+        att_base = *att_in;
+        while (G < 16 && 2 * (int64_t)fan_div * G * total <= n) { G *= 2; ++lgG; }
+      }
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (att == tries && tick.ctl)          // the redraw probe from ALL particles' first `tries` attempts
+          const_cast<double*>(tick.ctl)[8] = bm_probe((double)total / (double)n, tries);
+        if (att_out) *att_out = att_base + tries * G;
+      }
+      total *= G;
       if ((int64_t)blockIdx.x * 64 >= total) return;                        // the whole block (uniform): nothing listed for it
+    } else if (att_out && blockIdx.x == 0 && threadIdx.x == 0) {
+      *att_out = tries;
     }
     live = slot < total;
-    i = first ? (live ? slot : n - 1) : (int64_t)rows_in[live ? slot : 0];  // dead columns shadow a particle, never store
+    i = first ? (live ? slot : n - 1) : (int64_t)rows_in[live ? (slot >> lgG) : 0];  // dead columns shadow a particle, never store
   } else {
     const int ntiles = mt[0];
     const int32_t* tiles = mt + 4 + 3 * BM_KMAX;
@@ -268,7 +285,7 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
       // the normals of the attempt: lane (k, n) draws pairs k, k + 4, ... of particle n = its operands of steps 2c, 2c + 1
       {
         tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
-        const uint32_t d0 = (uint32_t)(att + t) * (uint32_t)npairs;
+        const uint32_t d0 = (uint32_t)(att_base + t * G + (nn & (G - 1))) * (uint32_t)npairs;
 #pragma unroll
         for (int c = 0; c < NS / 2; ++c) {
           const int q = k + 4 * c;
@@ -307,10 +324,12 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
           X[4 * p + q] = v;
         }
       }
-      // a column is in bounds when its four lanes are
-      const unsigned long long okb = __ballot(ok);
+      // a column is in bounds when its four lanes are; of a particle's G columns the lowest one in bounds is its proposal
+      // (attempts past the redraw cap do not count: the straggler pass proposes the current point for those)
+      const unsigned long long okb = __ballot(ok && pending && att_base + t * G + (nn & (G - 1)) < PROP_MAX_ATTEMPTS);
       const unsigned int okt = (unsigned int)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48)) & 0xFFFFu;
-      const bool now_ok = pending && ((okt >> nn) & 1u);
+      const unsigned int grp = okt & (((1u << G) - 1u) << (nn & ~(G - 1)));
+      const bool now_ok = ((okt >> nn) & 1u) && (grp & ((1u << nn) - 1u)) == 0u;
       // outputs of the columns whose attempt is in bounds
       if (now_ok) {
 #pragma unroll
@@ -332,7 +351,7 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
       } else if (now_ok && k == 0 && maha_up) {
         maha_up[i] = 0.0;
       }
-      if (now_ok) { pending = false; all_ok = true; }
+      if (grp) { pending = false; all_ok = true; }      // the particle is settled (by this column or by a lower one of its group)
     };
     attempt(0);
     if (MAXT > 1 && tries > 1 && __ballot(pending) != 0ull) attempt(1);
@@ -342,7 +361,7 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
     // the block's failures take ONE slot range of their mode's list (an atomic per wave -- 16 384 of them on one address at
     // 262 144 particles -- cost 110 us of a 195 us launch with a fifth of the first attempts out of bounds); a block whose
     // four tiles belong to different modes (at most K - 1 of them) falls back to one atomic per wave
-    const unsigned long long failb = __ballot(live && !all_ok && k == 0);
+    const unsigned long long failb = __ballot(live && !all_ok && k == 0 && (nn & (G - 1)) == 0);
     const int nf = __popcll(failb);
     if (lane == 0) { s_fail[wid] = nf | (__popcll(__ballot(live && k == 0)) << 8); s_mode[wid] = mode; }
     __syncthreads();
@@ -371,7 +390,7 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
       if (lane == 0 && nf) b0 = atomicAdd(cnt_out + mode, nf);
       slot0 = __shfl(b0, 0, 64);
     }
-    if (live && !all_ok && k == 0) rows_out[lbase + slot0 + __popcll(failb & ((1ull << lane) - 1ull))] = (int32_t)i;
+    if ((failb >> lane) & 1ull) rows_out[lbase + slot0 + __popcll(failb & ((1ull << lane) - 1ull))] = (int32_t)i;
     if (first && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl) {      // regime probe: mean attempts implied by this block's failures, 1 / (1 - f)
       const_cast<double*>(tick.ctl)[8] = bm_probe((double)nfail / fmax(1.0, (double)nlive), tries);
     }
@@ -380,7 +399,9 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
 
 // TPH_OPT_BLK_TRIES (0 = by dimension: a retry in place costs a whole tile pass, which pays below n_dim 64 -- regime sweep:
 // 65 536 x 50-D 71 -> 62 us, 262 144 x 32-D 99 -> 79 us at one attempt per particle; 131 072 x 100-D 479 -> 598 us at 1.13)
-static inline int bm_tries(const tph_ctx* ctx) { return ctx->blk_tries > 0 ? (ctx->blk_tries > 3 ? 3 : ctx->blk_tries) : (ctx->d >= 64 ? 1 : 2); }
+// (With the list rounds fanned out -- TPH_OPT_BLK_FAN -- a retry in place only pays at n_dim <= 32: 65 536 x 50-D at 1.3 / 1.8
+// estimated attempts per particle 145 / 205 us with one try against 171 / 235 us with two; 262 144 x 32-D at 2.6: 426 against 376.)
+static inline int bm_tries(const tph_ctx* ctx) { return ctx->blk_tries > 0 ? (ctx->blk_tries > 3 ? 3 : ctx->blk_tries) : (ctx->d > 32 ? 1 : 2); }
 
 // One round of the matrix-core blocked kernel on the ctx stream (mutate.hip drives the rounds of the one-mode path; several
 // modes: tph_blkm_propose_multi below).  The blocked copies of L (permuted steps) and L^-1 (natural steps) of every mode live in
@@ -421,13 +442,15 @@ template <int KERNEL, bool MULTI>
 static int blkm_launch(tph_ctx* ctx, int64_t blocks, double* u, int64_t n, int64_t ld, const double* means, const double* Lm, const double* Wm,
                        const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
                        double* up, double* mu_, double* mup, uint8_t* pend, const int32_t* cnt_in, const int32_t* rows_in, int att,
-                       int32_t* cnt_out, int32_t* rows_out, const int32_t* mt, int64_t tiles_max) {
+                       int32_t* cnt_out, int32_t* rows_out, const int32_t* mt, int64_t tiles_max, const int32_t* att_in = nullptr,
+                       int32_t* att_out = nullptr) {
   const int d = ctx->d, np = bm_panels(d);
   const int tries = bm_tries(ctx);
+  const int fan_div = ctx->blk_fan == 3 ? 4 : (ctx->blk_fan == 2 ? 1 : 2);      // TPH_OPT_BLK_FAN: 1 = half of the columns, 2 = all, 3 = a quarter
   const dim3 grid((unsigned)blocks);
 #define TPH_BM(NPV, BC, MT)                                                                                              \
   hipLaunchKernelGGL((k_propose_blkm<KERNEL, NPV, BC, MULTI, MT>), grid, dim3(256), 0, ctx->stream, u, n, ld, d, means, Lm, Wm, dof, \
-                     sigmas, bc, seed, tick, item0, up, mu_, mup, pend, cnt_in, rows_in, att, cnt_out, rows_out, mt, tiles_max, tries)
+                     sigmas, bc, seed, tick, item0, up, mu_, mup, pend, cnt_in, rows_in, att, cnt_out, rows_out, mt, tiles_max, tries, att_in, att_out, fan_div)
   // (the one-attempt instantiation keeps four waves per SIMD at n_dim = 100: 198 against 247 us at 131 072 particles)
 #define TPH_BM_NP(NPV)                                                                                                   \
   do {                                                                                                                   \
@@ -452,7 +475,7 @@ template <int KERNEL>
 static int blkm_round(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,
                       const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
                       double* up, double* mu_, double* mup, uint8_t* pend, const int32_t* cnt_in, const int32_t* rows_in, int att,
-                      int32_t* cnt_out, int32_t* rows_out) {
+                      int32_t* cnt_out, int32_t* rows_out, const int32_t* att_in, int32_t* att_out) {
   const int d = ctx->d;
   TPH_REQUIRE(d > 16 && d <= 112, "tph_propose (blocked, matrix cores): n_dim=%d outside 17..112", d);
   double *Lm, *Wm;
@@ -462,7 +485,7 @@ static int blkm_round(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
     if (blkm_refresh<KERNEL>(ctx, 1, chol, winv, Lm, Wm, &rebuilt)) return -1;
   }
   return blkm_launch<KERNEL, false>(ctx, (n + 63) / 64, u, n, ld, means, Lm, Wm, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend,
-                                    cnt_in, rows_in, att, cnt_out, rows_out, nullptr, 0);
+                                    cnt_in, rows_in, att, cnt_out, rows_out, nullptr, 0, att_in, att_out);
 }
 
 int tph_blkm_tries(const tph_ctx* ctx) { return bm_tries(ctx); }
@@ -470,13 +493,13 @@ int tph_blkm_tries(const tph_ctx* ctx) { return bm_tries(ctx); }
 int tph_blkm_round(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                    const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
                    const double* ctl, int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, const int32_t* cnt_in,
-                   const int32_t* rows_in, int att, int32_t* cnt_out, int32_t* rows_out) {
+                   const int32_t* rows_in, int att, int32_t* cnt_out, int32_t* rows_out, const int32_t* att_in, int32_t* att_out) {
   const tph_stepctl tick{tick0, ctl};
   if (kernel == TPH_KERNEL_TPCN)
     return blkm_round<TPH_KERNEL_TPCN>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend, cnt_in,
-                                       rows_in, att, cnt_out, rows_out);
+                                       rows_in, att, cnt_out, rows_out, att_in, att_out);
   return blkm_round<TPH_KERNEL_RWM>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend, cnt_in,
-                                    rows_in, att, cnt_out, rows_out);
+                                    rows_in, att, cnt_out, rows_out, att_in, att_out);
 }
 
 // Several modes: all `rounds` rounds of the blocked path over mode-pure tiles; whoever is still out of bounds afterwards is left

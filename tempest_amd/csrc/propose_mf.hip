@@ -177,7 +177,8 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
                                                              int64_t item0, double* __restrict__ up, const double* __restrict__ bfac,
                                                              int lgG, unsigned long long* __restrict__ queue, int audit,
                                                              const int32_t* __restrict__ todo_cnt, const int32_t* __restrict__ todo_rows,
-                                                             int att0) {
+                                                             int att0, const int32_t* __restrict__ att0_dev) {
+  if (att0_dev) att0 = *att0_dev;      // (list mode behind fanned-out rounds: the first untried attempt was decided on the device)
   // todo_cnt != NULL: only the particles LISTED in todo_rows[0 .. *todo_cnt) (those the blocked kernel's rounds left out of
   // bounds), from attempt att0 on; workgroups beyond the list exit before they load anything
   extern __shared__ __attribute__((aligned(16))) unsigned char mf_lds[];
@@ -570,7 +571,7 @@ static int mf_prepare(tph_ctx* ctx, const double* chol, const double* winv, mf_b
 template <int KERNEL>
 static int mf_launch(tph_ctx* ctx, const mf_bufs& b, const double* u, int64_t n, int64_t ld, const double* means, const double* sigmas,
                      const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0, double* up, const double* bfac,
-                     const int32_t* todo_cnt, const int32_t* todo_rows, int att0) {
+                     const int32_t* todo_cnt, const int32_t* todo_rows, int att0, const int32_t* att0_dev = nullptr) {
   const int d = ctx->d, np = mf_panels(d), dpad = 16 * np;
   const int64_t nchunks = (n + MF_CHUNK - 1) / MF_CHUNK;
   const int cus = ctx->n_simd / 4;
@@ -595,7 +596,7 @@ static int mf_launch(tph_ctx* ctx, const mf_bufs& b, const double* u, int64_t n,
       TPH_HIP(hipFuncSetAttribute((const void*)k_propose_mf<KERNEL, BC, NPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((k_propose_mf<KERNEL, BC, NPV>), dim3((unsigned)groups), dim3(64 * MF_WAVES), lds, ctx->stream,    \
                        u, n, ld, d, means, (const unsigned char*)b.pack, (const double*)b.LT, sigmas, bc, seed,           \
-                       tick, item0, up, bfac, lgG, b.queue, audit, todo_cnt, todo_rows, att0);                           \
+                       tick, item0, up, bfac, lgG, b.queue, audit, todo_cnt, todo_rows, att0, att0_dev);                           \
   } while (0)
 #define TPH_MF_NP(NPV) do { if (bc) TPH_MF(true, NPV); else TPH_MF(false, NPV); } while (0)
   switch (np) {
@@ -637,10 +638,11 @@ static int propose_mf(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
 template <int KERNEL>
 static int propose_mf_list(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,
                            const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
-                           double* up, double* maha_up, const int32_t* todo_cnt, const int32_t* todo_rows, int att0) {
+                           double* up, double* maha_up, const int32_t* todo_cnt, const int32_t* todo_rows, int att0,
+                           const int32_t* att0_dev) {
   mf_bufs b;
   if (mf_prepare<KERNEL>(ctx, chol, winv, &b)) return -1;
-  if (mf_launch<KERNEL>(ctx, b, u, n, ld, means, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0)) return -1;
+  if (mf_launch<KERNEL>(ctx, b, u, n, ld, means, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0, att0_dev)) return -1;
   if (KERNEL == TPH_KERNEL_TPCN || maha_up)
     if (launch_maha_tile<KERNEL, 1>(ctx, u, n, ld, means, b.Wb, up, maha_up, tick, nullptr, nullptr, dof, sigmas, seed, item0, nullptr,
                                     todo_cnt, todo_rows)) return -1;
@@ -650,11 +652,11 @@ static int propose_mf_list(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const
 int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                         const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
                         const double* ctl, int64_t item0, double* up, double* maha_up, const int32_t* todo_cnt, const int32_t* todo_rows,
-                        int att0) {
+                        int att0, const int32_t* att0_dev) {
   const tph_stepctl tick{tick0, ctl};
   if (kernel == TPH_KERNEL_TPCN)
-    return propose_mf_list<TPH_KERNEL_TPCN>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0);
-  return propose_mf_list<TPH_KERNEL_RWM>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0);
+    return propose_mf_list<TPH_KERNEL_TPCN>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0, att0_dev);
+  return propose_mf_list<TPH_KERNEL_RWM>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0, att0_dev);
 }
 
 int tph_propose_mf(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,

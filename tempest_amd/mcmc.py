@@ -304,7 +304,8 @@ class StepEngine:
         if screened:
             # crossovers of tools/regime_sweep.py (profiles/r04_regime_sweep.jsonl): blocked rounds + straggler pass against the
             # screened batches, whose time is flat in the attempt count up to ~10 attempts per particle
-            up_est, down_true = (3.0, 5.0) if nd >= 64 else ((2.9, 4.3) if nd > 32 else (8.0, 13.0))
+            # (re-fitted with the list rounds fanned out, TPH_OPT_BLK_FAN: gpurun sweep of round 4, profiles/r04_regime_sweep_fan.jsonl)
+            up_est, down_true = (3.0, 5.0) if nd >= 64 else ((3.4, 5.5) if nd > 32 else (8.0, 13.0))
         else:
             up_est, down_true = (4.5, 8.0) if nd >= 64 else (3.5, 5.0)
         if self.K != 1:
@@ -331,14 +332,24 @@ class StepEngine:
                 cap, floor = (6 if nd >= 64 else (8 if nd > 32 else 12)), 64.0
             else:
                 cap, floor = 24, 24576.0
-            # (a matrix-core round gives its failing columns `tries` attempts in place: TPH_OPT_BLK_TRIES, 1 at n_dim >= 64, 2 below)
-            f_round = f ** (1 if (nd >= 64 or not screened) else 2)
-            while rounds < cap and left * f_round >= floor:
-                left *= f_round
+            # (a matrix-core round gives its failing columns `tries` attempts in place: TPH_OPT_BLK_TRIES, 2 up to n_dim 32, 1 above)
+            f_round = f ** (1 if (nd > 32 or not screened) else 2)
+            fan_opt = int(os.environ.get("TEMPEST_AMD_BLK_FAN", "1"))
+            fan, fan_div = screened and self.K == 1 and fan_opt != 0, {2: 1, 3: 4}.get(fan_opt, 2)
+            left *= f_round                         # after round 0
+            while rounds < cap and left >= floor:
+                # a list round gives every listed particle G attempts side by side (TPH_OPT_BLK_FAN, propose_blkm.hip: the largest
+                # power of two <= 16 with G x list <= n / 2), so the list shrinks by f_round ** G
+                G = 1
+                while fan and G < 16 and 2 * fan_div * G * left <= self.n:
+                    G *= 2
+                left *= f_round ** G
                 rounds += 1
         if rounds != self.blocked:
             self.blocked = rounds
             self.ctx.set_option(OPT_BLOCKED, rounds)
+            from .device import OPT_BLK_FAN
+            self.ctx.set_option(OPT_BLK_FAN, int(os.environ.get("TEMPEST_AMD_BLK_FAN", "1")))      # (debugging aid)
         want_sm = self.K == 1 and not want_blk and walker_ok
         lanes = int(os.environ.get("TEMPEST_AMD_SM_LANES", "0"))      # 0: the library sizes the lane groups (8 or 16 lanes per particle)
         if want_sm != self.staged or lanes != self.sm_lanes:

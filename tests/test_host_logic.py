@@ -175,6 +175,19 @@ def test_proposal_regime_rule_d_gt_16(monkeypatch):
     assert not s100.staged and s100.blocked == 6
     s100._regime(3.1)
     assert s100.staged and s100.blocked == 0
+    s50 = Eng(50, 65536)                             # 33..63-D, with the list rounds fanned out: estimate 3.4 / true mean 5.5
+    s50._regime(30.0)
+    assert s50.staged and s50.blocked == 0
+    s50._regime(5.6)
+    assert s50.staged
+    s50._regime(5.4)
+    assert not s50.staged and 2 <= s50.blocked <= 8
+    s50._regime(3.3)
+    assert not s50.staged and s50.blocked >= 2
+    s50._regime(3.5)
+    assert s50.staged and s50.blocked == 0
+    s50._regime(1.3)                                  # one try per round above 32-D; a fanned-out second round empties the list
+    assert not s50.staged and 2 <= s50.blocked <= 4
     s32 = Eng(32, 262144)
     s32._regime(14.0)
     assert s32.staged

@@ -847,6 +847,53 @@ def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, rou
 
 
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+@pytest.mark.parametrize("d,rounds,tries,spread,n", [(33, 2, 1, 0.2, 5000), (50, 3, 3, 0.25, 4097), (100, 5, 1, 0.16, 3000), (24, 2, 2, 3.0, 900)])
+def test_blocked_list_rounds_fan_out(dev, kernel, d, rounds, tries, spread, n):
+    """TPH_OPT_BLK_FAN: a round over a LIST gives every listed particle G consecutive attempts side by side in its tile (G chosen
+    on the device from the list's length) and the first in bounds in attempt order wins; the attempt the next round -- and the
+    screened straggler pass -- goes on from travels through device memory.  Same attempts win as with one attempt per column and
+    round, the proposals equal to rounding and equal to the oracle's; on ensembles where
+    most first attempts fail, incl. one (spread 3) where nearly every particle runs into the cap of 256 attempts."""
+    rs = np.random.RandomState(5 + d)
+    means = np.full((1, d), 0.5)
+    A = rs.randn(d, d) / np.sqrt(d)
+    covs = ((A @ A.T + np.eye(d)) * (spread ** 2) / 2.0)[None]
+    _, chol, inv = ps.mode_statistics(means, covs)
+    dof = np.array([1e6])
+    sigmas = np.array([min(2.38 / np.sqrt(d), 0.99)])
+    assign = np.zeros(n, dtype=np.int32)
+    u = np.clip(0.5 + 0.2 * rs.randn(n, d), 0.001, 0.999)
+    flags = omc.bc_flags(d)
+    seed, tick, item0 = 4242, 9, 123
+    want_up, want_mu, want_mup = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, flags, seed, tick, item0)
+    modes = _Modes(means, chol, inv, dof, dev)
+    st, ft = torch.from_numpy(sigmas).to(dev), torch.from_numpy(flags).to(dev)
+    got = {}
+    c = ctx_for(d)
+    for fan in (1, 0):
+        c.set_option(0, 4); c.set_option(4, rounds); c.set_option(15, 1); c.set_option(16, tries); c.set_option(17, fan)
+        up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+        state = c.zeros(10)
+        c.propose(kernel, soa(u, dev), None, modes, st, ft, seed, tick, item0, up, mu_, mup, ctl=state)
+        got[fan] = (aos(up), mu_.cpu().numpy(), mup.cpu().numpy())
+    c.set_option(0, 0); c.set_option(4, 0); c.set_option(16, 0); c.set_option(17, 1)
+    # (to rounding, not bit for bit: WHICH kernel evaluates a particle's winning attempt -- a matrix-core round or the screened
+    # kernel's FP64 chain -- depends on the round that settles it, and the two sum a row in different orders)
+    np.testing.assert_allclose(got[1][0], got[0][0], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(got[1][2], got[0][2], rtol=1e-9, atol=1e-9)
+    np.testing.assert_array_equal(np.any(got[1][0] != u, axis=1), np.any(got[0][0] != u, axis=1))
+    np.testing.assert_allclose(got[1][0], want_up, rtol=1e-11, atol=1e-13)
+    if kernel == "tpcn":
+        np.testing.assert_allclose(got[1][2], want_mup, rtol=1e-8, atol=1e-8)
+    moved = np.any(np.abs(got[1][0] - u) > 1e-12, axis=1)
+    z0 = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, omc.bc_flags(d, list(range(d)), []), seed, tick, item0)[0]
+    failed_first = np.mean(np.any(np.abs(z0 - want_up) > 1e-9, axis=1))
+    assert failed_first > 0.15, failed_first                      # the list rounds have work
+    if spread >= 3.0:
+        assert np.mean(~moved) > 0.5                              # most particles ran into the redraw cap: the current point
+
+
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
 @pytest.mark.parametrize("bc", [None, "mixed"])
 @pytest.mark.parametrize("d,K,rounds,n", [(19, 3, 1, 3000), (32, 4, 3, 2999), (50, 2, 2, 1000), (100, 3, 4, 700), (33, 5, 24, 530)])
 def test_blocked_rounds_with_several_modes_vs_oracle_and_multilane(dev, kernel, bc, d, K, rounds, n):
