@@ -246,9 +246,17 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
   if (lane == 0) ahead = atomicAdd(&queue[0], 1ull);
 #ifdef MF_PROFILE
   long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_t = clock64();      // refill, setup, jobs, mfma + check, verify, cap, batches
+#ifdef MF_PROFILE_VERIFY      // (the four counters are the parts of the FP64 evaluation instead: Box-Muller round, wait for u, rows, tail)
+#define MF_PF(k) do { } while (0)
+#define MF_PV(k) do { const long long now_ = clock64(); pf[k] += now_ - pf_t; pf_t = now_; } while (0)
+#else
 #define MF_PF(k) do { const long long now_ = clock64(); pf[k] += now_ - pf_t; pf_t = now_; } while (0)
+#endif
 #else
 #define MF_PF(k) do { } while (0)
+#endif
+#ifndef MF_PV
+#define MF_PV(k) do { } while (0)
 #endif
 
   // FP64 evaluation of the attempt in column c, by the arithmetic of the other proposal kernels (lane = row; the normals of
@@ -261,6 +269,9 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
     const double uj0 = u[(size_t)rr0 * ld + R], uj1 = d > 64 ? u[(size_t)rr1 * ld + R] : 0.0;
     const double mu0 = (KERNEL == TPH_KERNEL_TPCN) ? means[rr0] : 0.0, mu1 = (KERNEL == TPH_KERNEL_TPCN) ? means[rr1] : 0.0;
     const double b = (KERNEL == TPH_KERNEL_TPCN) ? bfac[R] : sigma;
+#ifdef MF_PROFILE_VERIFY
+    pf_t = clock64();
+#endif
     tph_rng gz(seed, tk, TPH_TAG_NORMAL, (uint64_t)(item0 + R));
     for (int q = lane; q < npairs; q += 64) {
       double z0, z1;
@@ -269,6 +280,11 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
       zv[2 * q + 1] = z1;
     }
     mf_wave_sync();
+    MF_PV(0);
+#ifdef MF_PROFILE_VERIFY
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MF_PV(1);
+#endif
     double acc0 = 0.0, acc1 = 0.0;
     const int jm = d < 64 ? d : 64;
     if (d > 64) {
@@ -290,6 +306,7 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
 #pragma unroll 8
       for (int j = 0; j < jm; ++j) acc0 = fma(l0[j * 64], zv[j], acc0);
     }
+    MF_PV(2);
     bool ok = true;
     double x0 = 0.0, x1 = 0.0;
     if (lane < d) {
@@ -315,6 +332,7 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
       if (lane + 64 < d) up[(size_t)(lane + 64) * ld + R] = x1;
     }
     mf_wave_sync();
+    MF_PV(3);
     return all;
   };
 
