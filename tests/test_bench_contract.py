@@ -113,6 +113,9 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     assert d2["config"]["particles_global"] == 32768 and d2["config"]["particles_per_gpu"] == 16384
     assert d2["hip_callbacks"]["value"] and d2["hip_callbacks"]["same_schedule_as_value_run"]
     assert d2["weak_scaling"]["particles_global"] == 65536 and d2["weak_scaling"]["value"] > 0
+    phases = d2["comm"]["phase_ms_per_iteration_by_rank"]        # every rank's time per phase: which one is the straggler
+    assert set(phases) >= {"reweight", "train", "resample", "mutate", "commit"}
+    assert all(len(v) == 2 and all(t >= 0.0 for t in v) for v in phases.values()) and max(phases["mutate"]) > 0.0
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-hip-callbacks"] + common, capture_output=True,
                          text=True, timeout=600, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
