@@ -104,6 +104,11 @@ def test_screened_kernel_vs_oracle_and_row_walker(dev, kernel, bc, d, lanes):
         np.testing.assert_array_equal(got[0], walk[0])
         np.testing.assert_array_equal(got[2], walk[2])
         assert got[3][8] == walk[3][8]                          # the same attempts won
+    # the product path (audit off) is the same kernel without the extra evaluations: same proposals, counters and probe
+    fast = _run(6, d, kernel, u, modes, st, ft, seed, tick, item0, dev, lanes=lanes, audit=False)
+    np.testing.assert_array_equal(fast[0], got[0])
+    np.testing.assert_array_equal(fast[2], got[2])
+    assert fast[3][8] == got[3][8] and fast[4]["attempts"] == got[4]["attempts"] and fast[4]["contradictions"] == 0
 
 
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
