@@ -37,9 +37,13 @@ __global__ void __launch_bounds__(GMM_THREADS) k_gmm_estep(const double* __restr
       if (mode == 2 && label_out) label_out[i] = -1;
       continue;
     }
-    for (int j = 0; j < d; ++j) {
-      double v = x[(size_t)j * ld + i];
-      xs[j * GMM_THREADS] = shift ? (v - shift[j]) * scale[j] : v;
+    for (int j0 = 0; j0 < d; j0 += 8) {            // eight coordinates requested before the first is stored (one by one the fill
+      double v[8];                                 // of a row was a chain of d memory round trips)
+#pragma unroll
+      for (int a = 0; a < 8; ++a) v[a] = j0 + a < d ? x[(size_t)(j0 + a) * ld + i] : 0.0;
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+        if (j0 + a < d) xs[(j0 + a) * GMM_THREADS] = shift ? (v[a] - shift[j0 + a]) * scale[j0 + a] : v[a];
     }
     double pk[GMM_KMAX_RESP];
     double best = -INFINITY, minm = INFINITY;

@@ -581,10 +581,24 @@ __global__ void __launch_bounds__(256) k_wcov_tiled(const double* __restrict__ h
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int64_t r0 = t * COV_ROWS;
     __syncthreads();
-    for (int e = threadIdx.x; e < d * COV_ROWS; e += blockDim.x) {
-      int j = e / COV_ROWS, r = e % COV_ROWS;
-      int64_t i = r0 + r;
-      xs[j * COV_LD + r] = i < n ? hu[(size_t)j * cap + i] - mean[j] : 0.0;
+    {
+      // the tile's fill: wave w takes columns w, w + 4, ..., EIGHT of them requested before the first is stored (as one load and
+      // one store per trip the fill was a chain of d / 4 memory round trips per tile: config 3's launches 150 -> 133 us)
+      const int r = threadIdx.x & 63, jw = threadIdx.x >> 6;
+      const int64_t i = r0 + r;
+      for (int j0 = jw; j0 < d; j0 += 32) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int j = j0 + 4 * k;
+          v[k] = (j < d && i < n) ? hu[(size_t)j * cap + i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int j = j0 + 4 * k;
+          if (j < d) xs[j * COV_LD + r] = i < n ? v[k] - mean[j] : 0.0;
+        }
+      }
     }
     if (threadIdx.x < COV_ROWS) {
       int64_t i = r0 + threadIdx.x;
