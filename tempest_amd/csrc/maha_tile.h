@@ -43,16 +43,40 @@ __global__ void __launch_bounds__(64 * WV) k_maha_tile(double* __restrict__ u, i
 #endif
   const bool form = KERNEL == TPH_KERNEL_TPCN && (MODE == 1 || !tick.carry());
   if (MODE == 0) {
+    // (the rows of a lane's particle are requested eight at a time: one by one they are a chain of d / WV memory round trips)
     const bool pd = pend && live && pend[i];
-    for (int j = wid; j < d; j += WV) {
-      double uj = u[(size_t)j * ld + ii];
-      if (pd) { uj = up[(size_t)j * ld + i]; u[(size_t)j * ld + i] = uj; }
-      if (form) xs[(size_t)j * 64 + lane] = uj - means[j];
+    for (int j0 = wid; j0 < d; j0 += 8 * WV) {
+      double uj[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int j = j0 + a * WV;
+        uj[a] = j < d ? (pd ? up[(size_t)j * ld + i] : u[(size_t)j * ld + ii]) : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int j = j0 + a * WV;
+        if (j < d) {
+          if (pd) u[(size_t)j * ld + i] = uj[a];
+          if (form) xs[(size_t)j * 64 + lane] = uj[a] - means[j];
+        }
+      }
     }
     __syncthreads();
     if (pd && wid == 0) pend[i] = 0;
   } else if (form) {
-    for (int j = wid; j < d; j += WV) xs[(size_t)j * 64 + lane] = up[(size_t)j * ld + ii] - means[j];
+    for (int j0 = wid; j0 < d; j0 += 8 * WV) {
+      double v[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int j = j0 + a * WV;
+        v[a] = j < d ? up[(size_t)j * ld + ii] : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int j = j0 + a * WV;
+        if (j < d) xs[(size_t)j * 64 + lane] = v[a] - means[j];
+      }
+    }
     __syncthreads();
   }
   if (KERNEL != TPH_KERNEL_TPCN) {

@@ -1957,7 +1957,19 @@ __global__ void __launch_bounds__(256) k_cv_sum_blk(const double* __restrict__ h
     const double ww = i < n ? w[i] : 0.0;
     if (__ballot(ww != 0.0) == 0ull) continue;     // the four waves see the same 64 weights: uniform over the block
     __syncthreads();
-    for (int j = wid; j < d; j += 4) xs[(size_t)j * 64 + lane] = i < n ? hu[(size_t)j * cap + i] - mean[j] : 0.0;
+    for (int j0 = wid; j0 < d; j0 += 32) {        // eight coordinates requested before the first is stored
+      double v[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int j = j0 + 4 * a;
+        v[a] = (j < d && i < n) ? hu[(size_t)j * cap + i] : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int j = j0 + 4 * a;
+        if (j < d) xs[(size_t)j * 64 + lane] = i < n ? v[a] - mean[j] : 0.0;
+      }
+    }
     __syncthreads();
     double d2 = 0.0;
     tri_apply(Wb, d, xs, lane, wid, 4, [&](int, double y) { d2 = fma(y, y, d2); });
