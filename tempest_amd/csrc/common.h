@@ -164,7 +164,9 @@ int tph_blkm_multi(tph_ctx* ctx, int kernel, double* u, const int32_t* assign, i
 int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                         const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
                         const double* ctl, int64_t item0, double* up, double* maha_up, const int32_t* todo_cnt, const int32_t* todo_rows,
-                        int att0, const int32_t* att0_dev = nullptr);      // att0_dev: the first attempt read from the device instead
+                        int att0, const int32_t* att0_dev = nullptr,       // att0_dev: the first attempt read from the device instead
+                        int queue_zeroed = 0);                             // 1: the caller zeroed tph_mf_queue_words() on the stream already
+unsigned int* tph_mf_queue_words(tph_ctx* ctx);      // the 32 work-queue words of the screened kernel (allocates its buffers; NULL on error)
 
 // --------------------------------------------------------------------------------- device helpers
 #if defined(__HIPCC__)
@@ -461,6 +463,10 @@ __device__ __forceinline__ double maha_w(const double* __restrict__ W, const dou
 // back holding stale data on the second replay of a captured step; the same launch sequence issued eagerly was fine).
 static __global__ void k_zero_words(unsigned int* __restrict__ p, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+static __global__ void k_zero_words2(unsigned int* __restrict__ p, int n, unsigned int* __restrict__ q, int m) {      // two blocks of words, one launch
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+  for (int i = threadIdx.x; i < m; i += blockDim.x) q[i] = 0u;
 }
 
 // ---- wave / block reductions (wave64) ----

@@ -644,7 +644,10 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   int32_t* cnts = (int32_t*)(Wb + tb);               // [k] = particles whose attempts 0..k all left the cube (k < rounds)
   int32_t* atts = cnts + 32;                         // [k] = the first attempt the particles listed by round k have not tried yet
   int32_t* rows[2] = {cnts + 64, cnts + 64 + n};     // their rows: round k writes rows[k & 1], round k + 1 reads it
-  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)cnts, 64);
+  // (with the screened kernel as the straggler pass its work-queue words are zeroed by the same launch: one launch less per step)
+  unsigned int* mfq = (ctx->screen && d <= 112) ? tph_mf_queue_words(ctx) : nullptr;
+  if (mfq) hipLaunchKernelGGL(k_zero_words2, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)cnts, 64, mfq, 32);
+  else hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)cnts, 64);
   // A launch that is being CAPTURED into a hipGraph always records the rebuild: a replayed step never re-enters this host
   // code, so an epoch test made here would freeze the copies of the capture-time statistics while the caller refreshes the
   // fixed-address chol / winv between runs (the straggler pass and tpCN's carried form read those) -- two covariances inside
@@ -697,7 +700,8 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   // beyond its range, the multi-lane kernel
   if (ctx->screen && d <= 112)
     return tph_propose_mf_list(ctx, KERNEL, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick.tick, tick.ctl, item0, up, mup,
-                               cnts + (rounds - 1), rows[(rounds - 1) & 1], att_next, fan ? atts + (rounds - 1) : (const int32_t*)nullptr);
+                               cnts + (rounds - 1), rows[(rounds - 1) & 1], att_next, fan ? atts + (rounds - 1) : (const int32_t*)nullptr,
+                               mfq ? 1 : 0);
   // as many lanes per straggler as it has Box-Muller pairs: a straggler's chain of attempts is latency-bound (few blocks
   // have any work), so the pairs of an attempt are generated in ONE round and the rows spread over more lanes
   int lpp = 4;

@@ -553,8 +553,7 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
 // persistent buffers of the screened kernel (queue words | blocked L^-1 (tri.h, tpCN forms) | screening pack | transposed FP64
 // factor), rebuilt when the caller's mode statistics change
 struct mf_bufs { unsigned long long* queue; double* Wb; unsigned char* pack; double* LT; };
-template <int KERNEL>
-static int mf_prepare(tph_ctx* ctx, const double* chol, const double* winv, mf_bufs* b) {
+static int mf_alloc(tph_ctx* ctx, size_t* off_wb_, size_t* off_pack_, size_t* off_lt_) {
   const int d = ctx->d, np = mf_panels(d);
   const size_t tb8 = tri_blocked_doubles(d);
   const size_t off_wb = 128, off_pack = off_wb + sizeof(double) * tb8;
@@ -567,6 +566,18 @@ static int mf_prepare(tph_ctx* ctx, const double* chol, const double* winv, mf_b
     TPH_HIP(hipMalloc((void**)&ctx->mf_buf, need));
     ctx->mf_bytes = need;
   }
+  if (off_wb_) { *off_wb_ = off_wb; *off_pack_ = off_pack; *off_lt_ = off_lt; }
+  return 0;
+}
+unsigned int* tph_mf_queue_words(tph_ctx* ctx) {
+  if (ctx->d <= 16 || ctx->d > MF_MAX_DIM || mf_alloc(ctx, nullptr, nullptr, nullptr)) return nullptr;
+  return (unsigned int*)ctx->mf_buf;
+}
+template <int KERNEL>
+static int mf_prepare(tph_ctx* ctx, const double* chol, const double* winv, mf_bufs* b, bool zero = true) {
+  const int d = ctx->d, np = mf_panels(d);
+  size_t off_wb, off_pack, off_lt;
+  if (mf_alloc(ctx, &off_wb, &off_pack, &off_lt)) return -1;
   b->queue = (unsigned long long*)ctx->mf_buf;
   b->Wb = (double*)((char*)ctx->mf_buf + off_wb);
   b->pack = (unsigned char*)ctx->mf_buf + off_pack;
@@ -581,7 +592,7 @@ static int mf_prepare(tph_ctx* ctx, const double* chol, const double* winv, mf_b
     if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, winv, d, b->Wb);
     ctx->mf_epoch = capturing ? -1 : ctx->modes_epoch; ctx->mf_src = (const void*)chol; ctx->mf_kernel = KERNEL;
   }
-  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)b->queue, 32);
+  if (zero) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)b->queue, 32);
   return 0;
 }
 
@@ -657,9 +668,9 @@ template <int KERNEL>
 static int propose_mf_list(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,
                            const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0,
                            double* up, double* maha_up, const int32_t* todo_cnt, const int32_t* todo_rows, int att0,
-                           const int32_t* att0_dev) {
+                           const int32_t* att0_dev, bool queue_zeroed) {
   mf_bufs b;
-  if (mf_prepare<KERNEL>(ctx, chol, winv, &b)) return -1;
+  if (mf_prepare<KERNEL>(ctx, chol, winv, &b, !queue_zeroed)) return -1;
   if (mf_launch<KERNEL>(ctx, b, u, n, ld, means, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0, att0_dev)) return -1;
   if (KERNEL == TPH_KERNEL_TPCN || maha_up)
     if (launch_maha_tile<KERNEL, 1>(ctx, u, n, ld, means, b.Wb, up, maha_up, tick, nullptr, nullptr, dof, sigmas, seed, item0, nullptr,
@@ -670,11 +681,11 @@ static int propose_mf_list(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const
 int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                         const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
                         const double* ctl, int64_t item0, double* up, double* maha_up, const int32_t* todo_cnt, const int32_t* todo_rows,
-                        int att0, const int32_t* att0_dev) {
+                        int att0, const int32_t* att0_dev, int queue_zeroed) {
   const tph_stepctl tick{tick0, ctl};
   if (kernel == TPH_KERNEL_TPCN)
-    return propose_mf_list<TPH_KERNEL_TPCN>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0, att0_dev);
-  return propose_mf_list<TPH_KERNEL_RWM>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0, att0_dev);
+    return propose_mf_list<TPH_KERNEL_TPCN>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0, att0_dev, queue_zeroed != 0);
+  return propose_mf_list<TPH_KERNEL_RWM>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0, att0_dev, queue_zeroed != 0);
 }
 
 int tph_propose_mf(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
