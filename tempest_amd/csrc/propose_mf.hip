@@ -207,13 +207,27 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
   {
     double* dstl = (double*)(mf_lds + mf_tables_bytes(NP));
     const int nl = mf_lt_doubles(d);
-    for (int e = threadIdx.x; e < nl; e += blockDim.x) dstl[e] = LT[e];
+    // (eight values requested before the first is stored: one by one the copy is a chain of nl / 512 memory round trips in front
+    // of every launch -- 15 at 100-D --, which a launch over a short straggler list consists of)
+    for (int e0 = threadIdx.x; e0 < nl; e0 += 8 * (int)blockDim.x) {
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int e = e0 + k * (int)blockDim.x; v[k] = e < nl ? LT[e] : 0.0; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int e = e0 + k * (int)blockDim.x; if (e < nl) dstl[e] = v[k]; }
+    }
   }
   {
     const uint32_t* src = (const uint32_t*)(pack + 16);
     uint32_t* dst = (uint32_t*)mf_lds;
     const int words = NBLK * 128 + 2 * DPAD;
-    for (int e = threadIdx.x; e < words; e += blockDim.x) dst[e] = src[e];
+    for (int e0 = threadIdx.x; e0 < words; e0 += 8 * (int)blockDim.x) {
+      uint32_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int e = e0 + k * (int)blockDim.x; v[k] = e < words ? src[e] : 0u; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int e = e0 + k * (int)blockDim.x; if (e < words) dst[e] = v[k]; }
+    }
     for (int e = threadIdx.x; e < DPAD; e += blockDim.x) bcs[e] = (HAS_BC && e < d) ? bc[e] : (uint8_t)TPH_BC_STRICT;
   }
   const float inv_scale = ((const float*)pack)[0];
