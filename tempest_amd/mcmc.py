@@ -110,6 +110,13 @@ class StepEngine:
         self.unstaged = False          # d > 16 proposal kernel without LDS-staged matrices (redraw-dominated steps)
         self.blocked = 0               # d > 16: rounds of the blocked kernel (attempts in lockstep) before the straggler pass; 0 = off
         self.staged, self.sm_lanes = False, 0      # d > 16: row-walker kernel for redraw-dominated steps, its lanes per particle (log2)
+        import os
+        self._screened = os.environ.get("TEMPEST_AMD_SCREEN", "1") != "0" and d <= 112
+        if (d > 16 and K == 1 and not has_assign and self._screened and os.environ.get("TEMPEST_AMD_STAGED", "1") != "0"):
+            # Nothing is known about the redraw rate before an engine's first steps: they run as screened batches, whose time is
+            # flat in it (0.4-3 ms), instead of through the multi-lane kernel, whose time is not (30 ms per launch from the prior
+            # at 131 072 x 100-D: three such launches were 2 % of the config-5 shard's run); the probe of step 2 picks the regime.
+            self.staged = True
         # written by tph_adapt, polled here: the ring of step records and, behind it, the last record of a run made in ONE launch
         self._mail_all = torch.zeros(self.SLOTS + 1, 8, dtype=torch.float64).pin_memory()
         self.mailbox = self._mail_all[:self.SLOTS]
@@ -147,6 +154,8 @@ class StepEngine:
             self.ctx.set_option(OPT_ML_UNSTAGED, 1 if self.unstaged else 0)
             self.ctx.set_option(OPT_STAGED_REDRAW, 1 if self.staged else 0)
             self.ctx.set_option(OPT_SM_LANES, self.sm_lanes)
+            from .device import OPT_SCREEN
+            self.ctx.set_option(OPT_SCREEN, 1 if self._screened else 0)
         self.sigmas.fill_(sigma_init)
         self.pending.zero_()
         self.counts.copy_(counts)
