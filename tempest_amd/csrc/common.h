@@ -159,7 +159,7 @@ int tph_blkm_round(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, c
 int tph_blkm_multi(tph_ctx* ctx, int kernel, double* u, const int32_t* assign, int64_t n, int64_t ld, int K, const double* means,
                    const double* chol, const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed,
                    uint32_t tick0, const double* ctl, int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, int rounds,
-                   const int32_t** todo_cnt, const int32_t** todo_rows);
+                   const int32_t** todo_cnt, const int32_t** todo_rows, const int32_t** todo_att);      // todo_att[mode]: where its list goes on (or NULL)
 // the same over a device-side list of particles (count + rows), from attempt att0: the straggler pass behind the blocked kernel
 int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                         const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,

@@ -216,7 +216,8 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ 
                                                            int64_t item0, double* __restrict__ up,
                                                            double* __restrict__ maha_u, double* __restrict__ maha_up,
                                                            uint8_t* __restrict__ pend, const int32_t* __restrict__ todo,
-                                                           const int32_t* __restrict__ todo_rows, int att0) {
+                                                           const int32_t* __restrict__ todo_rows, int att0,
+                                                           const int32_t* __restrict__ att_by_mode) {
   // todo != NULL: straggler pass behind k_propose_blk -- only the particles it LISTED (todo[0] = count, todo_rows[] = the rows
   // whose attempts 0 .. att0-1 left the cube; a block beyond the list exits at once: 16 384 blocks scanning flags cost 69 us at
   // 262 144 x 32-D), starting from attempt att0; everything else of the step (pending moves, the others' proposals) is done already
@@ -335,7 +336,8 @@ __global__ void __launch_bounds__(ML_THREADS) k_propose_ml(double* __restrict__ 
   // iterations of a high-dimensional run (50-D: ~98 % of the attempts leave the unit cube) that is most of the work.  Draws,
   // attempt order and arithmetic are those of the sequential loop: the accepted proposal is bit-identical.
   const int nchunks = (d + LPP - 1) / LPP;
-  int att = todo ? att0 : 0, ch = 0, zgen = todo ? 0 : 2 * npairs;   // attempt 0: all normals are in zs already (generated above)
+  // (att_by_mode: behind fanned-out rounds over several modes every mode's list has gone through its own number of attempts)
+  int att = todo ? (att_by_mode ? att_by_mode[c] : att0) : 0, ch = 0, zgen = todo ? 0 : 2 * npairs;   // attempt 0: all normals are in zs already (generated above)
   bool active = !todo || live;
   while (__any(active)) {
     if (active) {
@@ -424,7 +426,7 @@ static int launch_propose_ml(tph_ctx* ctx, double* u, const int32_t* assign, int
                              const double* chol, const double* winv, const double* dof, const double* sigmas,
                              const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0, double* up, double* mu_,
                              double* mup, uint8_t* pend, const int32_t* todo = nullptr, const int32_t* todo_rows = nullptr,
-                             int att0 = 1) {
+                             int att0 = 1, const int32_t* att_by_mode = nullptr) {
   constexpr int PPB = ML_THREADS / LPP;
   const int d = ctx->d;
   const size_t base = sizeof(double) * 3 * (size_t)PPB * (d | 1);
@@ -440,7 +442,7 @@ static int launch_propose_ml(tph_ctx* ctx, double* u, const int32_t* assign, int
       TPH_HIP(hipFuncSetAttribute((const void*)k_propose_ml<KERNEL, LPP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)lds));                                                                          \
     hipLaunchKernelGGL((k_propose_ml<KERNEL, LPP, ST>), grid, dim3(ML_THREADS), lds, ctx->stream, u, assign, n, ld, d, means, \
-                       chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend, todo, todo_rows, att0);     \
+                       chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend, todo, todo_rows, att0, att_by_mode); \
   } while (0)
   if (stage == 1) TPH_ML_LAUNCH(1);
   else if (stage == 2) TPH_ML_LAUNCH(2);
@@ -1042,9 +1044,9 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
   if (!use_reg && ctx->d > 16 && ctx->d <= 112 && assign_dev && K > 1 && K <= 64 && ctx->blk_mfma &&
       (variant == 4 || (variant == 0 && ctx->blocked))) {
     const int rounds = ctx->blocked < 1 ? 1 : ctx->blocked;
-    const int32_t *todo_cnt = nullptr, *todo_rows = nullptr;
+    const int32_t *todo_cnt = nullptr, *todo_rows = nullptr, *todo_att = nullptr;
     if (tph_blkm_multi(ctx, kernel, u_dev, assign_dev, n, ld, K, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick0,
-                       ctl_dev, item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev, rounds, &todo_cnt, &todo_rows))
+                       ctl_dev, item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev, rounds, &todo_cnt, &todo_rows, &todo_att))
       return -1;
     int lpp = 4;
     while (lpp < 64 && lpp < (ctx->d + 1) / 2) lpp *= 2;
@@ -1058,10 +1060,10 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
     rc = kernel == TPH_KERNEL_TPCN                                                                                       \
              ? launch_propose_ml<TPH_KERNEL_TPCN, LL>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev,   \
                                                       bc_dev, seed, tick, item0, uprime_dev, maha_u_dev, maha_up_dev, nullptr, todo_cnt,  \
-                                                      todo_rows, att0)                                                                      \
+                                                      todo_rows, att0, todo_att)                                                            \
              : launch_propose_ml<TPH_KERNEL_RWM, LL>(ctx, u_dev, assign_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev,    \
                                                      bc_dev, seed, tick, item0, uprime_dev, maha_u_dev, maha_up_dev, nullptr, todo_cnt,   \
-                                                     todo_rows, att0);                                                                      \
+                                                     todo_rows, att0, todo_att);                                                            \
     break;
       TPH_ML_M(4) TPH_ML_M(8) TPH_ML_M(16) TPH_ML_M(32) TPH_ML_M(64)
 #undef TPH_ML_M

@@ -189,10 +189,17 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
     if (first) {
       live = valid && nn < count;
       i = order[start + (live ? nn : 0)];
+      if (att_out && valid && start == lbase && lane == 0) att_out[mode] = tries;     // (the mode's first tile speaks for it)
     } else {
       const int j16 = start - lbase, cm = cnt_in[mode];
-      live = valid && j16 + nn < cm;
-      i = live ? (int64_t)rows_in[lbase + j16 + nn] : (int64_t)order[start];
+      if (att_out) {                                   // fan-out, per mode: its list against its own particle count
+        att_base = att_in[mode];
+        const int nm = mt[4 + BM_KMAX + mode];
+        while (G < 16 && 2 * (int64_t)fan_div * G * cm <= nm) { G *= 2; ++lgG; }
+        if (valid && j16 == 0 && lane == 0) att_out[mode] = att_base + tries * G;
+      }
+      live = valid && j16 + nn < cm * G;
+      i = live ? (int64_t)rows_in[lbase + ((j16 + nn) >> lgG)] : (int64_t)order[start];
       if (att == tries && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl) {
         int64_t total = 0;
         for (int m = 0; m < mt[1]; ++m) total += cnt_in[m];
@@ -508,7 +515,7 @@ template <int KERNEL>
 static int blkm_multi(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n, int64_t ld, int K, const double* means, const double* chol,
                       const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick,
                       int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, int rounds, const int32_t** todo_cnt,
-                      const int32_t** todo_rows) {
+                      const int32_t** todo_rows, const int32_t** todo_att) {
   const int d = ctx->d;
   TPH_REQUIRE(d > 16 && d <= 112 && K >= 1 && K <= BM_KMAX, "tph_propose (blocked, several modes): n_dim=%d / K=%d out of range", d, K);
   TPH_REQUIRE(n < (1ll << 31), "tph_propose (blocked): %lld particles on one device", (long long)n);
@@ -518,7 +525,7 @@ static int blkm_multi(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n,
   if (blkm_refresh<KERNEL>(ctx, K, chol, winv, Lm, Wm, &rebuilt)) return -1;
   // tile table + order | counters of the rounds [rounds + 1][K] | the two list arrays | the concatenated list
   const int64_t tiles_max = (n + 15) / 16 + K + 1;
-  const size_t mtw = bm_mt_words(n, K), cntw = (size_t)(24 + 2) * BM_KMAX;
+  const size_t mtw = bm_mt_words(n, K), cntw = (size_t)2 * (24 + 2) * BM_KMAX;      // counters [26][K] | next attempts [26][K]
   const size_t need = sizeof(int32_t) * (mtw + cntw + 3 * (size_t)n + 64);
   if (ctx->mt_bytes < need) {
     TPH_HIP(hipStreamSynchronize(ctx->stream));
@@ -544,11 +551,16 @@ static int blkm_multi(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n,
   if (rounds > 24) rounds = 24;
   hipLaunchKernelGGL(k_zero_words, dim3(4), dim3(64), 0, ctx->stream, (unsigned int*)cnts, (int)cntw);
   const int64_t blocks = (tiles_max + 3) / 4;
+  int32_t* atts = cnts + (size_t)26 * BM_KMAX;        // [round][mode]: the first attempt the mode's list of that round has not tried
+  const bool fan = ctx->blk_fan != 0;
   for (int k = 0; k < rounds; ++k)
     if (blkm_launch<KERNEL, true>(ctx, blocks, u, n, ld, means, Lm, Wm, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend,
                                   k ? cnts + (size_t)(k - 1) * BM_KMAX : (const int32_t*)nullptr, (const int32_t*)rows[(k + 1) & 1],
-                                  k * bm_tries(ctx), cnts + (size_t)k * BM_KMAX, rows[k & 1], mt, tiles_max))
+                                  k * bm_tries(ctx), cnts + (size_t)k * BM_KMAX, rows[k & 1], mt, tiles_max,
+                                  (fan && k) ? atts + (size_t)(k - 1) * BM_KMAX : (const int32_t*)nullptr,
+                                  fan ? atts + (size_t)k * BM_KMAX : (int32_t*)nullptr))
       return -1;
+  *todo_att = fan ? atts + (size_t)(rounds - 1) * BM_KMAX : nullptr;
   int32_t* cnt_cat = cnts + (size_t)25 * BM_KMAX;
   hipLaunchKernelGGL(k_mt_concat, dim3(K), dim3(256), 0, ctx->stream, (const int32_t*)mt, (const int32_t*)(cnts + (size_t)(rounds - 1) * BM_KMAX),
                      (const int32_t*)rows[(rounds - 1) & 1], cnt_cat, rows_cat);
@@ -561,11 +573,11 @@ static int blkm_multi(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n,
 int tph_blkm_multi(tph_ctx* ctx, int kernel, double* u, const int32_t* assign, int64_t n, int64_t ld, int K, const double* means,
                    const double* chol, const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed,
                    uint32_t tick0, const double* ctl, int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, int rounds,
-                   const int32_t** todo_cnt, const int32_t** todo_rows) {
+                   const int32_t** todo_cnt, const int32_t** todo_rows, const int32_t** todo_att) {
   const tph_stepctl tick{tick0, ctl};
   if (kernel == TPH_KERNEL_TPCN)
     return blkm_multi<TPH_KERNEL_TPCN>(ctx, u, assign, n, ld, K, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend,
-                                       rounds, todo_cnt, todo_rows);
+                                       rounds, todo_cnt, todo_rows, todo_att);
   return blkm_multi<TPH_KERNEL_RWM>(ctx, u, assign, n, ld, K, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend,
-                                    rounds, todo_cnt, todo_rows);
+                                    rounds, todo_cnt, todo_rows, todo_att);
 }

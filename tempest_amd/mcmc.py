@@ -344,7 +344,7 @@ class StepEngine:
             # (a matrix-core round gives its failing columns `tries` attempts in place: TPH_OPT_BLK_TRIES, 2 up to n_dim 32, 1 above)
             f_round = f ** (1 if (nd > 32 or not screened) else 2)
             fan_opt = int(os.environ.get("TEMPEST_AMD_BLK_FAN", "1"))
-            fan, fan_div = screened and self.K == 1 and fan_opt != 0, {2: 1, 3: 4}.get(fan_opt, 2)
+            fan, fan_div = screened and fan_opt != 0, {2: 1, 3: 4}.get(fan_opt, 2)
             left *= f_round                         # after round 0
             while rounds < cap and left >= floor:
                 # a list round gives every listed particle G attempts side by side (TPH_OPT_BLK_FAN, propose_blkm.hip: the largest

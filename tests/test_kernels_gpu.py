@@ -923,16 +923,20 @@ def test_blocked_rounds_with_several_modes_vs_oracle_and_multilane(dev, kernel, 
     st, ft = torch.from_numpy(sigmas).to(dev), torch.from_numpy(flags).to(dev)
     at = torch.from_numpy(assign).to(dev)
     got = {}
-    for variant in (4, 3):
+    for variant in (4, 3, 40):                           # 40: variant 4 with the list rounds NOT fanned out (TPH_OPT_BLK_FAN = 0)
         c = ctx_for(d)
-        c.set_option(0, variant)
-        c.set_option(4, rounds if variant == 4 else 0)
+        c.set_option(0, 4 if variant == 40 else variant)
+        c.set_option(4, rounds if variant != 3 else 0)
         c.set_option(16, 1 if d in (19, 50) else 2)      # TPH_OPT_BLK_TRIES
+        c.set_option(17, 0 if variant == 40 else 1)      # TPH_OPT_BLK_FAN (per mode: width and next attempt from the mode's own list)
         up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
         state = c.zeros(10)
         c.propose(kernel, soa(u, dev), at, modes, st, ft, seed, tick, item0, up, mu_, mup, ctl=state)
         got[variant] = (aos(up), mu_.cpu().numpy(), mup.cpu().numpy(), state.cpu().numpy())
         c.close()
+    np.testing.assert_allclose(got[40][0], want_up, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(got[4][0], got[40][0], rtol=1e-12, atol=1e-15)
+    np.testing.assert_array_equal(np.any(got[4][0] != u, axis=1), np.any(got[40][0] != u, axis=1))
     np.testing.assert_allclose(got[4][0], want_up, rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(got[4][0], got[3][0], rtol=1e-11, atol=1e-13)
     strict = np.nonzero(flags == 0)[0]
