@@ -82,9 +82,10 @@ def test_graph_replay_of_the_blocked_proposal_follows_new_mode_statistics(kernel
 
 
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
-@pytest.mark.parametrize("variant", [5, 4, 3])
-def test_d_gt_16_proposal_paths_replayed_from_a_graph_equal_eager_launches(kernel, variant):
-    """tph_propose at n_dim > 16 captured ONCE (row-walker kernel 5, blocked kernel + straggler pass 4, multi-lane kernel 3) and
+@pytest.mark.parametrize("variant,rounds", [(5, 0), (4, 0), (4, 4), (6, 0), (3, 0)])
+def test_d_gt_16_proposal_paths_replayed_from_a_graph_equal_eager_launches(kernel, variant, rounds):
+    """tph_propose at n_dim > 16 captured ONCE (row-walker kernel 5, blocked kernel + straggler pass 4 -- also in four rounds, whose
+    list rounds fan out by a width and from an attempt that live in device memory --, screened batches 6, multi-lane kernel 3) and
     replayed after the caller has rewritten its fixed-address inputs -- new mode statistics, new positions, new step-control
     block: every replay must equal the eager launch on the same inputs bit for bit.  Pins the two things a replay cannot get
     from the host: the library's derived copies of L / L^-1 (rebuilt inside the graph) and its per-launch work-queue words
@@ -108,6 +109,7 @@ def test_d_gt_16_proposal_paths_replayed_from_a_graph_equal_eager_launches(kerne
     c = HipContext(d, device=0)
     c.set_option(0, variant)
     c.set_option(10, 1)
+    c.set_option(4, rounds)
     m0 = mk_modes(0.29)
     modes = SimpleNamespace(K=1, means_dev=t(m0[0]), chol_dev=t(m0[1]), winv_dev=t(m0[2]), dof_dev=t(np.array([1e6])))
     u, up, mu_, mup = t(rs.rand(d, n)), c.empty(d, n), c.empty(n), c.empty(n)
