@@ -54,6 +54,65 @@ def test_graph_run_is_bit_identical(kernel, clustering, like, d):
     np.testing.assert_array_equal(runs[0][2], runs[1][2])
 
 
+@pytest.mark.parametrize("clustering", [False, True])
+def test_graph_run_above_16_dimensions_makes_the_same_run(clustering, monkeypatch):
+    """The same at n_dim = 24, where a step is screened batches first and matrix-core rounds (fanned-out list rounds, the screened
+    or the multi-lane straggler pass) later -- with one mode, and with clustering on a separable four-mode target that the split
+    search does split at this size (several modes: mode-pure tiles, per-mode lists and attempts): graph replay and step-by-step
+    launches make the same run."""
+    import tempest_amd as tp
+    from tempest_amd.steps import train as tr
+    d = 24
+    dev = torch.device("cuda", 0)
+    mus = torch.zeros(4, d, dtype=torch.float64, device=dev)
+    for k, (a, b) in enumerate([(-6, -6), (-6, 6), (6, -6), (6, 6)]):
+        mus[k, 0], mus[k, 1] = a, b
+
+    def like(x):
+        q = ((x[:, None, :] - mus[None]) ** 2).sum(dim=2)
+        return torch.logsumexp(-0.5 * q / 0.09, dim=1)
+    ks = []
+    orig = tr.Trainer.run
+
+    def trun(self, w):
+        ms = orig(self, w)
+        ks.append(int(ms.K))
+        return ms
+    monkeypatch.setattr(tr.Trainer, "run", trun)
+    from tempest_amd import mcmc
+    captured = []                                        # (K of the engine) at every capture that produced a graph
+    orig_capture = mcmc.StepEngine._capture
+
+    def capture(self):
+        orig_capture(self)
+        if self.graph is not None:
+            captured.append(self.K)
+    monkeypatch.setattr(mcmc.StepEngine, "_capture", capture)
+    runs = []
+    for graph in (False, True):
+        ks.clear()
+        s = tp.Sampler(prior20, like, d, n_particles=1024, vectorize=True, clustering=clustering, random_state=11,
+                       sample="tpcn", graph=graph)
+        s.run(n_total=2048, progress=False)
+        runs.append((s.evidence()[0], _history(s), s.posterior()[0], s, list(ks)))
+    assert captured, "the step was never replayed as a graph"
+    if clustering:
+        assert any(K >= 2 for K in captured), captured      # an engine with several modes was captured and replayed
+    if clustering:
+        assert max(runs[0][4]) >= 2, runs[0][4]            # several modes were in play
+    # (Not bit for bit, unlike d <= 16: a captured graph keeps the number of rounds it was captured with while the eager path
+    # follows the regime rule step by step, so some winning attempts are evaluated by a matrix-core round in one run and by the
+    # FP64 chain of the screened kernel in the other -- the same attempt, the same proposal to the last bit or two.  The runs make
+    # the same decisions: same cluster counts, same steps per iteration, evidence and posterior equal to rounding.)
+    assert runs[0][4] == runs[1][4]
+    np.testing.assert_array_equal(runs[0][1]["steps"], runs[1][1]["steps"])
+    np.testing.assert_array_equal(runs[0][1]["beta"].shape, runs[1][1]["beta"].shape)
+    for k in ("beta", "logz", "acceptance", "efficiency"):
+        np.testing.assert_allclose(runs[0][1][k], runs[1][1][k], rtol=1e-9, atol=1e-12, err_msg=k)
+    np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=1e-10)
+    np.testing.assert_allclose(runs[0][2], runs[1][2], rtol=1e-8, atol=1e-10)
+
+
 @pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
 def test_graph_replay_of_the_blocked_proposal_follows_new_mode_statistics(kernel):
     """d > 16, every dimension reflective: every first attempt is in bounds, so the engine switches to the blocked proposal
