@@ -60,18 +60,35 @@ static __global__ void __launch_bounds__(256) k_blkm_pack(const double* __restri
 // m's list.  Layout of the ctx-owned block (int32): hdr[4] = {tiles, K, -, -} | mstart[64] | mcount[64] | cursor[64] |
 // tiles[][4] | order[n].
 constexpr int BM_KMAX = 64;
-__host__ __device__ static inline size_t bm_mt_words(int64_t n, int K) { return 4 + 3 * BM_KMAX + 4 * (size_t)((n + 15) / 16 + K + 1) + (size_t)n; }
+// (... | order[n] | blockcnt[ceil(n / 256)][K]: particles of every mode per 256-particle block, then their exclusive prefix over the
+// blocks.  order[] is a STABLE partition -- a mode's particles in index order --: with an atomic cursor the order inside a mode,
+// and with it the sample of particles behind the first workgroup's redraw probe, changed from launch to launch, and two runs
+// with the same seed chose different numbers of rounds: equal to rounding only.)
+__host__ __device__ static inline size_t bm_mt_words(int64_t n, int K) {
+  return 4 + 3 * BM_KMAX + 4 * (size_t)((n + 15) / 16 + K + 1) + (size_t)n + (size_t)((n + 255) / 256) * (size_t)K;
+}
 
-static __global__ void __launch_bounds__(256) k_mt_count(const int32_t* __restrict__ assign, int64_t n, int K, int32_t* __restrict__ mt) {
+static __global__ void __launch_bounds__(256) k_mt_count(const int32_t* __restrict__ assign, int64_t n, int K, int32_t* __restrict__ mt,
+                                                         int32_t* __restrict__ blockcnt) {
+  __shared__ int s_cnt[BM_KMAX];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int a = i < n ? assign[i] : -1;
   int32_t* mcount = mt + 4 + BM_KMAX;
+  if (threadIdx.x < K) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
   for (int m = 0; m < K; ++m) {
     const unsigned long long b = __ballot(a == m);
-    if (b && (threadIdx.x & 63) == 0) atomicAdd(&mcount[m], __popcll(b));
+    if (b && (threadIdx.x & 63) == 0) atomicAdd(&s_cnt[m], __popcll(b));
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    const int c = s_cnt[threadIdx.x];
+    blockcnt[(size_t)blockIdx.x * K + threadIdx.x] = c;
+    if (c) atomicAdd(&mcount[threadIdx.x], c);
   }
 }
-static __global__ void __launch_bounds__(256) k_mt_layout(int64_t n, int K, int32_t* __restrict__ mt) {
+static __global__ void __launch_bounds__(256) k_mt_layout(int64_t n, int K, int32_t* __restrict__ mt, int32_t* __restrict__ blockcnt,
+                                                          int nblocks) {
   __shared__ int s_start[BM_KMAX + 1], s_toff[BM_KMAX + 1];
   int32_t* mstart = mt + 4;
   const int32_t* mcount = mt + 4 + BM_KMAX;
@@ -87,6 +104,14 @@ static __global__ void __launch_bounds__(256) k_mt_layout(int64_t n, int K, int3
     s_start[K] = st; s_toff[K] = to;
     mt[0] = to; mt[1] = K;
   }
+  if (threadIdx.x < K) {                       // exclusive prefix of the mode's block counts, in block order
+    int run = 0;
+    for (int b = 0; b < nblocks; ++b) {
+      const int c = blockcnt[(size_t)b * K + threadIdx.x];
+      blockcnt[(size_t)b * K + threadIdx.x] = run;
+      run += c;
+    }
+  }
   __syncthreads();
   const int ntiles = s_toff[K];
   for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
@@ -100,20 +125,24 @@ static __global__ void __launch_bounds__(256) k_mt_layout(int64_t n, int K, int3
   }
 }
 static __global__ void __launch_bounds__(256) k_mt_scatter(const int32_t* __restrict__ assign, int64_t n, int K, int32_t* __restrict__ mt,
-                                                           int64_t tiles_max) {
+                                                           int64_t tiles_max, const int32_t* __restrict__ blockoff) {
+  __shared__ int s_w[4][BM_KMAX];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int a = i < n ? assign[i] : -1;
   const int32_t* mstart = mt + 4;
-  int32_t* cursor = mt + 4 + 2 * BM_KMAX;
   int32_t* order = mt + 4 + 3 * BM_KMAX + 4 * tiles_max;
+  int below = 0;
   for (int m = 0; m < K; ++m) {
     const unsigned long long b = __ballot(a == m);
-    if (!b) continue;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&cursor[m], __popcll(b));
-    base = __shfl(base, 0, 64);
-    if (a == m) order[mstart[m] + base + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)i;
+    if (lane == 0) s_w[wid][m] = __popcll(b);
+    if (a == m) below = __popcll(b & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  if (a >= 0 && a < K) {
+    int off = blockoff[(size_t)blockIdx.x * K + a] + below;
+    for (int w = 0; w < wid; ++w) off += s_w[w][a];
+    order[mstart[a] + off] = (int32_t)i;
   }
 }
 // the modes' failure lists of the last round, strung together for the straggler pass: rows_cat[0 .. *cnt_cat)
@@ -542,9 +571,10 @@ static int blkm_multi(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n,
   if (rebuilt || ctx->mt_assign != (const void*)assign || ctx->mt_n != n) {      // (the assignments are fixed while the statistics are)
     hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)mt, 4 + 3 * BM_KMAX);
     const unsigned gb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_mt_count, dim3(gb), dim3(256), 0, ctx->stream, assign, n, K, mt);
-    hipLaunchKernelGGL(k_mt_layout, dim3(1), dim3(256), 0, ctx->stream, n, K, mt);
-    hipLaunchKernelGGL(k_mt_scatter, dim3(gb), dim3(256), 0, ctx->stream, assign, n, K, mt, tiles_max);
+    int32_t* blockcnt = mt + 4 + 3 * BM_KMAX + 4 * tiles_max + n;
+    hipLaunchKernelGGL(k_mt_count, dim3(gb), dim3(256), 0, ctx->stream, assign, n, K, mt, blockcnt);
+    hipLaunchKernelGGL(k_mt_layout, dim3(1), dim3(256), 0, ctx->stream, n, K, mt, blockcnt, (int)gb);
+    hipLaunchKernelGGL(k_mt_scatter, dim3(gb), dim3(256), 0, ctx->stream, assign, n, K, mt, tiles_max, (const int32_t*)blockcnt);
     ctx->mt_assign = (const void*)assign; ctx->mt_n = n;
   }
   if (rounds < 1) rounds = 1;
