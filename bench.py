@@ -137,7 +137,7 @@ def reweight_roofline(device, n_rows, other_rows=(2_621_440, 10_485_760)):
             "other_points": points, "check_ess": float(s1 * s1 / s2)}
 
 
-def cpu_baseline(budget_s=10.0):
+def cpu_baseline(budget_s=5.0):
     """Oracle (NumPy port of the reference algorithm) on the host: 10-D Rosenbrock, N=4096, as many PS
     iterations as fit the time budget (at least the 3 warm-up + 2 annealing ones)."""
     from oracle.sampler import OracleSampler

@@ -81,8 +81,11 @@ int tph_synchronize(tph_ctx* ctx);
  * from attempt R on; 0 (default) = multi-lane kernel for everything.  The host switches on the redraw probe and sizes R from
  * it (a few attempts per particle: ~3 x the mean), like TPH_OPT_ML_UNSTAGED. */
 #define TPH_OPT_BLOCKED 4
-/* TPH_OPT_MODES_EPOCH: v > 0 = version of the mode statistics passed to tph_propose; the blocked copies of L and L^-1 are
- * rebuilt only when it (or the chol pointer) changes.  0 (default) = rebuilt on every call. */
+/* TPH_OPT_MODES_EPOCH: v > 0 = version of the mode statistics AND of the assignments passed to tph_propose: the blocked copies
+ * of L and L^-1, the screening packs and -- with several modes -- the grouping of the particles by mode (tile table, per-mode
+ * order) are rebuilt only when it (or the chol / assign_dev pointer, or n) changes.  A caller who keeps v > 0 must bump it
+ * whenever the CONTENTS of chol_dev, cholinv_dev or assign_dev change, also at an unchanged address (a caching allocator hands
+ * the same address back routinely).  0 (default) = everything rebuilt on every call. */
 #define TPH_OPT_MODES_EPOCH 5
 /* TPH_OPT_ROW_MIRROR: 1 (default) = tph_gather and tph_resample_put_global read a row-major mirror of (u, x, logl) that the
  * library keeps beside the dimension-major history (filled lazily, + (2 n_dim + 1) * 8 bytes per row; dropped by itself when

@@ -91,6 +91,7 @@ struct tph_ctx {
   const void* sm_src = nullptr;
   // screened-batch proposal kernel (propose_mf.hip): TPH_OPT_SCREEN / _MF_LANES / _MF_AUDIT and its persistent buffer
   int screen = 1, mf_lanes = 0, mf_audit = 0;
+  int mf_checked = 0;               // the screen's FP32 transcendental budget on this device: 0 not measured yet | 1 holds | -1 does not (screen off)
   void* mf_buf = nullptr;           // queue words | blocked L^-1 | FP16 pack of L + row error tables | transposed FP64 L
   size_t mf_bytes = 0;
   int mf_epoch = -1, mf_kernel = -1;
@@ -166,6 +167,8 @@ int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t 
                         const double* ctl, int64_t item0, double* up, double* maha_up, const int32_t* todo_cnt, const int32_t* todo_rows,
                         int att0, const int32_t* att0_dev = nullptr,       // att0_dev: the first attempt read from the device instead
                         int queue_zeroed = 0);                             // 1: the caller zeroed tph_mf_queue_words() on the stream already
+bool tph_mf_selftest(tph_ctx* ctx);                  // the device meets the screen's FP32 budget (measured once per context)
+bool tph_mf_screen(tph_ctx* ctx);                    // TPH_OPT_SCREEN on, n_dim in range AND the device passed the screen's self-test (run once)
 unsigned int* tph_mf_queue_words(tph_ctx* ctx);      // the 32 work-queue words of the screened kernel (allocates its buffers; NULL on error)
 
 // --------------------------------------------------------------------------------- device helpers

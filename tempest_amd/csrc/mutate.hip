@@ -647,7 +647,8 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   int32_t* atts = cnts + 32;                         // [k] = the first attempt the particles listed by round k have not tried yet
   int32_t* rows[2] = {cnts + 64, cnts + 64 + n};     // their rows: round k writes rows[k & 1], round k + 1 reads it
   // (with the screened kernel as the straggler pass its work-queue words are zeroed by the same launch: one launch less per step)
-  unsigned int* mfq = (ctx->screen && d <= 112) ? tph_mf_queue_words(ctx) : nullptr;
+  const bool screen = tph_mf_screen(ctx);
+  unsigned int* mfq = screen ? tph_mf_queue_words(ctx) : nullptr;
   if (mfq) hipLaunchKernelGGL(k_zero_words2, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)cnts, 64, mfq, 32);
   else hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)cnts, 64);
   // A launch that is being CAPTURED into a hipGraph always records the rebuild: a replayed step never re-enters this host
@@ -658,7 +659,7 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   int att_next = rounds;                            // the straggler pass starts here
   // the list rounds give a straggler several attempts side by side (propose_blkm.hip: fan-out) when the screened kernel finishes
   // the list: it reads the attempt to go on from on the device (the multi-lane straggler pass takes it by value)
-  const bool fan = mfma && ctx->screen && ctx->blk_fan;
+  const bool fan = mfma && screen && ctx->blk_fan;
   if (mfma) {
     const int tries = tph_blkm_tries(ctx);      // TPH_OPT_BLK_TRIES: attempts per round, in place
     for (int k = 0; k < rounds; ++k)
@@ -700,7 +701,7 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   // launch over a short list costs its workgroups' table loads, where the multi-lane kernel's straggler pass cost the chain
   // of its hardest particle's attempts: config 5's shard 357 us per launch, config 2 47-56 us) -- or, with the screen off or
   // beyond its range, the multi-lane kernel
-  if (ctx->screen && d <= 112)
+  if (screen)
     return tph_propose_mf_list(ctx, KERNEL, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick.tick, tick.ctl, item0, up, mup,
                                cnts + (rounds - 1), rows[(rounds - 1) & 1], att_next, fan ? atts + (rounds - 1) : (const int32_t*)nullptr,
                                mfq ? 1 : 0);
@@ -1025,7 +1026,7 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
   // redraw-dominated steps: attempts screened on the matrix cores, survivors in FP64 (propose_mf.hip; TPH_OPT_SCREEN, default)
   // or every attempt walked row by row in FP64 (propose_sm.hip)
   if (!use_reg && ctx->d > 16 && ctx->d <= 112 && !assign_dev && K == 1 &&
-      (variant == 6 || (variant == 0 && ctx->staged && !ctx->blocked && ctx->screen)))
+      ((variant == 6 && tph_mf_selftest(ctx)) || (variant == 0 && ctx->staged && !ctx->blocked && tph_mf_screen(ctx))))
     return tph_propose_mf(ctx, kernel, u_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick0, ctl_dev,
                           item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev);
   if (!use_reg && ctx->d > 16 && ctx->d <= 100 && !assign_dev && K == 1 &&

@@ -4,8 +4,9 @@
 //
 // Early in a high-dimensional run a step is tens to hundreds of attempts per particle (50-D at sigma_0: ~60; 100-D: ~290), and
 // all but one of them are thrown away -- the only thing the algorithm wants to know about them is THAT some coordinate left
-// [0, 1].  That question does not need FP64: with x~_r a low-precision value of coordinate r and m_r a rigorous bound of
-// |x~_r - x_r|, "x~_r < -m_r or x~_r > 1 + m_r" implies that the FP64 kernels find row r out of bounds too, i.e. the attempt
+// [0, 1].  That question does not need FP64: with x~_r a low-precision value of coordinate r and m_r a bound of
+// |x~_r - x_r| (every term derived, except the accuracy of the hardware's FP32 transcendentals in the Box-Muller pair, which is
+// MEASURED on gfx950 and re-checked on every context before the screen is first used: mf_selftest below), "x~_r < -m_r or x~_r > 1 + m_r" implies that the FP64 kernels find row r out of bounds too, i.e. the attempt
 // fails in FP64 as well.  An attempt the screen cannot kill is evaluated in FP64, by the arithmetic of the other proposal
 // kernels (same Philox counters, ascending-j FMA chain, v = fma(b, (L z)_r, base_r)), and THAT evaluation decides whether
 // it is the proposal.  So the screen only ever removes work: the proposal is the one the sequential loop returns, bit for bit
@@ -58,7 +59,11 @@ __host__ __device__ static inline size_t mf_wave_bytes(int npw, int dpad) {
   return (size_t)npw * dpad * 4 + 64 * 8 * 4 + 64 * 8 + 256 + 256 + (size_t)dpad * 8 + 64;
 }
 __host__ __device__ static inline size_t mf_tables_bytes(int np) { return (size_t)mf_nblk(np) * 512 + 2 * (size_t)(16 * np) * 4 + (size_t)(16 * np); }
-__host__ __device__ static inline size_t mf_shared_bytes(int np, int d) { return mf_tables_bytes(np) + sizeof(double) * (size_t)mf_lt_doubles(d); }
+// (rounded up to 16 B: for odd n_dim > 64 the factor is an odd number of doubles, and the per-wave regions behind it are read as
+// 16-byte vectors)
+__host__ __device__ static inline size_t mf_shared_bytes(int np, int d) {
+  return (mf_tables_bytes(np) + sizeof(double) * (size_t)mf_lt_doubles(d) + 15) & ~(size_t)15;
+}
 
 __device__ __forceinline__ void mf_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -790,4 +795,32 @@ extern "C" int tph_bench_mf_normals(tph_ctx* ctx, uint64_t seed, uint64_t first,
   for (int b = 0; b < grid; ++b) { mx = fmax(mx, h[3 * b]); mz = fmax(mz, h[3 * b + 1]); cnt += h[3 * b + 2]; }
   out3_host[0] = mx; out3_host[1] = mz; out3_host[2] = cnt;
   return 0;
+}
+
+// ---- the screen's one empirical assumption, re-checked on every context before its first screened launch ----------------------
+// The margin m_r is derived term by term except for |z~ - z| <= 2^-13, the accuracy of v_log_f32 / v_sqrt_f32 / v_sin_f32 /
+// v_cos_f32 in the Box-Muller pair: that figure was MEASURED on gfx950 (tph_bench_mf_normals over 2^32 blocks).  A part or a
+// ROCm release whose transcendentals are less accurate would let the screen drop an in-bounds attempt without any diagnostic
+// (TPH_OPT_MF_AUDIT is off by default).  So the first use of the screen on a context measures the error again -- the hand-made
+// edge blocks around the switch of the logarithm and a few million random blocks, ~50 us -- and keeps the screen only if the
+// budget holds; otherwise the FP64 kernels take over (one line on stderr says so).  Not run under stream capture (it reads its
+// result back): a capture that meets an unchecked context takes the FP64 path.
+bool tph_mf_screen(tph_ctx* ctx) { return ctx->screen && tph_mf_selftest(ctx); }
+bool tph_mf_selftest(tph_ctx* ctx) {
+  if (ctx->d <= 16 || ctx->d > MF_MAX_DIM) return false;
+  if (ctx->mf_checked > 0) return true;
+  if (ctx->mf_checked < 0) return false;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
+  double edge[3] = {1.0, 0.0, 0.0}, rnd[3] = {1.0, 0.0, 0.0};
+  const int rc = tph_bench_mf_normals(ctx, 0x5EEDull, 0, 1ull << 16, 1, edge) || tph_bench_mf_normals(ctx, 0x5EEDull, 1ull << 40, 1ull << 22, 0, rnd);
+  const double worst = fmax(edge[0], rnd[0]);
+  if (rc == 0 && worst <= 0x1.0p-13) {
+    ctx->mf_checked = 1;
+    return true;
+  }
+  ctx->mf_checked = -1;
+  fprintf(stderr, "tempest_hip: FP32 Box-Muller error %.3g exceeds the screen's budget 2^-13 on this device: redraw-dominated steps "
+                  "use the FP64 kernels (TPH_OPT_SCREEN off)\n", worst);
+  return false;
 }

@@ -225,6 +225,9 @@ class StepEngine:
                                self.n_max, self._mail_all, self.SLOTS, self.n_max * d + 1):
             return None
         self._poll(last, None, "the run")
+        if last[1] < 0.0:
+            from ._lib import TempestHipError
+            raise TempestHipError("MCMC run in one launch was abandoned on the device (a workgroup timed out at the grid barrier)")
         if last[1] == 0.0:
             from ._lib import TempestHipError
             raise TempestHipError("MCMC run in one launch ended without its stopping rule having fired")

@@ -84,6 +84,10 @@ class Sampler:
                 comm = c
             elif distributed:
                 raise ValueError("distributed=True needs an initialised torch.distributed process group")
+        if config.student_em and comm is not None:
+            # rejected here, before any rank has sampled the prior: inside the first Trainer.run the other ranks would already
+            # be waiting at a collective
+            raise ValueError("student_em=True is not available on a sharded run (the Student-t EM is a one-GPU extension)")
         # reserve the history of a typical run (~40-60 PS iterations) up front: growing it later means hipMalloc + copy +
         # hipFree of gigabytes in the middle of the run (measured: one 230 ms stall at the 16M -> 32M row step)
         world = comm.world_size if (comm is not None and comm.active) else 1

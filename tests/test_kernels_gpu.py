@@ -826,8 +826,6 @@ def test_blocked_proposal_kernel_vs_oracle_and_multilane(dev, kernel, bc, d, rou
         got[variant] = (aos(up), mu_.cpu().numpy(), mup.cpu().numpy(), state.cpu().numpy())
         c.set_option(4, 0)
         c.set_option(15, 1)
-    first_failed = np.mean(np.any((want_up != want_up), axis=1))       # placeholder: failures are visible through the oracle below
-    _ = first_failed
     np.testing.assert_allclose(got[4][0], want_up, rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(got[4][0], got[3][0], rtol=1e-11, atol=1e-13)
     strict = np.nonzero(flags == 0)[0]
