@@ -59,6 +59,53 @@ def check_bounds(u, periodic=None, reflective=None):
     return bool(inside.all()) if u.ndim == 1 else inside.all(axis=-1)
 
 
+class RegimeOptions:
+    """Debugging switches of the d > 16 proposal regime (TEMPEST_AMD_STAGED / _SCREEN / _BLK_MFMA / _BLK_FAN / _SM_LANES): read from
+    the environment ONCE, when an engine is built -- never in the step path."""
+    __slots__ = ("walker_ok", "screen", "blk_mfma", "fan", "sm_lanes")
+
+    def __init__(self, walker_ok=True, screen=True, blk_mfma=True, fan=1, sm_lanes=0):
+        self.walker_ok, self.screen, self.blk_mfma, self.fan, self.sm_lanes = walker_ok, screen, blk_mfma, int(fan), int(sm_lanes)
+
+    @classmethod
+    def from_env(cls, env=None):
+        import os
+        env = os.environ if env is None else env
+        return cls(walker_ok=env.get("TEMPEST_AMD_STAGED", "1") != "0", screen=env.get("TEMPEST_AMD_SCREEN", "1") != "0",
+                   blk_mfma=env.get("TEMPEST_AMD_BLK_MFMA", "1") != "0", fan=int(env.get("TEMPEST_AMD_BLK_FAN", "1")),
+                   sm_lanes=int(env.get("TEMPEST_AMD_SM_LANES", "0")))
+
+
+# Crossovers of the redraw probe (mean attempts per particle of a step) between the d > 16 proposal kernels.  One row per
+# dimension band (the first whose n_dim_min <= n_dim):  (n_dim_min, up, down, cap, floor) --
+#   up:    the blocked rounds are left when THEIR probe, the geometric estimate n / (n - first-attempt failures), reaches it;
+#   down:  they are taken up again when the TRUE mean reported by the screened batches / the row walker falls below it
+#          (the hard particles near a wall pull the true mean above the estimate: hence two numbers, DESIGN 3i);
+#   cap, floor: at most `cap` rounds, and only while the expected failure list still holds `floor` particles.
+# All fitted on one MI355X with tools/regime_sweep.py; `source` names the sweep a row came from.
+REGIME_THRESHOLDS = {
+    "screened": {"source": "profiles/r04_regime_sweep.jsonl, profiles/r04_regime_sweep_fan.jsonl (fanned-out list rounds)",
+                 "bands": ((64, 3.0, 5.0, 6, 64.0), (33, 3.4, 5.5, 8, 64.0), (17, 8.0, 13.0, 12, 64.0))},
+    "walker": {"source": "profiles/r03_propose_d50_d100.json (screen off: FP64 row walker, multi-lane straggler pass)",
+               "bands": ((64, 4.5, 8.0, 24, 24576.0), (17, 3.5, 5.0, 24, 24576.0))},
+    # several modes (matrix-core rounds over mode-pure tiles <-> per-mode screened batches / multi-lane kernel): leave at, return below
+    "several_modes": {"source": "profiles/r04_regime_sweep_fan.jsonl", "up": 13.0, "down": 8.0},
+    # multi-lane kernel: matrices from global memory (a quarter of the LDS) above, LDS-staged below
+    "unstaged": {"source": "profiles/r02_propose_d50_d100.json", "up": 8.0, "down": 4.0},
+    # a kernel switch retires the captured graph of the step: from the third switch in a row that comes within `recent` readings of
+    # the one before, the next has to wait (4, 8, ... 64 probe readings) -- a probe that sits on a threshold and flips every step
+    # costs a bounded number of captures (test_regime_rule_does_not_oscillate)
+    "dwell": {"first": 4, "max": 64, "recent": 8},
+}
+
+
+def regime_band(table, n_dim):
+    for row in REGIME_THRESHOLDS[table]["bands"]:
+        if n_dim >= row[0]:
+            return row[1:]
+    return REGIME_THRESHOLDS[table]["bands"][-1][1:]
+
+
 class StepEngine:
     """One MCMC step -- proposal, the two user callbacks, Metropolis update, sigma adaptation -- as a replayable
     hipGraph over persistent device buffers.
@@ -110,9 +157,13 @@ class StepEngine:
         self.unstaged = False          # d > 16 proposal kernel without LDS-staged matrices (redraw-dominated steps)
         self.blocked = 0               # d > 16: rounds of the blocked kernel (attempts in lockstep) before the straggler pass; 0 = off
         self.staged, self.sm_lanes = False, 0      # d > 16: row-walker kernel for redraw-dominated steps, its lanes per particle (log2)
+        self._opts = RegimeOptions.from_env()      # the regime's debugging switches, read here and nowhere in the step path
         import os
-        self._screened = os.environ.get("TEMPEST_AMD_SCREEN", "1") != "0" and d <= 112
-        if (d > 16 and K == 1 and not has_assign and self._screened and os.environ.get("TEMPEST_AMD_STAGED", "1") != "0"):
+        env = os.environ.get("TEMPEST_AMD_STEP_TIMEOUT")
+        self._step_timeout = float(env) if env else None      # seconds a step's record may take (None: until the stream goes idle)
+        self._since, self._dwell, self._quick = 1 << 30, 0, 0      # readings since the last kernel switch; readings the next must wait; quick switches in a row
+        self._screened = self._opts.screen and d <= 112
+        if (d > 16 and K == 1 and not has_assign and self._screened and self._opts.walker_ok):
             # Nothing is known about the redraw rate before an engine's first steps: they run as screened batches, whose time is
             # flat in it (0.4-3 ms), instead of through the multi-lane kernel, whose time is not (30 ms per launch from the prior
             # at 131 072 x 100-D: three such launches were 2 % of the config-5 shard's run); the probe of step 2 picks the regime.
@@ -235,12 +286,10 @@ class StepEngine:
 
     def _poll(self, rec, step, what, timeout=None):
         """Spin on a pinned record until its sequence field shows `step` (None: any step); errors as in wait_record."""
-        import os
         import time
         import torch
         if timeout is None:
-            env = os.environ.get("TEMPEST_AMD_STEP_TIMEOUT")
-            timeout = float(env) if env else None
+            timeout = self._step_timeout
         arrived = (lambda: rec[7] >= 0.0) if step is None else (lambda: rec[7] == step)
         spins, t0 = 0, None
         while not arrived():
@@ -262,12 +311,10 @@ class StepEngine:
         error only when the stream has gone IDLE without delivering the record (like tph_reweight_eval's poll) or, if a
         `timeout` in seconds is given (TEMPEST_AMD_STEP_TIMEOUT), after that long: a step may legitimately take minutes
         (an expensive likelihood, a callback that compiles on first use, a shared GPU)."""
-        import os
         import time
         import torch
         if timeout is None:
-            env = os.environ.get("TEMPEST_AMD_STEP_TIMEOUT")
-            timeout = float(env) if env else None
+            timeout = self._step_timeout
         rec = self.mailbox_np[step % self.SLOTS]
         spins, t0 = 0, None
         while rec[7] != step:
@@ -290,64 +337,66 @@ class StepEngine:
 
     def _regime(self, mean_attempts):
         """The d > 16 proposal kernels report the mean number of attempts per particle of the step, and the host picks the
-        kernel for the next steps from it.  A captured graph has its kernels baked in: when the rule asks for a different KERNEL
-        than the graph holds (blocked <-> walker <-> multi-lane; not for a different number of rounds), the graph is retired and
-        the step is captured again at its next launch -- an engine captured in a run's redraw-dominated first iterations would
-        otherwise walk rows for the rest of the run.  One mode:
-          * a step is a few attempts per particle: the blocked kernel (attempts in lockstep, lane = particle, matrix operands
-            through the scalar cache) -- attempt 0 of everybody, further rounds over the particles still out of bounds, the
-            rest finished by the multi-lane kernel.  Its probe is the geometric estimate n / (n - first-attempt failures);
-          * most attempts are redraws: the row-walker kernel (propose_sm.hip: a lane per attempt that stops at its first
-            out-of-bounds row, several attempts of a particle in flight -- as many as the attempt count makes worthwhile).
-            Its probe is the true mean, which the hard particles near a wall pull above the geometric estimate (131 072 x
-            100-D: estimate 2.8 / true 4.7: blocked 2.2 ms, walker 3.4 ms; estimate 5.8 / true 13.6: 5.1 vs 4.2 ms; 65 536 x
-            50-D: 2.1 / 2.7: 0.47 vs 0.57 ms; 4.2 / 7.2: 0.97 vs 0.78 ms; 262 144 x 32-D: 2.3 / 2.9: 0.62 vs 1.05 ms; 5.0 / 7.9:
-            1.6 vs 1.1 ms) -- hence the two thresholds, a little higher at n_dim >= 64.
-        Several modes: the multi-lane kernel, un-staged (matrices from global memory: a quarter of the LDS, four times the
-        resident waves) while redraws dominate, LDS-staged once a step is about one attempt."""
+        kernel for the next steps from it (thresholds: REGIME_THRESHOLDS above).  A captured graph has its kernels baked in: when
+        the rule asks for a different KERNEL than the graph holds (blocked <-> screened batches / walker <-> multi-lane; not for a
+        different number of rounds), the graph is retired and the step is captured again at its next launch -- an engine captured in
+        a run's redraw-dominated first iterations would otherwise walk rows for the rest of the run.  One mode:
+          * a step is a few attempts per particle: the blocked rounds (propose_blkm.hip: attempts in lockstep, 16 particles per
+            wave, both triangular products on the FP64 matrix cores) -- attempt 0 of everybody, further rounds over the particles
+            still out of bounds (fanned out), the rest finished by a screened launch over the list.  Its probe is the geometric
+            estimate n / (n - first-attempt failures);
+          * most attempts are redraws: the screened batches (propose_mf.hip; screen off: the FP64 row walker, propose_sm.hip).
+            Their probe is the true mean, which the hard particles near a wall pull above the geometric estimate (131 072 x
+            100-D: estimate 2.8 / true 4.7; 65 536 x 50-D: 2.1 / 2.7, 4.2 / 7.2) -- hence the two thresholds per band.
+        Several modes (K > 1, up to 64): the matrix-core rounds over mode-pure tiles while a step is a few attempts per particle,
+        their stragglers and the redraw-dominated steps through the per-mode screened batches (screen off: the multi-lane kernel,
+        un-staged while redraws dominate, LDS-staged once a step is about one attempt).
+        A switch back within a few readings of the last one makes the NEXT switch wait (REGIME_THRESHOLDS["dwell"]): a probe that
+        sits on a threshold and flips every step costs a bounded number of captures, not one per step."""
         if self.ctx.n_dim <= 16 or not mean_attempts > 0.0:
             return
-        import os
         before = (self.blocked > 0, bool(self.staged))
         from .device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_SCREEN, OPT_SM_LANES, OPT_STAGED_REDRAW
-        walker_ok = os.environ.get("TEMPEST_AMD_STAGED", "1") != "0"      # debugging aid (TPH_OPT_STAGED_REDRAW)
+        opts = getattr(self, "_opts", None) or RegimeOptions.from_env()
+        walker_ok = opts.walker_ok
         nd = self.ctx.n_dim
-        screened = os.environ.get("TEMPEST_AMD_SCREEN", "1") != "0" and nd <= 112      # TPH_OPT_SCREEN (debugging aid)
-        if screened:
-            # crossovers of tools/regime_sweep.py (profiles/r04_regime_sweep.jsonl): blocked rounds + straggler pass against the
-            # screened batches, whose time is flat in the attempt count up to ~10 attempts per particle
-            # (re-fitted with the list rounds fanned out, TPH_OPT_BLK_FAN: gpurun sweep of round 4, profiles/r04_regime_sweep_fan.jsonl)
-            up_est, down_true = (3.0, 5.0) if nd >= 64 else ((3.4, 5.5) if nd > 32 else (8.0, 13.0))
-        else:
-            up_est, down_true = (4.5, 8.0) if nd >= 64 else (3.5, 5.0)
+        screened = opts.screen and nd <= 112
+        up_est, down_true, cap, floor = regime_band("screened" if screened else "walker", nd)
         if self.K != 1:
-            # several modes: the matrix-core rounds over mode-pure tiles while a step is a few attempts per particle (propose_blkm.hip,
-            # up to 64 modes; what they leave goes to the multi-lane kernel); redraw-dominated steps: the multi-lane kernel alone
-            multi_ok = screened and self.K <= 64 and os.environ.get("TEMPEST_AMD_BLK_MFMA", "1") != "0"
-            want_blk = multi_ok and mean_attempts < (8.0 if self.blocked else 13.0)
+            sm_ = REGIME_THRESHOLDS["several_modes"]
+            multi_ok = screened and self.K <= 64 and opts.blk_mfma
+            want_blk = multi_ok and mean_attempts < (sm_["down"] if self.blocked else sm_["up"])
         elif self.blocked:             # geometric estimate
             want_blk = mean_attempts < up_est or not walker_ok
         else:                          # true mean (screened batches / row walker, or the multi-lane kernel of a run's first steps)
             want_blk = mean_attempts < down_true and (walker_ok or mean_attempts < 2.0)
-        if self.graph is not None and (want_blk, self.K == 1 and not want_blk and walker_ok) == before:
-            return                     # same kernel: the graph stays (its rounds and lane groups too)
+        want_sm = self.K == 1 and not want_blk and walker_ok
+        self._since = getattr(self, "_since", 1 << 30) + 1
+        self._dwell = getattr(self, "_dwell", 0)
+        if (want_blk, want_sm) == before:
+            if self.graph is not None:
+                return                 # same kernel: the graph stays (its rounds and lane groups too)
+        else:
+            dw = REGIME_THRESHOLDS["dwell"]
+            if self._since <= self._dwell:
+                return                 # a switch so soon after the last one: wait (the current kernel is correct, only not the fastest)
+            # consecutive switches each within a few readings of the one before: the second is still free (a run that crosses a
+            # band once each way), from the third on the wait doubles
+            self._quick = getattr(self, "_quick", 0) + 1 if self._since < max(dw["recent"], 2 * self._dwell) else 0
+            self._dwell = 0 if self._quick < 2 else min(dw["max"], dw["first"] << (self._quick - 2))
+            self._since = 0
         rounds = 0
         if want_blk:
             # A round that still has work costs at least one tile's latency (30-45 us at 100-D) however short its list: rounds
             # pay while the list fills the chip.  Expected list after k rounds: n (1 - 1/m)^k.  Measured against one round +
             # stragglers: 262 144 x 32-D -20 ... -26 %, 131 072 x 100-D -12 ... -17 %, 65 536 x 50-D +-0 (lists too short).
+            # (screened: the straggler pass is a screened launch over the list: it settles a short list in one launch's latency, a
+            # long one at ~8 us per straggler and wave -- rounds pay while the expected list is more than a few hundred particles)
             f, left = max(0.0, 1.0 - 1.0 / mean_attempts), float(self.n)
             rounds = 1
-            if screened:
-                # the straggler pass is a screened launch over the list: it settles a short list in one launch's latency, a long
-                # one at ~8 us per straggler and wave -- rounds pay while the expected list is more than a few hundred particles
-                cap, floor = (6 if nd >= 64 else (8 if nd > 32 else 12)), 64.0
-            else:
-                cap, floor = 24, 24576.0
             # (a matrix-core round gives its failing columns `tries` attempts in place: TPH_OPT_BLK_TRIES, 2 up to n_dim 32, 1 above)
             f_round = f ** (1 if (nd > 32 or not screened) else 2)
-            fan_opt = int(os.environ.get("TEMPEST_AMD_BLK_FAN", "1"))
-            fan, fan_div = screened and fan_opt != 0, {2: 1, 3: 4}.get(fan_opt, 2)
+            fan, fan_div = screened and opts.fan != 0, {2: 1, 3: 4}.get(opts.fan, 2)
             left *= f_round                         # after round 0
             while rounds < cap and left >= floor:
                 # a list round gives every listed particle G attempts side by side (TPH_OPT_BLK_FAN, propose_blkm.hip: the largest
@@ -361,15 +410,15 @@ class StepEngine:
             self.blocked = rounds
             self.ctx.set_option(OPT_BLOCKED, rounds)
             from .device import OPT_BLK_FAN
-            self.ctx.set_option(OPT_BLK_FAN, int(os.environ.get("TEMPEST_AMD_BLK_FAN", "1")))      # (debugging aid)
-        want_sm = self.K == 1 and not want_blk and walker_ok
-        lanes = int(os.environ.get("TEMPEST_AMD_SM_LANES", "0"))      # 0: the library sizes the lane groups (8 or 16 lanes per particle)
+            self.ctx.set_option(OPT_BLK_FAN, opts.fan)
+        lanes = opts.sm_lanes          # 0: the library sizes the lane groups (8 or 16 lanes per particle)
         if want_sm != self.staged or lanes != self.sm_lanes:
             self.staged, self.sm_lanes = want_sm, lanes
             self.ctx.set_option(OPT_STAGED_REDRAW, 1 if want_sm else 0)
             self.ctx.set_option(OPT_SM_LANES, lanes)
             self.ctx.set_option(OPT_SCREEN, 1 if screened else 0)
-        want = mean_attempts > (4.0 if self.unstaged else 8.0)      # hysteresis
+        un = REGIME_THRESHOLDS["unstaged"]
+        want = mean_attempts > (un["down"] if self.unstaged else un["up"])      # hysteresis
         if want != self.unstaged and self.graph is None:
             self.unstaged = want
             self.ctx.set_option(OPT_ML_UNSTAGED, 1 if want else 0)

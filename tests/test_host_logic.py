@@ -100,7 +100,9 @@ def test_proposal_regime_rule_d_gt_16(monkeypatch):
             self.opts[k] = v
 
     class Eng:
-        _regime = mcmc.StepEngine._regime
+        def _regime(self, m):          # the thresholds alone: every reading as if the last switch were long ago (the dwell: last test)
+            self._since, self._dwell, self._quick = 1 << 30, 0, 0
+            return mcmc.StepEngine._regime(self, m)
 
         def __init__(self, d, n, K=1):
             self.ctx, self.n, self.K, self.graph = Ctx(d), n, K, None
@@ -207,3 +209,90 @@ def test_proposal_regime_rule_d_gt_16(monkeypatch):
     assert 2 <= m4.blocked <= 4 and not m4.staged
     m4._regime(8.5)
     assert m4.blocked == 0 and not m4.staged
+
+
+def test_regime_rule_does_not_oscillate(monkeypatch):
+    """a redraw probe that sits on a threshold of StepEngine._regime and crosses it at every reading (the blocked
+    rounds report the geometric estimate, the screened batches the true mean: 3.1 >= 3.0 sends the step to the batches, whose 4.9 <
+    5.0 sends it back) must not retire and re-capture the step's graph at every step: after two free switches the next ones wait
+    4, 8, ... 64 readings.  Each threshold crossed ONCE, in either direction, switches at once; the debugging switches are read
+    when the engine is built, not per step."""
+    from tempest_amd import mcmc
+    for var in ("TEMPEST_AMD_SCREEN", "TEMPEST_AMD_STAGED", "TEMPEST_AMD_BLK_MFMA", "TEMPEST_AMD_BLK_FAN", "TEMPEST_AMD_SM_LANES"):
+        monkeypatch.delenv(var, raising=False)
+
+    class Ctx:
+        def __init__(self, d):
+            self.n_dim, self.opts, self.calls = d, {}, 0
+
+        def set_option(self, k, v):
+            self.opts[k] = v
+            self.calls += 1
+
+    class Eng:
+        _regime = mcmc.StepEngine._regime
+
+        def __init__(self, d, n, K=1):
+            self.ctx, self.n, self.K, self.graph = Ctx(d), n, K, None
+            self.blocked, self.staged, self.sm_lanes, self.unstaged = 0, False, 0, False
+            self._retired_graphs, self._keep = [], None
+            self._opts = mcmc.RegimeOptions.from_env()
+            self._since, self._dwell, self._quick = 1 << 30, 0, 0
+
+    for d, n in ((100, 131072), (50, 65536), (32, 262144)):
+        up, down, _, _ = mcmc.regime_band("screened", d)
+        # one crossing each way switches immediately, in both directions, at exactly the tabulated numbers
+        e = Eng(d, n)
+        e._regime(60.0)
+        assert e.staged and not e.blocked
+        e._regime(down + 0.01)
+        assert e.staged
+        e._regime(down - 0.01)
+        assert e.blocked >= 1 and not e.staged
+        e._regime(up - 0.01)
+        assert e.blocked >= 1
+        e._regime(up + 0.01)
+        assert e.staged and not e.blocked
+        # the probe flips at every reading: count the kernel switches (= graph retirements) over 400 readings
+        e = Eng(d, n)
+        e._regime(60.0)
+        switches, kinds = 0, []
+        for _ in range(400):
+            e.graph = object()                     # the step has been captured again since the last reading
+            was = (e.blocked > 0, e.staged)
+            e._regime(down - 0.01 if e.staged else up + 0.01)
+            now = (e.blocked > 0, e.staged)
+            if now != was:
+                switches += 1
+                assert e.graph is None and e._retired_graphs      # a switch retires the graph ...
+            else:
+                assert e.graph is not None                         # ... and nothing else does
+            kinds.append(now)
+        assert 4 <= switches <= 12, (d, switches)                  # 2 free + waits of 4, 8, 16, 32, 64, 64, ... readings
+        assert len(e._retired_graphs) == switches
+        # a run that has settled is free to switch again at once
+        for _ in range(200):
+            e._regime(1.05 if not e.staged else down - 0.01)
+        assert e.blocked >= 1 and not e.staged
+        e._regime(90.0)
+        assert e.staged and not e.blocked
+    # several modes: the same with the two-sided band of the matrix-core rounds
+    sm = mcmc.REGIME_THRESHOLDS["several_modes"]
+    e = Eng(32, 262144, K=4)
+    e._regime(20.0)
+    assert not e.blocked
+    switches = 0
+    for _ in range(400):
+        was = e.blocked > 0
+        e._regime(sm["up"] - 0.01 if not e.blocked else sm["down"] + 0.01)
+        switches += (e.blocked > 0) != was
+    assert switches <= 12
+    # the environment is not consulted per step: a switch flipped AFTER construction changes nothing for this engine
+    e = Eng(50, 65536)
+    monkeypatch.setenv("TEMPEST_AMD_SCREEN", "0")
+    e._regime(6.0)                                  # screened band of 50-D: 6.0 >= 5.5 keeps the batches; the walker band (5.0) too
+    e._regime(5.2)                                  # screened: 5.2 < 5.5 -> blocked rounds; with the screen off it would have stayed
+    assert e.blocked >= 1
+    import inspect
+    src = inspect.getsource(mcmc.StepEngine._regime)
+    assert "os.environ" not in src and "import os" not in src
