@@ -134,6 +134,12 @@ int tph_synchronize(tph_ctx* ctx);
  * is the proposal), with the screened kernel as the straggler pass (TPH_OPT_SCREEN); 0 = one attempt per particle and try;
  * 2 / 3 = the fanned-out list may fill all / a quarter of the ensemble's columns (experiments). */
 #define TPH_OPT_BLK_FAN 17
+/* TPH_OPT_HISTORY_VM: where u and x of the history live.  1 (default) = a history of >= 524 288 rows in a MAPPED address range
+ * (hipMemAddressReserve / hipMemCreate / hipMemMap) that grows in place -- memory is mapped behind what is there, an eighth at a
+ * time; nothing is reallocated or copied, so a history of 100 GB grows without a 2-3 x spike (tempest/state_manager.py:356-416
+ * appends without bound); smaller ones are plain allocations grown by doubling.  0 = plain allocations always; 2 = mapped
+ * always (tests).  The row-major mirror follows the history; logl and the cached mixture (16 bytes per row) are always plain. */
+#define TPH_OPT_HISTORY_VM 18
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- multi-GPU: one process per GPU --------------------------------------
@@ -192,6 +198,11 @@ int tph_history_append(tph_ctx* ctx, const double* u_dev, const double* x_dev, c
 int64_t tph_history_size(const tph_ctx* ctx);        /* N_h held by this ctx */
 int tph_history_iterations(const tph_ctx* ctx);      /* T */
 int tph_history_clear(tph_ctx* ctx);
+/* where the history's memory is (TPH_OPT_HISTORY_VM): out9 = { rows held, rows of u / x backed by memory, rows reserved (the
+ * leading dimension), 1 if u / x live in a mapped range, rows of the row-major mirror backed (0: no mirror), growth steps of the
+ * mapped ranges, re-reservations (mappings moved to a wider range), times the mirror was given back under memory pressure,
+ * copies of the whole history made while growing } */
+int tph_history_memory(tph_ctx* ctx, int64_t* out9_host);
 /* copy rows [off, off+n) to host: u/x as [n_dim][n] (dimension-major), logl/logmix as [n] */
 int tph_history_read(tph_ctx* ctx, int key, int64_t off, int64_t n, double* out_host);
 /* device base pointer and leading dimension (capacity) of a history array */

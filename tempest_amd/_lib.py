@@ -30,6 +30,7 @@ SIGNATURES = {
     "tph_history_size": (c_i64, [ptr]),
     "tph_history_iterations": (c_int, [ptr]),
     "tph_history_clear": (c_int, [ptr]),
+    "tph_history_memory": (c_int, [ptr, ptr]),
     "tph_history_read": (c_int, [ptr, c_int, c_i64, c_i64, ptr]),
     "tph_history_ptr": (c_int, [ptr, c_int, C.POINTER(ptr), C.POINTER(c_i64)]),
     "tph_history_load": (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, ptr, ptr, ptr, ptr]),

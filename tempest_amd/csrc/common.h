@@ -39,13 +39,38 @@ constexpr int TPH_WAVE = 64;
 
 struct tph_p2p;                         // p2p.hip: peer-mapped inboxes of the node's ranks
 
+// A set of equally spaced arrays ("slabs") that grow WITHOUT being copied: one address range reserved for all of them, physical
+// memory mapped at the front of every slab as the arrays fill (hipMemAddressReserve / hipMemCreate / hipMemMap; ctx.hip).  The
+// dimension-major history u[d][cap], x[d][cap] is one set of 2 d slabs with stride cap * 8 bytes; the row-major mirror is a set
+// of one.  Growing maps more memory behind what is there; outgrowing the reserved range moves the MAPPINGS to a wider range
+// (no byte is copied either way).
+struct tph_vm_set {
+  int device = 0;
+  char* base = nullptr;
+  size_t stride = 0;                    // bytes reserved per slab (a multiple of gran)
+  int slabs = 0;
+  size_t mapped = 0;                    // bytes mapped at the front of EVERY slab
+  size_t gran = 0;                      // mapping granularity
+  std::vector<hipMemGenericAllocationHandle_t> handles;      // [step][slab]
+  std::vector<size_t> step_off, step_bytes;                  // per growth step: where it sits in a slab
+  bool on() const { return base != nullptr; }
+};
+
 struct tph_ctx {
   int device = 0;
   int d = 0;
   hipStream_t stream = nullptr;
   // history, dimension-major with leading dimension `cap`
-  int64_t cap = 0, size = 0;
+  int64_t cap = 0, size = 0;        // cap: leading dimension of u and x (rows reserved per coordinate)
+  int64_t cap1 = 0;                 // rows logl and cmix are allocated for
   double *u = nullptr, *x = nullptr, *logl = nullptr, *cmix = nullptr;
+  // u and x of a large history live in mapped address ranges that grow in place (TPH_OPT_HISTORY_VM): no reallocation spike,
+  // no copy of tens of gigabytes when the history outgrows its reservation; small histories are plain allocations
+  tph_vm_set hist_vm;
+  int64_t hist_mapped = 0;          // rows of u / x backed by memory (== cap without the mapping)
+  int hist_vm_mode = 1;             // TPH_OPT_HISTORY_VM: 0 never | 1 histories of >= 524 288 rows (default) | 2 always
+  tph_vm_set rows_vm;               // the row-major mirror likewise
+  int64_t stat_mem[4] = {0, 0, 0, 0};   // tph_history_memory: growth steps of the mapping, re-reservations, mirror drops, copies
   // row-major MIRROR of (u, x, logl) for the indexed consumers (resample gather, one-sided shuffle): a random history row is
   // 2 d + 1 scattered 8-byte reads in the dimension-major arrays (one 64-byte sector each), but ONE contiguous record here.
   // Filled lazily, up to rows_size, by tph_rows_sync (resample.hip); dropped if it cannot be allocated.
@@ -140,6 +165,13 @@ void tph_p2p_release(tph_ctx* ctx);
 int tph_blocks(tph_ctx* ctx, int64_t n, int* T, int64_t* rows);   // equal-sized iteration blocks of the local history
 
 int tph_scratch_reserve(tph_ctx* ctx, size_t bytes);
+// mapped, growing arrays (ctx.hip)
+int tph_vm_reserve(tph_vm_set* v, int device, int slabs, size_t stride_bytes);
+int tph_vm_grow(tph_vm_set* v, size_t want_bytes_per_slab);            // 0 ok | 1 out of memory (nothing changed) | -1 error
+int tph_vm_restride(tph_vm_set* v, size_t new_stride_bytes, hipStream_t stream);
+void tph_vm_release(tph_vm_set* v);
+size_t tph_vm_granularity(int device);                                  // 0: the device cannot map memory this way
+void tph_rows_drop(tph_ctx* ctx);                                       // resample.hip: give the mirror's memory back (it is a cache)
 const double* tph_rows_sync(tph_ctx* ctx);          // resample.hip: mirror up to date for rows [0, size), or NULL (not in use)
 int tph_tri_inv(tph_ctx* ctx, const double* chol_dev, int K, double* winv_dev);   // modes.hip
 // propose_sm.hip: the whole proposal of a redraw-dominated step at 16 < d <= 100, one mode (pending moves, forms, u')

@@ -27,7 +27,23 @@ int tph_scratch_reserve(tph_ctx* ctx, size_t bytes) {
   if (ctx->scratch) TPH_HIP(hipFree(ctx->scratch));
   ctx->scratch = nullptr;
   ctx->scratch_bytes = 0;
-  TPH_HIP(hipMalloc(&ctx->scratch, nb));
+  hipError_t e = hipMalloc(&ctx->scratch, nb);
+  if (e != hipSuccess && nb > bytes) {              // not the doubled size: exactly what is asked for
+    (void)hipGetLastError();
+    nb = (bytes + 255) / 256 * 256;
+    e = hipMalloc(&ctx->scratch, nb);
+  }
+  if (e != hipSuccess && ctx->rows) {               // the row-major mirror is a cache: its memory goes back before this fails
+    (void)hipGetLastError();
+    tph_rows_drop(ctx);
+    e = hipMalloc(&ctx->scratch, nb);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->scratch = nullptr;
+    tph_set_error("tph_scratch_reserve: cannot allocate %zu bytes (%s)", nb, hipGetErrorString(e));
+    return -1;
+  }
   ctx->scratch_bytes = nb;
   return 0;
 }
@@ -70,30 +86,147 @@ static int table_upload(tph_ctx* ctx) {
   return 0;
 }
 
-static int history_reserve(tph_ctx* ctx, int64_t need) {
-  if (need <= ctx->cap) return 0;
-  int64_t nc = ctx->cap ? ctx->cap : 1024;
+// ------------------------------------------------------------------------- mapped, growing arrays (tph_vm_set)
+size_t tph_vm_granularity(int device) {
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  size_t g = 0;
+  if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || g == 0) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  // pieces of at least 2 MiB whatever the driver's minimum is: large fragments in the page tables, few driver calls
+  const size_t two_mb = (size_t)2 << 20;
+  return g >= two_mb ? g : (two_mb / g) * g;
+}
+
+int tph_vm_reserve(tph_vm_set* v, int device, int slabs, size_t stride_bytes) {
+  TPH_REQUIRE(!v->on() && slabs > 0, "tph_vm_reserve: bad argument");
+  const size_t g = tph_vm_granularity(device);
+  TPH_REQUIRE(g > 0, "tph_vm_reserve: the device does not report a mapping granularity");
+  TPH_REQUIRE(stride_bytes > 0 && stride_bytes % g == 0, "tph_vm_reserve: the stride must be a multiple of %zu bytes", g);
+  void* p = nullptr;
+  hipError_t e = hipMemAddressReserve(&p, stride_bytes * (size_t)slabs, g, nullptr, 0);
+  if (e != hipSuccess || !p) {
+    (void)hipGetLastError();
+    tph_set_error("tph_vm_reserve: cannot reserve %zu bytes of address space (%s)", stride_bytes * (size_t)slabs, hipGetErrorString(e));
+    return -1;
+  }
+  v->device = device; v->base = (char*)p; v->stride = stride_bytes; v->slabs = slabs; v->mapped = 0; v->gran = g;
+  v->handles.clear(); v->step_off.clear(); v->step_bytes.clear();
+  return 0;
+}
+
+static hipError_t vm_map_piece(const tph_vm_set* v, char* at, size_t bytes, hipMemGenericAllocationHandle_t h) {
+  hipError_t e = hipMemMap(at, bytes, 0, h, 0);
+  if (e != hipSuccess) return e;
+  hipMemAccessDesc acc = {};
+  acc.location.type = hipMemLocationTypeDevice;
+  acc.location.id = v->device;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  e = hipMemSetAccess(at, bytes, &acc, 1);
+  if (e != hipSuccess) (void)hipMemUnmap(at, bytes);
+  return e;
+}
+
+// every slab backed up to `want` bytes (rounded up to the granularity): one physical allocation per slab and step.  A step that
+// cannot be completed is undone entirely -- what was mapped before stays as it is (return 1: out of memory).
+int tph_vm_grow(tph_vm_set* v, size_t want) {
+  TPH_REQUIRE(v->on(), "tph_vm_grow: nothing reserved");
+  want = (want + v->gran - 1) / v->gran * v->gran;
+  if (want <= v->mapped) return 0;
+  TPH_REQUIRE(want <= v->stride, "tph_vm_grow: %zu bytes per array exceed the reserved %zu", want, v->stride);
+  const size_t off = v->mapped, bytes = want - v->mapped;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = v->device;
+  std::vector<hipMemGenericAllocationHandle_t> hs((size_t)v->slabs);
+  int done = 0;
+  hipError_t e = hipSuccess;
+  for (; done < v->slabs; ++done) {
+    e = hipMemCreate(&hs[done], bytes, &prop, 0);
+    if (e != hipSuccess) break;
+    e = vm_map_piece(v, v->base + (size_t)done * v->stride + off, bytes, hs[done]);
+    if (e != hipSuccess) { (void)hipMemRelease(hs[done]); break; }
+  }
+  if (done < v->slabs) {
+    (void)hipGetLastError();
+    for (int s = 0; s < done; ++s) {
+      (void)hipMemUnmap(v->base + (size_t)s * v->stride + off, bytes);
+      (void)hipMemRelease(hs[s]);
+    }
+    tph_set_error("tph_vm_grow: cannot back %d arrays with %zu more bytes each (%s)", v->slabs, bytes, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation ? 1 : -1;
+  }
+  v->handles.insert(v->handles.end(), hs.begin(), hs.end());
+  v->step_off.push_back(off);
+  v->step_bytes.push_back(bytes);
+  v->mapped = want;
+  return 0;
+}
+
+// the same physical memory behind a WIDER spacing of the slabs: a new address range, every piece unmapped from the old one and
+// mapped at its slab's new place.  The stream is drained first (kernels in flight still use the old addresses).
+int tph_vm_restride(tph_vm_set* v, size_t new_stride, hipStream_t stream) {
+  TPH_REQUIRE(v->on() && new_stride % v->gran == 0 && new_stride >= v->mapped, "tph_vm_restride: bad stride");
+  TPH_HIP(hipStreamSynchronize(stream));
+  void* p = nullptr;
+  hipError_t e = hipMemAddressReserve(&p, new_stride * (size_t)v->slabs, v->gran, nullptr, 0);
+  if (e != hipSuccess || !p) {
+    (void)hipGetLastError();
+    tph_set_error("tph_vm_restride: cannot reserve %zu bytes of address space (%s)", new_stride * (size_t)v->slabs, hipGetErrorString(e));
+    return -1;
+  }
+  char* nb = (char*)p;
+  for (size_t k = 0; k < v->step_off.size(); ++k)
+    for (int sl = 0; sl < v->slabs; ++sl) {
+      char* old_at = v->base + (size_t)sl * v->stride + v->step_off[k];
+      TPH_HIP(hipMemUnmap(old_at, v->step_bytes[k]));
+      hipError_t m = vm_map_piece(v, nb + (size_t)sl * new_stride + v->step_off[k], v->step_bytes[k], v->handles[k * (size_t)v->slabs + sl]);
+      TPH_REQUIRE(m == hipSuccess, "tph_vm_restride: re-mapping failed (%s): the history is lost", hipGetErrorString(m));
+    }
+  (void)hipMemAddressFree(v->base, v->stride * (size_t)v->slabs);
+  v->base = nb;
+  v->stride = new_stride;
+  return 0;
+}
+
+void tph_vm_release(tph_vm_set* v) {
+  if (!v->on()) return;
+  for (size_t k = 0; k < v->step_off.size(); ++k)
+    for (int sl = 0; sl < v->slabs; ++sl) {
+      (void)hipMemUnmap(v->base + (size_t)sl * v->stride + v->step_off[k], v->step_bytes[k]);
+      (void)hipMemRelease(v->handles[k * (size_t)v->slabs + sl]);
+    }
+  (void)hipMemAddressFree(v->base, v->stride * (size_t)v->slabs);
+  (void)hipGetLastError();
+  *v = tph_vm_set();
+}
+
+// ------------------------------------------------------------------------------------ history capacity
+constexpr int64_t HIST_VM_MIN_ROWS = 524288;     // below this a history is a plain allocation grown by doubling (cheap at that size)
+
+// logl and cmix (8 bytes per row each): plain allocations, doubled and copied -- a spike of 16 bytes per row
+static int history_reserve_scalars(tph_ctx* ctx, int64_t need) {
+  if (need <= ctx->cap1) return 0;
+  int64_t nc = ctx->cap1 ? ctx->cap1 : 1024;
   while (nc < need) nc *= 2;
   nc = (nc + 255) / 256 * 256;
-  // all four new arrays are allocated and filled before any old one is released: a failed allocation or copy frees what
-  // it had allocated and leaves the history exactly as it was (the four arrays share one leading dimension, so they
-  // can only be swapped together)
-  const size_t d = (size_t)ctx->d;
-  const size_t w = sizeof(double) * (size_t)ctx->size;
-  struct Arr { double** p; size_t rows; };
-  Arr arrs[4] = {{&ctx->u, d}, {&ctx->x, d}, {&ctx->logl, 1}, {&ctx->cmix, 1}};
-  double* fresh[4] = {nullptr, nullptr, nullptr, nullptr};
-  for (int a = 0; a < 4; ++a) {
-    hipError_t e = hipMalloc((void**)&fresh[a], sizeof(double) * arrs[a].rows * nc);
+  double* fresh[2] = {nullptr, nullptr};
+  double** arrs[2] = {&ctx->logl, &ctx->cmix};
+  for (int a = 0; a < 2; ++a) {
+    hipError_t e = hipMalloc((void**)&fresh[a], sizeof(double) * (size_t)nc);
     if (e != hipSuccess) {
-      for (int b = 0; b < a; ++b) (void)hipFree(fresh[b]);      // nothing has been swapped in yet: no leak, history intact
+      (void)hipGetLastError();
+      for (int b = 0; b < a; ++b) (void)hipFree(fresh[b]);
       tph_set_error("history_reserve: cannot grow the history to %lld rows (%s)", (long long)nc, hipGetErrorString(e));
       return -1;
     }
     if (ctx->size > 0) {
-      hipError_t c = hipMemcpy2DAsync(fresh[a], sizeof(double) * nc, *arrs[a].p, sizeof(double) * ctx->cap, w, arrs[a].rows,
-                                      hipMemcpyDeviceToDevice, ctx->stream);
-      if (c == hipSuccess) c = hipStreamSynchronize(ctx->stream);
+      hipError_t c = hipMemcpyAsync(fresh[a], *arrs[a], sizeof(double) * (size_t)ctx->size, hipMemcpyDeviceToDevice, ctx->stream);
       if (c != hipSuccess) {
         for (int b = 0; b <= a; ++b) (void)hipFree(fresh[b]);
         tph_set_error("history_reserve: copy failed (%s)", hipGetErrorString(c));
@@ -102,12 +235,129 @@ static int history_reserve(tph_ctx* ctx, int64_t need) {
     }
   }
   TPH_HIP(hipStreamSynchronize(ctx->stream));
-  for (int a = 0; a < 4; ++a) {
-    if (*arrs[a].p) (void)hipFree(*arrs[a].p);
-    *arrs[a].p = fresh[a];
+  for (int a = 0; a < 2; ++a) {
+    if (*arrs[a]) (void)hipFree(*arrs[a]);
+    *arrs[a] = fresh[a];
+  }
+  ctx->cap1 = nc;
+  return 0;
+}
+
+// u and x as plain allocations: all new arrays are allocated and filled before any old one is released, so a failed allocation
+// or copy leaves the history exactly as it was (the two arrays share one leading dimension and can only be swapped together)
+static int history_reserve_plain(tph_ctx* ctx, int64_t need) {
+  int64_t nc = ctx->cap ? ctx->cap : 1024;
+  while (nc < need) nc *= 2;
+  nc = (nc + 255) / 256 * 256;
+  const size_t d = (size_t)ctx->d;
+  const size_t w = sizeof(double) * (size_t)ctx->size;
+  double** arrs[2] = {&ctx->u, &ctx->x};
+  double* fresh[2] = {nullptr, nullptr};
+  for (int a = 0; a < 2; ++a) {
+    hipError_t e = hipMalloc((void**)&fresh[a], sizeof(double) * d * (size_t)nc);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      for (int b = 0; b < a; ++b) (void)hipFree(fresh[b]);
+      tph_set_error("history_reserve: cannot grow the history to %lld rows (%s)", (long long)nc, hipGetErrorString(e));
+      return -1;
+    }
+    if (ctx->size > 0) {
+      hipError_t c = hipMemcpy2DAsync(fresh[a], sizeof(double) * nc, *arrs[a], sizeof(double) * ctx->cap, w, d, hipMemcpyDeviceToDevice, ctx->stream);
+      if (c == hipSuccess) c = hipStreamSynchronize(ctx->stream);
+      if (c != hipSuccess) {
+        for (int b = 0; b <= a; ++b) (void)hipFree(fresh[b]);
+        tph_set_error("history_reserve: copy failed (%s)", hipGetErrorString(c));
+        return -1;
+      }
+      ctx->stat_mem[3] += 1;
+    }
+  }
+  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  for (int a = 0; a < 2; ++a) {
+    if (*arrs[a]) (void)hipFree(*arrs[a]);
+    *arrs[a] = fresh[a];
   }
   ctx->cap = nc;
+  ctx->hist_mapped = nc;
   return 0;
+}
+
+// u and x in a mapped range (state_manager.py:356-416 appends without bound: the reference's lists of arrays never move either).
+// Growth: the next `need` rows, and at least an eighth more than is mapped, so that the driver calls (2 n_dim allocations and
+// mappings per step) stay a handful per run; under memory pressure the mirror goes first (it is a cache), then exactly `need`.
+static int history_reserve_vm(tph_ctx* ctx, int64_t need) {
+  tph_vm_set& v = ctx->hist_vm;
+  const size_t g = tph_vm_granularity(ctx->device);
+  if (g == 0) return 2;                                        // not available: the caller falls back to plain allocations
+  const int64_t grow_rows = (int64_t)(g / sizeof(double));     // rows per mapping granule
+  auto round_rows = [&](int64_t r) { return (r + grow_rows - 1) / grow_rows * grow_rows; };
+  if (!v.on()) {
+    // address space for four times what is asked for (it costs nothing); the rows held so far move in with ONE copy
+    const int64_t rows_va = round_rows(need > (1ll << 40) / 4 ? need : 4 * need);
+    tph_vm_set fresh;
+    if (tph_vm_reserve(&fresh, ctx->device, 2 * ctx->d, sizeof(double) * (size_t)rows_va)) { (void)hipGetLastError(); return 2; }
+    const int rc = tph_vm_grow(&fresh, sizeof(double) * (size_t)round_rows(need));
+    if (rc) { tph_vm_release(&fresh); return rc == 1 ? -1 : 2; }
+    if (ctx->size > 0) {
+      const size_t w = sizeof(double) * (size_t)ctx->size;
+      hipError_t c = hipMemcpy2DAsync(fresh.base, fresh.stride, ctx->u, sizeof(double) * ctx->cap, w, ctx->d, hipMemcpyDeviceToDevice, ctx->stream);
+      if (c == hipSuccess)
+        c = hipMemcpy2DAsync(fresh.base + (size_t)ctx->d * fresh.stride, fresh.stride, ctx->x, sizeof(double) * ctx->cap, w, ctx->d,
+                             hipMemcpyDeviceToDevice, ctx->stream);
+      if (c == hipSuccess) c = hipStreamSynchronize(ctx->stream);
+      if (c != hipSuccess) {
+        tph_vm_release(&fresh);
+        tph_set_error("history_reserve: copy into the mapped range failed (%s)", hipGetErrorString(c));
+        return -1;
+      }
+      ctx->stat_mem[3] += 1;
+    }
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->u) (void)hipFree(ctx->u);
+    if (ctx->x) (void)hipFree(ctx->x);
+    v = fresh;
+    ctx->u = (double*)v.base;
+    ctx->x = (double*)(v.base + (size_t)ctx->d * v.stride);
+    ctx->cap = (int64_t)(v.stride / sizeof(double));
+    ctx->hist_mapped = (int64_t)(v.mapped / sizeof(double));
+    ctx->stat_mem[0] += 1;
+    return 0;
+  }
+  if (need > ctx->cap) {                                       // outgrown the reserved range: a wider one, mappings moved, nothing copied
+    int64_t rows_va = ctx->cap;
+    while (rows_va < need) rows_va *= 2;
+    if (tph_vm_restride(&v, sizeof(double) * (size_t)rows_va, ctx->stream)) return -1;
+    ctx->u = (double*)v.base;
+    ctx->x = (double*)(v.base + (size_t)ctx->d * v.stride);
+    ctx->cap = rows_va;
+    ctx->stat_mem[1] += 1;
+  }
+  int64_t want = ctx->hist_mapped + ctx->hist_mapped / 8;
+  if (want < need) want = need;
+  want = round_rows(want);
+  if (want > ctx->cap) want = ctx->cap;
+  int rc = tph_vm_grow(&v, sizeof(double) * (size_t)want);
+  if (rc == 1 && ctx->rows) {                                  // out of memory: the mirror's share goes back first
+    tph_rows_drop(ctx);
+    rc = tph_vm_grow(&v, sizeof(double) * (size_t)want);
+  }
+  if (rc == 1 && want > round_rows(need)) rc = tph_vm_grow(&v, sizeof(double) * (size_t)round_rows(need));
+  if (rc) return -1;
+  ctx->hist_mapped = (int64_t)(v.mapped / sizeof(double));
+  ctx->stat_mem[0] += 1;
+  return 0;
+}
+
+static int history_reserve(tph_ctx* ctx, int64_t need) {
+  if (history_reserve_scalars(ctx, need)) return -1;
+  if (need <= ctx->hist_mapped) return 0;
+  const bool want_vm = ctx->hist_vm.on() || ctx->hist_vm_mode == 2 || (ctx->hist_vm_mode == 1 && need >= HIST_VM_MIN_ROWS);
+  if (want_vm) {
+    const int rc = history_reserve_vm(ctx, need);
+    if (rc != 2) return rc;
+    ctx->hist_vm_mode = 0;                                     // the device cannot map memory this way: plain allocations from now on
+  }
+  return history_reserve_plain(ctx, need);
 }
 
 extern "C" int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void* hip_stream, tph_ctx** out) {
@@ -121,6 +371,7 @@ extern "C" int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void
   c->device = device;
   if (const char* env = getenv("TEMPEST_AMD_ROW_MIRROR")) c->rows_mode = atoi(env) ? 1 : 0;     // debugging aid (TPH_OPT_ROW_MIRROR)
   if (const char* env = getenv("TEMPEST_AMD_SORTED_DRAWS")) c->mc_sorted = atoi(env) ? 1 : 0;  // debugging aid (TPH_OPT_SORTED_DRAWS)
+  if (const char* env = getenv("TEMPEST_AMD_HISTORY_VM")) c->hist_vm_mode = atoi(env) < 0 ? 0 : (atoi(env) > 2 ? 2 : atoi(env));   // debugging aid (TPH_OPT_HISTORY_VM)
   c->d = n_dim;
   c->stream = (hipStream_t)hip_stream;
   {
@@ -159,8 +410,12 @@ extern "C" int tph_ctx_destroy(tph_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   tph_p2p_release(ctx);
-  void* bufs[] = {ctx->u, ctx->x, ctx->logl, ctx->cmix, ctx->table_dev, ctx->partials, ctx->small_dev, ctx->scratch, ctx->winv,
-                  ctx->blk_table, ctx->vv_buf, ctx->blk_buf, ctx->rows, ctx->sm_small, ctx->sm_scr, ctx->mf_buf, ctx->bm_buf, ctx->mt_buf};
+  const bool hist_mapped = ctx->hist_vm.on(), rows_mapped = ctx->rows_vm.on();
+  tph_vm_release(&ctx->hist_vm);
+  tph_vm_release(&ctx->rows_vm);
+  void* bufs[] = {hist_mapped ? nullptr : ctx->u, hist_mapped ? nullptr : ctx->x, ctx->logl, ctx->cmix, ctx->table_dev, ctx->partials,
+                  ctx->small_dev, ctx->scratch, ctx->winv, ctx->blk_table, ctx->vv_buf, ctx->blk_buf, rows_mapped ? nullptr : ctx->rows,
+                  ctx->sm_small, ctx->sm_scr, ctx->mf_buf, ctx->bm_buf, ctx->mt_buf};
   for (void* b : bufs) (void)hipFree(b);
   for (void* b : ctx->retired) (void)hipFree(b);
   (void)hipHostFree(ctx->pinned);
@@ -253,6 +508,7 @@ extern "C" int tph_set_option(tph_ctx* ctx, int option, int value) {
     case TPH_OPT_BLK_MFMA: ctx->blk_mfma = value ? 1 : 0; break;
     case TPH_OPT_BLK_TRIES: ctx->blk_tries = value < 0 ? 0 : (value > 3 ? 3 : value); break;
     case TPH_OPT_BLK_FAN: ctx->blk_fan = value < 0 ? 0 : (value > 3 ? 3 : value); break;
+    case TPH_OPT_HISTORY_VM: ctx->hist_vm_mode = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     default: TPH_REQUIRE(false, "tph_set_option: unknown option %d", option);
   }
   return 0;
@@ -266,6 +522,17 @@ extern "C" int tph_synchronize(tph_ctx* ctx) {
 
 extern "C" int64_t tph_history_size(const tph_ctx* ctx) { return ctx ? ctx->size : -1; }
 extern "C" int tph_history_iterations(const tph_ctx* ctx) { return ctx ? (int)ctx->beta_t.size() : -1; }
+
+// where the history's memory is: out[0] rows held, [1] rows of u / x backed by memory, [2] rows reserved (leading dimension),
+// [3] 1 = u / x in a mapped range, [4] rows of the row-major mirror backed (0: none), [5] growth steps of the mapped ranges,
+// [6] re-reservations (mappings moved), [7] times the mirror was given back under memory pressure, [8] copies of the whole history
+extern "C" int tph_history_memory(tph_ctx* ctx, int64_t* out9) {
+  TPH_REQUIRE(ctx && out9, "tph_history_memory: NULL argument");
+  out9[0] = ctx->size; out9[1] = ctx->hist_mapped; out9[2] = ctx->cap; out9[3] = ctx->hist_vm.on() ? 1 : 0;
+  out9[4] = ctx->rows ? ctx->rows_cap : 0;
+  out9[5] = ctx->stat_mem[0]; out9[6] = ctx->stat_mem[1]; out9[7] = ctx->stat_mem[2]; out9[8] = ctx->stat_mem[3];
+  return 0;
+}
 
 extern "C" int tph_history_clear(tph_ctx* ctx) {
   TPH_REQUIRE(ctx, "tph_history_clear: ctx is NULL");

@@ -377,22 +377,72 @@ __global__ void __launch_bounds__(256) k_rows_pack(const double* __restrict__ hu
   }
 }
 
+// the mirror's memory goes back (it is a cache of the dimension-major arrays): under memory pressure, or when it would take more
+// than its share of the device
+void tph_rows_drop(tph_ctx* ctx) {
+  if (!ctx->rows) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->rows_vm.on()) tph_vm_release(&ctx->rows_vm);
+  else (void)hipFree(ctx->rows);
+  (void)hipGetLastError();
+  ctx->rows = nullptr; ctx->rows_cap = 0; ctx->rows_size = 0;
+  ctx->rows_mode = 0;
+  ctx->stat_mem[2] += 1;
+}
+
+// may the mirror take `more` bytes on top of the `have` it holds?  Never more than a fifth of the device for the whole mirror,
+// and never so much that less than 15 % of the device stays free (the fit's working set, the sort buffers and the caller's own
+// tensors come out of that): a 100-D history of 10^8 rows does without a mirror -- its gather is a per-mille of an iteration.
+static bool rows_budget_ok(size_t have, size_t more) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return true; }
+  if (have + more > total_b / 5) return false;
+  return free_b >= more && free_b - more >= total_b / 20 * 3;
+}
+
 const double* tph_rows_sync(tph_ctx* ctx) {
   if (!ctx->rows_mode || ctx->size <= 0) return nullptr;
   const int d = ctx->d, rec = 2 * d + 1;
-  if (ctx->rows_cap < ctx->size) {                                // grow with the history's own capacity
+  const size_t recb = sizeof(double) * (size_t)rec;
+  if (ctx->rows_cap < ctx->size && ctx->hist_vm.on()) {
+    // the history grows in a mapped range: so does the mirror (a set of one array), an eighth at a time
+    tph_vm_set& v = ctx->rows_vm;
+    const size_t g = tph_vm_granularity(ctx->device);
+    int64_t want_rows = ctx->rows_cap + ctx->rows_cap / 8;
+    if (want_rows < ctx->size) want_rows = ctx->size;
+    size_t want = g ? ((size_t)want_rows * recb + g - 1) / g * g : 0;
+    bool ok = g > 0 && rows_budget_ok(v.on() ? v.mapped : 0, want - (v.on() ? v.mapped : 0));
+    if (ok && !v.on()) {
+      if (ctx->rows) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->rows); ctx->rows = nullptr; ctx->rows_cap = 0; ctx->rows_size = 0; }
+      const size_t va = ((size_t)ctx->cap * recb + g - 1) / g * g;
+      ok = tph_vm_reserve(&v, ctx->device, 1, va > want ? va : want) == 0;
+    }
+    if (ok && want > v.stride) {
+      size_t ns = v.stride;
+      while (ns < want) ns *= 2;
+      ok = tph_vm_restride(&v, ns, ctx->stream) == 0;
+    }
+    if (ok) ok = tph_vm_grow(&v, want) == 0;
+    if (!ok) {
+      (void)hipGetLastError();
+      tph_rows_drop(ctx);
+      ctx->rows_mode = 0;
+      return nullptr;
+    }
+    ctx->rows = (double*)v.base;
+    ctx->rows_cap = (int64_t)(v.mapped / recb);
+  } else if (ctx->rows_cap < ctx->size) {                                // a plain allocation, grown with the history's own capacity
     double* fresh = nullptr;
     const int64_t nc = ctx->cap > ctx->size ? ctx->cap : ctx->size;
-    if (hipMalloc((void**)&fresh, sizeof(double) * (size_t)nc * rec) != hipSuccess) {
+    if (!rows_budget_ok(0, (size_t)nc * recb) || hipMalloc((void**)&fresh, (size_t)nc * recb) != hipSuccess) {
       (void)hipGetLastError();
+      tph_rows_drop(ctx);
       ctx->rows_mode = 0;                                         // no room for a mirror: the dimension-major gather from now on
-      if (ctx->rows) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->rows); }
-      ctx->rows = nullptr; ctx->rows_cap = 0; ctx->rows_size = 0;
       return nullptr;
     }
     if (ctx->rows) {
       if (ctx->rows_size > 0 &&
-          hipMemcpyAsync(fresh, ctx->rows, sizeof(double) * (size_t)ctx->rows_size * rec, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+          hipMemcpyAsync(fresh, ctx->rows, (size_t)ctx->rows_size * recb, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
         (void)hipGetLastError();
         ctx->rows_size = 0;
       }

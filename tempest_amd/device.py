@@ -31,6 +31,7 @@ OPT_MF_AUDIT = 14              # TPH_OPT_MF_AUDIT
 OPT_BLK_MFMA = 15              # TPH_OPT_BLK_MFMA
 OPT_BLK_TRIES = 16             # TPH_OPT_BLK_TRIES
 OPT_BLK_FAN = 17               # TPH_OPT_BLK_FAN
+OPT_HISTORY_VM = 18            # TPH_OPT_HISTORY_VM
 BC_STRICT, BC_PERIODIC, BC_REFLECTIVE = 0, 1, 2
 
 TAG_PRIOR, TAG_NORMAL, TAG_GAMMA, TAG_ACCEPT, TAG_RESAMPLE, TAG_UPSAMPLE, TAG_REPAIR, TAG_SYST = 1, 2, 3, 4, 5, 6, 7, 8
@@ -133,6 +134,13 @@ class HipContext:
         p, ld = C.c_void_p(), C.c_int64()
         check(self.lib.tph_history_ptr(self._ctx, key, C.byref(p), C.byref(ld)), "tph_history_ptr")
         return p.value, ld.value
+
+    def history_memory(self):
+        """Where the history's memory is (tph_history_memory): a dict of row counts and growth counters."""
+        out = np.zeros(9, dtype=np.int64)
+        check(self.lib.tph_history_memory(self._ctx, _hptr(out)), "tph_history_memory")
+        keys = ("rows", "rows_backed", "rows_reserved", "mapped", "mirror_rows", "growth_steps", "rereservations", "mirror_drops", "copies")
+        return dict(zip(keys, (int(v) for v in out)))
 
     def history_clear(self):
         self._vv_centre = None
