@@ -134,11 +134,13 @@ int tph_synchronize(tph_ctx* ctx);
  * is the proposal), with the screened kernel as the straggler pass (TPH_OPT_SCREEN); 0 = one attempt per particle and try;
  * 2 / 3 = the fanned-out list may fill all / a quarter of the ensemble's columns (experiments). */
 #define TPH_OPT_BLK_FAN 17
-/* TPH_OPT_HISTORY_VM: where u and x of the history live.  1 (default) = a history of >= 524 288 rows in a MAPPED address range
- * (hipMemAddressReserve / hipMemCreate / hipMemMap) that grows in place -- memory is mapped behind what is there, an eighth at a
- * time; nothing is reallocated or copied, so a history of 100 GB grows without a 2-3 x spike (tempest/state_manager.py:356-416
+/* TPH_OPT_HISTORY_VM: where u and x of the history live.  1 (default) = a history asked to hold >= 16 GB of u and x -- or a
+ * plain one whose next doubling would not fit comfortably -- lives in a MAPPED address range (hipMemAddressReserve / hipMemCreate
+ * / hipMemMap, uniform pieces of 2 or 32 MiB) that grows in place: memory is mapped behind what is there, an eighth at a time,
+ * nothing is reallocated or copied, so a history of 100 GB grows without a 2-3 x spike (tempest/state_manager.py:356-416
  * appends without bound); smaller ones are plain allocations grown by doubling.  0 = plain allocations always; 2 = mapped
- * always (tests).  The row-major mirror follows the history; logl and the cached mixture (16 bytes per row) are always plain. */
+ * always (tests).  The row-major mirror follows the history (within a fifth of the device, and never below 15 % free memory:
+ * beyond that it is given back); logl and the cached mixture (16 bytes per row) are always plain. */
 #define TPH_OPT_HISTORY_VM 18
 int tph_set_option(tph_ctx* ctx, int option, int value);
 

@@ -44,15 +44,18 @@ struct tph_p2p;                         // p2p.hip: peer-mapped inboxes of the n
 // dimension-major history u[d][cap], x[d][cap] is one set of 2 d slabs with stride cap * 8 bytes; the row-major mirror is a set
 // of one.  Growing maps more memory behind what is there; outgrowing the reserved range moves the MAPPINGS to a wider range
 // (no byte is copied either way).
+// Every physical piece of a set has the SAME size (2 or 32 MiB, fixed when the range is reserved): on ROCm 7.2 hipMemSetAccess
+// fails with "invalid value" once pieces of different sizes meet in one reservation (tools/ubench_vmm_probe.hip,
+// profiles/r05_vmm_probe.json); uniform pieces map by the thousand, in ~13-16 us each, and stream as fast as hipMalloc'ed memory
+// (5.98-6.03 against 6.03 TB/s read).
 struct tph_vm_set {
   int device = 0;
   char* base = nullptr;
-  size_t stride = 0;                    // bytes reserved per slab (a multiple of gran)
+  size_t stride = 0;                    // bytes reserved per slab (a multiple of piece)
   int slabs = 0;
-  size_t mapped = 0;                    // bytes mapped at the front of EVERY slab
-  size_t gran = 0;                      // mapping granularity
-  std::vector<hipMemGenericAllocationHandle_t> handles;      // [step][slab]
-  std::vector<size_t> step_off, step_bytes;                  // per growth step: where it sits in a slab
+  size_t mapped = 0;                    // bytes mapped at the front of EVERY slab (a multiple of piece)
+  size_t piece = 0;                     // bytes of one physical allocation
+  std::vector<hipMemGenericAllocationHandle_t> handles;      // [piece index][slab]
   bool on() const { return base != nullptr; }
 };
 
@@ -166,11 +169,11 @@ int tph_blocks(tph_ctx* ctx, int64_t n, int* T, int64_t* rows);   // equal-sized
 
 int tph_scratch_reserve(tph_ctx* ctx, size_t bytes);
 // mapped, growing arrays (ctx.hip)
-int tph_vm_reserve(tph_vm_set* v, int device, int slabs, size_t stride_bytes);
+int tph_vm_reserve(tph_vm_set* v, int device, int slabs, size_t stride_bytes, size_t piece_bytes);
 int tph_vm_grow(tph_vm_set* v, size_t want_bytes_per_slab);            // 0 ok | 1 out of memory (nothing changed) | -1 error
 int tph_vm_restride(tph_vm_set* v, size_t new_stride_bytes, hipStream_t stream);
 void tph_vm_release(tph_vm_set* v);
-size_t tph_vm_granularity(int device);                                  // 0: the device cannot map memory this way
+size_t tph_vm_piece(int device, size_t first_bytes_per_slab);            // piece size for a set (0: the device cannot map memory this way)
 void tph_rows_drop(tph_ctx* ctx);                                       // resample.hip: give the mirror's memory back (it is a cache)
 const double* tph_rows_sync(tph_ctx* ctx);          // resample.hip: mirror up to date for rows [0, size), or NULL (not in use)
 int tph_tri_inv(tph_ctx* ctx, const double* chol_dev, int K, double* winv_dev);   // modes.hip

@@ -86,8 +86,25 @@ static int table_upload(tph_ctx* ctx) {
   return 0;
 }
 
+// rows x n doubles between two pitched device arrays (dimension-major blocks of the history): a kernel, because hipMemcpy2D
+// rejects addresses inside a mapped range (invalid argument on ROCm 7.2); 16 B per lane where the alignment allows
+__global__ void __launch_bounds__(256) k_copy2d(double* __restrict__ dst, int64_t dst_ld, const double* __restrict__ src, int64_t src_ld,
+                                                int64_t n) {
+  const double* s = src + (size_t)blockIdx.y * src_ld;
+  double* d = dst + (size_t)blockIdx.y * dst_ld;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = s[i];
+}
+static int copy2d(tph_ctx* ctx, double* dst, int64_t dst_ld, const double* src, int64_t src_ld, int64_t n, int rows) {
+  if (n <= 0 || rows <= 0) return 0;
+  int gx = tph_grid_for(n, 256, 4, 2048);
+  hipLaunchKernelGGL(k_copy2d, dim3(gx, rows), dim3(256), 0, ctx->stream, dst, dst_ld, src, src_ld, n);
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------------- mapped, growing arrays (tph_vm_set)
-size_t tph_vm_granularity(int device) {
+size_t tph_vm_piece(int device, size_t first_bytes_per_slab) {
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned;
   prop.location.type = hipMemLocationTypeDevice;
@@ -97,73 +114,73 @@ size_t tph_vm_granularity(int device) {
     (void)hipGetLastError();
     return 0;
   }
-  // pieces of at least 2 MiB whatever the driver's minimum is: large fragments in the page tables, few driver calls
-  const size_t two_mb = (size_t)2 << 20;
-  return g >= two_mb ? g : (two_mb / g) * g;
+  // 2 MiB pieces for small sets, 32 MiB once a slab starts at 64 MiB or more (a 100 GB history is ~3 000 pieces of ~15 us)
+  const size_t want = first_bytes_per_slab >= ((size_t)64 << 20) ? (size_t)32 << 20 : (size_t)2 << 20;
+  return want % g == 0 ? want : 0;
 }
 
-int tph_vm_reserve(tph_vm_set* v, int device, int slabs, size_t stride_bytes) {
-  TPH_REQUIRE(!v->on() && slabs > 0, "tph_vm_reserve: bad argument");
-  const size_t g = tph_vm_granularity(device);
-  TPH_REQUIRE(g > 0, "tph_vm_reserve: the device does not report a mapping granularity");
-  TPH_REQUIRE(stride_bytes > 0 && stride_bytes % g == 0, "tph_vm_reserve: the stride must be a multiple of %zu bytes", g);
+int tph_vm_reserve(tph_vm_set* v, int device, int slabs, size_t stride_bytes, size_t piece_bytes) {
+  TPH_REQUIRE(!v->on() && slabs > 0 && piece_bytes > 0, "tph_vm_reserve: bad argument");
+  TPH_REQUIRE(stride_bytes > 0 && stride_bytes % piece_bytes == 0, "tph_vm_reserve: the stride must be a multiple of %zu bytes", piece_bytes);
   void* p = nullptr;
-  hipError_t e = hipMemAddressReserve(&p, stride_bytes * (size_t)slabs, g, nullptr, 0);
+  hipError_t e = hipMemAddressReserve(&p, stride_bytes * (size_t)slabs, piece_bytes, nullptr, 0);
   if (e != hipSuccess || !p) {
     (void)hipGetLastError();
     tph_set_error("tph_vm_reserve: cannot reserve %zu bytes of address space (%s)", stride_bytes * (size_t)slabs, hipGetErrorString(e));
     return -1;
   }
-  v->device = device; v->base = (char*)p; v->stride = stride_bytes; v->slabs = slabs; v->mapped = 0; v->gran = g;
-  v->handles.clear(); v->step_off.clear(); v->step_bytes.clear();
+  v->device = device; v->base = (char*)p; v->stride = stride_bytes; v->slabs = slabs; v->mapped = 0; v->piece = piece_bytes;
+  v->handles.clear();
   return 0;
 }
 
-static hipError_t vm_map_piece(const tph_vm_set* v, char* at, size_t bytes, hipMemGenericAllocationHandle_t h) {
-  hipError_t e = hipMemMap(at, bytes, 0, h, 0);
+static hipError_t vm_map_piece(const tph_vm_set* v, char* at, hipMemGenericAllocationHandle_t h) {
+  hipError_t e = hipMemMap(at, v->piece, 0, h, 0);
   if (e != hipSuccess) return e;
   hipMemAccessDesc acc = {};
   acc.location.type = hipMemLocationTypeDevice;
   acc.location.id = v->device;
   acc.flags = hipMemAccessFlagsProtReadWrite;
-  e = hipMemSetAccess(at, bytes, &acc, 1);
-  if (e != hipSuccess) (void)hipMemUnmap(at, bytes);
+  e = hipMemSetAccess(at, v->piece, &acc, 1);
+  if (e != hipSuccess) (void)hipMemUnmap(at, v->piece);
   return e;
 }
 
-// every slab backed up to `want` bytes (rounded up to the granularity): one physical allocation per slab and step.  A step that
+// every slab backed up to `want` bytes (rounded up to whole pieces): one physical allocation per slab and piece.  A call that
 // cannot be completed is undone entirely -- what was mapped before stays as it is (return 1: out of memory).
 int tph_vm_grow(tph_vm_set* v, size_t want) {
   TPH_REQUIRE(v->on(), "tph_vm_grow: nothing reserved");
-  want = (want + v->gran - 1) / v->gran * v->gran;
+  want = (want + v->piece - 1) / v->piece * v->piece;
   if (want <= v->mapped) return 0;
   TPH_REQUIRE(want <= v->stride, "tph_vm_grow: %zu bytes per array exceed the reserved %zu", want, v->stride);
-  const size_t off = v->mapped, bytes = want - v->mapped;
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned;
   prop.location.type = hipMemLocationTypeDevice;
   prop.location.id = v->device;
-  std::vector<hipMemGenericAllocationHandle_t> hs((size_t)v->slabs);
-  int done = 0;
+  const size_t first = v->handles.size();
   hipError_t e = hipSuccess;
-  for (; done < v->slabs; ++done) {
-    e = hipMemCreate(&hs[done], bytes, &prop, 0);
-    if (e != hipSuccess) break;
-    e = vm_map_piece(v, v->base + (size_t)done * v->stride + off, bytes, hs[done]);
-    if (e != hipSuccess) { (void)hipMemRelease(hs[done]); break; }
-  }
-  if (done < v->slabs) {
-    (void)hipGetLastError();
-    for (int s = 0; s < done; ++s) {
-      (void)hipMemUnmap(v->base + (size_t)s * v->stride + off, bytes);
-      (void)hipMemRelease(hs[s]);
+  for (size_t off = v->mapped; off < want && e == hipSuccess; off += v->piece)
+    for (int sl = 0; sl < v->slabs; ++sl) {
+      hipMemGenericAllocationHandle_t h;
+      e = hipMemCreate(&h, v->piece, &prop, 0);
+      if (e != hipSuccess) break;
+      e = vm_map_piece(v, v->base + (size_t)sl * v->stride + off, h);
+      if (e != hipSuccess) { (void)hipMemRelease(h); break; }
+      v->handles.push_back(h);
     }
-    tph_set_error("tph_vm_grow: cannot back %d arrays with %zu more bytes each (%s)", v->slabs, bytes, hipGetErrorString(e));
-    return e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation ? 1 : -1;
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    for (size_t k = v->handles.size(); k > first; --k) {        // undo this call's pieces (in mapping order: piece-major, slab inner)
+      const size_t idx = k - 1;
+      const size_t off = (idx / (size_t)v->slabs) * v->piece;
+      const int sl = (int)(idx % (size_t)v->slabs);
+      (void)hipMemUnmap(v->base + (size_t)sl * v->stride + off, v->piece);
+      (void)hipMemRelease(v->handles[idx]);
+    }
+    v->handles.resize(first);
+    tph_set_error("tph_vm_grow: cannot back %d arrays up to %zu bytes each (%s)", v->slabs, want, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? 1 : -1;
   }
-  v->handles.insert(v->handles.end(), hs.begin(), hs.end());
-  v->step_off.push_back(off);
-  v->step_bytes.push_back(bytes);
   v->mapped = want;
   return 0;
 }
@@ -171,23 +188,23 @@ int tph_vm_grow(tph_vm_set* v, size_t want) {
 // the same physical memory behind a WIDER spacing of the slabs: a new address range, every piece unmapped from the old one and
 // mapped at its slab's new place.  The stream is drained first (kernels in flight still use the old addresses).
 int tph_vm_restride(tph_vm_set* v, size_t new_stride, hipStream_t stream) {
-  TPH_REQUIRE(v->on() && new_stride % v->gran == 0 && new_stride >= v->mapped, "tph_vm_restride: bad stride");
+  TPH_REQUIRE(v->on() && new_stride % v->piece == 0 && new_stride >= v->mapped, "tph_vm_restride: bad stride");
   TPH_HIP(hipStreamSynchronize(stream));
   void* p = nullptr;
-  hipError_t e = hipMemAddressReserve(&p, new_stride * (size_t)v->slabs, v->gran, nullptr, 0);
+  hipError_t e = hipMemAddressReserve(&p, new_stride * (size_t)v->slabs, v->piece, nullptr, 0);
   if (e != hipSuccess || !p) {
     (void)hipGetLastError();
     tph_set_error("tph_vm_restride: cannot reserve %zu bytes of address space (%s)", new_stride * (size_t)v->slabs, hipGetErrorString(e));
     return -1;
   }
   char* nb = (char*)p;
-  for (size_t k = 0; k < v->step_off.size(); ++k)
-    for (int sl = 0; sl < v->slabs; ++sl) {
-      char* old_at = v->base + (size_t)sl * v->stride + v->step_off[k];
-      TPH_HIP(hipMemUnmap(old_at, v->step_bytes[k]));
-      hipError_t m = vm_map_piece(v, nb + (size_t)sl * new_stride + v->step_off[k], v->step_bytes[k], v->handles[k * (size_t)v->slabs + sl]);
-      TPH_REQUIRE(m == hipSuccess, "tph_vm_restride: re-mapping failed (%s): the history is lost", hipGetErrorString(m));
-    }
+  for (size_t idx = 0; idx < v->handles.size(); ++idx) {
+    const size_t off = (idx / (size_t)v->slabs) * v->piece;
+    const int sl = (int)(idx % (size_t)v->slabs);
+    TPH_HIP(hipMemUnmap(v->base + (size_t)sl * v->stride + off, v->piece));
+    hipError_t m = vm_map_piece(v, nb + (size_t)sl * new_stride + off, v->handles[idx]);
+    TPH_REQUIRE(m == hipSuccess, "tph_vm_restride: re-mapping failed (%s): the history is lost", hipGetErrorString(m));
+  }
   (void)hipMemAddressFree(v->base, v->stride * (size_t)v->slabs);
   v->base = nb;
   v->stride = new_stride;
@@ -196,18 +213,36 @@ int tph_vm_restride(tph_vm_set* v, size_t new_stride, hipStream_t stream) {
 
 void tph_vm_release(tph_vm_set* v) {
   if (!v->on()) return;
-  for (size_t k = 0; k < v->step_off.size(); ++k)
-    for (int sl = 0; sl < v->slabs; ++sl) {
-      (void)hipMemUnmap(v->base + (size_t)sl * v->stride + v->step_off[k], v->step_bytes[k]);
-      (void)hipMemRelease(v->handles[k * (size_t)v->slabs + sl]);
-    }
+  for (size_t idx = 0; idx < v->handles.size(); ++idx) {
+    const size_t off = (idx / (size_t)v->slabs) * v->piece;
+    const int sl = (int)(idx % (size_t)v->slabs);
+    (void)hipMemUnmap(v->base + (size_t)sl * v->stride + off, v->piece);
+    (void)hipMemRelease(v->handles[idx]);
+  }
   (void)hipMemAddressFree(v->base, v->stride * (size_t)v->slabs);
   (void)hipGetLastError();
   *v = tph_vm_set();
 }
 
 // ------------------------------------------------------------------------------------ history capacity
-constexpr int64_t HIST_VM_MIN_ROWS = 524288;     // below this a history is a plain allocation grown by doubling (cheap at that size)
+// u and x move into a mapped range when they are asked to hold 16 GB or more, or when a plain history has to grow and the
+// doubling copy (old and new arrays alive together) would not leave 40 % of the free memory; below that a history is two plain
+// allocations grown by doubling -- cheap at that size, and nothing the measured configurations of 10^6 particles ever leave
+constexpr size_t HIST_VM_MIN_BYTES = (size_t)16 << 30;
+static bool history_wants_vm(const tph_ctx* ctx, int64_t need) {
+  if (ctx->hist_vm.on() || ctx->hist_vm_mode == 2) return true;
+  if (ctx->hist_vm_mode == 0) return false;
+  const size_t row = sizeof(double) * 2 * (size_t)ctx->d;
+  if (row * (size_t)need >= HIST_VM_MIN_BYTES) return true;
+  if (ctx->cap > 0 && ctx->size > 0) {
+    int64_t nc = ctx->cap;
+    while (nc < need) nc *= 2;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && row * (size_t)nc > free_b / 5 * 3) return true;
+    (void)hipGetLastError();
+  }
+  return false;
+}
 
 // logl and cmix (8 bytes per row each): plain allocations, doubled and copied -- a spike of 16 bytes per row
 static int history_reserve_scalars(tph_ctx* ctx, int64_t need) {
@@ -287,29 +322,29 @@ static int history_reserve_plain(tph_ctx* ctx, int64_t need) {
 // mappings per step) stay a handful per run; under memory pressure the mirror goes first (it is a cache), then exactly `need`.
 static int history_reserve_vm(tph_ctx* ctx, int64_t need) {
   tph_vm_set& v = ctx->hist_vm;
-  const size_t g = tph_vm_granularity(ctx->device);
+  const size_t g = v.on() ? v.piece : tph_vm_piece(ctx->device, sizeof(double) * (size_t)need);
   if (g == 0) return 2;                                        // not available: the caller falls back to plain allocations
-  const int64_t grow_rows = (int64_t)(g / sizeof(double));     // rows per mapping granule
+  const int64_t grow_rows = (int64_t)(g / sizeof(double));     // rows per piece
   auto round_rows = [&](int64_t r) { return (r + grow_rows - 1) / grow_rows * grow_rows; };
   if (!v.on()) {
     // address space for four times what is asked for (it costs nothing); the rows held so far move in with ONE copy
     const int64_t rows_va = round_rows(need > (1ll << 40) / 4 ? need : 4 * need);
     tph_vm_set fresh;
-    if (tph_vm_reserve(&fresh, ctx->device, 2 * ctx->d, sizeof(double) * (size_t)rows_va)) { (void)hipGetLastError(); return 2; }
+    if (tph_vm_reserve(&fresh, ctx->device, 2 * ctx->d, sizeof(double) * (size_t)rows_va, g)) { (void)hipGetLastError(); return 2; }
     const int rc = tph_vm_grow(&fresh, sizeof(double) * (size_t)round_rows(need));
     if (rc) { tph_vm_release(&fresh); return rc == 1 ? -1 : 2; }
     if (ctx->size > 0) {
       const size_t w = sizeof(double) * (size_t)ctx->size;
-      hipError_t c = hipMemcpy2DAsync(fresh.base, fresh.stride, ctx->u, sizeof(double) * ctx->cap, w, ctx->d, hipMemcpyDeviceToDevice, ctx->stream);
-      if (c == hipSuccess)
-        c = hipMemcpy2DAsync(fresh.base + (size_t)ctx->d * fresh.stride, fresh.stride, ctx->x, sizeof(double) * ctx->cap, w, ctx->d,
-                             hipMemcpyDeviceToDevice, ctx->stream);
-      if (c == hipSuccess) c = hipStreamSynchronize(ctx->stream);
+      const int64_t fld = (int64_t)(fresh.stride / sizeof(double));
+      int crc = copy2d(ctx, (double*)fresh.base, fld, ctx->u, ctx->cap, ctx->size, ctx->d);
+      if (!crc) crc = copy2d(ctx, (double*)(fresh.base + (size_t)ctx->d * fresh.stride), fld, ctx->x, ctx->cap, ctx->size, ctx->d);
+      hipError_t c = crc ? hipErrorUnknown : hipStreamSynchronize(ctx->stream);
       if (c != hipSuccess) {
         tph_vm_release(&fresh);
         tph_set_error("history_reserve: copy into the mapped range failed (%s)", hipGetErrorString(c));
         return -1;
       }
+      (void)w;
       ctx->stat_mem[3] += 1;
     }
     TPH_HIP(hipStreamSynchronize(ctx->stream));
@@ -351,8 +386,7 @@ static int history_reserve_vm(tph_ctx* ctx, int64_t need) {
 static int history_reserve(tph_ctx* ctx, int64_t need) {
   if (history_reserve_scalars(ctx, need)) return -1;
   if (need <= ctx->hist_mapped) return 0;
-  const bool want_vm = ctx->hist_vm.on() || ctx->hist_vm_mode == 2 || (ctx->hist_vm_mode == 1 && need >= HIST_VM_MIN_ROWS);
-  if (want_vm) {
+  if (history_wants_vm(ctx, need)) {
     const int rc = history_reserve_vm(ctx, need);
     if (rc != 2) return rc;
     ctx->hist_vm_mode = 0;                                     // the device cannot map memory this way: plain allocations from now on
@@ -589,10 +623,8 @@ extern "C" int tph_history_append(tph_ctx* ctx, const double* u_dev, const doubl
   TPH_HIP(hipSetDevice(ctx->device));
   if (history_reserve(ctx, ctx->size + n)) return -1;
   size_t w = sizeof(double) * (size_t)n;
-  TPH_HIP(hipMemcpy2DAsync(ctx->u + ctx->size, sizeof(double) * ctx->cap, u_dev, sizeof(double) * ld, w, ctx->d,
-                           hipMemcpyDeviceToDevice, ctx->stream));
-  TPH_HIP(hipMemcpy2DAsync(ctx->x + ctx->size, sizeof(double) * ctx->cap, x_dev, sizeof(double) * ld, w, ctx->d,
-                           hipMemcpyDeviceToDevice, ctx->stream));
+  if (copy2d(ctx, ctx->u + ctx->size, ctx->cap, u_dev, ld, n, ctx->d)) return -1;
+  if (copy2d(ctx, ctx->x + ctx->size, ctx->cap, x_dev, ld, n, ctx->d)) return -1;
   TPH_HIP(hipMemcpyAsync(ctx->logl + ctx->size, logl_dev, w, hipMemcpyDeviceToDevice, ctx->stream));
   ctx->beta_t.push_back(beta);
   ctx->logz_t.push_back(logz);
@@ -623,10 +655,11 @@ extern "C" int tph_history_load(tph_ctx* ctx, const double* u_host, const double
   if (n == 0) return 0;
   if (history_reserve(ctx, n)) return -1;
   size_t w = sizeof(double) * (size_t)n;
-  if (u_host)
-    TPH_HIP(hipMemcpy2DAsync(ctx->u, sizeof(double) * ctx->cap, u_host, w, w, ctx->d, hipMemcpyHostToDevice, ctx->stream));
-  if (x_host)
-    TPH_HIP(hipMemcpy2DAsync(ctx->x, sizeof(double) * ctx->cap, x_host, w, w, ctx->d, hipMemcpyHostToDevice, ctx->stream));
+  // (one 1-D copy per coordinate: hipMemcpy2D rejects addresses inside a mapped range)
+  for (int j = 0; j < ctx->d && u_host; ++j)
+    TPH_HIP(hipMemcpyAsync(ctx->u + (size_t)j * ctx->cap, u_host + (size_t)j * n, w, hipMemcpyHostToDevice, ctx->stream));
+  for (int j = 0; j < ctx->d && x_host; ++j)
+    TPH_HIP(hipMemcpyAsync(ctx->x + (size_t)j * ctx->cap, x_host + (size_t)j * n, w, hipMemcpyHostToDevice, ctx->stream));
   TPH_REQUIRE(logl_host, "tph_history_load: logl is NULL");
   TPH_HIP(hipMemcpyAsync(ctx->logl, logl_host, w, hipMemcpyHostToDevice, ctx->stream));
   if (table_upload(ctx)) return -1;
@@ -647,7 +680,8 @@ extern "C" int tph_history_read(tph_ctx* ctx, int key, int64_t off, int64_t n, d
     case TPH_KEY_U:
     case TPH_KEY_X: {
       const double* src = (key == TPH_KEY_U ? ctx->u : ctx->x) + off;
-      TPH_HIP(hipMemcpy2DAsync(out_host, w, src, sizeof(double) * ctx->cap, w, ctx->d, hipMemcpyDeviceToHost, ctx->stream));
+      for (int j = 0; j < ctx->d; ++j)
+        TPH_HIP(hipMemcpyAsync(out_host + (size_t)j * n, src + (size_t)j * ctx->cap, w, hipMemcpyDeviceToHost, ctx->stream));
       break;
     }
     case TPH_KEY_LOGL:

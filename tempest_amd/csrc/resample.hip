@@ -407,15 +407,16 @@ const double* tph_rows_sync(tph_ctx* ctx) {
   if (ctx->rows_cap < ctx->size && ctx->hist_vm.on()) {
     // the history grows in a mapped range: so does the mirror (a set of one array), an eighth at a time
     tph_vm_set& v = ctx->rows_vm;
-    const size_t g = tph_vm_granularity(ctx->device);
+    const size_t g = v.on() ? v.piece : tph_vm_piece(ctx->device, (size_t)ctx->size * recb);
     int64_t want_rows = ctx->rows_cap + ctx->rows_cap / 8;
     if (want_rows < ctx->size) want_rows = ctx->size;
     size_t want = g ? ((size_t)want_rows * recb + g - 1) / g * g : 0;
     bool ok = g > 0 && rows_budget_ok(v.on() ? v.mapped : 0, want - (v.on() ? v.mapped : 0));
+    if (!ok) tph_set_error("row-major mirror: %zu bytes would exceed its share of the device memory", want);
     if (ok && !v.on()) {
       if (ctx->rows) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->rows); ctx->rows = nullptr; ctx->rows_cap = 0; ctx->rows_size = 0; }
       const size_t va = ((size_t)ctx->cap * recb + g - 1) / g * g;
-      ok = tph_vm_reserve(&v, ctx->device, 1, va > want ? va : want) == 0;
+      ok = tph_vm_reserve(&v, ctx->device, 1, va > want ? va : want, g) == 0;
     }
     if (ok && want > v.stride) {
       size_t ns = v.stride;

@@ -433,3 +433,51 @@ def test_config5_shard_131072_funnel100_to_beta_one():
     assert abs(len(beta) - ref_it) <= 3
     assert abs(mean_v - np.mean([r["mean"][0] for r in runs])) < 0.4      # reference twin: 8.55
     assert abs(logz - mu) < 1.5             # same estimator, larger N: the twin's value up to the N-dependence of its bias
+
+
+def test_config5_full_2097152_funnel100_on_one_gpu():
+    """BASELINE config 5 at its STATED ensemble on one MI355X: 2 097 152 particles of the 100-D funnel (tpCN) to beta = 1 --
+    3.4 GB of history per iteration, ~100 GB at the end (tempest/state_manager.py:356-416 appends without bound).
+    u and x live in a mapped address range that grows in place (csrc/ctx.hip): not one copy of the history, no reallocation
+    spike; the row-major mirror is given back once it would take more than its share.  Same checks as the 131 072-particle shard:
+    the reference's N = 4096 twin walks 31 iterations to logZ -639.44 +- 0.09 and a posterior mean of v = 8.55 (the annealing
+    schedule is set by ESS ratios, which do not depend on N).  profiles/r05_c5_full_2097152.json: 55.7 s, 153 GB at the peak."""
+    import tempest_amd as tp
+    dev = torch.device("cuda", 0)
+    d, n = 100, 2097152
+    free, total = torch.cuda.mem_get_info(dev)
+    if free < 200 * 2 ** 30:
+        pytest.skip(f"needs ~155 GB of device memory, {free / 2 ** 30:.0f} GB free")
+    scale = torch.full((d,), 600.0, dtype=torch.float64, device=dev); scale[0] = 30.0
+    shift = torch.full((d,), -300.0, dtype=torch.float64, device=dev); shift[0] = -15.0
+
+    def loglike(x):
+        v = x[:, 0]
+        lv = -0.5 * (v / 3.0) ** 2 - np.log(3.0) - 0.5 * np.log(2 * np.pi)
+        lr = (-0.5 * (x[:, 1:] ** 2) * torch.exp(-v)[:, None]).sum(dim=1) - 0.5 * (d - 1) * v - 0.5 * (d - 1) * np.log(2 * np.pi)
+        return lv + lr
+    s = tp.Sampler(lambda u: u * scale + shift, loglike, d, n_particles=n, vectorize=True, clustering=False, random_state=0,
+                   backend="torch", batch_prior=True)
+    t0 = time.time()
+    s.run(n_total=4 * n, progress=False)
+    torch.cuda.synchronize(dev)
+    wall = time.time() - t0
+    st = s.state
+    ctx = st.ctx
+    logz = s.evidence()[0]
+    beta = np.asarray(st.get_history("beta")); steps = np.asarray(st.get_history("steps"))
+    # the weighted mean of v = 30 u_0 - 15 over the whole history, on the device (10^8 rows never cross PCIe)
+    m, s1, _ = st.reweight_eval([1.0])[0]
+    mean_v = 30.0 * float(ctx.weighted_moments(ctx.weights(1.0, m, s1))[0].item()) - 15.0
+    mem = ctx.history_memory()
+    mu, sd, runs = _ref("c5twin_funnel100_n4096")
+    ref_it = np.mean([r["iters"] for r in runs])
+    print(f"config5 FULL to beta=1: logZ={logz:.3f} (twin reference {mu:.2f} +- {sd:.2f}) iters={len(beta)} (reference twin {ref_it:.0f}) "
+          f"steps={int(steps[beta > 0].sum())} mean v={mean_v:.3f} wall={wall:.1f}s pms/s={steps[beta > 0].sum() * n / wall:.3g} memory={mem}")
+    assert beta[-1] == 1.0 and np.all(np.diff(beta) >= 0) and wall < 150.0
+    assert abs(len(beta) - ref_it) <= 3
+    assert abs(mean_v - np.mean([r["mean"][0] for r in runs])) < 0.4
+    assert abs(logz - mu) < 1.5
+    assert mem["rows"] == n * len(beta) and mem["mapped"] == 1 and mem["copies"] == 0      # grown in place, never copied
+    del s
+    torch.cuda.empty_cache()
