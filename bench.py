@@ -307,6 +307,11 @@ def main():
                       "note": "library counters (tph_comm_stats) of rank 0 over the initialisation, warm-up and timed iterations; "
                               "shuffle_rows = this rank's slots refilled per iteration, (world-1)/world of them cross xGMI on average"}
         assert p2p_all == p2p_any, "the ranks disagree about the peer-to-peer layer"      # tph_comm_p2p_attach agrees by construction
+        # every rank's own account of the peer-to-peer attach (the self-test runs inside tph_comm_p2p_attach): on, or why not
+        reasons = [None] * world
+        dist.all_gather_object(reasons, {"rank": rank, "device": local_rank, "p2p": bool(p2p_here),
+                                         "reason": getattr(s.state.comm, "p2p_reason", "?")})
+        comm_block["p2p_by_rank"] = reasons
     pms = float(np.sum(steps_t[beta_t > 0])) * n_global
     value = pms / dt
 
@@ -333,6 +338,23 @@ def main():
         _, logz = core._logz_at(1.0)
         sync()
         t_run = time.perf_counter() - t_run0
+        # A digest of what the run arrived at: the evidence and the final ensemble (u and logl of ALL ranks in slot order), bit for
+        # bit.  With the canonical partition (csrc/common.h: tph_part) a run on N GPUs is the same floating-point computation as
+        # the run on one, so the SCALE lines (N = 2, 4, 8) and the BENCH line (N = 1) of one seed must carry the SAME digest.
+        import hashlib
+        u_fin, l_fin = s.state.get_current("u"), s.state.get_current("logl")
+        if use_dist:
+            u_fin, l_fin = s.state.comm.gather_rows(u_fin), s.state.comm.gather_rows(l_fin)
+        hsh = hashlib.sha256(np.ascontiguousarray(u_fin).tobytes())
+        hsh.update(np.ascontiguousarray(l_fin).tobytes())
+        sched = hashlib.sha256(np.asarray(s.state._scalars["logz"], dtype=np.float64).tobytes())
+        sched.update(np.asarray(s.state._scalars["beta"], dtype=np.float64).tobytes())
+        from tempest_amd.device import vshards_for
+        extra["digest"] = {"logz_hex": float(logz).hex(), "ensemble_sha256": hsh.hexdigest(), "schedule_sha256": sched.hexdigest(),
+                           "virtual_shards": vshards_for(n_global) if n_global % 256 == 0 else 1,
+                           "note": "equal across --gpus N for every N that divides virtual_shards (same seed, same particle count): "
+                                   "the sharded run is bitwise the one-GPU run (tests/test_distributed.py::test_world_size_invariance_is_bitwise)"}
+        del u_fin, l_fin
         tail_steps = np.asarray(s.state._scalars["steps"][tail0:]); tail_beta = np.asarray(s.state._scalars["beta"][tail0:])
         if len(tail_steps) and core.timing["mutate"] > 0:
             tail_pms = float(np.sum(tail_steps[tail_beta > 0])) * n_global

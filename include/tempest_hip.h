@@ -361,13 +361,21 @@ int tph_adapt(tph_ctx* ctx, int kernel, double* sums_dev /* in; out when partial
                                       s % mailbox_slots, its field [7] = s is stored last (system-scope release), so the host can poll for it */,
               int mailbox_slots,
               const double* partials_dev /* NULL, or tph_accept's block partials of n particles: their column sums
-                                            are formed here (into sums_dev) instead of by a kernel of their own.  With a
-                                            communicator attached they are THIS RANK's sums and the kernel all-reduces them
-                                            with the peers in place (needs tph_comm_p2p_attach): a sharded step then has the
+                                            are formed here (into sums_dev) instead of by a kernel of their own, in the
+                                            canonical order (per virtual shard, then in shard order: tph_accept_sums_global).
+                                            With a communicator attached they are THIS RANK's shard sums and the kernel exchanges
+                                            them with the peers in place (needs tph_comm_p2p_attach): a sharded step then has the
                                             launches of a single-GPU step and no host call.  Returns 1 (nothing launched) when
-                                            that exchange is not attached or 1 + K doubles exceed its 32 KB slot: all-reduce the
-                                            sums of tph_accept yourself and call again with partials_dev = NULL */,
+                                            that exchange is not attached or the rank's shard sums exceed its 32 KB slot:
+                                            combine the ranks with tph_accept_sums_global and call again with partials_dev = NULL */,
               int64_t n);
+/* The step's sums (#accepted, sum alpha_c) over ALL ranks from this rank's block partials (tph_accept with sums_dev = NULL),
+ * in the CANONICAL order: the particle slots are cut into V virtual shards (V from the global particle count alone: the largest
+ * of 48, 16, 12, 8, 6, 4, 3, 2, 1 with n_global % (256 V) == 0), a shard's sums are formed by a fixed procedure that sees only
+ * the shard's blocks, and the V shard sums are added in shard order -- the same summation tree on any number of ranks that
+ * divides V, so the adapted sigma does not depend on it.  host_paced != 0: the exchange goes through the all-gather callback even
+ * where the peer-to-peer exchange is attached (user callbacks on the host may keep the ranks minutes apart). */
+int tph_accept_sums_global(tph_ctx* ctx, const double* partials_dev, int64_t n, int K, double* sums_dev, int host_paced);
 int tph_cluster_counts(tph_ctx* ctx, const int32_t* assign_dev, int64_t n, int K, double* counts_dev);
 
 /* ---- proposal fit (student.py:6-116 effective form, modes.py:58-119,131-288) -------------------- */

@@ -61,6 +61,7 @@ SIGNATURES = {
     "tph_accept": (c_int, [ptr, c_int, c_dbl, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i64, c_i64,
                            c_int, ptr, c_u64, c_u32, c_i64, ptr, ptr, ptr, ptr]),
     "tph_adapt": (c_int, [ptr, c_int, ptr, ptr, c_int, c_dbl, c_int, c_int, c_int, ptr, ptr, ptr, c_int, ptr, c_i64]),
+    "tph_accept_sums_global": (c_int, [ptr, ptr, c_i64, c_int, ptr, c_int]),
     "tph_posterior_rows": (c_int, [ptr, c_int, ptr, c_i64, ptr, c_dbl, ptr, ptr, ptr]),
     "tph_index_compose": (c_int, [ptr, ptr, ptr, c_i64, ptr]),
     "tph_cluster_counts": (c_int, [ptr, ptr, c_i64, c_int, ptr]),

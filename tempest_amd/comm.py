@@ -71,6 +71,7 @@ class Comm:
         self.world_size = self._dist.get_world_size(group) if self._dist else 1
         self.rank = self._dist.get_rank(group) if self._dist else 0
         self._p2p_ctx = None          # weakref to the DeviceContext whose library carries the small collectives itself
+        self.p2p_reason = "not attached"      # why the peer-to-peer layer is on or off on this rank (bench.py prints it per rank)
 
     @property
     def active(self):
@@ -141,6 +142,8 @@ class Comm:
         self._p2p_ctx = None
         if os.environ.get("TEMPEST_AMD_P2P", "1") != "0":
             self._attach_p2p(ctx)
+        else:
+            self.p2p_reason = "switched off (TEMPEST_AMD_P2P=0)"
         return buf
 
     def _attach_p2p(self, ctx):
@@ -150,10 +153,11 @@ class Comm:
         library agrees on the self-test through the all-reduce attached above.  TEMPEST_AMD_P2P=0 turns it off."""
         import socket
         import weakref
+        export_error = None
         try:
             handle = ctx.p2p_export()
-        except Exception:
-            handle = None
+        except Exception as e:
+            handle, export_error = None, f"{type(e).__name__}: {e}"[:200]
         mine = (socket.gethostname(), ctx.device.index, handle)
         everyone = [None] * self.world_size
         if self.world_size > 1:
@@ -161,11 +165,22 @@ class Comm:
         else:
             everyone = [mine]
         same_node = len({h for h, _, _ in everyone}) == 1
-        if not same_node or any(h is None for _, _, h in everyone) or self.world_size > 16:
+        if not same_node:
+            self.p2p_reason = "off: the ranks are on different hosts (" + ", ".join(sorted({h for h, _, _ in everyone})) + ")"
+            return False
+        if any(h is None for _, _, h in everyone):
+            missing = [r for r, (_, _, h) in enumerate(everyone) if h is None]
+            self.p2p_reason = (f"off: rank(s) {missing} could not export an inbox"
+                               + (f" (here: {export_error})" if export_error else ""))
+            return False
+        if self.world_size > 16:
+            self.p2p_reason = "off: more than 16 ranks"
             return False
         if ctx.p2p_attach([h for _, _, h in everyone]):
             self._p2p_ctx = weakref.ref(ctx)
+            self.p2p_reason = "on: inboxes mapped, 48-exchange self-test passed on every rank"
             return True
+        self.p2p_reason = "off: the attach self-test failed on some rank (mapping or exchange pattern): " + str(ctx.last_error())[:160]
         return False
 
     def all_gather_v(self, t):

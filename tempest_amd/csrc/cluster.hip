@@ -366,7 +366,7 @@ extern "C" int tph_compact_indices(tph_ctx* ctx, const double* w_dev, int64_t n,
   double* rank = flag + n;
   unsigned grid = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_flag_kept, dim3(grid), dim3(256), 0, ctx->stream, w_dev, n, thr_dev, flag);
-  int rc = tph_cdf(ctx, flag, n, nullptr, rank);
+  int rc = tph_cdf_plain(ctx, flag, n, nullptr, rank);      // a prefix COUNT of 0 / 1 flags: exact in any order
   if (rc) return rc;
   hipLaunchKernelGGL(k_kept_list, dim3(grid), dim3(256), 0, ctx->stream, flag, rank, n, idx_dev);
   TPH_LAUNCH_CHECK();

@@ -122,7 +122,7 @@ struct tph_ctx {
   int mf_checked = 0;               // the screen's FP32 transcendental budget on this device: 0 not measured yet | 1 holds | -1 does not (screen off)
   void* mf_buf = nullptr;           // queue words | blocked L^-1 | FP16 pack of L + row error tables | transposed FP64 L
   size_t mf_bytes = 0;
-  int mf_epoch = -1, mf_kernel = -1;
+  int mf_epoch = -1, mf_kernel = -1, mf_K = 0;
   const void* mf_src = nullptr;
   // matrix-core round kernel of the blocked path (propose_blkm.hip): TPH_OPT_BLK_MFMA and its blocked copies of L and L^-1
   int blk_mfma = 1;
@@ -136,8 +136,11 @@ struct tph_ctx {
   size_t mt_bytes = 0;
   const void* mt_assign = nullptr;
   int64_t mt_n = 0;
+  int mt_epoch = -1, mt_K = 0;
   std::vector<void*> retired;       // outgrown buffers a captured hipGraph of an earlier step may still address: freed with the ctx
   double* vv_buf = nullptr;         // small persistent buffers of tph_volume_variation (moments, factors, blocked L^-1)
+  double* adapt_buf = nullptr;      // shard sums of an MCMC step's acceptance statistics (k_adapt, k_accept_sums): fixed address
+  size_t adapt_bytes = 0;
   size_t vv_bytes = 0;
   uint64_t vv_seq = 0;
   // ---- communicator (tph_comm_attach): one process per GPU, this ctx holds one shard of every iteration's particles
@@ -161,13 +164,41 @@ enum { TPH_OP_SUM = 0, TPH_OP_MAX = 1, TPH_OP_MIN = 2 };
 int tph_comm_require(tph_ctx* ctx, size_t bytes, const char* who);
 int tph_comm_allreduce(tph_ctx* ctx, size_t off, int64_t count, int dtype, int op);
 int tph_comm_allgather(tph_ctx* ctx, size_t send_off, size_t recv_off, int64_t count, int dtype);
+int tph_comm_allgather_cb(tph_ctx* ctx, size_t send_off, size_t recv_off, int64_t count, int dtype);   // through the callback whatever the size (host-paced callers)
 // p2p.hip: one single-block exchange kernel on the ctx stream instead of the callback, for messages of <= 32 KB
 bool tph_p2p_fits(const tph_ctx* ctx, int64_t count, int dtype);
 int tph_p2p_exchange(tph_ctx* ctx, const void* src, void* dst, int64_t count, int dtype, int op /* < 0: all-gather */);
 void tph_p2p_release(tph_ctx* ctx);
 int tph_blocks(tph_ctx* ctx, int64_t n, int* T, int64_t* rows);   // equal-sized iteration blocks of the local history
 
+// ---- the canonical partition: what makes a run on G GPUs the SAME floating-point computation as the run on one ---------------
+// Every reduction over the particles of an iteration (the reweight triples, the cumulative weights, the moments of the proposal
+// fit, the acceptance sums of an MCMC step) is formed per VIRTUAL SHARD and the V per-shard results are folded in shard order.
+// A virtual shard is a fixed range of n_particles / V particle slots -- V depends on n_particles alone (tph_vshards_for), never
+// on the number of GPUs --; a rank of a G-GPU run owns V / G consecutive ones, the one-GPU run owns all V, and a shard's partial
+// result is computed by a procedure that sees only the shard's rows.  So the summation tree of every global quantity is the same
+// for every G that divides V: bitwise the same run (tests/test_distributed.py: worlds 1, 2, 3, 4).  History rows of virtual
+// shard v: for every committed iteration t the `nv` rows from t * n_loc + v * nv ("piece" (t, v)).
+struct tph_part {
+  int T;            // committed iterations (pieces per virtual shard); 1 when the history has no block structure
+  int64_t n_loc;    // rows per iteration held by this rank
+  int vl;           // virtual shards of this rank
+  int V;            // virtual shards of the whole run (vl * world when canonical)
+  int64_t nv;       // rows of one piece
+  bool canonical;   // V was chosen from n_particles alone and divides evenly: results do not depend on the number of ranks
+};
+__host__ __device__ static inline int tph_vshards_inline(long long n_global) {
+  const int cand[9] = {48, 16, 12, 8, 6, 4, 3, 2, 1};
+  for (int i = 0; i < 9; ++i)
+    if (n_global > 0 && n_global % ((long long)cand[i] * 256) == 0) return cand[i];
+  return 1;
+}
+int tph_vshards_for(int64_t n_global);                 // the largest of 48, 16, 12, 8, 6, 4, 3, 2, 1 with n_global % (256 V) == 0
+tph_part tph_partition(const tph_ctx* ctx, int64_t n); // partition of the first n == ctx->size history rows (else: one piece)
+int tph_partials_reserve(tph_ctx* ctx, size_t bytes);  // ctx->partials of at least that many bytes
+
 int tph_scratch_reserve(tph_ctx* ctx, size_t bytes);
+int tph_cdf_plain(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev, double* cdf_dev);   // resample.hip: the plain scan
 // mapped, growing arrays (ctx.hip)
 int tph_vm_reserve(tph_vm_set* v, int device, int slabs, size_t stride_bytes, size_t piece_bytes);
 int tph_vm_grow(tph_vm_set* v, size_t want_bytes_per_slab);            // 0 ok | 1 out of memory (nothing changed) | -1 error
@@ -195,7 +226,8 @@ int tph_blkm_round(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, c
 int tph_blkm_multi(tph_ctx* ctx, int kernel, double* u, const int32_t* assign, int64_t n, int64_t ld, int K, const double* means,
                    const double* chol, const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed,
                    uint32_t tick0, const double* ctl, int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, int rounds,
-                   const int32_t** todo_cnt, const int32_t** todo_rows, const int32_t** todo_att);      // todo_att[mode]: where its list goes on (or NULL)
+                   const int32_t** todo_cnt, const int32_t** todo_rows, const int32_t** todo_att,       // todo_att[mode]: where its list goes on (or NULL)
+                   const int32_t** per_mode = nullptr);      // != NULL: no concatenated list; per_mode[0..2] = counts[K], the list array, the modes' offsets into it
 // the same over a device-side list of particles (count + rows), from attempt att0: the straggler pass behind the blocked kernel
 int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,
                         const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
@@ -204,7 +236,17 @@ int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t 
                         int queue_zeroed = 0);                             // 1: the caller zeroed tph_mf_queue_words() on the stream already
 bool tph_mf_selftest(tph_ctx* ctx);                  // the device meets the screen's FP32 budget (measured once per context)
 bool tph_mf_screen(tph_ctx* ctx);                    // TPH_OPT_SCREEN on, n_dim in range AND the device passed the screen's self-test (run once)
-unsigned int* tph_mf_queue_words(tph_ctx* ctx);      // the 32 work-queue words of the screened kernel (allocates its buffers; NULL on error)
+unsigned int* tph_mf_queue_words(tph_ctx* ctx);
+// several proposal modes: the particles grouped by mode (propose_blkm.hip; device pointers into ctx-owned memory: order[n], mstart[K], mcount[K])
+int tph_mode_lists(tph_ctx* ctx, const int32_t* assign, int64_t n, int K, const int32_t** order, const int32_t** mstart, const int32_t** mcount);
+// screened batches mode by mode over those lists (a whole redraw-dominated step), and over the modes' failure lists of the matrix-core rounds
+int tph_propose_mf_modes(tph_ctx* ctx, int kernel, double* u, const int32_t* assign, int64_t n, int64_t ld, int K, const double* means,
+                         const double* chol, const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed,
+                         uint32_t tick0, const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend);
+int tph_propose_mf_mode_lists(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, int K, const double* means, const double* chol,
+                              const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
+                              const double* ctl, int64_t item0, double* up, double* maha_up, const int32_t* cnts, const int32_t* rows,
+                              const int32_t* offs, int att0, const int32_t* atts);      // the 32 work-queue words of the screened kernel (allocates its buffers; NULL on error)
 
 // --------------------------------------------------------------------------------- device helpers
 #if defined(__HIPCC__)

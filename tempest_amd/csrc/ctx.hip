@@ -448,7 +448,7 @@ extern "C" int tph_ctx_destroy(tph_ctx* ctx) {
   tph_vm_release(&ctx->hist_vm);
   tph_vm_release(&ctx->rows_vm);
   void* bufs[] = {hist_mapped ? nullptr : ctx->u, hist_mapped ? nullptr : ctx->x, ctx->logl, ctx->cmix, ctx->table_dev, ctx->partials,
-                  ctx->small_dev, ctx->scratch, ctx->winv, ctx->blk_table, ctx->vv_buf, ctx->blk_buf, rows_mapped ? nullptr : ctx->rows,
+                  ctx->small_dev, ctx->scratch, ctx->winv, ctx->blk_table, ctx->vv_buf, ctx->adapt_buf, ctx->blk_buf, rows_mapped ? nullptr : ctx->rows,
                   ctx->sm_small, ctx->sm_scr, ctx->mf_buf, ctx->bm_buf, ctx->mt_buf};
   for (void* b : bufs) (void)hipFree(b);
   for (void* b : ctx->retired) (void)hipFree(b);
@@ -492,6 +492,9 @@ int tph_comm_allreduce(tph_ctx* ctx, size_t off, int64_t count, int dtype, int o
 }
 int tph_comm_allgather(tph_ctx* ctx, size_t send_off, size_t recv_off, int64_t count, int dtype) {
   if (tph_p2p_fits(ctx, count, dtype)) return tph_p2p_exchange(ctx, ctx->comm_buf + send_off, ctx->comm_buf + recv_off, count, dtype, -1);
+  return tph_comm_allgather_cb(ctx, send_off, recv_off, count, dtype);
+}
+int tph_comm_allgather_cb(tph_ctx* ctx, size_t send_off, size_t recv_off, int64_t count, int dtype) {
   const int rc = ctx->comm_allgather(ctx->comm_user, (int64_t)send_off, (int64_t)recv_off, count, dtype);
   ctx->stat[1] += 1; ctx->stat[2] += count * (dtype == TPH_DT_I32 ? 4 : 8) * (int64_t)ctx->world;
   TPH_REQUIRE(rc == 0, "all-gather callback failed (%d)", rc);
@@ -506,6 +509,39 @@ int tph_blocks(tph_ctx* ctx, int64_t n, int* T, int64_t* rows) {
     TPH_REQUIRE(v == r, "sharded runs need the same number of particles in every iteration (%lld vs %lld)", (long long)v, (long long)r);
   *T = (int)ctx->n_local_t.size();
   *rows = r;
+  return 0;
+}
+
+int tph_vshards_for(int64_t n_global) { return tph_vshards_inline((long long)n_global); }
+tph_part tph_partition(const tph_ctx* ctx, int64_t n) {
+  tph_part p{1, n, 1, ctx->world, n, false};
+  if (n != ctx->size || ctx->n_local_t.empty()) return p;
+  const int64_t nl = ctx->n_local_t[0], ng = ctx->n_global_t[0];
+  for (size_t t = 0; t < ctx->n_local_t.size(); ++t)
+    if (ctx->n_local_t[t] != nl || ctx->n_global_t[t] != ng) return p;
+  p.T = (int)ctx->n_local_t.size();
+  p.n_loc = nl;
+  p.nv = nl;
+  if (ng == nl * (int64_t)ctx->world && ng % 256 == 0) {
+    const int V = tph_vshards_for(ng);
+    if (V % ctx->world == 0) {
+      p.vl = V / ctx->world;
+      p.V = V;
+      p.nv = ng / V;
+      p.canonical = true;
+    }
+  }
+  return p;
+}
+int tph_partials_reserve(tph_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->partials_bytes) return 0;
+  size_t nb = ctx->partials_bytes;
+  while (nb < bytes) nb *= 2;
+  TPH_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->partials) TPH_HIP(hipFree(ctx->partials));
+  ctx->partials = nullptr;
+  TPH_HIP(hipMalloc((void**)&ctx->partials, nb));
+  ctx->partials_bytes = nb;
   return 0;
 }
 

@@ -18,9 +18,12 @@ __global__ void __launch_bounds__(64 * WV) k_maha_tile(double* __restrict__ u, i
                                                        uint8_t* __restrict__ pend, const unsigned long long* __restrict__ queue,
                                                        const double* __restrict__ dof, const double* __restrict__ sigmas,
                                                        uint64_t seed, int64_t item0, double* __restrict__ bfac_out,
-                                                       const int32_t* __restrict__ todo_cnt, const int32_t* __restrict__ todo_rows) {
+                                                       const int32_t* __restrict__ todo_cnt, const int32_t* __restrict__ todo_rows,
+                                                       const int32_t* __restrict__ todo_off) {
   // todo_cnt != NULL: only the particles LISTED in todo_rows[0 .. *todo_cnt) (the closing pass behind a screened launch over
-  // the blocked kernel's failures); a block beyond the list exits at once
+  // the blocked kernel's failures; one MODE's particles of a run with several proposal modes: the list then starts *todo_off
+  // entries into todo_rows, and means / Wb / dof / sigmas are that mode's); a block beyond the list exits at once
+  if (todo_off) todo_rows += *todo_off;
   extern __shared__ double sh[];
   double* xs = sh;                                 // [d][64]
   double* sc = sh + (size_t)d * 64;                // [WV][64]
@@ -108,7 +111,7 @@ template <int KERNEL, int MODE>
 static int launch_maha_tile(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const double* means, const double* Wb, double* up,
                             double* maha, tph_stepctl tick, uint8_t* pend, const unsigned long long* queue, const double* dof,
                             const double* sigmas, uint64_t seed, int64_t item0, double* bfac_out, const int32_t* todo_cnt = nullptr,
-                            const int32_t* todo_rows = nullptr) {
+                            const int32_t* todo_rows = nullptr, const int32_t* todo_off = nullptr) {
   const int d = ctx->d;
   const int wv = d <= 32 ? 4 : d <= 64 ? 8 : 16;
   const size_t lds = sizeof(double) * ((size_t)d * 64 + (size_t)wv * 64);
@@ -118,7 +121,7 @@ static int launch_maha_tile(tph_ctx* ctx, double* u, int64_t n, int64_t ld, cons
     if (lds > 64 * 1024)                                                                                                 \
       TPH_HIP(hipFuncSetAttribute((const void*)k_maha_tile<KERNEL, WV, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((k_maha_tile<KERNEL, WV, MODE>), grid, dim3(64 * WV), lds, ctx->stream, u, n, ld, d, means, Wb, up, maha, \
-                       tick, pend, queue, dof, sigmas, seed, item0, bfac_out, todo_cnt, todo_rows);                      \
+                       tick, pend, queue, dof, sigmas, seed, item0, bfac_out, todo_cnt, todo_rows, todo_off);            \
   } while (0)
   if (wv == 4) TPH_MT(4); else if (wv == 8) TPH_MT(8); else TPH_MT(16);
 #undef TPH_MT

@@ -382,14 +382,48 @@ extern "C" int tph_trim_threshold_global(tph_ctx* ctx, const double* w_dev, int6
   return 0;
 }
 
+// ---- segments: the stretches of a working set that belong to the virtual shards of the canonical partition (common.h) ----------
+// seg[2 z], seg[2 z + 1] = first row and number of rows of segment z.  A kernel launched with gridDim.z segments works on each
+// as if it were the whole input: same row partition over gridDim.x blocks, block partials of segment z behind those of z - 1.
+#define SEG_SHIFT(hu, wt, labels, n, seg)                               \
+  do {                                                                  \
+    if (seg) {                                                          \
+      const long long off_ = seg[2 * blockIdx.z];                       \
+      n = seg[2 * blockIdx.z + 1];                                      \
+      hu += off_;                                                       \
+      wt += off_;                                                       \
+      if (labels) labels += off_;                                       \
+    }                                                                   \
+  } while (0)
+// out[c] = ((rows[0][c] + rows[1][c]) + rows[2][c]) + ... : the V per-shard results in shard order (deterministic, and the same
+// tree for every number of ranks that divides V)
+__global__ void __launch_bounds__(256) k_fold_cols(const double* __restrict__ rows, int V, int ncol, double* __restrict__ out) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncol; c += gridDim.x * blockDim.x) {
+    double s = rows[c];
+    for (int v = 1; v < V; ++v) s += rows[(size_t)v * ncol + c];
+    out[c] = s;
+  }
+}
+// (min, max) per coordinate over the segments' ranges (order-free)
+__global__ void __launch_bounds__(256) k_fold_range(const double* __restrict__ vr, int V, int d, double* __restrict__ range) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= d) return;
+  double mn = DBL_MAX, mx = -DBL_MAX;
+  for (int v = 0; v < V; ++v) { mn = fmin(mn, vr[(size_t)v * 2 * d + 2 * j]); mx = fmax(mx, vr[(size_t)v * 2 * d + 2 * j + 1]); }
+  range[2 * j] = mn; range[2 * j + 1] = mx;
+}
+
 // -------------------------------------------------------------------------- weighted first moments
 // sums[0] = sum wt ; sums[1+j] = sum wt * u_j ; range[2j], range[2j+1] = min, max of u_j over rows with wt > 0
 // (wt = counts or real weights, optional label filter)
 template <typename WT>
 __global__ void __launch_bounds__(256) k_wsum(const double* __restrict__ hu, int64_t cap, int d, const WT* __restrict__ wt,
                                               const int32_t* __restrict__ labels, int label, int64_t n,
-                                              double* __restrict__ partials) {
-  // grid: (row blocks, 1 + d): blockIdx.y == 0 -> sum of weights, else coordinate blockIdx.y-1
+                                              double* __restrict__ partials, const long long* __restrict__ seg = nullptr) {
+  // grid: (row blocks, 1 + d [, segments]): blockIdx.y == 0 -> sum of weights, else coordinate blockIdx.y-1.
+  // seg != NULL: blockIdx.z picks the segment [seg[2z], seg[2z] + seg[2z+1]) of the rows (a virtual shard's stretch of the
+  // working set, see tph_fit_modes): the block partials of segment z depend on that segment's rows and on gridDim.x alone
+  SEG_SHIFT(hu, wt, labels, n, seg);
   const int col = blockIdx.y;
   const double* src = col ? hu + (size_t)(col - 1) * cap : nullptr;
   double s = 0.0, mn = DBL_MAX, mx = -DBL_MAX;
@@ -421,7 +455,7 @@ __global__ void __launch_bounds__(256) k_wsum(const double* __restrict__ hu, int
   mx = tph_block_max(mx, sh);
   mn = -tph_block_max(-mn, sh);
   if (threadIdx.x == 0) {
-    double* p = partials + ((size_t)blockIdx.x * gridDim.y + col) * 3;
+    double* p = partials + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + col) * 3;
     p[0] = s; p[1] = mn; p[2] = mx;
   }
 }
@@ -430,6 +464,10 @@ __global__ void __launch_bounds__(256) k_wsum(const double* __restrict__ hu, int
 __global__ void __launch_bounds__(256) k_wsum_final(const double* __restrict__ partials, int nblocks, int ncol,
                                                     double* __restrict__ sums, double* __restrict__ range) {
   int c = blockIdx.x;
+  // (blockIdx.y: segment -- its partials, its sums[ncol] and range[2 (ncol - 1)])
+  partials += (size_t)blockIdx.y * nblocks * ncol * 3;
+  sums += (size_t)blockIdx.y * ncol;
+  if (range) range += (size_t)blockIdx.y * 2 * (ncol - 1);
   double s = 0.0, mn = DBL_MAX, mx = -DBL_MAX;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
     const double* p = partials + ((size_t)b * ncol + c) * 3;
@@ -448,6 +486,8 @@ __global__ void __launch_bounds__(256) k_wsum_final(const double* __restrict__ p
 __global__ void __launch_bounds__(256) k_colsum2(const double* __restrict__ partials, int nblocks, int ncol,
                                                  double* __restrict__ out) {
   int c = blockIdx.x;
+  partials += (size_t)blockIdx.y * nblocks * ncol;      // (blockIdx.y: segment)
+  out += (size_t)blockIdx.y * ncol;
   double s = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partials[(size_t)b * ncol + c];
   __shared__ double sh[4];
@@ -479,7 +519,9 @@ __host__ __device__ inline int cov_slices(int npl) {
 template <typename WT>
 __global__ void __launch_bounds__(256) k_wcov(const double* __restrict__ hu, int64_t cap, int d, const WT* __restrict__ wt,
                                               const int32_t* __restrict__ labels, int label, int64_t n,
-                                              const double* __restrict__ mean, double* __restrict__ partials) {
+                                              const double* __restrict__ mean, double* __restrict__ partials,
+                                              const long long* __restrict__ seg = nullptr) {
+  SEG_SHIFT(hu, wt, labels, n, seg);
   extern __shared__ double sh[];
   double* xs = sh;                               // [d][65]
   double* ws = sh + (size_t)d * COV_LD;          // [64]
@@ -528,7 +570,7 @@ __global__ void __launch_bounds__(256) k_wcov(const double* __restrict__ hu, int
       }
     }
   }
-  double* mine = partials + ((size_t)blockIdx.x * S + slice) * npl;
+  double* mine = partials + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * S + slice) * npl;
 #pragma unroll
   for (int k = 0; k < COV_NPT; ++k) {
     int p = pslot + k * slots;
@@ -550,7 +592,9 @@ __host__ __device__ inline int cov_tile_slices(int d) {
 template <typename WT>
 __global__ void __launch_bounds__(256) k_wcov_tiled(const double* __restrict__ hu, int64_t cap, int d, const WT* __restrict__ wt,
                                                     const int32_t* __restrict__ labels, int label, int64_t n,
-                                                    const double* __restrict__ mean, double* __restrict__ partials) {
+                                                    const double* __restrict__ mean, double* __restrict__ partials,
+                                                    const long long* __restrict__ seg = nullptr) {
+  SEG_SHIFT(hu, wt, labels, n, seg);
   extern __shared__ double sh[];
   double* xs = sh;                               // [d][65]
   double* ws = sh + (size_t)d * COV_LD;          // [64]
@@ -632,7 +676,7 @@ __global__ void __launch_bounds__(256) k_wcov_tiled(const double* __restrict__ h
       }
     }
   }
-  double* mine = partials + (size_t)blockIdx.x * npl;
+  double* mine = partials + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * npl;
   if (SL == 1) {
 #pragma unroll
     for (int k = 0; k < MAXI; ++k) {
@@ -681,7 +725,9 @@ constexpr int COV_MF_MAXP = 9;                  // block pairs per wave: 36 pair
 template <typename WT>
 __global__ void __launch_bounds__(256) k_wcov_mfma(const double* __restrict__ hu, int64_t cap, int d, const WT* __restrict__ wt,
                                                    const int32_t* __restrict__ labels, int label, int64_t n,
-                                                   const double* __restrict__ mean, double* __restrict__ partials) {
+                                                   const double* __restrict__ mean, double* __restrict__ partials,
+                                                   const long long* __restrict__ seg = nullptr) {
+  SEG_SHIFT(hu, wt, labels, n, seg);
   extern __shared__ double sh[];
   const int NB = (d + 15) / 16, dp = NB * 16, pairs = NB * (NB + 1) / 2;
   double* xs = sh;                               // [dp][65], dims >= d are zero
@@ -726,7 +772,7 @@ __global__ void __launch_bounds__(256) k_wcov_mfma(const double* __restrict__ hu
     }
   }
   const int npl = d * (d + 1) / 2;
-  double* mine = partials + (size_t)blockIdx.x * npl;
+  double* mine = partials + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * npl;
 #pragma unroll
   for (int k = 0; k < COV_MF_MAXP; ++k) {
     if (offa[k] < 0) continue;
@@ -743,13 +789,13 @@ __global__ void __launch_bounds__(256) k_wcov_mfma(const double* __restrict__ hu
 // returns the number of partial rows per block
 template <typename WT>
 static int launch_wcov(tph_ctx* ctx, const double* src, int64_t src_ld, const WT* wt, const int32_t* labels, int label, int64_t n,
-                       const double* mean, double* partials, int nblk, int* rows_per_block) {
+                       const double* mean, double* partials, int nblk, int* rows_per_block, const long long* seg = nullptr, int nseg = 1) {
   const int d = ctx->d, npl = d * (d + 1) / 2;
   if (d >= 16 && d <= 128 && ctx->cov_kernel == 2) {      // matrix cores on request (TPH_OPT_COV_KERNEL: 0 auto = 1 register blocks | 2 MFMA)
     const size_t lds = sizeof(double) * ((size_t)((d + 15) / 16 * 16) * COV_LD + COV_ROWS);
     if (lds > 64 * 1024)
       TPH_HIP(hipFuncSetAttribute((const void*)k_wcov_mfma<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_wcov_mfma<WT>, dim3(nblk), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials);
+    hipLaunchKernelGGL(k_wcov_mfma<WT>, dim3(nblk, 1, nseg), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials, seg);
     *rows_per_block = 1;
     return 0;
   }
@@ -758,14 +804,14 @@ static int launch_wcov(tph_ctx* ctx, const double* src, int64_t src_ld, const WT
     const size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS + (SL > 1 ? npl : 0));
     if (lds > 64 * 1024)
       TPH_HIP(hipFuncSetAttribute((const void*)k_wcov_tiled<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_wcov_tiled<WT>, dim3(nblk), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials);
+    hipLaunchKernelGGL(k_wcov_tiled<WT>, dim3(nblk, 1, nseg), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials, seg);
     *rows_per_block = 1;
     return 0;
   }
   const size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS);
   if (lds > 64 * 1024)
     TPH_HIP(hipFuncSetAttribute((const void*)k_wcov<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_wcov<WT>, dim3(nblk), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials);
+  hipLaunchKernelGGL(k_wcov<WT>, dim3(nblk, 1, nseg), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials, seg);
   *rows_per_block = cov_slices(npl);
   return 0;
 }
@@ -775,7 +821,9 @@ static int launch_wcov(tph_ctx* ctx, const double* src, int64_t src_ld, const WT
 template <typename WT, int D>
 __global__ void __launch_bounds__(256) k_wcov_small(const double* __restrict__ hu, int64_t cap, const WT* __restrict__ wt,
                                                     const int32_t* __restrict__ labels, int label, int64_t n,
-                                                    const double* __restrict__ mean, double* __restrict__ partials) {
+                                                    const double* __restrict__ mean, double* __restrict__ partials,
+                                                    const long long* __restrict__ seg = nullptr) {
+  SEG_SHIFT(hu, wt, labels, n, seg);
   constexpr int NPL = D * (D + 1) / 2;
   double acc[NPL];
 #pragma unroll
@@ -808,7 +856,7 @@ __global__ void __launch_bounds__(256) k_wcov_small(const double* __restrict__ h
     }
   }
   __shared__ double sh[4];
-  double* mine = partials + (size_t)blockIdx.x * NPL;
+  double* mine = partials + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * NPL;
 #pragma unroll
   for (int k = 0; k < NPL; ++k) {
     double t = tph_block_sum(acc[k], sh);
@@ -822,9 +870,9 @@ static inline int wcov_small_blocks(int nblk) { return nblk < 768 ? nblk : 768; 
 
 template <typename WT>
 static bool launch_wcov_small(tph_ctx* ctx, const double* src, int64_t src_ld, const WT* wt, const int32_t* labels, int label,
-                              int64_t n, const double* mean, double* partials, int nblk) {
+                              int64_t n, const double* mean, double* partials, int nblk, const long long* seg = nullptr, int nseg = 1) {
   switch (ctx->d) {
-#define C(DD) case DD: hipLaunchKernelGGL((k_wcov_small<WT, DD>), dim3(nblk), dim3(256), 0, ctx->stream, src, src_ld, wt, labels, label, n, mean, partials); return true;
+#define C(DD) case DD: hipLaunchKernelGGL((k_wcov_small<WT, DD>), dim3(nblk, 1, nseg), dim3(256), 0, ctx->stream, src, src_ld, wt, labels, label, n, mean, partials, seg); return true;
     C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12)
 #undef C
     default: return false;
@@ -1275,23 +1323,42 @@ int tph_tri_inv(tph_ctx* ctx, const double* chol_dev, int K, double* winv_dev) {
 }
 
 // ------------------------------------------------------------------------------------ fit_modes
-// ---- compaction of the up-sampled set -------------------------------------------------------------------------------
+// ---- the working set of the fit: the rows with a multiplicity, shard by shard -------------------------------------------------
 // The fit reads u five times (first moments, covariance, two histogram levels, candidate collection), but only rows with a
 // non-zero multiplicity matter, and their share falls as the history grows (4 n_particles kept rows of N_h: 60 % at iteration
 // 6, 13 % at iteration 24 of the bench run).  One order-preserving stream compaction (block counts -> offsets -> scatter)
 // gathers those rows into a dense SoA working set; the five passes then stream 8d B per KEPT row instead of per history row.
+// The compaction walks the history VIRTUAL SHARD BY VIRTUAL SHARD (common.h: tph_part; inside a shard in iteration order), so
+// every shard's kept rows are ONE stretch of the working set -- a segment.  The moment kernels reduce each segment as if it
+// were the whole input (SEG_SHIFT above) and the per-shard results are added in shard order: the same summation tree whether
+// the V shards live on one GPU or on G, i.e. a fitted covariance that does not depend on the number of ranks.
 constexpr int NZ_ROWS = 1024;   // history rows per block (4 tiles of 256)
-constexpr int64_t FIT_COMPACT_MIN = 262144;   // below this the five passes are launch-bound anyway
-__global__ void __launch_bounds__(256) k_nz_count(const int32_t* __restrict__ counts, int64_t n, int* __restrict__ blockcnt) {
+constexpr int64_t FIT_COMPACT_MIN = 262144;   // below this the working set is sized for the whole history (no host read of the kept count)
+struct nz_geom {
+  long long n_loc, nv, n;         // rows per iteration on this rank | rows per piece | rows of the history
+  int T, vl, bpp;                 // pieces per shard | shards | blocks per piece
+};
+// block b (shard-major: shard, iteration, block of the piece) -> its rows [r0, r0 + cnt)
+__device__ __forceinline__ void nz_block_rows(const nz_geom& g, int b, long long& r0, int& cnt) {
+  const int per_shard = g.T * g.bpp;
+  const int v = b / per_shard, rem = b - v * per_shard;
+  const int t = rem / g.bpp, sb = rem - t * g.bpp;
+  const long long q0 = (long long)sb * NZ_ROWS;
+  r0 = (long long)t * g.n_loc + (long long)v * g.nv + q0;
+  const long long left = g.nv - q0;
+  cnt = (int)(left < NZ_ROWS ? left : NZ_ROWS);
+}
+__global__ void __launch_bounds__(256) k_nz_count(const int32_t* __restrict__ counts, nz_geom g, int* __restrict__ blockcnt) {
   __shared__ int s_c;
   if (threadIdx.x == 0) s_c = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * NZ_ROWS;
+  long long base; int rows;
+  nz_block_rows(g, blockIdx.x, base, rows);
   int c = 0;
 #pragma unroll
   for (int t = 0; t < NZ_ROWS / 256; ++t) {
-    int64_t i = base + t * 256 + threadIdx.x;
-    c += (i < n && counts[i] > 0) ? 1 : 0;
+    const int q = t * 256 + threadIdx.x;
+    c += (q < rows && counts[base + q] > 0) ? 1 : 0;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
@@ -1317,17 +1384,29 @@ __global__ void __launch_bounds__(1024) k_nz_offsets(int* __restrict__ blockcnt,
   long long run = s_part[threadIdx.x];
   for (int b = lo; b < hi; ++b) { int v = blockcnt[b]; blockcnt[b] = (int)run; run += v; }
 }
+// seg[2 v], seg[2 v + 1] = first kept row and number of kept rows of shard v (from the exclusive offsets of its first block)
+__global__ void k_nz_segments(const int* __restrict__ offsets, const long long* __restrict__ total, int vl, int per_shard,
+                              long long* __restrict__ seg) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= vl) return;
+  const long long a = offsets[(size_t)v * per_shard], b = v + 1 < vl ? (long long)offsets[(size_t)(v + 1) * per_shard] : total[0];
+  seg[2 * v] = a;
+  seg[2 * v + 1] = b - a;
+}
+__global__ void k_seg_whole(long long n, long long* __restrict__ seg) { if (!threadIdx.x && !blockIdx.x) { seg[0] = 0; seg[1] = n; } }
 __global__ void __launch_bounds__(256) k_nz_scatter(const double* __restrict__ u, int64_t cap, int d,
                                                     const int32_t* __restrict__ counts, const int32_t* __restrict__ labels,
-                                                    int64_t n, const int* __restrict__ offsets, double* __restrict__ uc,
+                                                    nz_geom g, const int* __restrict__ offsets, double* __restrict__ uc,
                                                     int64_t ldc, int32_t* __restrict__ cc, int32_t* __restrict__ lc) {
   __shared__ int s_wave[4];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   int64_t out = offsets[blockIdx.x];
-  const int64_t base = (int64_t)blockIdx.x * NZ_ROWS;
+  long long base; int rows;
+  nz_block_rows(g, blockIdx.x, base, rows);
   for (int t = 0; t < NZ_ROWS / 256; ++t) {
-    const int64_t i = base + t * 256 + threadIdx.x;
-    const int cnt = i < n ? counts[i] : 0;
+    const int q = t * 256 + threadIdx.x;
+    const int64_t i = base + q;
+    const int cnt = q < rows ? counts[i] : 0;
     const bool keep = cnt > 0;
     const unsigned long long mask = __ballot(keep);
     const int below = __popcll(mask & ((1ull << lane) - 1ull));
@@ -1352,102 +1431,6 @@ __global__ void __launch_bounds__(256) k_nz_scatter(const double* __restrict__ u
     out += tot;
     __syncthreads();
   }
-}
-
-extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int32_t* labels_dev, int64_t n, int K,
-                             double* means_dev, double* covs_dev, double* chol_dev, double* inv_dev, double* cholinv_dev) {
-  TPH_REQUIRE(ctx && counts_dev && means_dev && covs_dev && chol_dev && inv_dev, "tph_fit_modes: NULL argument");
-  TPH_REQUIRE(n > 0 && n <= ctx->size && K >= 1, "tph_fit_modes: bad sizes");
-  TPH_REQUIRE(K == 1 || labels_dev, "tph_fit_modes: K>1 needs labels");
-  const int d = ctx->d;
-  // ---- working set: the history itself, or (large histories) the dense copy of the rows with multiplicity > 0
-  const double* src = ctx->u;
-  int64_t src_ld = ctx->cap;
-  const int64_t n_hist = n;
-  int64_t m_keep = -1;
-  const int nzb = (int)((n_hist + NZ_ROWS - 1) / NZ_ROWS);
-  int* blockcnt = (int*)ctx->partials;
-  if (n_hist >= FIT_COMPACT_MIN && (size_t)nzb * sizeof(int) <= ctx->partials_bytes) {
-    long long* total = (long long*)ctx->small_dev;
-    hipLaunchKernelGGL(k_nz_count, dim3(nzb), dim3(256), 0, ctx->stream, counts_dev, n_hist, blockcnt);
-    hipLaunchKernelGGL(k_nz_offsets, dim3(1), dim3(1024), 0, ctx->stream, blockcnt, nzb, total);
-    TPH_LAUNCH_CHECK();
-    TPH_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-    TPH_HIP(hipStreamSynchronize(ctx->stream));
-    long long m = *(long long*)ctx->pinned;
-    if (m > 0 && 2 * m <= n_hist) m_keep = m;          // otherwise streaming the history is as cheap
-  }
-  if (m_keep > 0) n = m_keep;
-  const int nblk = cov_blocks(n);
-  const int rblk = tph_grid_for(n, 256, 4, 512);
-  // scratch layout
-  size_t o = 0;
-  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
-  size_t o_part = take(sizeof(double) * cov_scratch_doubles(d, nblk));                  // cov partials + column sums
-  size_t o_part1 = take(sizeof(double) * (size_t)rblk * (1 + d) * 3);                  // first-moment partials
-  size_t o_sums = take(sizeof(double) * (1 + d));
-  size_t o_range = take(sizeof(double) * 2 * d);
-  size_t o_mean = take(sizeof(double) * d);
-  size_t o_h1 = take(sizeof(unsigned int) * (size_t)d * MED_BINS);
-  size_t o_h2 = take(sizeof(unsigned int) * (size_t)d * 2 * MED_BINS);
-  size_t o_sel = take(sizeof(long long) * (size_t)d * 2 * 4);
-  size_t o_vals = take(sizeof(double) * (size_t)d * 2 * MED_CAP);
-  size_t o_cnts = take(sizeof(int) * (size_t)d * 2 * MED_CAP);
-  size_t o_fill = take(sizeof(int) * ((size_t)d * 2 + 1));
-  size_t o_uc = 0, o_cc = 0, o_lc = 0;
-  if (m_keep > 0) {
-    o_uc = take(sizeof(double) * (size_t)d * (size_t)m_keep);
-    o_cc = take(sizeof(int32_t) * (size_t)m_keep);
-    o_lc = take(sizeof(int32_t) * (size_t)m_keep);
-  }
-  if (tph_scratch_reserve(ctx, o)) return -1;
-  char* base = (char*)ctx->scratch;
-  if (m_keep > 0) {
-    double* uc = (double*)(base + o_uc);
-    int32_t* cc = (int32_t*)(base + o_cc);
-    int32_t* lc = K > 1 ? (int32_t*)(base + o_lc) : nullptr;
-    hipLaunchKernelGGL(k_nz_scatter, dim3(nzb), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, d, counts_dev, labels_dev, n_hist,
-                       blockcnt, uc, m_keep, cc, lc);
-    TPH_LAUNCH_CHECK();
-    src = uc; src_ld = m_keep; counts_dev = cc;
-    if (K > 1) labels_dev = lc;
-  }
-  double* part = (double*)(base + o_part);
-  double* part1 = (double*)(base + o_part1);
-  double* sums = (double*)(base + o_sums);
-  double* range = (double*)(base + o_range);
-  double* mean = (double*)(base + o_mean);
-  unsigned int* h1 = (unsigned int*)(base + o_h1);
-  unsigned int* h2 = (unsigned int*)(base + o_h2);
-  long long* sel = (long long*)(base + o_sel);
-  double* vals = (double*)(base + o_vals);
-  int* cnts = (int*)(base + o_cnts);
-  int* fill = (int*)(base + o_fill);
-  int* overflow = fill + (size_t)d * 2;
-  for (int k = 0; k < K; ++k) {
-    const int32_t* lab = K > 1 ? labels_dev : nullptr;
-    // first moments -> arithmetic mean (centre of np.cov)
-    hipLaunchKernelGGL(k_wsum<int32_t>, dim3(rblk, 1 + d), dim3(256), 0, ctx->stream, src, src_ld, d, counts_dev, lab, k, n,
-                       part1);
-    hipLaunchKernelGGL(k_wsum_final, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums, range);
-    hipLaunchKernelGGL(k_mean_from_sums, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, sums, d, mean);
-    // covariance (student.py:62-63)
-    if (moments_launch_cov(ctx, counts_dev, true, lab, k, n, mean, sums, 1, covs_dev + (size_t)k * d * d, part, nblk, src, src_ld))
-      return -1;
-    // per-dimension median (student.py:61)
-    TPH_HIP(hipMemsetAsync(h1, 0, sizeof(unsigned int) * (size_t)d * MED_BINS, ctx->stream));
-    TPH_HIP(hipMemsetAsync(h2, 0, sizeof(unsigned int) * (size_t)d * 2 * MED_BINS, ctx->stream));
-    TPH_HIP(hipMemsetAsync(fill, 0, sizeof(int) * ((size_t)d * 2 + 1), ctx->stream));
-    dim3 hg(tph_grid_for(n, 256, 8, 256), d);
-    hipLaunchKernelGGL(k_med_hist1, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n, range, h1);
-    hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(256), 0, ctx->stream, h1, 1, sums, sel);
-    hipLaunchKernelGGL(k_med_hist2, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n, range, sel, h2);
-    hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(256), 0, ctx->stream, h2, 2, sums, sel);
-    hipLaunchKernelGGL(k_med_collect, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n, range, sel, vals, cnts, fill);
-    hipLaunchKernelGGL(k_med_finish, dim3(d), dim3(256), 0, ctx->stream, sel, range, vals, cnts, fill, means_dev + (size_t)k * d, overflow);
-    TPH_LAUNCH_CHECK();
-  }
-  return tph_chol_inv(ctx, covs_dev, K, chol_dev, inv_dev, cholinv_dev);
 }
 
 // ---- proposal fit over a SHARDED history (tph_comm_attach): the fit of the global up-sampled set ---------------------------
@@ -1525,122 +1508,192 @@ __global__ void k_med_pack(const double* __restrict__ vals, const int* __restric
   }
 }
 
-extern "C" int tph_fit_modes_global(tph_ctx* ctx, const int32_t* counts_dev, const int32_t* labels_dev, int64_t n, int K,
-                                    double* means_dev, double* covs_dev, double* chol_dev, double* inv_dev, double* cholinv_dev) {
-  TPH_REQUIRE(ctx && counts_dev && means_dev && covs_dev && chol_dev && inv_dev, "tph_fit_modes_global: NULL argument");
-  if (!ctx->comm_active()) return tph_fit_modes(ctx, counts_dev, labels_dev, n, K, means_dev, covs_dev, chol_dev, inv_dev, cholinv_dev);
-  TPH_REQUIRE(n > 0 && n <= ctx->size && K >= 1, "tph_fit_modes_global: bad sizes");
-  TPH_REQUIRE(K == 1 || labels_dev, "tph_fit_modes_global: K>1 needs labels");
-  const int d = ctx->d, G = ctx->world;
-  // working set: this rank's shard, or (large shards) the dense copy of its rows with multiplicity > 0, as in tph_fit_modes --
-  // a local choice: the rows and their order are the same, only the block boundaries of the partial sums move
+
+// The proposal fit of the up-sampled set (tempest/train.py:91-122, modes.py:131-288, student.py:60-64), on one GPU or over a
+// sharded history: every statistic is a sum or an order statistic over rows.  Sums are formed per virtual shard and folded in
+// shard order (with a communicator the per-shard sums of all ranks are all-gathered first: rank order = shard order); ranges and
+// the histogram levels of the median select are order-free (max / integer sums: all-reduced), the (value, multiplicity)
+// candidates of the final median bins are gathered.  `use_comm` false with a communicator attached: the fit of this rank's rows.
+static int fit_modes_impl(tph_ctx* ctx, const int32_t* counts_dev, const int32_t* labels_dev, int64_t n, int K, double* means_dev,
+                          double* covs_dev, double* chol_dev, double* inv_dev, double* cholinv_dev, bool use_comm) {
+  const int d = ctx->d, G = use_comm ? ctx->world : 1;
+  const int npl = d * (d + 1) / 2;
+  TPH_REQUIRE(npl <= COV_NPT * 256, "covariance kernel supports n_dim <= 100 (got %d)", d);
+  const tph_part part = tph_partition(ctx, n);
+  const int vl = part.vl, V = use_comm ? part.vl * ctx->world : part.vl;
+  const int64_t n_hist = n;
+  // ---- working set
+  nz_geom g;
+  g.n_loc = part.n_loc; g.nv = part.nv; g.n = n_hist; g.T = part.T; g.vl = vl;
+  g.bpp = (int)((part.nv + NZ_ROWS - 1) / NZ_ROWS);
+  const int per_shard = g.T * g.bpp, nzb = vl * per_shard;
+  const bool pieces = part.T * vl > 1;
+  const bool compact = pieces || n_hist >= FIT_COMPACT_MIN;
   const double* src = ctx->u;
   int64_t src_ld = ctx->cap;
-  const int64_t n_hist = n;
-  int64_t m_keep = -1;
-  const int nzb = (int)((n_hist + NZ_ROWS - 1) / NZ_ROWS);
-  int* blockcnt = (int*)ctx->partials;
-  if (n_hist >= FIT_COMPACT_MIN && (size_t)nzb * sizeof(int) <= ctx->partials_bytes) {
-    long long* total = (long long*)ctx->small_dev;
-    hipLaunchKernelGGL(k_nz_count, dim3(nzb), dim3(256), 0, ctx->stream, counts_dev, n_hist, blockcnt);
+  int64_t m_cap = n_hist;                         // rows of the working set (its leading dimension); kept rows <= m_cap
+  int* blockcnt = nullptr;
+  long long* total = (long long*)ctx->small_dev;
+  if (compact) {
+    if (tph_partials_reserve(ctx, sizeof(int) * (size_t)nzb)) return -1;
+    blockcnt = (int*)ctx->partials;
+    hipLaunchKernelGGL(k_nz_count, dim3(nzb), dim3(256), 0, ctx->stream, counts_dev, g, blockcnt);
     hipLaunchKernelGGL(k_nz_offsets, dim3(1), dim3(1024), 0, ctx->stream, blockcnt, nzb, total);
     TPH_LAUNCH_CHECK();
-    TPH_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-    TPH_HIP(hipStreamSynchronize(ctx->stream));
-    long long m = *(long long*)ctx->pinned;
-    if (m > 0 && 2 * m <= n_hist) m_keep = m;
+    if (n_hist >= FIT_COMPACT_MIN) {              // large: the working set is sized by the kept rows (one 8-byte host read)
+      TPH_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+      TPH_HIP(hipStreamSynchronize(ctx->stream));
+      const long long m = *(long long*)ctx->pinned;
+      m_cap = m > 0 ? m : 1;
+      if (!pieces && 2 * m > n_hist) m_cap = -1;  // one segment and most rows kept: streaming the history itself is as cheap
+    }
   }
-  if (m_keep > 0) n = m_keep;
-  const int nblk = cov_blocks(n);
-  const int rblk = tph_grid_for(n, 256, 4, 512);
-  const int npl = d * (d + 1) / 2;
+  const bool dense = compact && m_cap > 0;
+  if (!dense) m_cap = n_hist;
+  // block counts of the reductions: functions of the SHARD's shape (rows per shard of the history) and of V, never of vl
+  const int64_t rows_v = part.nv * (int64_t)part.T;
+  const int Vt = part.canonical ? part.V : 1;
+  int rblk = tph_grid_for(rows_v, 256, 4, 512 / Vt > 1 ? 512 / Vt : 1);
+  int nblk = cov_blocks(rows_v);
+  { const int capb = (d <= 12 ? 768 : 2048) / Vt; if (nblk > capb) nblk = capb > 1 ? capb : 1; }
+  const int rpb = d <= 12 ? 1 : ((d >= 16) ? 1 : cov_slices(npl));
+  // scratch layout
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
-  size_t o_part = take(sizeof(double) * cov_scratch_doubles(d, nblk));
-  size_t o_part1 = take(sizeof(double) * (size_t)rblk * (1 + d) * 3);
+  size_t o_part = take(sizeof(double) * ((size_t)vl * nblk * (d <= 12 ? 1 : cov_slices(npl)) * npl));   // cov block partials
+  size_t o_part1 = take(sizeof(double) * (size_t)vl * rblk * (1 + d) * 3);                                // first-moment partials
+  size_t o_vs = take(sizeof(double) * (size_t)V * (size_t)(npl > 1 + d ? npl : 1 + d));                   // per-shard sums (local, or gathered)
+  size_t o_vr = take(sizeof(double) * (size_t)vl * 2 * d);
+  size_t o_sums = take(sizeof(double) * (1 + d));
+  size_t o_csum = take(sizeof(double) * npl);
   size_t o_range = take(sizeof(double) * 2 * d);
   size_t o_mean = take(sizeof(double) * d);
+  size_t o_seg = take(sizeof(long long) * 2 * (size_t)vl);
+  size_t o_h1 = take(sizeof(unsigned int) * (size_t)d * MED_BINS);
+  size_t o_h2 = take(sizeof(unsigned int) * (size_t)d * 2 * MED_BINS);
   size_t o_sel = take(sizeof(long long) * (size_t)d * 2 * 4);
   size_t o_vals = take(sizeof(double) * (size_t)d * 2 * MED_CAP);
   size_t o_cnts = take(sizeof(int) * (size_t)d * 2 * MED_CAP);
-  size_t o_ovf = take(sizeof(int));
+  size_t o_fill = take(sizeof(int) * ((size_t)d * 2 + 1));
   size_t o_uc = 0, o_cc = 0, o_lc = 0;
-  if (m_keep > 0) {
-    o_uc = take(sizeof(double) * (size_t)d * (size_t)m_keep);
-    o_cc = take(sizeof(int32_t) * (size_t)m_keep);
-    o_lc = take(sizeof(int32_t) * (size_t)m_keep);
+  if (dense) {
+    o_uc = take(sizeof(double) * (size_t)d * (size_t)m_cap);
+    o_cc = take(sizeof(int32_t) * (size_t)m_cap);
+    o_lc = take(sizeof(int32_t) * (size_t)m_cap);
   }
   if (tph_scratch_reserve(ctx, o)) return -1;
   char* base = (char*)ctx->scratch;
-  if (m_keep > 0) {
+  long long* seg = (long long*)(base + o_seg);
+  int64_t n_work = n_hist;                        // rows the order-free passes (histograms) walk
+  if (dense) {
     double* uc = (double*)(base + o_uc);
     int32_t* cc = (int32_t*)(base + o_cc);
     int32_t* lc = K > 1 ? (int32_t*)(base + o_lc) : nullptr;
-    hipLaunchKernelGGL(k_nz_scatter, dim3(nzb), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, d, counts_dev, labels_dev, n_hist,
-                       blockcnt, uc, m_keep, cc, lc);
+    if (n_hist < FIT_COMPACT_MIN) TPH_HIP(hipMemsetAsync(cc, 0, sizeof(int32_t) * (size_t)m_cap, ctx->stream));   // rows behind the kept ones count 0
+    hipLaunchKernelGGL(k_nz_scatter, dim3(nzb), dim3(256), 0, ctx->stream, ctx->u, ctx->cap, d, counts_dev, labels_dev, g, blockcnt, uc,
+                       m_cap, cc, lc);
+    hipLaunchKernelGGL(k_nz_segments, dim3((vl + 63) / 64), dim3(64), 0, ctx->stream, (const int*)blockcnt, (const long long*)total, vl, per_shard, seg);
     TPH_LAUNCH_CHECK();
-    src = uc; src_ld = m_keep; counts_dev = cc;
+    src = uc; src_ld = m_cap; counts_dev = cc;
     if (K > 1) labels_dev = lc;
+    n_work = m_cap;
+  } else {
+    hipLaunchKernelGGL(k_seg_whole, dim3(1), dim3(1), 0, ctx->stream, (long long)n_hist, seg);
+    TPH_LAUNCH_CHECK();
   }
-  double* part = (double*)(base + o_part);
+  double* part_c = (double*)(base + o_part);
   double* part1 = (double*)(base + o_part1);
+  double* vs = (double*)(base + o_vs);
+  double* vr = (double*)(base + o_vr);
+  double* sums = (double*)(base + o_sums);
+  double* csum = (double*)(base + o_csum);
   double* range = (double*)(base + o_range);
   double* mean = (double*)(base + o_mean);
+  unsigned int* h1 = (unsigned int*)(base + o_h1);
+  unsigned int* h2 = (unsigned int*)(base + o_h2);
   long long* sel = (long long*)(base + o_sel);
   double* vals = (double*)(base + o_vals);
   int* cnts = (int*)(base + o_cnts);
-  int* overflow = (int*)(base + o_ovf);
-  // staging layout (fixed offsets, the largest user is the second histogram level / the gathered candidates)
-  const size_t c_sums = 0;                                                   // (1+d) f64
-  const size_t c_rng = ((sizeof(double) * (1 + d)) + 255) / 256 * 256;       // 2d f64
-  const size_t c_big = c_rng + ((sizeof(double) * 2 * d) + 255) / 256 * 256;  // histograms / covariance sums / candidate lists
-  const size_t big_need = sizeof(unsigned int) * (size_t)d * 2 * MED_BINS + sizeof(int) * (size_t)d * 2 * (G + 1) + 4096;
-  if (tph_comm_require(ctx, c_big + big_need, "tph_fit_modes_global")) return -2;
-  double* sums = (double*)(ctx->comm_buf + c_sums);
-  double* rng = (double*)(ctx->comm_buf + c_rng);
-  TPH_HIP(hipMemsetAsync(overflow, 0, sizeof(int), ctx->stream));
+  int* fill = (int*)(base + o_fill);
+  int* overflow = fill + (size_t)d * 2;
+  // staging of the sharded fit (fixed offsets; the largest user is the second histogram level / the gathered candidates / the
+  // gathered covariance sums)
+  const size_t c_rng = 0;                                                            // 2d f64
+  const size_t c_big = ((sizeof(double) * 2 * d) + 255) / 256 * 256;                 // shard sums | histograms | candidate lists
+  if (use_comm) {
+    const size_t gather_need = sizeof(double) * (size_t)(vl + V) * (size_t)(npl > 1 + d ? npl : 1 + d) + 512;
+    const size_t med_need = sizeof(unsigned int) * (size_t)d * 2 * MED_BINS + sizeof(int) * (size_t)d * 2 * (G + 1) + 4096;
+    if (tph_comm_require(ctx, c_big + (gather_need > med_need ? gather_need : med_need), "tph_fit_modes_global")) return -2;
+    TPH_HIP(hipMemsetAsync(overflow, 0, sizeof(int), ctx->stream));
+  }
+  // per-shard sums [vl][ncol] -> the run's sums: all-gather (rank order = shard order) when sharded, then the fold in shard order
+  auto fold_shards = [&](const double* mine, int ncol, double* out) -> int {
+    const double* rows = mine;
+    if (use_comm) {
+      const size_t one = sizeof(double) * (size_t)vl * ncol, all_off = c_big + (one + 255) / 256 * 256;
+      TPH_HIP(hipMemcpyAsync(ctx->comm_buf + c_big, mine, one, hipMemcpyDeviceToDevice, ctx->stream));
+      if (tph_comm_allgather(ctx, c_big, all_off, (int64_t)vl * ncol, TPH_DT_F64)) return -2;
+      rows = (const double*)(ctx->comm_buf + all_off);
+    }
+    hipLaunchKernelGGL(k_fold_cols, dim3((ncol + 255) / 256), dim3(256), 0, ctx->stream, rows, V, ncol, out);
+    TPH_LAUNCH_CHECK();
+    return 0;
+  };
   for (int k = 0; k < K; ++k) {
     const int32_t* lab = K > 1 ? labels_dev : nullptr;
-    // first moments, data range
-    hipLaunchKernelGGL(k_wsum<int32_t>, dim3(rblk, 1 + d), dim3(256), 0, ctx->stream, src, src_ld, d, counts_dev, lab, k, n, part1);
-    hipLaunchKernelGGL(k_wsum_final, dim3(1 + d), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, sums, range);
-    hipLaunchKernelGGL(k_pack_range, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, range, d, rng);
+    // first moments -> arithmetic mean (centre of np.cov), data range
+    hipLaunchKernelGGL(k_wsum<int32_t>, dim3(rblk, 1 + d, vl), dim3(256), 0, ctx->stream, src, src_ld, d, counts_dev, lab, k, n_work, part1,
+                       (const long long*)seg);
+    hipLaunchKernelGGL(k_wsum_final, dim3(1 + d, vl), dim3(256), 0, ctx->stream, part1, rblk, 1 + d, vs, vr);
+    hipLaunchKernelGGL(k_fold_range, dim3((d + 255) / 256), dim3(256), 0, ctx->stream, (const double*)vr, vl, d, range);
     TPH_LAUNCH_CHECK();
-    if (tph_comm_allreduce(ctx, c_sums, 1 + d, TPH_DT_F64, TPH_OP_SUM)) return -2;
-    if (tph_comm_allreduce(ctx, c_rng, 2 * d, TPH_DT_F64, TPH_OP_MAX)) return -2;
-    hipLaunchKernelGGL(k_unpack_range, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, rng, d, range);
-    hipLaunchKernelGGL(k_mean_from_sums, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, sums, d, mean);
-    // centred second moments about the global mean: local lower triangle -> all-reduce -> student.py:62-63
-    {
-      double* csum = (double*)(ctx->comm_buf + c_big);
-      const int S = cov_slices(npl);
-      TPH_REQUIRE(npl <= COV_NPT * 256, "covariance kernel supports n_dim <= 100 (got %d)", d);
-      if (d <= 12) {
-        const int nb = wcov_small_blocks(nblk);
-        bool ok = launch_wcov_small<int32_t>(ctx, src, src_ld, counts_dev, lab, k, n, mean, part, nb);
-        TPH_REQUIRE(ok, "covariance: no register kernel for n_dim=%d", d);
-        hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nb, npl, csum);
-      } else {
-        int rpb = S;
-        if (launch_wcov<int32_t>(ctx, src, src_ld, counts_dev, lab, k, n, mean, part, nblk, &rpb)) return -1;
-        hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk * rpb, npl, csum);
-      }
+    if (fold_shards(vs, 1 + d, sums)) return -2;
+    if (use_comm) {
+      double* rng = (double*)(ctx->comm_buf + c_rng);
+      hipLaunchKernelGGL(k_pack_range, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, range, d, rng);
       TPH_LAUNCH_CHECK();
-      if (tph_comm_allreduce(ctx, c_big, npl, TPH_DT_F64, TPH_OP_SUM)) return -2;
+      if (tph_comm_allreduce(ctx, c_rng, 2 * d, TPH_DT_F64, TPH_OP_MAX)) return -2;
+      hipLaunchKernelGGL(k_unpack_range, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, rng, d, range);
+    }
+    hipLaunchKernelGGL(k_mean_from_sums, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, sums, d, mean);
+    // covariance (student.py:62-63): centred second moments about the (global) mean, per shard, folded
+    {
+      int rows_pb = 1;
+      if (d <= 12) {
+        bool ok = launch_wcov_small<int32_t>(ctx, src, src_ld, counts_dev, lab, k, n_work, mean, part_c, nblk, seg, vl);
+        TPH_REQUIRE(ok, "covariance: no register kernel for n_dim=%d", d);
+      } else {
+        if (launch_wcov<int32_t>(ctx, src, src_ld, counts_dev, lab, k, n_work, mean, part_c, nblk, &rows_pb, seg, vl)) return -1;
+      }
+      hipLaunchKernelGGL(k_colsum2, dim3(npl, vl), dim3(256), 0, ctx->stream, part_c, nblk * rows_pb, npl, vs);
+      TPH_LAUNCH_CHECK();
+      if (fold_shards(vs, npl, csum)) return -2;
       hipLaunchKernelGGL(k_cov_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum, sums, d, 1, covs_dev + (size_t)k * d * d);
       TPH_LAUNCH_CHECK();
     }
-    // per-dimension median: two all-reduced histogram levels, then the gathered candidates of the final bins
-    {
+    (void)rpb;
+    // per-dimension median (student.py:61): two histogram levels (all-reduced when sharded), then the candidates of the final bins
+    dim3 hg(tph_grid_for(n_work, 256, 8, 256), d);
+    if (!use_comm) {
+      TPH_HIP(hipMemsetAsync(h1, 0, sizeof(unsigned int) * (size_t)d * MED_BINS, ctx->stream));
+      TPH_HIP(hipMemsetAsync(h2, 0, sizeof(unsigned int) * (size_t)d * 2 * MED_BINS, ctx->stream));
+      TPH_HIP(hipMemsetAsync(fill, 0, sizeof(int) * ((size_t)d * 2 + 1), ctx->stream));
+      hipLaunchKernelGGL(k_med_hist1, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n_work, range, h1);
+      hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(256), 0, ctx->stream, h1, 1, sums, sel);
+      hipLaunchKernelGGL(k_med_hist2, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n_work, range, sel, h2);
+      hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(256), 0, ctx->stream, h2, 2, sums, sel);
+      hipLaunchKernelGGL(k_med_collect, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n_work, range, sel, vals, cnts, fill);
+      hipLaunchKernelGGL(k_med_finish, dim3(d), dim3(256), 0, ctx->stream, sel, range, vals, cnts, fill, means_dev + (size_t)k * d, overflow);
+      TPH_LAUNCH_CHECK();
+    } else {
       unsigned int* h = (unsigned int*)(ctx->comm_buf + c_big);
-      dim3 hg(tph_grid_for(n, 256, 8, 256), d);
       TPH_HIP(hipMemsetAsync(h, 0, sizeof(unsigned int) * (size_t)d * MED_BINS, ctx->stream));
-      hipLaunchKernelGGL(k_med_hist1, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n, range, h);
+      hipLaunchKernelGGL(k_med_hist1, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n_work, range, h);
       TPH_LAUNCH_CHECK();
       if (tph_comm_allreduce(ctx, c_big, (int64_t)d * MED_BINS, TPH_DT_I32, TPH_OP_SUM)) return -2;
       hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(256), 0, ctx->stream, h, 1, sums, sel);
       TPH_HIP(hipMemsetAsync(h, 0, sizeof(unsigned int) * (size_t)d * 2 * MED_BINS, ctx->stream));
-      hipLaunchKernelGGL(k_med_hist2, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n, range, sel, h);
+      hipLaunchKernelGGL(k_med_hist2, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n_work, range, sel, h);
       TPH_LAUNCH_CHECK();
       if (tph_comm_allreduce(ctx, c_big, (int64_t)d * 2 * MED_BINS, TPH_DT_I32, TPH_OP_SUM)) return -2;
       hipLaunchKernelGGL(k_med_select, dim3(d, 2), dim3(256), 0, ctx->stream, h, 2, sums, sel);
@@ -1648,7 +1701,7 @@ extern "C" int tph_fit_modes_global(tph_ctx* ctx, const int32_t* counts_dev, con
       int* fill_mine = (int*)(ctx->comm_buf + c_big);                 // [d*2]
       int* fill_all = fill_mine + (size_t)d * 2;                      // [G][d*2]
       TPH_HIP(hipMemsetAsync(fill_mine, 0, sizeof(int) * (size_t)d * 2, ctx->stream));
-      hipLaunchKernelGGL(k_med_collect, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n, range, sel, vals, cnts, fill_mine);
+      hipLaunchKernelGGL(k_med_collect, hg, dim3(256), 0, ctx->stream, src, src_ld, counts_dev, lab, k, n_work, range, sel, vals, cnts, fill_mine);
       TPH_LAUNCH_CHECK();
       if (tph_comm_allgather(ctx, c_big, c_big + sizeof(int) * (size_t)d * 2, (int64_t)d * 2, TPH_DT_I32)) return -2;
       std::vector<int> fh((size_t)G * d * 2);
@@ -1678,6 +1731,22 @@ extern "C" int tph_fit_modes_global(tph_ctx* ctx, const int32_t* counts_dev, con
     }
   }
   return tph_chol_inv(ctx, covs_dev, K, chol_dev, inv_dev, cholinv_dev);
+}
+
+extern "C" int tph_fit_modes(tph_ctx* ctx, const int32_t* counts_dev, const int32_t* labels_dev, int64_t n, int K,
+                             double* means_dev, double* covs_dev, double* chol_dev, double* inv_dev, double* cholinv_dev) {
+  TPH_REQUIRE(ctx && counts_dev && means_dev && covs_dev && chol_dev && inv_dev, "tph_fit_modes: NULL argument");
+  TPH_REQUIRE(n > 0 && n <= ctx->size && K >= 1, "tph_fit_modes: bad sizes");
+  TPH_REQUIRE(K == 1 || labels_dev, "tph_fit_modes: K>1 needs labels");
+  return fit_modes_impl(ctx, counts_dev, labels_dev, n, K, means_dev, covs_dev, chol_dev, inv_dev, cholinv_dev, false);
+}
+
+extern "C" int tph_fit_modes_global(tph_ctx* ctx, const int32_t* counts_dev, const int32_t* labels_dev, int64_t n, int K,
+                                    double* means_dev, double* covs_dev, double* chol_dev, double* inv_dev, double* cholinv_dev) {
+  TPH_REQUIRE(ctx && counts_dev && means_dev && covs_dev && chol_dev && inv_dev, "tph_fit_modes_global: NULL argument");
+  TPH_REQUIRE(n > 0 && n <= ctx->size && K >= 1, "tph_fit_modes_global: bad sizes");
+  TPH_REQUIRE(K == 1 || labels_dev, "tph_fit_modes_global: K>1 needs labels");
+  return fit_modes_impl(ctx, counts_dev, labels_dev, n, K, means_dev, covs_dev, chol_dev, inv_dev, cholinv_dev, ctx->comm_active());
 }
 
 // ------------------------------------------------------------------------------ volume variation

@@ -76,7 +76,7 @@ extern "C" int tph_inf_repair_src(tph_ctx* ctx, double* u_dev, double* x_dev, do
   int64_t* list = (int64_t*)(rank + n);
   unsigned grid = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_flag_finite, dim3(grid), dim3(256), 0, ctx->stream, logl_dev, n, flag);
-  int rc = tph_cdf(ctx, flag, n, nullptr, rank);  // scratch already large enough: no reallocation
+  int rc = tph_cdf_plain(ctx, flag, n, nullptr, rank);  // scratch already large enough: no reallocation
   if (rc) return rc;
   hipLaunchKernelGGL(k_finite_list, dim3(grid), dim3(256), 0, ctx->stream, flag, rank, n, list);
   hipLaunchKernelGGL(k_inf_repair, dim3(grid), dim3(256), 0, ctx->stream, u_dev, x_dev, logl_dev, n, ld, ctx->d, flag, rank,
@@ -1033,6 +1033,11 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
       (variant == 5 || (variant == 0 && ctx->staged && !ctx->blocked)))
     return tph_propose_sm(ctx, kernel, u_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick0, ctl_dev,
                           item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev);
+  // ... with several modes: the same batches mode by mode over the particles of each (propose_mf.hip: tph_propose_mf_modes)
+  if (!use_reg && ctx->d > 16 && ctx->d <= 112 && assign_dev && K > 1 && K <= 64 &&
+      ((variant == 6 && tph_mf_selftest(ctx)) || (variant == 0 && ctx->staged && !ctx->blocked && tph_mf_screen(ctx))))
+    return tph_propose_mf_modes(ctx, kernel, u_dev, assign_dev, n, ld, K, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick0,
+                                ctl_dev, item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev);
   if (!use_reg && ctx->d > 16 && ctx->d <= (ctx->blk_mfma ? 112 : 100) && !assign_dev && K == 1 && (variant == 4 || (variant == 0 && ctx->blocked))) {
     if (kernel == TPH_KERNEL_TPCN)
       return launch_propose_blk<TPH_KERNEL_TPCN>(ctx, u_dev, n, ld, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed,
@@ -1046,15 +1051,23 @@ extern "C" int tph_propose(tph_ctx* ctx, int kernel, double* u_dev, const int32_
       (variant == 4 || (variant == 0 && ctx->blocked))) {
     const int rounds = ctx->blocked < 1 ? 1 : ctx->blocked;
     const int32_t *todo_cnt = nullptr, *todo_rows = nullptr, *todo_att = nullptr;
+    const int32_t* per_mode[3] = {nullptr, nullptr, nullptr};
+    const bool screen = tph_mf_screen(ctx);
     if (tph_blkm_multi(ctx, kernel, u_dev, assign_dev, n, ld, K, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick0,
-                       ctl_dev, item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev, rounds, &todo_cnt, &todo_rows, &todo_att))
+                       ctl_dev, item0, uprime_dev, maha_u_dev, maha_up_dev, pending_dev, rounds, &todo_cnt, &todo_rows, &todo_att,
+                       screen ? per_mode : nullptr))
       return -1;
+    const int att0 = (rounds > 24 ? 24 : rounds) * tph_blkm_tries(ctx);
+    // the stragglers of the rounds: screened windows per mode (each mode's failure list with its own matrices), as the one-mode
+    // path finishes its list; with the screen off, the multi-lane kernel over the concatenated list
+    if (screen)
+      return tph_propose_mf_mode_lists(ctx, kernel, u_dev, n, ld, K, means_dev, chol_dev, inv_dev, dof_dev, sigmas_dev, bc_dev, seed, tick0, ctl_dev,
+                                       item0, uprime_dev, maha_up_dev, per_mode[0], per_mode[1], per_mode[2], att0, todo_att);
     int lpp = 4;
     while (lpp < 64 && lpp < (ctx->d + 1) / 2) lpp *= 2;
     const int keep = ctx->ml_unstaged;
     ctx->ml_unstaged = 1;
     int rc = 0;
-    const int att0 = (rounds > 24 ? 24 : rounds) * tph_blkm_tries(ctx);
     switch (lpp) {
 #define TPH_ML_M(LL)                                                                                                     \
   case LL:                                                                                                               \
@@ -1188,18 +1201,65 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accept(double beta, double* __r
   }
 }
 
-// column sums of the block partials in block order (deterministic): one thread-block per column.  (Folding this
-// into k_accept behind a last-block ticket was measured SLOWER: the agent-scope release fence writes back the L2 lines
-// the accepted rows have just dirtied, +13 us, against a 5 us kernel that follows with no gap.)
-__global__ void __launch_bounds__(256) k_colsum(const double* __restrict__ partials, int nblocks, int ncol,
-                                                double* __restrict__ out, tph_stepctl tick) {
+// ---- the step's sums (#accepted, sum alpha_c) from the block partials of k_accept, in the CANONICAL order (common.h: tph_part) ----
+// The particle slots of a step are cut into the virtual shards of the canonical partition (vl of them on this rank, each a whole
+// number `mper` of 256-particle blocks); a shard's column sums are formed by ONE wave -- lane l adds partials l, l + 64, ... in
+// order, then a fixed shuffle tree -- and the V shard sums of the whole run are added in shard order.  The same tree on one GPU
+// and on G: the adapted sigma, and with it every later proposal, does not depend on the number of ranks.  (Folding the sums
+// into k_accept behind a last-block ticket was measured SLOWER: the agent-scope release fence writes back the L2 lines the
+// accepted rows have just dirtied, +13 us, against a 5 us kernel that follows with no gap.)
+static tph_part active_partition(const tph_ctx* ctx, int64_t n) {
+  tph_part p{1, n, 1, ctx->world, n, false};
+  const int64_t ng = n * (int64_t)ctx->world;
+  if (ng % 256 == 0) {
+    const int V = tph_vshards_for(ng);
+    if (V % ctx->world == 0) { p.vl = V / ctx->world; p.V = V; p.nv = ng / V; p.canonical = true; }
+  }
+  return p;
+}
+// vs[v * ncol + col] = sum over the blocks of local shard v of partials[block][col]; every wave of the workgroup takes pairs
+__device__ __forceinline__ void vshard_colsums(const double* __restrict__ partials, int nblocks, int vl, int ncol, double* __restrict__ vs) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int mper = nblocks / vl;                 // (vl == 1: all blocks)
+  for (int p = wid; p < vl * ncol; p += nw) {
+    const int v = p / ncol, col = p - v * ncol;
+    const double* src = partials + (size_t)v * mper * ncol + col;
+    double s = 0.0;
+    for (int b = lane; b < mper; b += 64) s += src[(size_t)b * ncol];
+    s = tph_wave_sum(s);
+    if (lane == 0) vs[p] = s;
+  }
+}
+// out[col] = ((vs[0][col] + vs[1][col]) + vs[2][col]) + ...  over V shards
+__device__ __forceinline__ void vshard_fold(const double* __restrict__ vs, int V, int ncol, double* __restrict__ out) {
+  for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
+    double s = vs[c];
+    for (int v = 1; v < V; ++v) s += vs[(size_t)v * ncol + c];
+    out[c] = s;
+  }
+}
+__global__ void __launch_bounds__(1024) k_accept_sums(const double* __restrict__ partials, int nblocks, int vl, int ncol,
+                                                      double* __restrict__ vs, double* __restrict__ out, tph_stepctl tick) {
   if (tick.done()) return;
-  int cidx = blockIdx.x;
-  double s = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partials[(size_t)b * ncol + cidx];
-  __shared__ double sh[4];
-  s = tph_block_sum(s, sh);
-  if (threadIdx.x == 0) out[cidx] = s;
+  vshard_colsums(partials, nblocks, vl, ncol, vs);
+  __syncthreads();
+  if (out) vshard_fold(vs, vl, ncol, out);
+}
+__global__ void __launch_bounds__(256) k_fold_shards(const double* __restrict__ vs, int V, int ncol, double* __restrict__ out) {
+  vshard_fold(vs, V, ncol, out);
+}
+// scratch of the shard sums: [vl][ncol] of this rank, then [V][ncol] of the run; a fixed address per ctx (captured steps keep it)
+static double* adapt_scratch(tph_ctx* ctx, size_t doubles) {
+  if (ctx->adapt_bytes < sizeof(double) * doubles) {
+    size_t nb = ctx->adapt_bytes ? ctx->adapt_bytes : 4096;
+    while (nb < sizeof(double) * doubles) nb *= 2;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
+    if (ctx->adapt_buf) ctx->retired.push_back(ctx->adapt_buf);      // a captured step of an earlier engine may still point here
+    ctx->adapt_buf = nullptr; ctx->adapt_bytes = 0;
+    if (hipMalloc((void**)&ctx->adapt_buf, nb) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    ctx->adapt_bytes = nb;
+  }
+  return ctx->adapt_buf;
 }
 
 extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, double* x_dev, double* logl_dev,
@@ -1232,8 +1292,44 @@ extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, 
     hipLaunchKernelGGL(k_accept<TPH_KERNEL_RWM>, dim3(grid), dim3(ACC_THREADS), 0, ctx->stream, beta, u_dev, x_dev, logl_dev,
                        uprime_dev, xprime_dev, loglprime_dev, maha_u_dev, maha_up_dev, assign_dev, n, ld, ctx->d, K, dof_dev,
                        seed, tick, item0, partials, pending_dev);
-  if (sums_dev)
-    hipLaunchKernelGGL(k_colsum, dim3(1 + K), dim3(256), 0, ctx->stream, partials, (int)grid, 1 + K, sums_dev, tick);
+  if (sums_dev) {
+    // this rank's sums in the canonical order (a sharded caller combines the ranks with tph_accept_sums_global instead)
+    const tph_part part = active_partition(ctx, n);
+    double* vs = adapt_scratch(ctx, (size_t)(part.vl + part.V) * (1 + K));
+    TPH_REQUIRE(vs, "tph_accept: cannot allocate the shard sums");
+    hipLaunchKernelGGL(k_accept_sums, dim3(1), dim3(((size_t)part.vl * (1 + K)) > 4 ? 1024 : 256), 0, ctx->stream, (const double*)partials, (int)grid,
+                       part.vl, 1 + K, vs, sums_dev, tick);
+  }
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
+// The step's sums over ALL ranks from this rank's block partials (tph_accept with sums_dev = NULL): per-shard sums -> all-gather
+// (rank order = shard order; the peer-to-peer exchange when attached and not `host_paced`, else the callback) -> fold in shard
+// order.  For callers that run tph_adapt without the folded exchange (no peer mapping, or user callbacks on the host between the
+// collectives).  Without a communicator: the same sums of the one rank.
+extern "C" int tph_accept_sums_global(tph_ctx* ctx, const double* partials_dev, int64_t n, int K, double* sums_dev, int host_paced) {
+  TPH_REQUIRE(ctx && partials_dev && sums_dev && n > 0 && K >= 1 && K <= 4096, "tph_accept_sums_global: bad argument");
+  const tph_part part = active_partition(ctx, n);
+  const int ncol = 1 + K, nblocks = (int)((n + ACC_THREADS - 1) / ACC_THREADS);
+  const tph_stepctl tick{0u, nullptr};
+  const int threads = ((size_t)part.vl * ncol) > 4 ? 1024 : 256;
+  if (!ctx->comm_active()) {
+    double* vs = adapt_scratch(ctx, (size_t)(part.vl + part.V) * ncol);
+    TPH_REQUIRE(vs, "tph_accept_sums_global: cannot allocate the shard sums");
+    hipLaunchKernelGGL(k_accept_sums, dim3(1), dim3(threads), 0, ctx->stream, partials_dev, nblocks, part.vl, ncol, vs, sums_dev, tick);
+    TPH_LAUNCH_CHECK();
+    return 0;
+  }
+  const size_t one = sizeof(double) * (size_t)part.vl * ncol, all = (one + 255) / 256 * 256;
+  if (tph_comm_require(ctx, all + one * ctx->world, "tph_accept_sums_global")) return -2;
+  hipLaunchKernelGGL(k_accept_sums, dim3(1), dim3(threads), 0, ctx->stream, partials_dev, nblocks, part.vl, ncol, (double*)ctx->comm_buf,
+                     (double*)nullptr, tick);
+  TPH_LAUNCH_CHECK();
+  if (host_paced ? tph_comm_allgather_cb(ctx, 0, all, (int64_t)part.vl * ncol, TPH_DT_F64)
+                 : tph_comm_allgather(ctx, 0, all, (int64_t)part.vl * ncol, TPH_DT_F64))
+    return -2;
+  hipLaunchKernelGGL(k_fold_shards, dim3(1), dim3(256), 0, ctx->stream, (const double*)(ctx->comm_buf + all), part.vl * ctx->world, ncol, sums_dev);
   TPH_LAUNCH_CHECK();
   return 0;
 }
@@ -1244,20 +1340,24 @@ extern "C" int tph_accept(tph_ctx* ctx, int kernel, double beta, double* u_dev, 
 __global__ void __launch_bounds__(1024) k_adapt(int kernel, const double* __restrict__ sums, const double* __restrict__ counts, int K, double n_global,
                         int d, int n_steps, int n_max, double* __restrict__ sigmas, double* __restrict__ state,
                         double* __restrict__ mailbox, int slots, const double* __restrict__ partials, int nblocks,
-                        double* __restrict__ sums_out, int exchange, p2p_args peers) {
+                        double* __restrict__ sums_out, int exchange, p2p_args peers, int vl, double* __restrict__ vs) {
   if (state[1] != 0.0) return;          // stopping rule already fired: later (speculative) steps are no-ops (on every rank)
-  if (partials) {                        // the column sums of tph_accept's block partials, folded in here
-    __shared__ double sh[16];
-    for (int col = 0; col <= K; ++col) {
-      double s = 0.0;
-      for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partials[(size_t)b * (1 + K) + col];
-      s = tph_block_sum(s, sh);
-      if (threadIdx.x == 0) sums_out[col] = s;
-    }
+  if (partials) {                        // the sums of tph_accept's block partials, folded in here (canonical order: see above)
+    const int ncol = 1 + K;
+    vshard_colsums(partials, nblocks, vl, ncol, vs);
     __syncthreads();
-    // sharded run: the ranks' sums meet here, through the peer-mapped inboxes (p2p.h) -- the all-reduce of the step costs
-    // no launch and no host call; every rank adds the slots in rank order, so all adapt identically
-    if (exchange && !p2p_block_exchange(peers, sums_out, sums_out, 1 + K, TPH_OP_SUM)) return;
+    const double* all = vs;
+    int V = vl;
+    // sharded run: the ranks' shard sums meet here, through the peer-mapped inboxes (p2p.h) -- the exchange of the step costs
+    // no launch and no host call; every rank folds the V shard sums in shard order, so all adapt identically, and as on one GPU
+    if (exchange) {
+      double* gathered = vs + (size_t)vl * ncol;
+      if (!p2p_block_exchange(peers, (const double*)vs, gathered, vl * ncol, -1)) return;
+      all = gathered;
+      V = vl * peers.world;
+    }
+    vshard_fold(all, V, ncol, sums_out);
+    __syncthreads();
     sums = sums_out;
   }
   if (threadIdx.x != 0) return;
@@ -1271,27 +1371,35 @@ extern "C" int tph_adapt(tph_ctx* ctx, int kernel, double* sums_dev, const doubl
   TPH_REQUIRE(!partials_dev || n > 0, "tph_adapt: partials need the particle count");
   TPH_REQUIRE(!mailbox_host || mailbox_slots >= 1, "tph_adapt: mailbox needs at least one slot");
   const int nparts = (int)((n + ACC_THREADS - 1) / ACC_THREADS);
-  const int threads = (partials_dev && nparts > 1024) ? 1024 : 256;      // the folded column sums are the only parallel work
+  tph_part part{1, n, 1, ctx->world, n, false};
+  double* vs = nullptr;
+  if (partials_dev) {
+    part = active_partition(ctx, n);
+    vs = adapt_scratch(ctx, (size_t)(part.vl + part.V) * (1 + K));
+    TPH_REQUIRE(vs, "tph_adapt: cannot allocate the shard sums");
+  }
+  const int threads = (partials_dev && (size_t)part.vl * (1 + K) > 4) ? 1024 : 256;      // a wave per (shard, column) pair
   p2p_args peers{};
   int exchange = 0;
   if (partials_dev && ctx->comm_active()) {
-    // not attached, or 1 + K doubles do not fit one 32 KB slot: a usage condition the caller can act on (code 1: all-reduce the
-    // sums of tph_accept yourself and pass partials_dev = NULL); an exchange that FAILED earlier keeps its own message
-    if (!tph_p2p_fits(ctx, 1 + K, TPH_DT_F64)) {
+    // not attached, or this rank's shard sums do not fit one 32 KB slot: a usage condition the caller can act on (code 1: combine
+    // the ranks with tph_accept_sums_global and pass partials_dev = NULL); an exchange that FAILED earlier keeps its own message
+    const int64_t cnt = (int64_t)part.vl * (1 + K);
+    if (!tph_p2p_fits(ctx, cnt, TPH_DT_F64)) {
       tph_set_error("tph_adapt: folding the block partials of a SHARDED step needs the peer-to-peer exchange (tph_comm_p2p_attach) and "
-                    "1 + K = %d doubles within one %zu-byte slot; all-reduce the sums of tph_accept yourself and pass partials_dev = NULL",
-                    1 + K, (size_t)TPH_P2P_SLOT);
+                    "vl (1 + K) = %lld doubles within one %zu-byte slot; combine the ranks with tph_accept_sums_global and pass partials_dev = NULL",
+                    (long long)cnt, (size_t)TPH_P2P_SLOT);
       return 1;
     }
-    const p2p_args* a = tph_p2p_ready(ctx, 1 + K, TPH_DT_F64);
+    const p2p_args* a = tph_p2p_ready(ctx, cnt, TPH_DT_F64);
     if (!a) return -2;                    // the sticky error of a timed-out exchange (text set by tph_p2p_ready)
     peers = *a;
     exchange = 1;
-    ctx->stat[0] += 1;                    // the step's all-reduce, folded into k_adapt
+    ctx->stat[0] += 1;                    // the step's exchange, folded into k_adapt
   }
   hipLaunchKernelGGL(k_adapt, dim3(1), dim3(threads), 0, ctx->stream, kernel, (const double*)sums_dev, counts_dev, K, n_global,
                      n_dim, n_steps, n_max, sigmas_dev, state_dev, mailbox_host, mailbox_slots, partials_dev, nparts, sums_dev,
-                     exchange, peers);
+                     exchange, peers, part.vl, vs);
   TPH_LAUNCH_CHECK();
   return 0;
 }

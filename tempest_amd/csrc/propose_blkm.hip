@@ -538,13 +538,58 @@ int tph_blkm_round(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, c
                                     rows_in, att, cnt_out, rows_out, att_in, att_out);
 }
 
+// The grouping of the particles by mode in the ctx-owned block (layout above), rebuilt when the caller's statistics version
+// (TPH_OPT_MODES_EPOCH), the assignments' address or n change -- the assignments are fixed while the statistics are.
+static int mode_table(tph_ctx* ctx, const int32_t* assign, int64_t n, int K) {
+  const int64_t tiles_max = (n + 15) / 16 + K + 1;
+  const size_t mtw = bm_mt_words(n, K), cntw = (size_t)2 * (24 + 2) * BM_KMAX;
+  const size_t need = sizeof(int32_t) * (mtw + cntw + 3 * (size_t)n + 64);
+  bool rebuild = ctx->modes_epoch <= 0 || ctx->mt_epoch != ctx->modes_epoch || ctx->mt_assign != (const void*)assign || ctx->mt_n != n ||
+                 ctx->mt_K != K;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  TPH_HIP(hipStreamIsCapturing(ctx->stream, &cap));
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  if (capturing) rebuild = true;                    // a replayed step never re-enters this host code
+  if (ctx->mt_bytes < need) {
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->mt_buf) ctx->retired.push_back(ctx->mt_buf);
+    ctx->mt_buf = nullptr; ctx->mt_bytes = 0;
+    TPH_HIP(hipMalloc((void**)&ctx->mt_buf, need));
+    ctx->mt_bytes = need;
+    rebuild = true;
+  }
+  if (rebuild) {
+    int32_t* mt = (int32_t*)ctx->mt_buf;
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)mt, 4 + 3 * BM_KMAX);
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    int32_t* blockcnt = mt + 4 + 3 * BM_KMAX + 4 * tiles_max + n;
+    hipLaunchKernelGGL(k_mt_count, dim3(gb), dim3(256), 0, ctx->stream, assign, n, K, mt, blockcnt);
+    hipLaunchKernelGGL(k_mt_layout, dim3(1), dim3(256), 0, ctx->stream, n, K, mt, blockcnt, (int)gb);
+    hipLaunchKernelGGL(k_mt_scatter, dim3(gb), dim3(256), 0, ctx->stream, assign, n, K, mt, tiles_max, (const int32_t*)blockcnt);
+    TPH_LAUNCH_CHECK();
+    ctx->mt_assign = (const void*)assign; ctx->mt_n = n; ctx->mt_K = K;
+    ctx->mt_epoch = capturing ? -1 : ctx->modes_epoch;
+  }
+  return 0;
+}
+int tph_mode_lists(tph_ctx* ctx, const int32_t* assign, int64_t n, int K, const int32_t** order, const int32_t** mstart, const int32_t** mcount) {
+  TPH_REQUIRE(assign && K >= 1 && K <= BM_KMAX && n > 0, "mode lists: bad argument");
+  if (mode_table(ctx, assign, n, K)) return -1;
+  const int32_t* mt = (const int32_t*)ctx->mt_buf;
+  const int64_t tiles_max = (n + 15) / 16 + K + 1;
+  *mstart = mt + 4;
+  *mcount = mt + 4 + BM_KMAX;
+  *order = mt + 4 + 3 * BM_KMAX + 4 * tiles_max;
+  return 0;
+}
+
 // Several modes: all `rounds` rounds of the blocked path over mode-pure tiles; whoever is still out of bounds afterwards is left
 // in ONE list (*todo_cnt entries of todo_rows, both device pointers into ctx-owned memory) for the caller's straggler pass.
 template <int KERNEL>
 static int blkm_multi(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n, int64_t ld, int K, const double* means, const double* chol,
                       const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, tph_stepctl tick,
                       int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, int rounds, const int32_t** todo_cnt,
-                      const int32_t** todo_rows, const int32_t** todo_att) {
+                      const int32_t** todo_rows, const int32_t** todo_att, const int32_t** per_mode) {
   const int d = ctx->d;
   TPH_REQUIRE(d > 16 && d <= 112 && K >= 1 && K <= BM_KMAX, "tph_propose (blocked, several modes): n_dim=%d / K=%d out of range", d, K);
   TPH_REQUIRE(n < (1ll << 31), "tph_propose (blocked): %lld particles on one device", (long long)n);
@@ -555,28 +600,11 @@ static int blkm_multi(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n,
   // tile table + order | counters of the rounds [rounds + 1][K] | the two list arrays | the concatenated list
   const int64_t tiles_max = (n + 15) / 16 + K + 1;
   const size_t mtw = bm_mt_words(n, K), cntw = (size_t)2 * (24 + 2) * BM_KMAX;      // counters [26][K] | next attempts [26][K]
-  const size_t need = sizeof(int32_t) * (mtw + cntw + 3 * (size_t)n + 64);
-  if (ctx->mt_bytes < need) {
-    TPH_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->mt_buf) ctx->retired.push_back(ctx->mt_buf);
-    ctx->mt_buf = nullptr; ctx->mt_bytes = 0;
-    TPH_HIP(hipMalloc((void**)&ctx->mt_buf, need));
-    ctx->mt_bytes = need;
-    rebuilt = true;
-  }
+  if (mode_table(ctx, assign, n, K)) return -1;
   int32_t* mt = (int32_t*)ctx->mt_buf;
   int32_t* cnts = mt + mtw;
   int32_t* rows[2] = {cnts + cntw, cnts + cntw + n};
   int32_t* rows_cat = cnts + cntw + 2 * n;
-  if (rebuilt || ctx->mt_assign != (const void*)assign || ctx->mt_n != n) {      // (the assignments are fixed while the statistics are)
-    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)mt, 4 + 3 * BM_KMAX);
-    const unsigned gb = (unsigned)((n + 255) / 256);
-    int32_t* blockcnt = mt + 4 + 3 * BM_KMAX + 4 * tiles_max + n;
-    hipLaunchKernelGGL(k_mt_count, dim3(gb), dim3(256), 0, ctx->stream, assign, n, K, mt, blockcnt);
-    hipLaunchKernelGGL(k_mt_layout, dim3(1), dim3(256), 0, ctx->stream, n, K, mt, blockcnt, (int)gb);
-    hipLaunchKernelGGL(k_mt_scatter, dim3(gb), dim3(256), 0, ctx->stream, assign, n, K, mt, tiles_max, (const int32_t*)blockcnt);
-    ctx->mt_assign = (const void*)assign; ctx->mt_n = n;
-  }
   if (rounds < 1) rounds = 1;
   if (rounds > 24) rounds = 24;
   hipLaunchKernelGGL(k_zero_words, dim3(4), dim3(64), 0, ctx->stream, (unsigned int*)cnts, (int)cntw);
@@ -591,6 +619,16 @@ static int blkm_multi(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n,
                                   fan ? atts + (size_t)k * BM_KMAX : (int32_t*)nullptr))
       return -1;
   *todo_att = fan ? atts + (size_t)(rounds - 1) * BM_KMAX : nullptr;
+  if (per_mode) {
+    // the modes' failure lists as they are: mode m's entries [mstart[m], mstart[m] + cnt[m]) of the last round's list array
+    // (the per-mode screened launches of propose_mf.hip read offset and length on the device)
+    per_mode[0] = cnts + (size_t)(rounds - 1) * BM_KMAX;
+    per_mode[1] = rows[(rounds - 1) & 1];
+    per_mode[2] = mt + 4;
+    *todo_cnt = nullptr;
+    *todo_rows = nullptr;
+    return 0;
+  }
   int32_t* cnt_cat = cnts + (size_t)25 * BM_KMAX;
   hipLaunchKernelGGL(k_mt_concat, dim3(K), dim3(256), 0, ctx->stream, (const int32_t*)mt, (const int32_t*)(cnts + (size_t)(rounds - 1) * BM_KMAX),
                      (const int32_t*)rows[(rounds - 1) & 1], cnt_cat, rows_cat);
@@ -603,11 +641,11 @@ static int blkm_multi(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n,
 int tph_blkm_multi(tph_ctx* ctx, int kernel, double* u, const int32_t* assign, int64_t n, int64_t ld, int K, const double* means,
                    const double* chol, const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed,
                    uint32_t tick0, const double* ctl, int64_t item0, double* up, double* mu_, double* mup, uint8_t* pend, int rounds,
-                   const int32_t** todo_cnt, const int32_t** todo_rows, const int32_t** todo_att) {
+                   const int32_t** todo_cnt, const int32_t** todo_rows, const int32_t** todo_att, const int32_t** per_mode) {
   const tph_stepctl tick{tick0, ctl};
   if (kernel == TPH_KERNEL_TPCN)
     return blkm_multi<TPH_KERNEL_TPCN>(ctx, u, assign, n, ld, K, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend,
-                                       rounds, todo_cnt, todo_rows, todo_att);
+                                       rounds, todo_cnt, todo_rows, todo_att, per_mode);
   return blkm_multi<TPH_KERNEL_RWM>(ctx, u, assign, n, ld, K, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend,
-                                    rounds, todo_cnt, todo_rows, todo_att);
+                                    rounds, todo_cnt, todo_rows, todo_att, per_mode);
 }

@@ -182,8 +182,10 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
                                                              int64_t item0, double* __restrict__ up, const double* __restrict__ bfac,
                                                              int lgG, unsigned long long* __restrict__ queue, int audit,
                                                              const int32_t* __restrict__ todo_cnt, const int32_t* __restrict__ todo_rows,
-                                                             int att0, const int32_t* __restrict__ att0_dev) {
+                                                             int att0, const int32_t* __restrict__ att0_dev,
+                                                             const int32_t* __restrict__ todo_off, int direct_tries) {
   if (att0_dev) att0 = *att0_dev;      // (list mode behind fanned-out rounds: the first untried attempt was decided on the device)
+  if (todo_off) todo_rows += *todo_off; // (several modes: this mode's stretch of the list array; means / pack / LT / sigmas are the mode's)
   // todo_cnt != NULL: only the particles LISTED in todo_rows[0 .. *todo_cnt) (those the blocked kernel's rounds left out of
   // bounds), from attempt att0 on; workgroups beyond the list exit before they load anything
   extern __shared__ __attribute__((aligned(16))) unsigned char mf_lds[];
@@ -373,7 +375,7 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
         }
         const int e = __ffsll((long long)need) - 1;
         need &= need - 1ull;
-        if (lane == e) { ps_row = todo_rows ? todo_rows[pool_row + pool_next] : (int)(pool_row + pool_next); ps_a0 = att0; ps_fresh = todo_cnt != nullptr; }
+        if (lane == e) { ps_row = todo_rows ? todo_rows[pool_row + pool_next] : (int)(pool_row + pool_next); ps_a0 = att0; ps_fresh = todo_cnt != nullptr && direct_tries > 0; }
         ++pool_next;
         fresh |= 1ull << e;
       }
@@ -571,13 +573,14 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
 
 // persistent buffers of the screened kernel (queue words | blocked L^-1 (tri.h, tpCN forms) | screening pack | transposed FP64
 // factor), rebuilt when the caller's mode statistics change
+// (K modes: K blocked inverse factors, K screening packs, K transposed factors, each behind the other)
 struct mf_bufs { unsigned long long* queue; double* Wb; unsigned char* pack; double* LT; };
-static int mf_alloc(tph_ctx* ctx, size_t* off_wb_, size_t* off_pack_, size_t* off_lt_) {
+static int mf_alloc(tph_ctx* ctx, size_t* off_wb_, size_t* off_pack_, size_t* off_lt_, int K = 1) {
   const int d = ctx->d, np = mf_panels(d);
   const size_t tb8 = tri_blocked_doubles(d);
-  const size_t off_wb = 128, off_pack = off_wb + sizeof(double) * tb8;
-  const size_t off_lt = (off_pack + mf_pack_bytes(np) + 255) & ~(size_t)255;
-  const size_t need = off_lt + sizeof(double) * (size_t)mf_lt_doubles(d);
+  const size_t off_wb = 128, off_pack = off_wb + sizeof(double) * tb8 * (size_t)K;
+  const size_t off_lt = (off_pack + mf_pack_bytes(np) * (size_t)K + 255) & ~(size_t)255;
+  const size_t need = off_lt + sizeof(double) * (size_t)mf_lt_doubles(d) * (size_t)K;
   if (ctx->mf_bytes < need) {
     TPH_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->mf_buf) ctx->retired.push_back(ctx->mf_buf);
@@ -593,10 +596,10 @@ unsigned int* tph_mf_queue_words(tph_ctx* ctx) {
   return (unsigned int*)ctx->mf_buf;
 }
 template <int KERNEL>
-static int mf_prepare(tph_ctx* ctx, const double* chol, const double* winv, mf_bufs* b, bool zero = true) {
+static int mf_prepare(tph_ctx* ctx, const double* chol, const double* winv, mf_bufs* b, bool zero = true, int K = 1) {
   const int d = ctx->d, np = mf_panels(d);
   size_t off_wb, off_pack, off_lt;
-  if (mf_alloc(ctx, &off_wb, &off_pack, &off_lt)) return -1;
+  if (mf_alloc(ctx, &off_wb, &off_pack, &off_lt, K)) return -1;
   b->queue = (unsigned long long*)ctx->mf_buf;
   b->Wb = (double*)((char*)ctx->mf_buf + off_wb);
   b->pack = (unsigned char*)ctx->mf_buf + off_pack;
@@ -606,10 +609,10 @@ static int mf_prepare(tph_ctx* ctx, const double* chol, const double* winv, mf_b
   TPH_HIP(hipStreamIsCapturing(ctx->stream, &cap));
   const bool capturing = cap != hipStreamCaptureStatusNone;
   if (capturing || ctx->modes_epoch <= 0 || ctx->mf_epoch != ctx->modes_epoch || ctx->mf_src != (const void*)chol ||
-      ctx->mf_kernel != KERNEL) {
-    hipLaunchKernelGGL(k_mf_pack, dim3(1), dim3(256), 0, ctx->stream, chol, d, np, b->pack, b->LT);
-    if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_tri_block, dim3(1), dim3(256), 0, ctx->stream, winv, d, b->Wb);
-    ctx->mf_epoch = capturing ? -1 : ctx->modes_epoch; ctx->mf_src = (const void*)chol; ctx->mf_kernel = KERNEL;
+      ctx->mf_kernel != KERNEL || ctx->mf_K != K) {
+    hipLaunchKernelGGL(k_mf_pack, dim3(K), dim3(256), 0, ctx->stream, chol, d, np, b->pack, b->LT);
+    if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_tri_block, dim3(K), dim3(256), 0, ctx->stream, winv, d, b->Wb);
+    ctx->mf_epoch = capturing ? -1 : ctx->modes_epoch; ctx->mf_src = (const void*)chol; ctx->mf_kernel = KERNEL; ctx->mf_K = K;
   }
   if (zero) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)b->queue, 32);
   return 0;
@@ -619,7 +622,8 @@ static int mf_prepare(tph_ctx* ctx, const double* chol, const double* winv, mf_b
 template <int KERNEL>
 static int mf_launch(tph_ctx* ctx, const mf_bufs& b, const double* u, int64_t n, int64_t ld, const double* means, const double* sigmas,
                      const uint8_t* bc, uint64_t seed, tph_stepctl tick, int64_t item0, double* up, const double* bfac,
-                     const int32_t* todo_cnt, const int32_t* todo_rows, int att0, const int32_t* att0_dev = nullptr) {
+                     const int32_t* todo_cnt, const int32_t* todo_rows, int att0, const int32_t* att0_dev = nullptr,
+                     const int32_t* todo_off = nullptr, int direct_tries = MF_DIRECT) {
   const int d = ctx->d, np = mf_panels(d), dpad = 16 * np;
   const int64_t nchunks = (n + MF_CHUNK - 1) / MF_CHUNK;
   const int cus = ctx->n_simd / 4;
@@ -644,7 +648,7 @@ static int mf_launch(tph_ctx* ctx, const mf_bufs& b, const double* u, int64_t n,
       TPH_HIP(hipFuncSetAttribute((const void*)k_propose_mf<KERNEL, BC, NPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((k_propose_mf<KERNEL, BC, NPV>), dim3((unsigned)groups), dim3(64 * MF_WAVES), lds, ctx->stream,    \
                        u, n, ld, d, means, (const unsigned char*)b.pack, (const double*)b.LT, sigmas, bc, seed,           \
-                       tick, item0, up, bfac, lgG, b.queue, audit, todo_cnt, todo_rows, att0, att0_dev);                           \
+                       tick, item0, up, bfac, lgG, b.queue, audit, todo_cnt, todo_rows, att0, att0_dev, todo_off, direct_tries);   \
   } while (0)
 #define TPH_MF_NP(NPV) do { if (bc) TPH_MF(true, NPV); else TPH_MF(false, NPV); } while (0)
   switch (np) {
@@ -695,6 +699,90 @@ static int propose_mf_list(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const
     if (launch_maha_tile<KERNEL, 1>(ctx, u, n, ld, means, b.Wb, up, maha_up, tick, nullptr, nullptr, dof, sigmas, seed, item0, nullptr,
                                     todo_cnt, todo_rows)) return -1;
   return 0;
+}
+
+// ---- several proposal modes (tempest/mcmc.py:225-249 applies each walker's own cluster mean / factor in its redraw loop) --------
+// The screening pack, the transposed factor and the blocked inverse factor of ONE mode fill a workgroup's LDS, so the modes are
+// served one after the other, each by launches over the list of ITS particles: the stable partition `order` of the matrix-core
+// rounds (propose_blkm.hip: tph_mode_lists -- a mode's particles in index order, mstart[m] entries into order[], mcount[m] of
+// them), or a mode's stretch of their failure lists.  A launch reads its list's offset and length on the device (todo_off,
+// todo_cnt), so the host needs neither.  Proposals are the single-mode kernel's, attempt for attempt: a particle's arithmetic
+// sees its own mode's matrices only.
+template <int KERNEL>
+static int propose_mf_modes(tph_ctx* ctx, double* u, const int32_t* assign, int64_t n, int64_t ld, int K, const double* means,
+                            const double* chol, const double* winv, const double* dof, const double* sigmas, const uint8_t* bc,
+                            uint64_t seed, tph_stepctl tick, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend) {
+  const int d = ctx->d, np = mf_panels(d);
+  TPH_REQUIRE(d > 16 && d <= MF_MAX_DIM && K >= 1 && K <= 64, "tph_propose (screened batches, several modes): n_dim=%d / K=%d out of range", d, K);
+  TPH_REQUIRE(n < (1ll << 31), "tph_propose (screened batches): %lld particles on one device", (long long)n);
+  const int32_t *order = nullptr, *mstart = nullptr, *mcount = nullptr;
+  if (tph_mode_lists(ctx, assign, n, K, &order, &mstart, &mcount)) return -1;
+  mf_bufs b;
+  if (mf_prepare<KERNEL>(ctx, chol, winv, &b, true, K)) return -1;
+  const size_t tb8 = tri_blocked_doubles(d);
+  const bool chores = pend || KERNEL == TPH_KERNEL_TPCN || maha_u;
+  const bool closing = KERNEL == TPH_KERNEL_TPCN || maha_up || tick.ctl;
+  for (int m = 0; m < K; ++m) {
+    mf_bufs bm = b;
+    bm.Wb = b.Wb + (size_t)m * tb8;
+    bm.pack = b.pack + (size_t)m * mf_pack_bytes(np);
+    bm.LT = b.LT + (size_t)m * mf_lt_doubles(d);
+    const double* mu = means ? means + (size_t)m * d : nullptr;
+    const double* dm = dof ? dof + m : nullptr;
+    if (m) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)b.queue, 2);     // the work-queue cursor; the counters run on
+    if (chores)
+      if (launch_maha_tile<KERNEL, 0>(ctx, u, n, ld, mu, bm.Wb, up, maha_u, tick, pend, nullptr, dm, sigmas + m, seed, item0, maha_up,
+                                      mcount + m, order, mstart + m)) return -1;
+    if (mf_launch<KERNEL>(ctx, bm, u, n, ld, mu, sigmas + m, bc, seed, tick, item0, up, maha_up, mcount + m, order, 0, nullptr, mstart + m, 0)) return -1;
+    if (closing)
+      if (launch_maha_tile<KERNEL, 1>(ctx, u, n, ld, mu, bm.Wb, up, maha_up, tick, nullptr, m == K - 1 ? b.queue : nullptr, dm, sigmas + m, seed,
+                                      item0, nullptr, mcount + m, order, mstart + m)) return -1;
+  }
+  return 0;
+}
+int tph_propose_mf_modes(tph_ctx* ctx, int kernel, double* u, const int32_t* assign, int64_t n, int64_t ld, int K, const double* means,
+                         const double* chol, const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed,
+                         uint32_t tick0, const double* ctl, int64_t item0, double* up, double* maha_u, double* maha_up, uint8_t* pend) {
+  const tph_stepctl tick{tick0, ctl};
+  if (kernel == TPH_KERNEL_TPCN)
+    return propose_mf_modes<TPH_KERNEL_TPCN>(ctx, u, assign, n, ld, K, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend);
+  return propose_mf_modes<TPH_KERNEL_RWM>(ctx, u, assign, n, ld, K, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend);
+}
+
+// the straggler pass behind the matrix-core rounds over SEVERAL modes: mode m's failures are entries [offs[m], offs[m] + cnts[m])
+// of `rows`, their first untried attempt is atts[m] (all device-side); screened windows per mode, then (tpCN) the form at u'
+template <int KERNEL>
+static int propose_mf_mode_lists(tph_ctx* ctx, double* u, int64_t n, int64_t ld, int K, const double* means, const double* chol,
+                                 const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed,
+                                 tph_stepctl tick, int64_t item0, double* up, double* maha_up, const int32_t* cnts, const int32_t* rows,
+                                 const int32_t* offs, int att0, const int32_t* atts) {
+  const int d = ctx->d, np = mf_panels(d);
+  mf_bufs b;
+  if (mf_prepare<KERNEL>(ctx, chol, winv, &b, true, K)) return -1;
+  const size_t tb8 = tri_blocked_doubles(d);
+  for (int m = 0; m < K; ++m) {
+    mf_bufs bm = b;
+    bm.Wb = b.Wb + (size_t)m * tb8;
+    bm.pack = b.pack + (size_t)m * mf_pack_bytes(np);
+    bm.LT = b.LT + (size_t)m * mf_lt_doubles(d);
+    const double* mu = means ? means + (size_t)m * d : nullptr;
+    if (m) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)b.queue, 2);
+    if (mf_launch<KERNEL>(ctx, bm, u, n, ld, mu, sigmas + m, bc, seed, tick, item0, up, maha_up, cnts + m, rows, att0, atts ? atts + m : nullptr,
+                          offs + m, MF_DIRECT)) return -1;
+    if (KERNEL == TPH_KERNEL_TPCN || maha_up)
+      if (launch_maha_tile<KERNEL, 1>(ctx, u, n, ld, mu, bm.Wb, up, maha_up, tick, nullptr, nullptr, dof ? dof + m : nullptr, sigmas + m, seed,
+                                      item0, nullptr, cnts + m, rows, offs + m)) return -1;
+  }
+  return 0;
+}
+int tph_propose_mf_mode_lists(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, int K, const double* means, const double* chol,
+                              const double* winv, const double* dof, const double* sigmas, const uint8_t* bc, uint64_t seed, uint32_t tick0,
+                              const double* ctl, int64_t item0, double* up, double* maha_up, const int32_t* cnts, const int32_t* rows,
+                              const int32_t* offs, int att0, const int32_t* atts) {
+  const tph_stepctl tick{tick0, ctl};
+  if (kernel == TPH_KERNEL_TPCN)
+    return propose_mf_mode_lists<TPH_KERNEL_TPCN>(ctx, u, n, ld, K, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_up, cnts, rows, offs, att0, atts);
+  return propose_mf_mode_lists<TPH_KERNEL_RWM>(ctx, u, n, ld, K, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_up, cnts, rows, offs, att0, atts);
 }
 
 int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,

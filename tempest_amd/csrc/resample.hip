@@ -8,8 +8,26 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
+// the plain three-pass scan (library-internal prefix counts: flags of kept rows, of finite rows; their scratch layout counts on the
+// num_tiles(n) doubles this takes at the front of ctx->scratch)
+int tph_cdf_plain(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev, double* cdf_dev) {
+  if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)tph_scan::num_tiles(n))) return -1;
+  double* tiles = (double*)ctx->scratch;
+  return thr_dev ? tph_scan::inclusive<tph_scan::MASKED>(ctx, w_dev, n, thr_dev, tiles, cdf_dev)
+                 : tph_scan::inclusive<tph_scan::PLAIN>(ctx, w_dev, n, nullptr, tiles, cdf_dev);
+}
+static int cdf_pieces(tph_ctx* ctx, const double* w_dev, const double* thr_dev, double* cdf_dev, const tph_part& part);
 extern "C" int tph_cdf(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev, double* cdf_dev) {
   TPH_REQUIRE(ctx && w_dev && cdf_dev && n > 0, "tph_cdf: bad argument");
+  // (an input that lives in ctx->scratch is a library-internal array, never the weights of the history)
+  const bool internal = ctx->scratch && (const char*)w_dev >= (const char*)ctx->scratch && (const char*)w_dev < (const char*)ctx->scratch + ctx->scratch_bytes;
+  if (!ctx->comm_active() && !internal) {
+    // the weights of the whole history on one GPU: cumulative sums piece by piece of the canonical partition (common.h), as the
+    // ranks of a sharded run form them -- the same numbers for any number of GPUs (a weight vector that is not the history's,
+    // or a history without the partition: the plain three-pass scan below)
+    const tph_part part = tph_partition(ctx, n);
+    if (part.canonical) return cdf_pieces(ctx, w_dev, thr_dev, cdf_dev, part);
+  }
   if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)tph_scan::num_tiles(n))) return -1;
   double* tiles = (double*)ctx->scratch;
   return thr_dev ? tph_scan::inclusive<tph_scan::MASKED>(ctx, w_dev, n, thr_dev, tiles, cdf_dev)
@@ -34,8 +52,10 @@ __global__ void __launch_bounds__(256) k_resample_systematic(const double* __res
                                                              int64_t* __restrict__ idx) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_out) return;
-  double pos = (u0 + (double)(i0 + i)) / (double)size_global;
-  int64_t k = count_below<true>(cdf, n, renorm, pos);
+  // (the position scaled to the cumulative weights, not the weights divided down to the position: the form the sharded
+  // selection uses, k_select_global -- one predicate on every number of GPUs)
+  const double p = (u0 + (double)(i0 + i)) / (double)size_global * renorm;
+  int64_t k = count_below<true>(cdf, n, 1.0, p);
   idx[i] = k < n ? k : n - 1;
 }
 
@@ -57,7 +77,8 @@ __global__ void __launch_bounds__(256) k_resample_multinomial(tph_cdf_index ix, 
   double U, U1;
   g.uniform2(0, U, U1);
   const int64_t n = ix.n[0];
-  int64_t k = tph_count_below<false>(ix, ix.lvl[0][n - 1], U);
+  const double p = U * ix.lvl[0][n - 1];       // as k_select_global: the draw scaled to the total, compared with the sums themselves
+  int64_t k = tph_count_below<false>(ix, 1.0, p);
   idx[i] = k < n ? k : n - 1;
 }
 
@@ -153,16 +174,22 @@ __global__ void __launch_bounds__(256) k_seg_totals(const double* __restrict__ t
 }
 // table = (glo[T], ghi[T], total) of rank `rank` from the gathered totals all[G][T], accumulated in global (iteration-major)
 // order by ONE thread: identical on every rank
-__global__ void k_block_table(const double* __restrict__ all, int G, int T, int rank, double* __restrict__ table) {
+// (pieces: a rank holds vl virtual shards of every iteration -- common.h: tph_part --, its piece (t, v') is entry t * vl + v' of
+// its list; the global order is iteration, rank, shard.  The totals are added in that order whatever G is: the table, and with it
+// every cumulative weight, is the same on any number of GPUs that divides V.)
+__global__ void k_block_table(const double* __restrict__ all, int G, int T, int vl, int rank, double* __restrict__ table) {
   if (blockIdx.x || threadIdx.x) return;
+  const int P = T * vl;
   double run = 0.0;
   for (int t = 0; t < T; ++t)
-    for (int g = 0; g < G; ++g) {
-      if (g == rank) table[t] = run;
-      run += all[(size_t)g * T + t];
-      if (g == rank) table[T + t] = run;
-    }
-  table[2 * T] = run;
+    for (int g = 0; g < G; ++g)
+      for (int v = 0; v < vl; ++v) {
+        const int p = t * vl + v;
+        if (g == rank) table[p] = run;
+        run += all[(size_t)g * P + p];
+        if (g == rank) table[P + p] = run;
+      }
+  table[2 * P] = run;
 }
 // tile sums of a block -> exclusive offsets + glo[t] (one workgroup per block; sequential over chunks of 256 tiles)
 __global__ void __launch_bounds__(256) k_seg_offsets(double* __restrict__ tiles, int tpb, const double* __restrict__ table) {
@@ -204,6 +231,47 @@ __global__ void __launch_bounds__(tph_scan::THREADS) k_seg_apply(const double* _
   store_tile(out, base, lim, x, [=](double v, int64_t p) { return p == lim - 1 ? hi : fmin(fmax(v, lo), hi); });
 }
 
+// the segmented scan over the P = T * vl pieces of the canonical partition (one rank: all V shards; `comm`: the totals of all
+// ranks gathered first).  Leaves the piece table in ctx->blk_table.
+static int cdf_pieces(tph_ctx* ctx, const double* w_dev, const double* thr_dev, double* cdf_dev, const tph_part& part) {
+  const int G = ctx->comm_active() ? ctx->world : 1;
+  const int P = part.T * part.vl;
+  const int64_t rows = part.nv;
+  const int tpb = (int)tph_scan::num_tiles(rows);
+  const size_t a_tiles = (sizeof(double) * (size_t)P * tpb + 255) / 256 * 256;
+  if (tph_scratch_reserve(ctx, a_tiles + sizeof(double) * (size_t)P)) return -1;
+  if (G > 1 || ctx->comm_active())
+    if (tph_comm_require(ctx, sizeof(double) * (size_t)P * (G + 1), "tph_cdf_global")) return -2;
+  if (ctx->blk_table_cap < 2 * P + 1) {
+    int nc = ctx->blk_table_cap ? ctx->blk_table_cap : 513;
+    while (nc < 2 * P + 1) nc = 2 * nc + 1;
+    TPH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->blk_table) TPH_HIP(hipFree(ctx->blk_table));
+    ctx->blk_table = nullptr; ctx->blk_table_cap = 0;
+    TPH_HIP(hipMalloc((void**)&ctx->blk_table, sizeof(double) * (size_t)nc));
+    ctx->blk_table_cap = nc;
+  }
+  double* tiles = (double*)ctx->scratch;
+  double* mine = ctx->comm_active() ? (double*)ctx->comm_buf : (double*)((char*)ctx->scratch + a_tiles);   // [P] this rank's piece totals
+  const double* all = mine;                                                                                // [G][P]
+  const dim3 grid((unsigned)((size_t)P * tpb)), blk(tph_scan::THREADS);
+  if (thr_dev) hipLaunchKernelGGL(k_seg_tile_sums<tph_scan::MASKED>, grid, blk, 0, ctx->stream, w_dev, rows, tpb, thr_dev, tiles);
+  else hipLaunchKernelGGL(k_seg_tile_sums<tph_scan::PLAIN>, grid, blk, 0, ctx->stream, w_dev, rows, tpb, thr_dev, tiles);
+  hipLaunchKernelGGL(k_seg_totals, dim3(P), dim3(256), 0, ctx->stream, tiles, tpb, mine);
+  TPH_LAUNCH_CHECK();
+  if (ctx->comm_active()) {
+    if (tph_comm_allgather(ctx, 0, sizeof(double) * (size_t)P, P, TPH_DT_F64)) return -2;
+    all = mine + P;
+  }
+  hipLaunchKernelGGL(k_block_table, dim3(1), dim3(1), 0, ctx->stream, all, G, part.T, part.vl, ctx->comm_active() ? ctx->rank : 0, ctx->blk_table);
+  hipLaunchKernelGGL(k_seg_offsets, dim3(P), dim3(256), 0, ctx->stream, tiles, tpb, ctx->blk_table);
+  if (thr_dev) hipLaunchKernelGGL(k_seg_apply<tph_scan::MASKED>, grid, blk, 0, ctx->stream, w_dev, rows, tpb, P, thr_dev, tiles, ctx->blk_table, cdf_dev);
+  else hipLaunchKernelGGL(k_seg_apply<tph_scan::PLAIN>, grid, blk, 0, ctx->stream, w_dev, rows, tpb, P, thr_dev, tiles, ctx->blk_table, cdf_dev);
+  TPH_LAUNCH_CHECK();
+  ctx->blk_T = P; ctx->blk_rows = rows;
+  return 0;
+}
+
 extern "C" int tph_cdf_global(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev, double* cdf_dev,
                               double* total_host) {
   TPH_REQUIRE(ctx && w_dev && cdf_dev && n > 0, "tph_cdf_global: bad argument");
@@ -219,36 +287,10 @@ extern "C" int tph_cdf_global(tph_ctx* ctx, const double* w_dev, int64_t n, cons
   }
   int T; int64_t rows;
   if (tph_blocks(ctx, n, &T, &rows)) return -2;
-  const int G = ctx->world;
-  const int tpb = (int)tph_scan::num_tiles(rows);
-  if (tph_scratch_reserve(ctx, sizeof(double) * (size_t)T * tpb)) return -1;
-  if (tph_comm_require(ctx, sizeof(double) * (size_t)T * (G + 1), "tph_cdf_global")) return -2;
-  if (ctx->blk_table_cap < 2 * T + 1) {
-    int nc = ctx->blk_table_cap ? ctx->blk_table_cap : 513;
-    while (nc < 2 * T + 1) nc = 2 * nc + 1;
-    TPH_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->blk_table) TPH_HIP(hipFree(ctx->blk_table));
-    ctx->blk_table = nullptr; ctx->blk_table_cap = 0;
-    TPH_HIP(hipMalloc((void**)&ctx->blk_table, sizeof(double) * (size_t)nc));
-    ctx->blk_table_cap = nc;
-  }
-  double* tiles = (double*)ctx->scratch;
-  double* mine = (double*)ctx->comm_buf;                 // [T] this rank's block totals
-  double* all = mine + T;                                // [G][T]
-  const dim3 grid((unsigned)((size_t)T * tpb)), blk(tph_scan::THREADS);
-  if (thr_dev) hipLaunchKernelGGL(k_seg_tile_sums<tph_scan::MASKED>, grid, blk, 0, ctx->stream, w_dev, rows, tpb, thr_dev, tiles);
-  else hipLaunchKernelGGL(k_seg_tile_sums<tph_scan::PLAIN>, grid, blk, 0, ctx->stream, w_dev, rows, tpb, thr_dev, tiles);
-  hipLaunchKernelGGL(k_seg_totals, dim3(T), dim3(256), 0, ctx->stream, tiles, tpb, mine);
-  TPH_LAUNCH_CHECK();
-  if (tph_comm_allgather(ctx, 0, sizeof(double) * (size_t)T, T, TPH_DT_F64)) return -2;
-  hipLaunchKernelGGL(k_block_table, dim3(1), dim3(1), 0, ctx->stream, all, G, T, ctx->rank, ctx->blk_table);
-  hipLaunchKernelGGL(k_seg_offsets, dim3(T), dim3(256), 0, ctx->stream, tiles, tpb, ctx->blk_table);
-  if (thr_dev) hipLaunchKernelGGL(k_seg_apply<tph_scan::MASKED>, grid, blk, 0, ctx->stream, w_dev, rows, tpb, T, thr_dev, tiles, ctx->blk_table, cdf_dev);
-  else hipLaunchKernelGGL(k_seg_apply<tph_scan::PLAIN>, grid, blk, 0, ctx->stream, w_dev, rows, tpb, T, thr_dev, tiles, ctx->blk_table, cdf_dev);
-  TPH_LAUNCH_CHECK();
-  ctx->blk_T = T; ctx->blk_rows = rows;
+  const tph_part part = tph_partition(ctx, n);
+  if (cdf_pieces(ctx, w_dev, thr_dev, cdf_dev, part)) return -2;
   if (total_host) {
-    TPH_HIP(hipMemcpyAsync(ctx->pinned, ctx->blk_table + 2 * T, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TPH_HIP(hipMemcpyAsync(ctx->pinned, ctx->blk_table + 2 * (size_t)ctx->blk_T, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     TPH_HIP(hipStreamSynchronize(ctx->stream));
     *total_host = ctx->pinned[0];
   }
@@ -618,7 +660,7 @@ __global__ void __launch_bounds__(256) k_multinomial_counts(tph_cdf_index ix,
     tph_rng g(seed, tick, tag, (uint64_t)r);
     double U, U1;
     g.uniform2(0, U, U1);
-    int64_t k = tph_count_below<false>(ix, total, U);
+    int64_t k = tph_count_below<false>(ix, 1.0, U * total);      // (as k_counts_global)
     if (k >= n) k = n - 1;
     atomicAdd(&counts[k], 1);
   }
@@ -652,10 +694,11 @@ __global__ void __launch_bounds__(256) k_mc_merge(tph_cdf_index ix, const uint64
   int run = 0;
   auto draw = [&](const uint64_t key, const bool first) {
     const double U = (double)key * 0x1.0p-53;
-    auto below = [&](int64_t i) { return a[i] / total <= U; };
+    const double pp = U * total;                                          // (as k_counts_global: one predicate on any number of GPUs)
+    auto below = [&](int64_t i) { return a[i] <= pp; };
     int64_t lo, hi;                                                       // the count lies in [lo, hi]
     if (first) {
-      lo = hi = tph_count_below<false>(ix, total, U);
+      lo = hi = tph_count_below<false>(ix, 1.0, pp);
     } else if (K < n && below(K)) {                                       // beyond the previous row: gallop forward
       lo = K + 1;
       int64_t step = 1;

@@ -54,64 +54,102 @@ __device__ __forceinline__ trip trip_block_reduce(trip t, double* sh) {
   return t;
 }
 
-// One streaming pass for NB trial betas.  Each block owns a CONTIGUOUS segment of the history (measured +20 % over a
-// grid-stride sweep on MI355X: fewer DRAM pages open per channel at a time) and keeps U independent 16-B
-// non-temporal loads of l and of C in flight per lane.  Each lane keeps a running (m, s1, s2) per beta and rescales
-// only when a 4-row chunk raises its maximum (about one exp per row).
+// Geometry of the streaming pass (host): the rows of every VIRTUAL SHARD of the canonical partition (common.h: tph_part) are
+// cut into blocks that depend on the shard's own shape only -- nv rows per piece, T pieces -- never on how many shards this
+// rank holds, so a shard's block partials, and the triple merged from them, are the same numbers on every number of GPUs.
+// A workgroup takes either a run of RB rows inside one piece (large pieces) or PPB whole pieces (small ones); RB is at least
+// 16 384 rows (contiguous 128 KB per array and block: +18 % over a grid-stride sweep, DESIGN K2) and as many more as keep a
+// shard within 2048 / V blocks.
+struct k2_geom {
+  long long n_loc, nv, RB;
+  int T, vl, BPP, PPB, bv;        // blocks per piece | pieces per block | blocks per virtual shard
+};
+static k2_geom k2_geometry(const tph_ctx* ctx, const tph_part& p) {
+  k2_geom g;
+  g.n_loc = p.n_loc; g.nv = p.nv; g.T = p.T; g.vl = p.vl;
+  const int cap = ctx->reduce_grid > 0 ? ctx->reduce_grid : 2048;
+  const long long bv_max = cap / p.V > 1 ? cap / p.V : 1;
+  long long rb = (p.nv * (long long)p.T + bv_max - 1) / bv_max;
+  rb = (rb + 4095) / 4096 * 4096;
+  if (rb < 16384) rb = 16384;
+  g.RB = rb;
+  if (rb >= p.nv) {
+    g.PPB = (int)(rb / p.nv);
+    if (g.PPB > p.T) g.PPB = p.T;
+    g.BPP = 1;
+    g.bv = (p.T + g.PPB - 1) / g.PPB;
+  } else {
+    g.BPP = (int)((p.nv + rb - 1) / rb);
+    g.PPB = 1;
+    g.bv = p.T * g.BPP;
+  }
+  return g;
+}
+
+// One streaming pass for NB trial betas.  Each block owns a CONTIGUOUS run of rows (measured +20 % over a grid-stride sweep
+// on MI355X: fewer DRAM pages open per channel at a time) and keeps U independent 16-B non-temporal loads of l and of C in
+// flight per lane.  Each lane keeps a running (m, s1, s2) per beta and rescales only when a 4-row chunk raises its maximum
+// (about one exp per row).
 template <int NB, int U>
 __global__ void __launch_bounds__(TPH_RED_THREADS) k_reweight_reduce(const double* __restrict__ logl,
-                                                                      const double* __restrict__ cmix, int64_t n,
+                                                                      const double* __restrict__ cmix, k2_geom g,
                                                                       tph_betas betas, double* __restrict__ partials) {
   static_assert(U % 2 == 0, "chunks are consumed in pairs (4 rows)");
   double m[NB], s1[NB], s2[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) { m[b] = -DBL_MAX; s1[b] = 0.0; s2[b] = 0.0; }
 
-  const int64_t n2 = n >> 1;
   const double2* __restrict__ l2 = reinterpret_cast<const double2*>(logl);
   const double2* __restrict__ c2 = reinterpret_cast<const double2*>(cmix);
   constexpr int64_t STEP = (int64_t)TPH_RED_THREADS * U;
-  int64_t per = (n2 + gridDim.x - 1) / gridDim.x;
-  per = (per + STEP - 1) / STEP * STEP;
-  const int64_t lo = (int64_t)blockIdx.x * per;
-  const int64_t hi = lo + per < n2 ? lo + per : n2;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += STEP) {
-    double2 l[U], c[U];
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const int64_t j = i + (int64_t)k * TPH_RED_THREADS;
-      if (j < hi) { l[k] = nt_load2(l2 + j); c[k] = nt_load2(c2 + j); }
-      else { l[k] = make_double2(0.0, 0.0); c[k] = make_double2(INFINITY, INFINITY); }   // v = -inf: contributes 0
-    }
-#pragma unroll
-    for (int k = 0; k < U; k += 2) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const double be = betas.b[b];
-        double v0 = be * l[k].x - c[k].x, v1 = be * l[k].y - c[k].y;
-        double v2 = be * l[k + 1].x - c[k + 1].x, v3 = be * l[k + 1].y - c[k + 1].y;
-        double vm = fmax(fmax(v0, v1), fmax(v2, v3));
-        if (vm > m[b]) {
-          double f = exp(m[b] - vm);
-          s1[b] *= f;
-          s2[b] *= f * f;
-          m[b] = vm;
-        }
-        double e0 = exp(v0 - m[b]), e1 = exp(v1 - m[b]), e2 = exp(v2 - m[b]), e3 = exp(v3 - m[b]);
-        s1[b] += (e0 + e1) + (e2 + e3);
-        s2[b] += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
-      }
-    }
-  }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd tail
-    double l = logl[n - 1], c = cmix[n - 1];
+  const int v = blockIdx.x / g.bv, bb = blockIdx.x - v * g.bv;
+  int t0, t1;
+  long long q0, q1;
+  if (g.BPP == 1) { t0 = bb * g.PPB; t1 = t0 + g.PPB < g.T ? t0 + g.PPB : g.T; q0 = 0; q1 = g.nv; }
+  else { t0 = bb / g.BPP; t1 = t0 + 1; q0 = (long long)(bb - t0 * g.BPP) * g.RB; q1 = q0 + g.RB < g.nv ? q0 + g.RB : g.nv; }
+  auto one_row = [&](long long r) {          // a row at an odd end of a run (thread 0): pieces of an odd length only
+    const double l = logl[r], c = cmix[r];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      double v = betas.b[b] * l - c;
-      if (v > m[b]) { double f = exp(m[b] - v); s1[b] *= f; s2[b] *= f * f; m[b] = v; }
-      double e = exp(v - m[b]);
+      const double vv = betas.b[b] * l - c;
+      if (vv > m[b]) { const double f = exp(m[b] - vv); s1[b] *= f; s2[b] *= f * f; m[b] = vv; }
+      const double e = exp(vv - m[b]);
       s1[b] += e;
       s2[b] += e * e;
+    }
+  };
+  for (int t = t0; t < t1; ++t) {
+    long long r0 = (long long)t * g.n_loc + (long long)v * g.nv + q0, r1 = r0 + (q1 - q0);
+    if ((r0 & 1) && r0 < r1) { if (threadIdx.x == 0) one_row(r0); ++r0; }
+    if ((r1 & 1) && r0 < r1) { if (threadIdx.x == 0) one_row(r1 - 1); --r1; }
+    const int64_t lo = r0 >> 1, hi = r1 >> 1;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += STEP) {
+      double2 l[U], c[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int64_t j = i + (int64_t)k * TPH_RED_THREADS;
+        if (j < hi) { l[k] = nt_load2(l2 + j); c[k] = nt_load2(c2 + j); }
+        else { l[k] = make_double2(0.0, 0.0); c[k] = make_double2(INFINITY, INFINITY); }   // v = -inf: contributes 0
+      }
+#pragma unroll
+      for (int k = 0; k < U; k += 2) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const double be = betas.b[b];
+          double v0 = be * l[k].x - c[k].x, v1 = be * l[k].y - c[k].y;
+          double v2 = be * l[k + 1].x - c[k + 1].x, v3 = be * l[k + 1].y - c[k + 1].y;
+          double vm = fmax(fmax(v0, v1), fmax(v2, v3));
+          if (vm > m[b]) {
+            double f = exp(m[b] - vm);
+            s1[b] *= f;
+            s2[b] *= f * f;
+            m[b] = vm;
+          }
+          double e0 = exp(v0 - m[b]), e1 = exp(v1 - m[b]), e2 = exp(v2 - m[b]), e3 = exp(v3 - m[b]);
+          s1[b] += (e0 + e1) + (e2 + e3);
+          s2[b] += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+        }
+      }
     }
   }
   // Block reduction of all NB triples with ONE exp per lane and beta: block-wide maxima first (shuffles of max only),
@@ -124,20 +162,20 @@ __global__ void __launch_bounds__(TPH_RED_THREADS) k_reweight_reduce(const doubl
   double M[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    double v = m[b];
+    double vv = m[b];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    M[b] = v;
-    if (lane == 0) sh_m[wid][b] = v;
+    for (int o = 32; o > 0; o >>= 1) vv = fmax(vv, __shfl_xor(vv, o, 64));
+    M[b] = vv;
+    if (lane == 0) sh_m[wid][b] = vv;
   }
   __syncthreads();
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    double v = sh_m[0][b];
+    double vv = sh_m[0][b];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) v = fmax(v, sh_m[w][b]);
-    M[b] = v;
-    const double f = exp(m[b] - v);            // lanes without rows: m = -DBL_MAX, s = 0
+    for (int w = 1; w < NW; ++w) vv = fmax(vv, sh_m[w][b]);
+    M[b] = vv;
+    const double f = exp(m[b] - vv);            // lanes without rows: m = -DBL_MAX, s = 0
     double a1 = s1[b] * f, a2 = s2[b] * (f * f);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_down(a1, o, 64); a2 += __shfl_down(a2, o, 64); }
@@ -157,95 +195,118 @@ __global__ void __launch_bounds__(TPH_RED_THREADS) k_reweight_reduce(const doubl
   }
 }
 
-// merge the per-block partials of all betas: one block per beta
-__global__ void __launch_bounds__(256) k_reweight_finalize(const double* __restrict__ partials, int nblocks, int nb,
-                                                           double* __restrict__ out) {
-  int b = blockIdx.x;
-  trip t{-DBL_MAX, 0.0, 0.0};
-  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
-    const double* p = partials + ((size_t)i * nb + b) * 3;
-    t = trip_merge(t, trip{p[0], p[1], p[2]});
+// The triple of ONE virtual shard and one beta from the shard's `bv` block partials, by one wave: the shard's maximum first
+// (no exp), then every partial rescaled to it (one exp each) and plain sums -- lane l takes partials l, l + 64, ... in order,
+// the lanes meet in a fixed shuffle tree.  The same instructions on the same numbers wherever the shard lives.
+__device__ __forceinline__ trip vshard_triple(const double* __restrict__ partials, int v, int bv, int nb, int b, int lane) {
+  const double* base = partials + ((size_t)v * bv * nb + b) * 3;
+  double mx = -DBL_MAX;
+  for (int i = lane; i < bv; i += 64) mx = fmax(mx, base[(size_t)i * nb * 3]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+  double a1 = 0.0, a2 = 0.0;
+  for (int i = lane; i < bv; i += 64) {
+    const double* q = base + (size_t)i * nb * 3;
+    const double f = exp(q[0] - mx);
+    a1 += q[1] * f;
+    a2 += q[2] * (f * f);
   }
-  __shared__ double sh[3 * 4];
-  t = trip_block_reduce(t, sh);
-  if (threadIdx.x == 0) {
-    if (t.m == -DBL_MAX) t.m = -INFINITY;  // empty input
-    out[b * 3 + 0] = t.m; out[b * 3 + 1] = t.s1; out[b * 3 + 2] = t.s2;
-  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_down(a1, o, 64); a2 += __shfl_down(a2, o, 64); }
+  return trip{mx, a1, a2};
 }
 
-// The same merge for tph_reweight_eval, results straight into PINNED HOST memory: one block, wave b merges beta b, and
-// a sequence number is stored last (system-scope release).  The host polls that word instead of queueing a device-to-
-// host copy and waiting on the stream: the ~25 adaptive-beta passes of one PS iteration are latency-bound, not
-// bandwidth-bound, and this removes a copy packet and the runtime's completion path from every one of them.
-__global__ void __launch_bounds__(1024) k_reweight_finalize_host(const double* __restrict__ partials, int nblocks, int nb,
-                                                                 double* __restrict__ out_host, double* __restrict__ seq_host,
-                                                                 double seq) {
+// per-shard triples [vl][nb][3] of this rank (what a sharded run all-gathers): one workgroup per shard, wave b = beta b
+__global__ void __launch_bounds__(1024) k_reweight_vshards(const double* __restrict__ partials, int bv, int nb, double* __restrict__ out) {
+  const int b = threadIdx.x >> 6, lane = threadIdx.x & 63, v = blockIdx.x;
+  if (b >= nb) return;
+  const trip t = vshard_triple(partials, v, bv, nb, b, lane);
+  if (lane == 0) { double* o = out + ((size_t)v * nb + b) * 3; o[0] = t.m; o[1] = t.s1; o[2] = t.s2; }
+}
+
+// The V per-shard triples folded in shard order, one wave per beta (lane 0 folds: V <= 48).  shards != NULL: the triples as
+// stored (gathered from all ranks, [V][nb][3]); else they are formed here from this rank's block partials (one GPU: no store in
+// between, the same values).  out_host != NULL: results into pinned host memory with a sequence word behind them (system-scope
+// release) -- tph_reweight_eval polls that word instead of queueing a device-to-host copy and waiting on the stream: the ~25
+// adaptive-beta passes of one PS iteration are latency-bound, and this removes a copy packet and the runtime's completion path
+// from every one of them.
+__global__ void __launch_bounds__(1024) k_reweight_fold(const double* __restrict__ partials, int bv, const double* __restrict__ shards,
+                                                        int V, int nb, double* __restrict__ out, double* __restrict__ seq_host, double seq) {
   const int b = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (b < nb) {
-    trip t{-DBL_MAX, 0.0, 0.0};
-    for (int i = lane; i < nblocks; i += 64) {
-      const double* p = partials + ((size_t)i * nb + b) * 3;
-      t = trip_merge(t, trip{p[0], p[1], p[2]});
+    trip acc{-DBL_MAX, 0.0, 0.0};
+    for (int v = 0; v < V; ++v) {
+      trip t;
+      if (shards) { const double* q = shards + ((size_t)v * nb + b) * 3; t = trip{q[0], q[1], q[2]}; }
+      else t = vshard_triple(partials, v, bv, nb, b, lane);
+      if (lane == 0) acc = v == 0 ? t : trip_merge(acc, t);
     }
-    t = trip_wave_reduce(t);
     if (lane == 0) {
-      if (t.m == -DBL_MAX) t.m = -INFINITY;  // empty input
-      out_host[b * 3 + 0] = t.m; out_host[b * 3 + 1] = t.s1; out_host[b * 3 + 2] = t.s2;
+      if (acc.m == -DBL_MAX) acc.m = -INFINITY;  // empty input
+      out[b * 3 + 0] = acc.m; out[b * 3 + 1] = acc.s1; out[b * 3 + 2] = acc.s2;
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence_system();
-    __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (seq_host) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence_system();
+      __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
-}
-
-// contiguous segment per block; 1024 blocks (4 per CU) once there is enough work for 16 rows per lane and trip
-static int reduce_grid(const tph_ctx* ctx, int64_t n) {
-  if (ctx->reduce_grid > 0) return ctx->reduce_grid < TPH_RED_BLOCKS ? ctx->reduce_grid : TPH_RED_BLOCKS;
-  return tph_grid_for(n, TPH_RED_THREADS, 16, 1024);
 }
 
 template <int NB>
-static void launch_reduce(tph_ctx* ctx, int grid, const tph_betas& bt) {
+static void launch_reduce(tph_ctx* ctx, const k2_geom& g, const tph_betas& bt) {
   // loads in flight per lane and array: 8 for one beta (pure streaming), fewer as the per-row exp work grows
   constexpr int U = NB == 1 ? 8 : (NB <= 4 ? 4 : 2);
-  hipLaunchKernelGGL((k_reweight_reduce<NB, U>), dim3(grid), dim3(TPH_RED_THREADS), 0, ctx->stream, ctx->logl, ctx->cmix,
-                     ctx->size, bt, ctx->partials);
+  hipLaunchKernelGGL((k_reweight_reduce<NB, U>), dim3((unsigned)(g.vl * g.bv)), dim3(TPH_RED_THREADS), 0, ctx->stream, ctx->logl, ctx->cmix,
+                     g, bt, ctx->partials);
 }
 
-
-static void launch_reduce_nb(tph_ctx* ctx, int grid, const tph_betas& bt, int nb) {
+static void launch_reduce_nb(tph_ctx* ctx, const k2_geom& g, const tph_betas& bt, int nb) {
   switch (nb) {
-    case 1: launch_reduce<1>(ctx, grid, bt); break;
-    case 2: launch_reduce<2>(ctx, grid, bt); break;
-    case 3: launch_reduce<3>(ctx, grid, bt); break;
-    case 4: launch_reduce<4>(ctx, grid, bt); break;
-    case 5: launch_reduce<5>(ctx, grid, bt); break;
-    case 6: launch_reduce<6>(ctx, grid, bt); break;
-    case 7: launch_reduce<7>(ctx, grid, bt); break;
-    case 8: launch_reduce<8>(ctx, grid, bt); break;
-    case 9: launch_reduce<9>(ctx, grid, bt); break;
-    case 10: launch_reduce<10>(ctx, grid, bt); break;
-    case 11: launch_reduce<11>(ctx, grid, bt); break;
-    case 12: launch_reduce<12>(ctx, grid, bt); break;
-    case 13: launch_reduce<13>(ctx, grid, bt); break;
-    case 14: launch_reduce<14>(ctx, grid, bt); break;
-    case 15: launch_reduce<15>(ctx, grid, bt); break;
-    default: launch_reduce<16>(ctx, grid, bt); break;
+    case 1: launch_reduce<1>(ctx, g, bt); break;
+    case 2: launch_reduce<2>(ctx, g, bt); break;
+    case 3: launch_reduce<3>(ctx, g, bt); break;
+    case 4: launch_reduce<4>(ctx, g, bt); break;
+    case 5: launch_reduce<5>(ctx, g, bt); break;
+    case 6: launch_reduce<6>(ctx, g, bt); break;
+    case 7: launch_reduce<7>(ctx, g, bt); break;
+    case 8: launch_reduce<8>(ctx, g, bt); break;
+    case 9: launch_reduce<9>(ctx, g, bt); break;
+    case 10: launch_reduce<10>(ctx, g, bt); break;
+    case 11: launch_reduce<11>(ctx, g, bt); break;
+    case 12: launch_reduce<12>(ctx, g, bt); break;
+    case 13: launch_reduce<13>(ctx, g, bt); break;
+    case 14: launch_reduce<14>(ctx, g, bt); break;
+    case 15: launch_reduce<15>(ctx, g, bt); break;
+    default: launch_reduce<16>(ctx, g, bt); break;
   }
 }
 
-// with a communicator: this rank's triples -> all-gather -> the same fixed-order merge over the G rank triples
-// (a rank whose shard holds no finite row contributes (-inf, 0, 0), which the merge ignores)
-static int gather_rank_triples(tph_ctx* ctx, int grid, int nb, const double** gathered) {
-  const size_t mine = 0, all = 1024;                      // nb <= 16: 384 B per rank
-  if (tph_comm_require(ctx, all + sizeof(double) * 3 * (size_t)nb * ctx->world, "tph_reweight (sharded)")) return -2;
-  hipLaunchKernelGGL(k_reweight_finalize, dim3(nb), dim3(256), 0, ctx->stream, ctx->partials, grid, nb, (double*)(ctx->comm_buf + mine));
+// the streaming pass over the whole local history and the fold of the per-shard triples into `out` (device memory, or pinned
+// host memory with the sequence word); with a communicator the per-shard triples of all ranks are gathered in between
+static int reweight_pass(tph_ctx* ctx, const tph_betas& bt, int nb, double* out, double* seq_host, double seq) {
+  const tph_part part = tph_partition(ctx, ctx->size);
+  const k2_geom g = k2_geometry(ctx, part);
+  if (tph_partials_reserve(ctx, sizeof(double) * 3 * (size_t)nb * g.vl * g.bv)) return -1;
+  launch_reduce_nb(ctx, g, bt, nb);
   TPH_LAUNCH_CHECK();
-  if (tph_comm_allgather(ctx, mine, all, 3 * (int64_t)nb, TPH_DT_F64)) return -2;
-  *gathered = (const double*)(ctx->comm_buf + all);
+  if (ctx->comm_active()) {
+    // this rank's per-shard triples -> all-gather (rank order = shard order) -> the same fold over the V gathered triples
+    // (a shard without a finite row contributes (-DBL_MAX, 0, 0), which the merge ignores)
+    const size_t mine = 0, one = sizeof(double) * 3 * (size_t)nb * g.vl, all = (one + 255) / 256 * 256;
+    if (tph_comm_require(ctx, all + one * ctx->world, "tph_reweight (sharded)")) return -2;
+    hipLaunchKernelGGL(k_reweight_vshards, dim3(g.vl), dim3(1024), 0, ctx->stream, ctx->partials, g.bv, nb, (double*)(ctx->comm_buf + mine));
+    TPH_LAUNCH_CHECK();
+    if (tph_comm_allgather(ctx, mine, all, 3 * (int64_t)nb * g.vl, TPH_DT_F64)) return -2;
+    hipLaunchKernelGGL(k_reweight_fold, dim3(1), dim3(1024), 0, ctx->stream, (const double*)nullptr, 0, (const double*)(ctx->comm_buf + all),
+                       g.vl * ctx->world, nb, out, seq_host, seq);
+  } else {
+    hipLaunchKernelGGL(k_reweight_fold, dim3(1), dim3(1024), 0, ctx->stream, (const double*)ctx->partials, g.bv, (const double*)nullptr, g.vl, nb,
+                       out, seq_host, seq);
+  }
+  TPH_LAUNCH_CHECK();
   return 0;
 }
 
@@ -255,19 +316,7 @@ extern "C" int tph_reweight_partials(tph_ctx* ctx, const double* betas_host, int
   TPH_REQUIRE(ctx->size > 0, "tph_reweight_partials: empty history");
   tph_betas bt;
   for (int i = 0; i < TPH_MAX_NB; ++i) bt.b[i] = i < nb ? betas_host[i] : 0.0;
-  int grid = reduce_grid(ctx, ctx->size);
-  TPH_REQUIRE((size_t)grid * nb * 3 * sizeof(double) <= ctx->partials_bytes, "tph_reweight_partials: scratch too small");
-  launch_reduce_nb(ctx, grid, bt, nb);
-  TPH_LAUNCH_CHECK();
-  const double* parts = ctx->partials;
-  int nparts = grid;
-  if (ctx->comm_active()) {
-    if (gather_rank_triples(ctx, grid, nb, &parts)) return -2;
-    nparts = ctx->world;
-  }
-  hipLaunchKernelGGL(k_reweight_finalize, dim3(nb), dim3(256), 0, ctx->stream, parts, nparts, nb, out_dev);
-  TPH_LAUNCH_CHECK();
-  return 0;
+  return reweight_pass(ctx, bt, nb, out_dev, nullptr, 0.0);
 }
 
 extern "C" int tph_reweight_eval(tph_ctx* ctx, const double* betas_host, int nb, double* out_host) {
@@ -276,22 +325,11 @@ extern "C" int tph_reweight_eval(tph_ctx* ctx, const double* betas_host, int nb,
   TPH_REQUIRE(ctx->size > 0, "tph_reweight_eval: empty history");
   tph_betas bt;
   for (int i = 0; i < TPH_MAX_NB; ++i) bt.b[i] = i < nb ? betas_host[i] : 0.0;
-  int grid = reduce_grid(ctx, ctx->size);
-  TPH_REQUIRE((size_t)grid * nb * 3 * sizeof(double) <= ctx->partials_bytes, "tph_reweight_eval: scratch too small");
-  launch_reduce_nb(ctx, grid, bt, nb);
-  TPH_LAUNCH_CHECK();
-  const double* parts = ctx->partials;
-  int nparts = grid;
-  if (ctx->comm_active()) {           // global triples: merge the ranks' results on the device, deliver through the same mailbox
-    if (gather_rank_triples(ctx, grid, nb, &parts)) return -2;
-    nparts = ctx->world;
-  }
   // results + sequence word in the ctx's pinned block: [0, 48) triples, [4095] sequence
   volatile double* seqp = ctx->pinned + 4095;
   const double seq = (double)(++ctx->eval_seq);
-  hipLaunchKernelGGL(k_reweight_finalize_host, dim3(1), dim3(1024), 0, ctx->stream, parts, nparts, nb, ctx->pinned,
-                     ctx->pinned + 4095, seq);
-  TPH_LAUNCH_CHECK();
+  const int rc = reweight_pass(ctx, bt, nb, ctx->pinned, ctx->pinned + 4095, seq);
+  if (rc) return rc;
   uint64_t spins = 0;
   while (*seqp != seq) {
     __builtin_ia32_pause();
@@ -315,13 +353,14 @@ extern "C" int tph_bench_reweight_time(tph_ctx* ctx, double beta, int nb, int re
   TPH_REQUIRE(nb >= 1 && nb <= TPH_MAX_NB && ctx->size > 0, "tph_bench_reweight_time: bad nb / empty history");
   tph_betas bt;
   for (int i = 0; i < TPH_MAX_NB; ++i) bt.b[i] = beta * (1.0 - 0.01 * i);
-  int grid = reduce_grid(ctx, ctx->size);
+  const k2_geom g = k2_geometry(ctx, tph_partition(ctx, ctx->size));
+  if (tph_partials_reserve(ctx, sizeof(double) * 3 * (size_t)nb * g.vl * g.bv)) return -1;
   hipEvent_t e0, e1;
   TPH_HIP(hipEventCreate(&e0));
   TPH_HIP(hipEventCreate(&e1));
-  launch_reduce_nb(ctx, grid, bt, nb);  // warm
+  launch_reduce_nb(ctx, g, bt, nb);  // warm
   TPH_HIP(hipEventRecord(e0, ctx->stream));
-  for (int r = 0; r < reps; ++r) launch_reduce_nb(ctx, grid, bt, nb);
+  for (int r = 0; r < reps; ++r) launch_reduce_nb(ctx, g, bt, nb);
   TPH_HIP(hipEventRecord(e1, ctx->stream));
   TPH_HIP(hipEventSynchronize(e1));
   float ms = 0.f;

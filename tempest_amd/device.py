@@ -49,6 +49,14 @@ def _ptr(t, dtype=None):
     return t.data_ptr()
 
 
+def vshards_for(n_global: int) -> int:
+    """Virtual shards of the canonical partition (csrc/common.h: tph_vshards_for)."""
+    for v in (48, 16, 12, 8, 6, 4, 3, 2, 1):
+        if n_global > 0 and n_global % (v * 256) == 0:
+            return v
+    return 1
+
+
 def _hptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -134,6 +142,10 @@ class HipContext:
         p, ld = C.c_void_p(), C.c_int64()
         check(self.lib.tph_history_ptr(self._ctx, key, C.byref(p), C.byref(ld)), "tph_history_ptr")
         return p.value, ld.value
+
+    def last_error(self) -> str:
+        msg = self.lib.tph_last_error()
+        return msg.decode() if msg else ""
 
     def history_memory(self):
         """Where the history's memory is (tph_history_memory): a dict of row counts and growth counters."""
@@ -440,6 +452,13 @@ class HipContext:
                                  mailbox.data_ptr() if mailbox is not None else None,
                                  mailbox.shape[0] if mailbox is not None else 0,
                                  _ptr(partials) if partials is not None else None, int(n)), "tph_adapt")
+
+    def accept_sums_global(self, partials, n, K, sums, host_paced=False):
+        """The step's (#accepted, sum alpha_c) over all ranks from accept()'s block partials, in the canonical shard order
+        (tph_accept_sums_global); the one rank's sums without a communicator."""
+        check(self.lib.tph_accept_sums_global(self._ctx, _ptr(partials), int(n), int(K), _ptr(sums), 1 if host_paced else 0),
+              "tph_accept_sums_global")
+        return sums
 
     def cluster_counts(self, assign, n, K):
         out = self.empty(K)

@@ -62,10 +62,15 @@ def check_bounds(u, periodic=None, reflective=None):
 class RegimeOptions:
     """Debugging switches of the d > 16 proposal regime (TEMPEST_AMD_STAGED / _SCREEN / _BLK_MFMA / _BLK_FAN / _SM_LANES): read from
     the environment ONCE, when an engine is built -- never in the step path."""
-    __slots__ = ("walker_ok", "screen", "blk_mfma", "fan", "sm_lanes")
+    __slots__ = ("walker_ok", "screen", "blk_mfma", "fan", "sm_lanes", "pin")
 
-    def __init__(self, walker_ok=True, screen=True, blk_mfma=True, fan=1, sm_lanes=0):
+    def __init__(self, walker_ok=True, screen=True, blk_mfma=True, fan=1, sm_lanes=0, pin=""):
         self.walker_ok, self.screen, self.blk_mfma, self.fan, self.sm_lanes = walker_ok, screen, blk_mfma, int(fan), int(sm_lanes)
+        # TEMPEST_AMD_REGIME=screened: every d > 16 step of a one-mode run through the screened batches, whatever the probe says.
+        # Their proposals are the FP64 row walker's bit for bit and a particle's arithmetic never depends on its neighbours, so a
+        # run pinned there is bitwise the same on any number of GPUs (the adaptive rule sends a step to the matrix-core rounds by
+        # the RANK's own list lengths, and those kernels agree with the batches to rounding only)
+        self.pin = pin
 
     @classmethod
     def from_env(cls, env=None):
@@ -73,7 +78,7 @@ class RegimeOptions:
         env = os.environ if env is None else env
         return cls(walker_ok=env.get("TEMPEST_AMD_STAGED", "1") != "0", screen=env.get("TEMPEST_AMD_SCREEN", "1") != "0",
                    blk_mfma=env.get("TEMPEST_AMD_BLK_MFMA", "1") != "0", fan=int(env.get("TEMPEST_AMD_BLK_FAN", "1")),
-                   sm_lanes=int(env.get("TEMPEST_AMD_SM_LANES", "0")))
+                   sm_lanes=int(env.get("TEMPEST_AMD_SM_LANES", "0")), pin=env.get("TEMPEST_AMD_REGIME", ""))
 
 
 # Crossovers of the redraw probe (mean attempts per particle of a step) between the d > 16 proposal kernels.  One row per
@@ -137,7 +142,11 @@ class StepEngine:
         self.n_steps, self.n_max, self.comm_active = n_steps, n_max, comm_active
         # with the library's peer-to-peer exchange attached, the all-reduce of the step's sums is a kernel on the ctx stream:
         # it belongs to the step (and to its graph) like every other launch; otherwise the host calls the process group
-        self.inline_reduce = bool(comm_active and ctx.p2p_active and 8 * (1 + K) <= 32768)   # one exchange slot (p2p.h)
+        # (this rank's shard sums -- vl (1 + K) doubles, vl = its virtual shards of the canonical partition -- must fit one slot)
+        from .device import vshards_for
+        world = max(1, int(round(n_global / n))) if n else 1
+        vl = vshards_for(n * world) // world if (n * world) % 256 == 0 and vshards_for(n * world) % world == 0 else 1
+        self.inline_reduce = bool(comm_active and ctx.p2p_active and 8 * vl * (1 + K) <= 32768)   # one exchange slot (p2p.h)
         self.up, self.maha_u, self.maha_up = ctx.empty(d, n), ctx.empty(n), ctx.empty(n)
         self.u = self.logl = self.assign = self.modes = None
         if use_graph:       # fixed-address copies of everything a captured step reads or writes
@@ -163,7 +172,7 @@ class StepEngine:
         self._step_timeout = float(env) if env else None      # seconds a step's record may take (None: until the stream goes idle)
         self._since, self._dwell, self._quick = 1 << 30, 0, 0      # readings since the last kernel switch; readings the next must wait; quick switches in a row
         self._screened = self._opts.screen and d <= 112
-        if (d > 16 and K == 1 and not has_assign and self._screened and self._opts.walker_ok):
+        if (d > 16 and self._screened and self._opts.walker_ok and ((K == 1 and not has_assign) or (1 < K <= 64 and has_assign))):
             # Nothing is known about the redraw rate before an engine's first steps: they run as screened batches, whose time is
             # flat in it (0.4-3 ms), instead of through the multi-lane kernel, whose time is not (30 ms per launch from the prior
             # at 131 072 x 100-D: three such launches were 2 % of the config-5 shard's run); the probe of step 2 picks the regime.
@@ -231,9 +240,9 @@ class StepEngine:
         ctx.propose(self.kernel, self.u, self.assign, self.modes, self.sigmas, self.bc, self.seed, 1, self.item0,
                     self.up, self.maha_u, self.maha_up, ctl=self.ctl, pending=self.pending)
         # the block partials of the Metropolis kernel are summed inside tph_adapt (one launch less per step), which on a
-        # sharded run also exchanges the sums with the peers (tph_comm_p2p_*); without that exchange the host all-reduces
-        # the column sums between the two launches
-        sums = self.sums if (self.comm_active and not self.inline_reduce) else None
+        # sharded run also exchanges the shard sums with the peers (tph_comm_p2p_*); without that exchange the ranks are combined
+        # between the two launches (step(): tph_accept_sums_global)
+        sums = None
         if self.plugin is not None:       # callbacks compiled into the Metropolis kernel (hipcallbacks.py)
             from .device import KERNEL_ID
             xp = lp = None
@@ -358,19 +367,23 @@ class StepEngine:
         before = (self.blocked > 0, bool(self.staged))
         from .device import OPT_BLOCKED, OPT_ML_UNSTAGED, OPT_SCREEN, OPT_SM_LANES, OPT_STAGED_REDRAW
         opts = getattr(self, "_opts", None) or RegimeOptions.from_env()
+        if opts.pin == "screened" and self.staged:
+            return                     # pinned to the screened batches (RegimeOptions.pin)
         walker_ok = opts.walker_ok
         nd = self.ctx.n_dim
         screened = opts.screen and nd <= 112
         up_est, down_true, cap, floor = regime_band("screened" if screened else "walker", nd)
+        multi_ok = screened and self.K <= 64 and opts.blk_mfma
         if self.K != 1:
             sm_ = REGIME_THRESHOLDS["several_modes"]
-            multi_ok = screened and self.K <= 64 and opts.blk_mfma
             want_blk = multi_ok and mean_attempts < (sm_["down"] if self.blocked else sm_["up"])
         elif self.blocked:             # geometric estimate
             want_blk = mean_attempts < up_est or not walker_ok
         else:                          # true mean (screened batches / row walker, or the multi-lane kernel of a run's first steps)
             want_blk = mean_attempts < down_true and (walker_ok or mean_attempts < 2.0)
-        want_sm = self.K == 1 and not want_blk and walker_ok
+        # redraw-dominated steps: the screened batches -- with several modes one mode after the other over the particles of each
+        # (propose_mf.hip: tph_propose_mf_modes); the multi-lane kernel only where the screen is off or K > 64
+        want_sm = (self.K == 1 or multi_ok) and not want_blk and walker_ok
         self._since = getattr(self, "_since", 1 << 30) + 1
         self._dwell = getattr(self, "_dwell", 0)
         if (want_blk, want_sm) == before:
@@ -480,7 +493,7 @@ class StepEngine:
             if self.use_graph and self.runs >= 2:
                 self._capture()
         if self.comm_active and not self.inline_reduce:
-            comm.all_reduce_sum(self.sums)
+            self.ctx.accept_sums_global(self.partials, self.n, self.K, self.sums)
             self._adapt()
 
 
@@ -552,8 +565,7 @@ class DeviceMCMC:
             if self.plugin is not None:               # callbacks compiled into the Metropolis kernel (hipcallbacks.py)
                 from .device import KERNEL_ID
                 self.plugin.accept(KERNEL_ID[self.kernel], self.beta, u, x, logl, up, maha_u, maha_up, assign, K,
-                                   modes.dof_dev, self.rng.seed, self.rng.next(), self.item0, sums if active else None,
-                                   partials=partials)
+                                   modes.dof_dev, self.rng.seed, self.rng.next(), self.item0, None, partials=partials)
             else:
                 xp = self.prior(up)                   # (d, n) SoA tensor
                 if self.blobs is None:
@@ -561,14 +573,14 @@ class DeviceMCMC:
                 else:
                     lp, bp = self.loglike(xp, return_blobs=True)
                 ctx.accept(self.kernel, self.beta, u, x, logl, up, xp, lp, maha_u, maha_up, assign, K, modes.dof_dev,
-                           self.rng.seed, self.rng.next(), self.item0, sums if active else None, partials=partials)
+                           self.rng.seed, self.rng.next(), self.item0, None, partials=partials)
                 if self.blobs is not None:
                     # an accepted row now holds its proposal, bit for bit (a proposal equal to the current point -- the
                     # redraw cap -- has the current point's blob anyway)
                     moved = (u == up).all(dim=0).cpu().numpy()
                     self.blobs[moved] = np.asarray(bp)[moved]
             if active:          # this path runs host callbacks (or blobs): the ranks are paced by them, not by the device
-                self.comm.all_reduce_sum(sums, host_paced=True)
+                ctx.accept_sums_global(partials, n, K, sums, host_paced=True)
             # one GPU: tph_adapt sums the Metropolis kernel's block partials itself (one launch less per step)
             ctx.adapt(self.kernel, sums, counts, K, n_global, self.n_steps, self.n_max, sigmas, state,
                       partials=None if active else partials, n=n)

@@ -373,3 +373,86 @@ def parity_gpu_worker(rank, world, port, out_dir):
     json.dump(out, open(os.path.join(out_dir, f"parity{rank}.json"), "w"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BITWISE world-size invariance: with the canonical partition (csrc/common.h: tph_part) every global
+# quantity -- reweight triples, cumulative weights, the moments of the proposal fit, the acceptance sums of every MCMC step --
+# is formed per virtual shard and folded in shard order, so a run on G ranks is the SAME floating-point computation as the run
+# on one, for every G that divides V(n_particles).  49 152 = 3 * 2^14 particles: V = 48 (worlds 1, 2, 3, 4, ...); 65 536: V = 16
+# (worlds 1, 2, 4, ...: the size at which a two-rank run used to part from the one-rank run at iteration 17).  Above 16
+# dimensions the run is pinned to the screened batches (TEMPEST_AMD_REGIME=screened: the adaptive regime picks kernels by each
+# rank's own list lengths, and those kernels agree to rounding only).
+BITWISE_CASES = {
+    "rosen10_49152": dict(n_dim=10, target="rosen", n=49152, worlds=(2, 3, 4), sample="tpcn", resample="mult"),
+    "rosen10_65536": dict(n_dim=10, target="rosen", n=65536, worlds=(2, 4), sample="tpcn", resample="mult"),
+    "gauss10_syst_12288": dict(n_dim=10, target="gauss", n=12288, worlds=(2, 3, 4), sample="rwm", resample="syst"),
+    "gauss50_12288": dict(n_dim=50, target="gauss", n=12288, worlds=(2, 3, 4), sample="tpcn", resample="mult", pin="screened"),
+}
+
+
+def bitwise_run(name, device=0):
+    """One seeded run of BITWISE_CASES[name] on the current process group (or none).  Everything returned must be EQUAL for every
+    world size: the schedule, every iteration's evidence / ESS / acceptance, the final evidence and a digest of the final ensemble
+    (u and logl of all ranks in slot order) and of the whole history's log-likelihoods."""
+    import hashlib
+    import numpy as np
+    import torch
+    import tempest_amd as tp
+    c = BITWISE_CASES[name]
+    d = c["n_dim"]
+    dev = torch.device("cuda", device)
+    mean = torch.linspace(-2, 2, d, dtype=torch.float64, device=dev)
+
+    def gauss(x):
+        return -0.5 * ((x - mean) ** 2).sum(dim=1) - 0.5 * d * float(np.log(2 * np.pi))
+
+    def rosen(x):
+        return -(10.0 * (x[:, ::2] ** 2 - x[:, 1::2]) ** 2 + (x[:, ::2] - 1.0) ** 2).sum(dim=1)
+    keep = os.environ.get("TEMPEST_AMD_REGIME")
+    if c.get("pin"):
+        os.environ["TEMPEST_AMD_REGIME"] = c["pin"]
+    try:
+        s = tp.Sampler(lambda u: 20 * u - 10, {"gauss": gauss, "rosen": rosen}[c["target"]], d, n_particles=c["n"], vectorize=True,
+                       clustering=False, sample=c["sample"], resample=c["resample"], random_state=5, device=device)
+        s.run(n_total=2 * c["n"], progress=False)
+    finally:
+        if c.get("pin"):
+            if keep is None:
+                del os.environ["TEMPEST_AMD_REGIME"]
+            else:
+                os.environ["TEMPEST_AMD_REGIME"] = keep
+    st = s.state
+    comm = st.comm
+    u = st.get_current("u")
+    logl = st.get_current("logl")
+    hist = np.asarray(st.get_history("logl", flat=True))
+    if comm is not None and comm.active:
+        u, logl = comm.gather_rows(u), comm.gather_rows(logl)
+        # the history in GLOBAL order: iteration-major, then rank (each rank holds its slots of every iteration)
+        T = len(st.get_history("beta"))
+        per = hist.size // T
+        allh = comm.gather_rows(hist.reshape(T, per).T.copy())            # (world * per, T), rank-major rows
+        hist = allh.T.reshape(-1)                                         # iteration-major; inside: rank, then slot = global slot order
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(u).tobytes())
+    h.update(np.ascontiguousarray(logl).tobytes())
+    hh = hashlib.sha256(np.ascontiguousarray(hist).tobytes())
+    return {"logz": float(s.evidence()[0]).hex(), "beta": [float(v).hex() for v in st.get_history("beta")],
+            "steps": [int(v) for v in st.get_history("steps")], "logz_t": [float(v).hex() for v in st.get_history("logz")],
+            "ess": [float(v).hex() for v in st.get_history("ess")], "acc": [float(v).hex() for v in st.get_history("acceptance")],
+            "eff": [float(v).hex() for v in st.get_history("efficiency")], "ensemble_sha256": h.hexdigest(),
+            "history_logl_sha256": hh.hexdigest(), "logz_float": float(s.evidence()[0])}
+
+
+def bitwise_gpu_worker(rank, world, port, out_dir):
+    """`world` ranks sharing cuda:0 over gloo: every case of BITWISE_CASES that admits this world size."""
+    import json
+    import torch.distributed as dist
+    _init(rank, world, port)
+    only = os.environ.get("TEMPEST_AMD_TEST_CASES")
+    out = {name: bitwise_run(name) for name, c in BITWISE_CASES.items()
+           if world in c["worlds"] and (not only or name in only.split(","))}
+    json.dump(out, open(os.path.join(out_dir, f"bitwise{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()

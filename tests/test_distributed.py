@@ -149,3 +149,45 @@ def test_world2_at_n_dim_above_16_is_the_same_sampler_statistically(tmp_path, mo
         assert abs(two["logz"] - one["logz"]) < 0.5, (name, two["logz"], one["logz"])
         assert two["post_n"] == one["post_n"], name
         print(name, "iterations", len(one["beta"]), len(two["beta"]), "logz", one["logz"], two["logz"])
+
+
+_ONE_RANK = {}
+
+
+def _one_rank(name):
+    from tests._dist_workers import bitwise_run
+    if name not in _ONE_RANK:
+        _ONE_RANK[name] = bitwise_run(name)
+    return _ONE_RANK[name]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,p2p", [(2, True), (3, True), (4, True), (2, False), (4, False)])
+def test_world_size_invariance_is_bitwise(tmp_path, monkeypatch, world, p2p):
+    """a run on 2, 3 or 4 ranks IS the run on one -- the same bits in every iteration's beta, evidence, ESS,
+    acceptance and step count, in the final evidence, in the final ensemble and in the whole history -- with the small collectives
+    through the peer-to-peer exchange and through the process group, at 10 dimensions (49 152 and 65 536 particles, tpCN /
+    multinomial; RWM / systematic) and at 50 (pinned to the screened batches).  What makes it so: the canonical partition into
+    virtual shards (csrc/common.h: tph_part) under every cross-rank sum -- reweight triples, cumulative weights, the moments of
+    the proposal fit, the acceptance sums of a step."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    from tests._dist_workers import BITWISE_CASES, bitwise_gpu_worker
+    if not p2p:
+        monkeypatch.setenv("TEMPEST_AMD_P2P", "0")
+        monkeypatch.setenv("TEMPEST_AMD_TEST_CASES", "rosen10_49152,gauss50_12288")
+    _spawn(bitwise_gpu_worker, world, tmp_path)
+    rs = [json.load(open(tmp_path / f"bitwise{r}.json")) for r in range(world)]
+    keys = ("logz", "beta", "steps", "logz_t", "ess", "acc", "eff", "ensemble_sha256", "history_logl_sha256")
+    assert rs[0], "no case ran for this world size"
+    for name, got in rs[0].items():
+        assert world in BITWISE_CASES[name]["worlds"]
+        for r in range(1, world):
+            assert rs[r][name] == got, (name, "rank", r)                   # every rank holds the same global results
+        one = _one_rank(name)
+        for k in keys:
+            assert got[k] == one[k], (name, k, "world", world, "p2p", p2p,
+                                      [i for i, (a, b) in enumerate(zip(got[k], one[k])) if a != b][:3] if isinstance(got[k], list) else (got[k], one[k]))
+        print(name, "world", world, "p2p", p2p, "iterations", len(one["beta"]), "steps", sum(one["steps"]), "logz", one["logz_float"],
+              "ensemble", one["ensemble_sha256"][:16])

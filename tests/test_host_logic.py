@@ -199,16 +199,20 @@ def test_proposal_regime_rule_d_gt_16(monkeypatch):
     assert s32.blocked == 2
     s32._regime(8.1)
     assert s32.staged
-    # several modes: the matrix-core rounds over mode-pure tiles below ~8 estimated attempts, the multi-lane kernel above
+    # several modes: the matrix-core rounds over mode-pure tiles below ~8 estimated attempts, the screened batches mode by mode
+    # above (round 5; the multi-lane kernel only with the screen off: previous test)
     m4 = Eng(32, 262144, K=4)
     m4._regime(20.0)
-    assert m4.blocked == 0 and not m4.staged and m4.unstaged
+    assert m4.blocked == 0 and m4.staged
     m4._regime(12.0)
     assert m4.blocked == 12 and not m4.staged
     m4._regime(1.2)
     assert 2 <= m4.blocked <= 4 and not m4.staged
     m4._regime(8.5)
-    assert m4.blocked == 0 and not m4.staged
+    assert m4.blocked == 0 and m4.staged
+    m80 = Eng(32, 262144, K=80)                        # more modes than the mode tables hold: the multi-lane kernel
+    m80._regime(20.0)
+    assert m80.blocked == 0 and not m80.staged and m80.unstaged
 
 
 def test_regime_rule_does_not_oscillate(monkeypatch):

@@ -233,3 +233,69 @@ def test_screened_kernel_badly_scaled_factor(dev):
         assert a[4]["contradictions"] == 0
         np.testing.assert_array_equal(a[0], b[0])
         assert a[3][8] > 1.02                            # some first attempts do leave the cube
+
+
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+@pytest.mark.parametrize("d,K,bc", [(24, 3, None), (50, 2, "mixed"), (100, 4, None), (33, 5, None)])
+def test_screened_kernel_with_several_modes_vs_oracle_and_single_mode_launches(dev, kernel, d, K, bc):
+    """tempest/mcmc.py:225-249 applies each walker's own cluster mean / factor / sigma in its redraw loop at any dimension.
+    Several proposal modes on the screened batches: the modes are served one after the other over the
+    particles of each (csrc/propose_mf.hip: tph_propose_mf_modes).  On a redraw-dominated ensemble with K modes of different
+    means, factors, sigmas and sizes (one of them nearly empty): proposals and both Mahalanobis forms equal the oracle's
+    sequential loop to rounding, every particle's proposal equals -- BIT FOR BIT -- what the one-mode kernel gives when run on
+    that mode's particles alone with that mode's statistics, the audit finds no contradiction, and the probe is the mean number
+    of attempts over ALL particles."""
+    n = 1400 if d < 64 else 1000
+    rs = np.random.RandomState(977 + d + K)
+    means = 0.5 + 0.08 * rs.randn(K, d)
+    covs = np.empty((K, d, d))
+    for m in range(K):
+        A = rs.randn(d, d) / np.sqrt(d)
+        covs[m] = (A @ A.T + np.eye(d)) * ((0.22 + 0.04 * m) ** 2 / 2.0)
+    _, chol, inv = ps.mode_statistics(means, covs)
+    u = rs.rand(n, d)
+    u[:30] = np.clip(u[:30], 0.45, 0.55)
+    assign = rs.randint(0, K, size=n).astype(np.int32)
+    assign[assign == K - 1] = 0                              # the last mode keeps three particles only
+    assign[[5, 600, n - 1]] = K - 1
+    dof = np.full(K, 1e6)
+    sigmas = (2.38 / np.sqrt(d)) * (1.0 - 0.1 * np.arange(K))
+    flags = omc.bc_flags(d, [1], [min(4, d - 1)]) if bc else omc.bc_flags(d)
+    seed, tick, item0 = 4242, 11, 2_000_000_000
+    want_up, want_mu, want_mup = omc.propose(kernel, u, assign, means, chol, inv, dof, sigmas, flags, seed, tick, item0)
+    from tempest_amd.device import HipContext
+    modes = _Modes(means, chol, inv, dof, dev)
+    st, ft = torch.from_numpy(sigmas).to(dev), torch.from_numpy(flags).to(dev)
+    at = torch.from_numpy(assign).to(dev)
+    got = {}
+    for audit in (True, False):
+        c = HipContext(d, device=0)
+        c.set_option(OPT_VARIANT, 6)
+        c.set_option(OPT_MF_AUDIT, 1 if audit else 0)
+        up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+        state = c.zeros(10)
+        c.propose(kernel, soa(u, dev), at, modes, st, ft, seed, tick, item0, up, mu_, mup, ctl=state)
+        got[audit] = (aos(up), mu_.cpu().numpy(), mup.cpu().numpy(), state.cpu().numpy(), c.mf_counters())
+        c.close()
+    g = got[True]
+    np.testing.assert_allclose(g[0], want_up, rtol=1e-11, atol=1e-13)
+    strict = np.nonzero(flags == 0)[0]
+    assert np.all((g[0][:, strict] >= 0) & (g[0][:, strict] <= 1))
+    if kernel == "tpcn":
+        np.testing.assert_allclose(g[1], want_mu, rtol=1e-9)
+        np.testing.assert_allclose(g[2], want_mup, rtol=1e-8, atol=1e-8)
+    cnt = g[4]
+    assert cnt["contradictions"] == 0 and cnt["particles"] == n, cnt
+    assert g[3][8] == cnt["attempts"] / n and g[3][8] > 2.0, (g[3][8], cnt)
+    np.testing.assert_array_equal(got[False][0], g[0])         # the product path (audit off): the same proposals and forms
+    np.testing.assert_array_equal(got[False][2], g[2])
+    assert got[False][4]["attempts"] == cnt["attempts"]
+    # mode by mode against the ONE-mode kernel on that mode's particles (item0 shifted so that every particle keeps its draws)
+    for m in range(K):
+        rows = np.nonzero(assign == m)[0]
+        one = _Modes(means[m:m + 1], chol[m:m + 1], inv[m:m + 1], dof[m:m + 1], dev)
+        sm = torch.from_numpy(sigmas[m:m + 1].copy()).to(dev)
+        for r in rows[:: max(1, len(rows) // 40)]:              # a sample of the mode's particles, each as an ensemble of one
+            single = _run(6, d, kernel, u[r:r + 1], one, sm, ft, seed, tick, item0 + int(r), dev)
+            np.testing.assert_array_equal(single[0][0], g[0][r])
+            assert single[2][0] == g[2][r]
