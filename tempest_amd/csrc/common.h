@@ -236,6 +236,8 @@ int tph_propose_mf_list(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t 
                         int queue_zeroed = 0);                             // 1: the caller zeroed tph_mf_queue_words() on the stream already
 bool tph_mf_selftest(tph_ctx* ctx);                  // the device meets the screen's FP32 budget (measured once per context)
 bool tph_mf_screen(tph_ctx* ctx);                    // TPH_OPT_SCREEN on, n_dim in range AND the device passed the screen's self-test (run once)
+// the screened kernel's queue block: 16 counters (64-bit), then one chunk cursor per workgroup (<= 256); in 32-bit words:
+constexpr int TPH_MF_QWORDS = 2 * (16 + 256), TPH_MF_QCURSORS = 32;
 unsigned int* tph_mf_queue_words(tph_ctx* ctx);
 // several proposal modes: the particles grouped by mode (propose_blkm.hip; device pointers into ctx-owned memory: order[n], mstart[K], mcount[K])
 int tph_mode_lists(tph_ctx* ctx, const int32_t* assign, int64_t n, int K, const int32_t** order, const int32_t** mstart, const int32_t** mcount);

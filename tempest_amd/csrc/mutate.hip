@@ -649,7 +649,7 @@ static int launch_propose_blk(tph_ctx* ctx, double* u, int64_t n, int64_t ld, co
   // (with the screened kernel as the straggler pass its work-queue words are zeroed by the same launch: one launch less per step)
   const bool screen = tph_mf_screen(ctx);
   unsigned int* mfq = screen ? tph_mf_queue_words(ctx) : nullptr;
-  if (mfq) hipLaunchKernelGGL(k_zero_words2, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)cnts, 64, mfq, 32);
+  if (mfq) hipLaunchKernelGGL(k_zero_words2, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)cnts, 64, mfq, TPH_MF_QWORDS);
   else hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)cnts, 64);
   // A launch that is being CAPTURED into a hipGraph always records the rebuild: a replayed step never re-enters this host
   // code, so an epoch test made here would freeze the copies of the capture-time statistics while the caller refreshes the

@@ -172,8 +172,15 @@ static __global__ void __launch_bounds__(256) k_mf_pack(const double* __restrict
     }
 }
 
-// queue words: [0] next chunk, [1] sum of attempts, [2] particles decided, [3] audit contradictions, [4] FP64 verifications,
-// [5] attempts screened, [6] Box-Muller pair jobs
+// queue words (64-bit): [1] sum of attempts, [2] particles decided, [3] audit contradictions, [4] FP64 verifications,
+// [5] attempts screened, [6] Box-Muller pair jobs; [16 + g] chunk cursor of workgroup g.
+// Particles are dealt in chunks of 4 from PER-WORKGROUP ranges: workgroup g owns a contiguous share of the chunks and its waves
+// take them in order, so the 8 particles that share a 64-byte sector of a coordinate's row of u (the kernel reads u by particle:
+// lane = row, 8 bytes from each of n_dim different lines) are fetched by waves of ONE workgroup within a few microseconds of each
+// other -- from its L1 / its XCD's L2 instead of once per wave from HBM -- and the FP64 verification's re-read of the same rows
+// finds them there too.  One global cursor dealt neighbouring chunks to different XCDs: FETCH_SIZE 1.02 GB per launch at
+// 131 072 x 100-D against 0.105 GB of u (profiles/r04_roofline_c5.json).  A workgroup that has emptied its share takes chunks
+// from the others' (work stealing at the tail: the attempt counts of particles differ by orders of magnitude).
 template <int KERNEL, bool HAS_BC, int NP>
 __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __restrict__ u, int64_t n, int64_t ld, int d,
                                                              const double* __restrict__ means, const unsigned char* __restrict__ pack,
@@ -263,8 +270,24 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
   int pool_next = 0, pool_cnt = 0;
   bool exhausted = false;
   unsigned long long n_att = 0, n_dec = 0, n_bad = 0, n_ver = 0, n_scr = 0, n_job = 0;
+  // chunk dealing: own share first, then the others' (lane 0; ~0ull: nothing left anywhere)
+  const int64_t per_group = (nchunks + gridDim.x - 1) / gridDim.x;
+  int steal_k = 0;
+  auto grab = [&]() -> unsigned long long {
+    for (int k = steal_k; k < (int)gridDim.x; ++k) {
+      const int g = (int)((blockIdx.x + k) % gridDim.x);
+      const int64_t lo = (int64_t)g * per_group;
+      const int64_t cnt = (lo + per_group < nchunks ? lo + per_group : nchunks) - lo;
+      if (cnt <= 0) continue;
+      if (k > 0 && (int64_t)__hip_atomic_load(&queue[16 + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cnt) continue;
+      const unsigned long long c = atomicAdd(&queue[16 + g], 1ull);
+      if ((int64_t)c < cnt) { steal_k = k; return (unsigned long long)(lo + (int64_t)c); }
+    }
+    steal_k = (int)gridDim.x;
+    return ~0ull;
+  };
   unsigned long long ahead = 0;
-  if (lane == 0) ahead = atomicAdd(&queue[0], 1ull);
+  if (lane == 0) ahead = grab();
 #ifdef MF_PROFILE
   long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_t = clock64();      // refill, setup, jobs, mfma + check, verify, cap, batches
 #ifdef MF_PROFILE_VERIFY      // (the four counters are the parts of the FP64 evaluation instead: Box-Muller round, wait for u, rows, tail)
@@ -367,8 +390,8 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
         if (pool_next >= pool_cnt) {
           if (exhausted) break;
           const unsigned long long c = __shfl(ahead, 0, 64);
-          if ((int64_t)c >= nchunks) { exhausted = true; break; }
-          if (lane == 0) ahead = atomicAdd(&queue[0], 1ull);
+          if (c == ~0ull) { exhausted = true; break; }
+          if (lane == 0) ahead = grab();
           pool_row = (int64_t)c * chunk;
           pool_cnt = (int)((n - pool_row) < chunk ? (n - pool_row) : chunk);
           pool_next = 0;
@@ -444,6 +467,7 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
 #pragma unroll 1
         for (int j0 = 0; j0 < 8 * A; j0 += 64) {
           const int j = j0 + lane, i = j >> 3, q = j & 7;
+          float zmx = 0.0f;
           if (i < A && q < nq) {
             const int c = list[i];
             const int2 ra = coltab[c];
@@ -451,8 +475,20 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
             float z0, z1;
             mf_normal2(gz, (uint32_t)ra.y * (uint32_t)npairs + (uint32_t)(8 * p + q), z0, z1);
             const mf_h2 h = __builtin_amdgcn_cvt_pkrtz(z0, z1);
-            zscr[c * 8 + q] = __builtin_bit_cast(uint32_t, h);
-            atomicMax(&colzm[c], __float_as_uint(fmaxf(fabsf(z0), fabsf(z1))));
+            // (the pair slots of columns c and c + 8 sit 64 words apart: the second eight rotate theirs by four, so that neither
+            // this store nor the panel's 8-byte operand reads below meet in a bank)
+            zscr[c * 8 + (q ^ (((c >> 3) & 1) << 2))] = __builtin_bit_cast(uint32_t, h);
+            zmx = fmaxf(fabsf(z0), fabsf(z1));
+          }
+          // max |z~| of the column: its (up to) 8 pair jobs sit in 8 consecutive lanes -- a butterfly through the data-parallel
+          // path (quad swaps, then the mirrored half), ONE lane updates the column's word.  (An LDS atomic per job put 8 lanes on
+          // one address: 8-way serialised, the bulk of the kernel's bank-conflict cycles.)
+          zmx = fmaxf(zmx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zmx), 0xB1, 0xf, 0xf, true)));
+          zmx = fmaxf(zmx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zmx), 0x4E, 0xf, 0xf, true)));
+          zmx = fmaxf(zmx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zmx), 0x141, 0xf, 0xf, true)));
+          if (i < A && q == 0) {
+            const int c = list[i];
+            colzm[c] = __float_as_uint(fmaxf(__uint_as_float(colzm[c]), zmx));
           }
         }
         n_job += (unsigned long long)(A * nq);
@@ -460,7 +496,7 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
         MF_PF(2);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          if ((alive >> (16 * t)) & 0xFFFFull) Z[t][p] = *(const mf_h4*)&zscr[(16 * t + (lane & 15)) * 8 + 2 * (lane >> 4)];
+          if ((alive >> (16 * t)) & 0xFFFFull) Z[t][p] = *(const mf_h4*)&zscr[(16 * t + (lane & 15)) * 8 + ((2 * (lane >> 4)) ^ (((lane >> 3) & 1) << 2))];
         // rows 16p .. 16p+15 of every column
         mf_f4 acc[4];
 #pragma unroll
@@ -578,7 +614,7 @@ struct mf_bufs { unsigned long long* queue; double* Wb; unsigned char* pack; dou
 static int mf_alloc(tph_ctx* ctx, size_t* off_wb_, size_t* off_pack_, size_t* off_lt_, int K = 1) {
   const int d = ctx->d, np = mf_panels(d);
   const size_t tb8 = tri_blocked_doubles(d);
-  const size_t off_wb = 128, off_pack = off_wb + sizeof(double) * tb8 * (size_t)K;
+  const size_t off_wb = 4096, off_pack = off_wb + sizeof(double) * tb8 * (size_t)K;      // (the queue block: TPH_MF_QWORDS words)
   const size_t off_lt = (off_pack + mf_pack_bytes(np) * (size_t)K + 255) & ~(size_t)255;
   const size_t need = off_lt + sizeof(double) * (size_t)mf_lt_doubles(d) * (size_t)K;
   if (ctx->mf_bytes < need) {
@@ -614,7 +650,7 @@ static int mf_prepare(tph_ctx* ctx, const double* chol, const double* winv, mf_b
     if (KERNEL == TPH_KERNEL_TPCN) hipLaunchKernelGGL(k_tri_block, dim3(K), dim3(256), 0, ctx->stream, winv, d, b->Wb);
     ctx->mf_epoch = capturing ? -1 : ctx->modes_epoch; ctx->mf_src = (const void*)chol; ctx->mf_kernel = KERNEL; ctx->mf_K = K;
   }
-  if (zero) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)b->queue, 32);
+  if (zero) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)b->queue, TPH_MF_QWORDS);
   return 0;
 }
 
@@ -729,7 +765,7 @@ static int propose_mf_modes(tph_ctx* ctx, double* u, const int32_t* assign, int6
     bm.LT = b.LT + (size_t)m * mf_lt_doubles(d);
     const double* mu = means ? means + (size_t)m * d : nullptr;
     const double* dm = dof ? dof + m : nullptr;
-    if (m) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)b.queue, 2);     // the work-queue cursor; the counters run on
+    if (m) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)b.queue + TPH_MF_QCURSORS, TPH_MF_QWORDS - TPH_MF_QCURSORS);     // the chunk cursors; the counters run on
     if (chores)
       if (launch_maha_tile<KERNEL, 0>(ctx, u, n, ld, mu, bm.Wb, up, maha_u, tick, pend, nullptr, dm, sigmas + m, seed, item0, maha_up,
                                       mcount + m, order, mstart + m)) return -1;
@@ -766,7 +802,7 @@ static int propose_mf_mode_lists(tph_ctx* ctx, double* u, int64_t n, int64_t ld,
     bm.pack = b.pack + (size_t)m * mf_pack_bytes(np);
     bm.LT = b.LT + (size_t)m * mf_lt_doubles(d);
     const double* mu = means ? means + (size_t)m * d : nullptr;
-    if (m) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)b.queue, 2);
+    if (m) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, ctx->stream, (unsigned int*)b.queue + TPH_MF_QCURSORS, TPH_MF_QWORDS - TPH_MF_QCURSORS);
     if (mf_launch<KERNEL>(ctx, bm, u, n, ld, mu, sigmas + m, bc, seed, tick, item0, up, maha_up, cnts + m, rows, att0, atts ? atts + m : nullptr,
                           offs + m, MF_DIRECT)) return -1;
     if (KERNEL == TPH_KERNEL_TPCN || maha_up)
