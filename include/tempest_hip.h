@@ -142,6 +142,10 @@ int tph_synchronize(tph_ctx* ctx);
  * always (tests).  The row-major mirror follows the history (within a fifth of the device, and never below 15 % free memory:
  * beyond that it is given back); logl and the cached mixture (16 bytes per row) are always plain. */
 #define TPH_OPT_HISTORY_VM 18
+/* TPH_OPT_MF_DEAL: how the screened kernel deals its particles (chunks of 4) to the waves: 0 (default) = one global cursor;
+ * 1 = per-workgroup contiguous ranges with stealing; 2 = eight ranges, one per XCD's workgroups (the 8 particles behind one
+ * 64-byte sector of u then go through one L2: half the HBM reads, not faster -- csrc/propose_mf.hip).  Same proposals. */
+#define TPH_OPT_MF_DEAL 19
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- multi-GPU: one process per GPU --------------------------------------

@@ -119,6 +119,7 @@ struct tph_ctx {
   const void* sm_src = nullptr;
   // screened-batch proposal kernel (propose_mf.hip): TPH_OPT_SCREEN / _MF_LANES / _MF_AUDIT and its persistent buffer
   int screen = 1, mf_lanes = 0, mf_audit = 0;
+  int mf_deal = 0;                  // TPH_OPT_MF_DEAL: 0 = one global chunk cursor (default) | 1 = per-workgroup ranges with stealing | 2 = eight ranges (one per XCD)
   int mf_checked = 0;               // the screen's FP32 transcendental budget on this device: 0 not measured yet | 1 holds | -1 does not (screen off)
   void* mf_buf = nullptr;           // queue words | blocked L^-1 | FP16 pack of L + row error tables | transposed FP64 L
   size_t mf_bytes = 0;

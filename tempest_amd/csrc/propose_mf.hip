@@ -174,13 +174,16 @@ static __global__ void __launch_bounds__(256) k_mf_pack(const double* __restrict
 
 // queue words (64-bit): [1] sum of attempts, [2] particles decided, [3] audit contradictions, [4] FP64 verifications,
 // [5] attempts screened, [6] Box-Muller pair jobs; [16 + g] chunk cursor of workgroup g.
-// Particles are dealt in chunks of 4 from PER-WORKGROUP ranges: workgroup g owns a contiguous share of the chunks and its waves
-// take them in order, so the 8 particles that share a 64-byte sector of a coordinate's row of u (the kernel reads u by particle:
-// lane = row, 8 bytes from each of n_dim different lines) are fetched by waves of ONE workgroup within a few microseconds of each
-// other -- from its L1 / its XCD's L2 instead of once per wave from HBM -- and the FP64 verification's re-read of the same rows
-// finds them there too.  One global cursor dealt neighbouring chunks to different XCDs: FETCH_SIZE 1.02 GB per launch at
-// 131 072 x 100-D against 0.105 GB of u (profiles/r04_roofline_c5.json).  A workgroup that has emptied its share takes chunks
-// from the others' (work stealing at the tail: the attempt counts of particles differ by orders of magnitude).
+// Particles are dealt to the waves in chunks of 4 from ONE global cursor (queue[16]).  Where the launch's HBM reads come from
+// (FETCH_SIZE 1.09 GB per launch at 131 072 x 100-D from the prior, against 0.105 GB of u; measured round 5,
+// profiles/r05_mf_ab.json): the kernel reads u BY PARTICLE -- lane = row, 8 bytes from each of n_dim different lines, once
+// when a particle takes a slot and once per FP64 verification -- so a (particle, row) read touches a whole 64-byte sector
+// (131 072 x 100 x 64 B = 0.84 GB if nobody shares), and the 8 particles behind one sector are dealt to waves of different
+// XCDs, each with its own L2.  Dealing from ranges that keep sector neighbours in one L2 (TPH_OPT_MF_DEAL = 2: eight ranges, one
+// per XCD's workgroups) halves the reads (0.51 GB) -- and makes the launch no faster at 100-D and 14-22 % SLOWER at 32-D / 50-D;
+// per-workgroup ranges (= 1): reads -19 %, 32-D 14 % faster, 50-D 8 % slower, 100-D +-0.  The loads overlap with the vector work
+// that bounds the kernel; what the ranges cost is balance (the attempt counts of particles differ by orders of magnitude).
+// The global cursor stays the default.
 template <int KERNEL, bool HAS_BC, int NP>
 __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __restrict__ u, int64_t n, int64_t ld, int d,
                                                              const double* __restrict__ means, const unsigned char* __restrict__ pack,
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
                                                              int lgG, unsigned long long* __restrict__ queue, int audit,
                                                              const int32_t* __restrict__ todo_cnt, const int32_t* __restrict__ todo_rows,
                                                              int att0, const int32_t* __restrict__ att0_dev,
-                                                             const int32_t* __restrict__ todo_off, int direct_tries) {
+                                                             const int32_t* __restrict__ todo_off, int direct_tries, int local_deal) {
   if (att0_dev) att0 = *att0_dev;      // (list mode behind fanned-out rounds: the first untried attempt was decided on the device)
   if (todo_off) todo_rows += *todo_off; // (several modes: this mode's stretch of the list array; means / pack / LT / sigmas are the mode's)
   // todo_cnt != NULL: only the particles LISTED in todo_rows[0 .. *todo_cnt) (those the blocked kernel's rounds left out of
@@ -270,12 +273,15 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
   int pool_next = 0, pool_cnt = 0;
   bool exhausted = false;
   unsigned long long n_att = 0, n_dec = 0, n_bad = 0, n_ver = 0, n_scr = 0, n_job = 0;
-  // chunk dealing: own share first, then the others' (lane 0; ~0ull: nothing left anywhere)
-  const int64_t per_group = (nchunks + gridDim.x - 1) / gridDim.x;
+  // chunk dealing (lane 0; ~0ull: nothing left anywhere).  local_deal = 0 (default): ONE cursor for all workgroups.
+  // 1: every workgroup owns a contiguous share of the chunks and deals it in order, then takes from the others' (stealing at
+  // the tail); 2: eight shares, one per group of workgroups blockIdx.x mod 8 (the XCDs take workgroups round-robin).
+  const int ranges = local_deal == 1 ? (int)gridDim.x : (local_deal == 2 ? ((int)gridDim.x < 8 ? (int)gridDim.x : 8) : 1);
+  const int64_t per_group = (nchunks + ranges - 1) / ranges;
   int steal_k = 0;
   auto grab = [&]() -> unsigned long long {
-    for (int k = steal_k; k < (int)gridDim.x; ++k) {
-      const int g = (int)((blockIdx.x + k) % gridDim.x);
+    for (int k = steal_k; k < ranges; ++k) {
+      const int g = (int)((blockIdx.x + (unsigned)k) % (unsigned)ranges);
       const int64_t lo = (int64_t)g * per_group;
       const int64_t cnt = (lo + per_group < nchunks ? lo + per_group : nchunks) - lo;
       if (cnt <= 0) continue;
@@ -283,7 +289,7 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
       const unsigned long long c = atomicAdd(&queue[16 + g], 1ull);
       if ((int64_t)c < cnt) { steal_k = k; return (unsigned long long)(lo + (int64_t)c); }
     }
-    steal_k = (int)gridDim.x;
+    steal_k = ranges;
     return ~0ull;
   };
   unsigned long long ahead = 0;
@@ -467,7 +473,6 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
 #pragma unroll 1
         for (int j0 = 0; j0 < 8 * A; j0 += 64) {
           const int j = j0 + lane, i = j >> 3, q = j & 7;
-          float zmx = 0.0f;
           if (i < A && q < nq) {
             const int c = list[i];
             const int2 ra = coltab[c];
@@ -475,20 +480,12 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
             float z0, z1;
             mf_normal2(gz, (uint32_t)ra.y * (uint32_t)npairs + (uint32_t)(8 * p + q), z0, z1);
             const mf_h2 h = __builtin_amdgcn_cvt_pkrtz(z0, z1);
-            // (the pair slots of columns c and c + 8 sit 64 words apart: the second eight rotate theirs by four, so that neither
-            // this store nor the panel's 8-byte operand reads below meet in a bank)
-            zscr[c * 8 + (q ^ (((c >> 3) & 1) << 2))] = __builtin_bit_cast(uint32_t, h);
-            zmx = fmaxf(fabsf(z0), fabsf(z1));
-          }
-          // max |z~| of the column: its (up to) 8 pair jobs sit in 8 consecutive lanes -- a butterfly through the data-parallel
-          // path (quad swaps, then the mirrored half), ONE lane updates the column's word.  (An LDS atomic per job put 8 lanes on
-          // one address: 8-way serialised, the bulk of the kernel's bank-conflict cycles.)
-          zmx = fmaxf(zmx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zmx), 0xB1, 0xf, 0xf, true)));
-          zmx = fmaxf(zmx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zmx), 0x4E, 0xf, 0xf, true)));
-          zmx = fmaxf(zmx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zmx), 0x141, 0xf, 0xf, true)));
-          if (i < A && q == 0) {
-            const int c = list[i];
-            colzm[c] = __float_as_uint(fmaxf(__uint_as_float(colzm[c]), zmx));
+            zscr[c * 8 + q] = __builtin_bit_cast(uint32_t, h);
+            // (an LDS atomic without a return value: its 8 jobs per column serialise in the LDS unit -- 66 M bank-conflict cycles per
+            // launch at 131 072 x 100-D -- but BESIDE the vector work that bounds the kernel.  Replaced by a DPP butterfly over the 8
+            // lanes and one plain update, the conflicts fell by 95 % and the launch got 4-7 % SLOWER: nine more VALU instructions
+            // per job batch on the critical path.  Measured round 5, profiles/r05_mf_ab.json; the atomic stays.)
+            atomicMax(&colzm[c], __float_as_uint(fmaxf(fabsf(z0), fabsf(z1))));
           }
         }
         n_job += (unsigned long long)(A * nq);
@@ -496,7 +493,7 @@ __global__ void __launch_bounds__(64 * MF_WAVES) k_propose_mf(const double* __re
         MF_PF(2);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          if ((alive >> (16 * t)) & 0xFFFFull) Z[t][p] = *(const mf_h4*)&zscr[(16 * t + (lane & 15)) * 8 + ((2 * (lane >> 4)) ^ (((lane >> 3) & 1) << 2))];
+          if ((alive >> (16 * t)) & 0xFFFFull) Z[t][p] = *(const mf_h4*)&zscr[(16 * t + (lane & 15)) * 8 + 2 * (lane >> 4)];
         // rows 16p .. 16p+15 of every column
         mf_f4 acc[4];
 #pragma unroll
@@ -684,7 +681,7 @@ static int mf_launch(tph_ctx* ctx, const mf_bufs& b, const double* u, int64_t n,
       TPH_HIP(hipFuncSetAttribute((const void*)k_propose_mf<KERNEL, BC, NPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((k_propose_mf<KERNEL, BC, NPV>), dim3((unsigned)groups), dim3(64 * MF_WAVES), lds, ctx->stream,    \
                        u, n, ld, d, means, (const unsigned char*)b.pack, (const double*)b.LT, sigmas, bc, seed,           \
-                       tick, item0, up, bfac, lgG, b.queue, audit, todo_cnt, todo_rows, att0, att0_dev, todo_off, direct_tries);   \
+                       tick, item0, up, bfac, lgG, b.queue, audit, todo_cnt, todo_rows, att0, att0_dev, todo_off, direct_tries, ctx->mf_deal);   \
   } while (0)
 #define TPH_MF_NP(NPV) do { if (bc) TPH_MF(true, NPV); else TPH_MF(false, NPV); } while (0)
   switch (np) {
