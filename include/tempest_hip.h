@@ -60,6 +60,9 @@ int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void* hip_strea
 int tph_ctx_destroy(tph_ctx* ctx);
 int tph_set_stream(tph_ctx* ctx, void* hip_stream);
 int tph_synchronize(tph_ctx* ctx);
+/* loads every code object of the library now (one empty launch per translation unit, then a stream synchronisation) instead of
+ * at the first use of each kernel family in the middle of a run's first iterations; safe to call from a start-up thread */
+int tph_warmup(tph_ctx* ctx);
 /* TPH_OPT_PROPOSE_VARIANT selects the proposal kernel: 0 = automatic (registers for n_dim <= 16, multi-lane above, blocked
  * when TPH_OPT_BLOCKED is set, row walker when TPH_OPT_STAGED_REDRAW is), 1 = one lane per particle with LDS columns (any n_dim), 2 = one lane per particle in
  * registers (n_dim <= 16), 3 = several lanes per particle with the matrices staged in LDS, 4 = blocked + straggler pass

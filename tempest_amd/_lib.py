@@ -25,6 +25,7 @@ SIGNATURES = {
     "tph_ctx_destroy": (c_int, [ptr]),
     "tph_set_stream": (c_int, [ptr, ptr]),
     "tph_synchronize": (c_int, [ptr]),
+    "tph_warmup": (c_int, [ptr]),
     "tph_set_option": (c_int, [ptr, c_int, c_int]),
     "tph_history_append": (c_int, [ptr, ptr, ptr, ptr, c_i64, c_i64, c_dbl, c_dbl, c_i64]),
     "tph_history_size": (c_i64, [ptr]),

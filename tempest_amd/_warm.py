@@ -109,8 +109,21 @@ def start(config, state):
         def ctx():
             torch.cuda.set_device(dev)
             c = state.ctx
-            # ... and the library's own code object: any launch loads it (a 64-particle prior draw into a scratch tensor)
-            c.prior_draw(torch.empty(d, 64, dtype=torch.float64, device=dev), 0, 0)
-            c.synchronize()
+            # ... and the library's own code objects, ALL of them (one per translation unit: an empty launch of each loads it) --
+            # met one by one in a run's first iterations they were its first reweight, fit, resample, d > 16 proposal, clustering fit
+            c.warmup()
         w.add("device_context", ctx)
+    # the kernel families the library's own host code launches through torch around a clustering fit / a several-modes fit
+    # (cluster.py, modes.py: label bookkeeping): first used in the middle of iteration 4 they were 0.22 s of config 3's first run
+    if getattr(config, "clustering", False):
+        li = torch.arange(8, device=dev) % 3
+        for name, fn in (("cl_bincount", lambda: torch.bincount(li, minlength=4).to(torch.float64)),
+                         ("cl_cumsum", lambda: (torch.cumsum((li > 0).to(torch.int32), 0) - 1).clamp(min=0).to(torch.int32)),
+                         ("cl_index", lambda: (li.to(torch.int32))[li.long()].contiguous()),
+                         ("cl_compare_sum", lambda: int((li == 1).sum().item())),
+                         ("cl_where", lambda: torch.where(x > 0, x, torch.zeros_like(x)).sum()),
+                         ("cl_cat_stack", lambda: torch.cat([torch.stack([x.sum(), x.sum()]), x.reshape(-1)]).cpu()),
+                         ("cl_softmax", lambda: torch.softmax(x, dim=0).T.contiguous()),
+                         ("cl_nonzero", lambda: torch.nonzero(li >= 1).reshape(-1))):
+            w.add(name, on_side_stream(fn))
     return w

@@ -199,6 +199,16 @@ tph_part tph_partition(const tph_ctx* ctx, int64_t n); // partition of the first
 int tph_partials_reserve(tph_ctx* ctx, size_t bytes);  // ctx->partials of at least that many bytes
 
 int tph_scratch_reserve(tph_ctx* ctx, size_t bytes);
+void tph_warm_cluster(hipStream_t stream);
+void tph_warm_modes(hipStream_t stream);
+void tph_warm_mutate(hipStream_t stream);
+void tph_warm_p2p(hipStream_t stream);
+void tph_warm_propose_blkm(hipStream_t stream);
+void tph_warm_propose_mf(hipStream_t stream);
+void tph_warm_propose_sm(hipStream_t stream);
+void tph_warm_resample(hipStream_t stream);
+void tph_warm_reweight(hipStream_t stream);
+void tph_warm_student(hipStream_t stream);
 int tph_cdf_plain(tph_ctx* ctx, const double* w_dev, int64_t n, const double* thr_dev, double* cdf_dev);   // resample.hip: the plain scan
 // mapped, growing arrays (ctx.hip)
 int tph_vm_reserve(tph_vm_set* v, int device, int slabs, size_t stride_bytes, size_t piece_bytes);

@@ -586,6 +586,31 @@ extern "C" int tph_set_option(tph_ctx* ctx, int option, int value) {
   return 0;
 }
 
+// Every translation unit of the library is a code object of its own, loaded by the HIP runtime when one of its kernels is first
+// launched -- 20 MB of them (the proposal kernels' template instantiations), tens of milliseconds each as the first process on a
+// machine.  A run met them one by one in its first iterations (first reweight, first fit, first resample, first d > 16 proposal,
+// first clustering fit).  This launches one empty kernel of each unit: called from the Sampler's start-up thread, the loads
+// happen beside torch's own, before the first iteration needs them.
+extern "C" int tph_warmup(tph_ctx* ctx) {
+  TPH_REQUIRE(ctx, "tph_warmup: ctx is NULL");
+  TPH_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, s, (unsigned int*)nullptr, 0);
+  tph_warm_cluster(s);
+  tph_warm_modes(s);
+  tph_warm_mutate(s);
+  tph_warm_p2p(s);
+  tph_warm_propose_blkm(s);
+  tph_warm_propose_mf(s);
+  tph_warm_propose_sm(s);
+  tph_warm_resample(s);
+  tph_warm_reweight(s);
+  tph_warm_student(s);
+  TPH_LAUNCH_CHECK();
+  TPH_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 extern "C" int tph_synchronize(tph_ctx* ctx) {
   TPH_REQUIRE(ctx, "tph_synchronize: ctx is NULL");
   TPH_HIP(hipStreamSynchronize(ctx->stream));

@@ -1344,6 +1344,8 @@ __global__ void __launch_bounds__(1024) k_adapt(int kernel, const double* __rest
   if (state[1] != 0.0) return;          // stopping rule already fired: later (speculative) steps are no-ops (on every rank)
   if (partials) {                        // the sums of tph_accept's block partials, folded in here (canonical order: see above)
     const int ncol = 1 + K;
+    __shared__ double s_vs[1024];          // the rank's shard sums stay in LDS when they fit (one GPU: no trip through memory)
+    if (vl * ncol <= 1024) vs = exchange ? vs : s_vs;
     vshard_colsums(partials, nblocks, vl, ncol, vs);
     __syncthreads();
     const double* all = vs;
@@ -1437,3 +1439,6 @@ extern "C" int tph_cluster_counts(tph_ctx* ctx, const int32_t* assign_dev, int64
   TPH_LAUNCH_CHECK();
   return 0;
 }
+
+// (tph_warmup: the first launch of a kernel of this translation unit loads its code object; an empty launch pre-pays that)
+void tph_warm_mutate(hipStream_t stream) { hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, (unsigned int*)nullptr, 0); }

@@ -649,3 +649,6 @@ int tph_blkm_multi(tph_ctx* ctx, int kernel, double* u, const int32_t* assign, i
   return blkm_multi<TPH_KERNEL_RWM>(ctx, u, assign, n, ld, K, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, mu_, mup, pend,
                                     rounds, todo_cnt, todo_rows, todo_att, per_mode);
 }
+
+// (tph_warmup: the first launch of a kernel of this translation unit loads its code object; an empty launch pre-pays that)
+void tph_warm_propose_blkm(hipStream_t stream) { hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, (unsigned int*)nullptr, 0); }

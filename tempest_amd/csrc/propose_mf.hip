@@ -945,3 +945,6 @@ bool tph_mf_selftest(tph_ctx* ctx) {
                   "use the FP64 kernels (TPH_OPT_SCREEN off)\n", worst);
   return false;
 }
+
+// (tph_warmup: the first launch of a kernel of this translation unit loads its code object; an empty launch pre-pays that)
+void tph_warm_propose_mf(hipStream_t stream) { hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, (unsigned int*)nullptr, 0); }

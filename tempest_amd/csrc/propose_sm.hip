@@ -467,3 +467,6 @@ int tph_propose_sm(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, c
     return propose_sm<TPH_KERNEL_TPCN>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend);
   return propose_sm<TPH_KERNEL_RWM>(ctx, u, n, ld, means, chol, winv, dof, sigmas, bc, seed, tick, item0, up, maha_u, maha_up, pend);
 }
+
+// (tph_warmup: the first launch of a kernel of this translation unit loads its code object; an empty launch pre-pays that)
+void tph_warm_propose_sm(hipStream_t stream) { hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, (unsigned int*)nullptr, 0); }

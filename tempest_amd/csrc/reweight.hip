@@ -224,27 +224,35 @@ __global__ void __launch_bounds__(1024) k_reweight_vshards(const double* __restr
   if (lane == 0) { double* o = out + ((size_t)v * nb + b) * 3; o[0] = t.m; o[1] = t.s1; o[2] = t.s2; }
 }
 
-// The V per-shard triples folded in shard order, one wave per beta (lane 0 folds: V <= 48).  shards != NULL: the triples as
-// stored (gathered from all ranks, [V][nb][3]); else they are formed here from this rank's block partials (one GPU: no store in
-// between, the same values).  out_host != NULL: results into pinned host memory with a sequence word behind them (system-scope
-// release) -- tph_reweight_eval polls that word instead of queueing a device-to-host copy and waiting on the stream: the ~25
-// adaptive-beta passes of one PS iteration are latency-bound, and this removes a copy packet and the runtime's completion path
-// from every one of them.
+// The V per-shard triples folded in shard order.  shards != NULL: the triples as stored (gathered from all ranks, [V][nb][3]);
+// else they are formed here from this rank's block partials (one GPU: the same values, no trip through memory): the 16 waves
+// share the (shard, beta) pairs -- a pair's triple is one wave's work (vshard_triple) --, park the triples in LDS, and wave b's
+// first lane folds beta b's V triples in shard order (V <= 48: a serial chain of merges, ~1 us).  out_host != NULL: results into
+// pinned host memory with a sequence word behind them (system-scope release) -- tph_reweight_eval polls that word instead of
+// queueing a device-to-host copy and waiting on the stream: the ~25 adaptive-beta passes of one PS iteration are latency-bound,
+// and this removes a copy packet and the runtime's completion path from every one of them.
 __global__ void __launch_bounds__(1024) k_reweight_fold(const double* __restrict__ partials, int bv, const double* __restrict__ shards,
                                                         int V, int nb, double* __restrict__ out, double* __restrict__ seq_host, double seq) {
-  const int b = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (b < nb) {
-    trip acc{-DBL_MAX, 0.0, 0.0};
-    for (int v = 0; v < V; ++v) {
-      trip t;
-      if (shards) { const double* q = shards + ((size_t)v * nb + b) * 3; t = trip{q[0], q[1], q[2]}; }
-      else t = vshard_triple(partials, v, bv, nb, b, lane);
-      if (lane == 0) acc = v == 0 ? t : trip_merge(acc, t);
+  __shared__ double s_t[48 * TPH_MAX_NB * 3];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  if (!shards) {
+    for (int p = w; p < V * nb; p += nw) {
+      const int v = p / nb, b = p - v * nb;
+      const trip t = vshard_triple(partials, v, bv, nb, b, lane);
+      if (lane == 0) { s_t[3 * p] = t.m; s_t[3 * p + 1] = t.s1; s_t[3 * p + 2] = t.s2; }
     }
-    if (lane == 0) {
-      if (acc.m == -DBL_MAX) acc.m = -INFINITY;  // empty input
-      out[b * 3 + 0] = acc.m; out[b * 3 + 1] = acc.s1; out[b * 3 + 2] = acc.s2;
+    __syncthreads();
+  }
+  const double* src = shards ? shards : s_t;
+  if (w < nb && lane == 0) {
+    const int b = w;
+    trip acc{src[(size_t)b * 3], src[(size_t)b * 3 + 1], src[(size_t)b * 3 + 2]};
+    for (int v = 1; v < V; ++v) {
+      const double* q = src + ((size_t)v * nb + b) * 3;
+      acc = trip_merge(acc, trip{q[0], q[1], q[2]});
     }
+    if (acc.m == -DBL_MAX) acc.m = -INFINITY;  // empty input
+    out[b * 3 + 0] = acc.m; out[b * 3 + 1] = acc.s1; out[b * 3 + 2] = acc.s2;
   }
   if (seq_host) {
     __syncthreads();
@@ -543,3 +551,6 @@ extern "C" int tph_sum_sq_max(tph_ctx* ctx, const double* w_dev, int64_t n, doub
   for (int i = 0; i < 3; ++i) out_host[i] = ctx->pinned[i];
   return 0;
 }
+
+// (tph_warmup: the first launch of a kernel of this translation unit loads its code object; an empty launch pre-pays that)
+void tph_warm_reweight(hipStream_t stream) { hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, (unsigned int*)nullptr, 0); }

@@ -75,3 +75,6 @@ extern "C" int tph_student_weights(tph_ctx* ctx, const double* delta_dev, const 
   TPH_LAUNCH_CHECK();
   return 0;
 }
+
+// (tph_warmup: the first launch of a kernel of this translation unit loads its code object; an empty launch pre-pays that)
+void tph_warm_student(hipStream_t stream) { hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, (unsigned int*)nullptr, 0); }

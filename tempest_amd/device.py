@@ -119,6 +119,10 @@ class HipContext:
     def set_option(self, option, value):
         check(self.lib.tph_set_option(self._ctx, int(option), int(value)), "tph_set_option")
 
+    def warmup(self):
+        """Load every code object of the library now (tph_warmup) instead of at each kernel family's first use."""
+        check(self.lib.tph_warmup(self._ctx), "tph_warmup")
+
     def synchronize(self):
         check(self.lib.tph_synchronize(self._ctx), "tph_synchronize")
 

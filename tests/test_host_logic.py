@@ -300,3 +300,19 @@ def test_regime_rule_does_not_oscillate(monkeypatch):
     import inspect
     src = inspect.getsource(mcmc.StepEngine._regime)
     assert "os.environ" not in src and "import os" not in src
+
+
+def test_virtual_shards_of_the_canonical_partition():
+    """csrc/common.h: tph_vshards_for and its Python twin -- V depends on the particle count alone (never on the number of
+    ranks): the largest of 48, 16, 12, 8, 6, 4, 3, 2, 1 with n % (256 V) == 0.  The BASELINE ensembles are powers of two (V = 16:
+    1, 2, 4, 8 or 16 GPUs give the same bits); 3 * 2^k particles also admit 3, 6, 12, 24, 48."""
+    from tempest_amd.device import vshards_for
+    assert vshards_for(1048576) == 16 and vshards_for(2097152) == 16 and vshards_for(65536) == 16 and vshards_for(262144) == 16
+    assert vshards_for(49152) == 48 and vshards_for(12288) == 48 and vshards_for(3 * 4096) == 48
+    assert vshards_for(512) == 2 and vshards_for(1024) == 4 and vshards_for(256) == 1 and vshards_for(768) == 3
+    assert vshards_for(1000) == 1 and vshards_for(4096) == 16 and vshards_for(2048) == 8
+    for n in (256 * k for k in range(1, 200)):
+        v = vshards_for(n)
+        assert n % (256 * v) == 0 and v in (48, 16, 12, 8, 6, 4, 3, 2, 1)
+        assert all(n % (256 * w) != 0 for w in (48, 16, 12, 8, 6, 4, 3, 2, 1) if w > v)
+    # the C side exports the same rule through the bench digest only; the kernels are pinned by tests/test_distributed.py (GPU)
