@@ -90,16 +90,13 @@ def device_volume_variation(ctx, w_dev, n_global, comm=None) -> float:
     centre = None
     if d <= 12:
         # one pass for mean and covariance: moments about the previous call's mean; the library leaves the new mean in the
-        # same buffer.  First call: any point inside the data will do -- the first stored row, or on a sharded run (where the
-        # centre must be the same on every rank) the centre of the unit cube
+        # same buffer.  First call: any point inside the data will do -- the centre of the unit cube, on one GPU and on every
+        # rank of a sharded run alike (the centre is part of the arithmetic: the same one keeps the statistic bitwise the same
+        # on any number of ranks)
         centre = getattr(ctx, "_vv_centre", None)
         if centre is None:
-            if comm is not None and comm.active:
-                import torch
-                centre = torch.full((d,), 0.5, dtype=torch.float64, device=ctx.device)
-            else:
-                from .device import KEY_U
-                centre = ctx.posterior_rows(None, 1, key=KEY_U)[0][0].contiguous().clone()
+            import torch
+            centre = torch.full((d,), 0.5, dtype=torch.float64, device=ctx.device)
             ctx._vv_centre = centre
     return float(ctx.volume_variation(w_dev, centre))
 

@@ -388,6 +388,9 @@ BITWISE_CASES = {
     "rosen10_65536": dict(n_dim=10, target="rosen", n=65536, worlds=(2, 4), sample="tpcn", resample="mult"),
     "gauss10_syst_12288": dict(n_dim=10, target="gauss", n=12288, worlds=(2, 3, 4), sample="rwm", resample="syst"),
     "gauss50_12288": dict(n_dim=50, target="gauss", n=12288, worlds=(2, 3, 4), sample="tpcn", resample="mult", pin="screened"),
+    # dynamic mode (tempest/steps/reweight.py:427-495): the beta search is driven by the volume variation of the weighted history,
+    # whose moments and Mahalanobis sum are formed over the same partition
+    "gauss10_dynamic_12288": dict(n_dim=10, target="gauss", n=12288, worlds=(2, 3, 4), sample="tpcn", resample="mult", vv=0.5),
 }
 
 
@@ -414,7 +417,8 @@ def bitwise_run(name, device=0):
         os.environ["TEMPEST_AMD_REGIME"] = c["pin"]
     try:
         s = tp.Sampler(lambda u: 20 * u - 10, {"gauss": gauss, "rosen": rosen}[c["target"]], d, n_particles=c["n"], vectorize=True,
-                       clustering=False, sample=c["sample"], resample=c["resample"], random_state=5, device=device)
+                       clustering=False, sample=c["sample"], resample=c["resample"], random_state=5, device=device,
+                       volume_variation=c.get("vv"))
         s.run(n_total=2 * c["n"], progress=False)
     finally:
         if c.get("pin"):
@@ -441,7 +445,8 @@ def bitwise_run(name, device=0):
     return {"logz": float(s.evidence()[0]).hex(), "beta": [float(v).hex() for v in st.get_history("beta")],
             "steps": [int(v) for v in st.get_history("steps")], "logz_t": [float(v).hex() for v in st.get_history("logz")],
             "ess": [float(v).hex() for v in st.get_history("ess")], "acc": [float(v).hex() for v in st.get_history("acceptance")],
-            "eff": [float(v).hex() for v in st.get_history("efficiency")], "ensemble_sha256": h.hexdigest(),
+            "eff": [float(v).hex() for v in st.get_history("efficiency")], "cv": [float(v).hex() for v in st.get_history("cv")],
+            "ensemble_sha256": h.hexdigest(),
             "history_logl_sha256": hh.hexdigest(), "logz_float": float(s.evidence()[0])}
 
 

@@ -176,10 +176,10 @@ def test_world_size_invariance_is_bitwise(tmp_path, monkeypatch, world, p2p):
     from tests._dist_workers import BITWISE_CASES, bitwise_gpu_worker
     if not p2p:
         monkeypatch.setenv("TEMPEST_AMD_P2P", "0")
-        monkeypatch.setenv("TEMPEST_AMD_TEST_CASES", "rosen10_49152,gauss50_12288")
+        monkeypatch.setenv("TEMPEST_AMD_TEST_CASES", "rosen10_49152,gauss50_12288,gauss10_dynamic_12288")
     _spawn(bitwise_gpu_worker, world, tmp_path)
     rs = [json.load(open(tmp_path / f"bitwise{r}.json")) for r in range(world)]
-    keys = ("logz", "beta", "steps", "logz_t", "ess", "acc", "eff", "ensemble_sha256", "history_logl_sha256")
+    keys = ("logz", "beta", "steps", "logz_t", "ess", "acc", "eff", "cv", "ensemble_sha256", "history_logl_sha256")
     assert rs[0], "no case ran for this world size"
     for name, got in rs[0].items():
         assert world in BITWISE_CASES[name]["worlds"]
