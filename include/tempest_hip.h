@@ -149,6 +149,11 @@ int tph_warmup(tph_ctx* ctx);
  * 1 = per-workgroup contiguous ranges with stealing; 2 = eight ranges, one per XCD's workgroups (the 8 particles behind one
  * 64-byte sector of u then go through one L2: half the HBM reads, not faster -- csrc/propose_mf.hip).  Same proposals. */
 #define TPH_OPT_MF_DEAL 19
+/* TPH_OPT_BLK_STAGE: 1 = the one-try rounds of the matrix-core blocked kernel (one mode) stage every panel's matrix blocks in
+ * LDS once per workgroup -- loaded while the previous panel's products run, one barrier per panel, two buffers -- instead of
+ * streaming them to each of its four waves (default, 1: 160 -> 142 us per round at 100-D x 131072, 48.8 -> 47.3 at 50-D x 65536,
+ * profiles/r05_blkm_stage.json); 0 = streamed.  Same proposals bit for bit (same instructions on the same operands). */
+#define TPH_OPT_BLK_STAGE 20
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- multi-GPU: one process per GPU --------------------------------------

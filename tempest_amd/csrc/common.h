@@ -128,6 +128,7 @@ struct tph_ctx {
   // matrix-core round kernel of the blocked path (propose_blkm.hip): TPH_OPT_BLK_MFMA and its blocked copies of L and L^-1
   int blk_mfma = 1;
   int blk_tries = 0;                // TPH_OPT_BLK_TRIES: attempts a round of the matrix-core kernel gives its failing columns in place (0 = by n_dim)
+  int blk_stage = 1;                // TPH_OPT_BLK_STAGE: 1 (default) = one-try rounds of one mode stage the panels' matrix blocks in LDS (k_propose_blkm_lds; bitwise the same draws)
   int blk_fan = 1;                  // TPH_OPT_BLK_FAN: list rounds give a straggler up to 16 attempts side by side (1 = default)
   void* bm_buf = nullptr;
   size_t bm_bytes = 0;

@@ -433,6 +433,321 @@ __global__ void __launch_bounds__(256) k_propose_blkm(double* __restrict__ u, in
   }
 }
 
+template <int KERNEL, int NP, bool HAS_BC>
+__global__ void __launch_bounds__(256) k_propose_blkm_lds(double* __restrict__ u, int64_t n, int64_t ld, int d, const double* __restrict__ means_all,
+                                                      const double* __restrict__ Lm_all, const double* __restrict__ Wm_all,
+                                                      const double* __restrict__ dof, const double* __restrict__ sigmas,
+                                                      const uint8_t* __restrict__ bc, uint64_t seed, tph_stepctl tick, int64_t item0,
+                                                      double* __restrict__ up, double* __restrict__ maha_u, double* __restrict__ maha_up,
+                                                      uint8_t* __restrict__ pend, const int32_t* __restrict__ cnt_in,
+                                                      const int32_t* __restrict__ rows_in, int att, int32_t* __restrict__ cnt_out,
+                                                      int32_t* __restrict__ rows_out, const int32_t* __restrict__ mt, int64_t tiles_max, int tries,
+                                                      const int32_t* __restrict__ att_in, int32_t* __restrict__ att_out, int fan_div) {
+  // cnt_in == NULL: round 0, attempt 0 of every particle and the chores of the step (pending moves, form at u, Gamma scale);
+  // cnt_in != NULL: attempt `att` of the particles listed by the round before; the step scale comes from where round 0 parked it.
+  // MULTI: several modes -- the wave's tile, its mode and the mode's stretch of the lists come from the tile table mt (above).
+  constexpr int NS = 4 * NP;
+  constexpr bool MULTI = false;
+  extern __shared__ double bm_lds[];          // two panel buffers of NS blocks (64 doubles each)
+  __shared__ int s_fail[4], s_mode[4];
+  __shared__ int s_base;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int k = lane >> 4, nn = lane & 15;
+  const bool first = cnt_in == nullptr;
+  const int64_t T = (int64_t)blockIdx.x * 4 + wid;
+  int mode = 0, lbase = 0;                // the wave's mode; where its mode's stretch of the list arrays starts
+  bool live;
+  int64_t i;
+  // FAN-OUT (one mode, att_out given): a listed particle gets G consecutive columns of a tile -- its next G attempts side by side,
+  // the first in bounds in attempt order wins -- with G the largest power of two (<= 16) that keeps the fanned-out list within a
+  // fraction 1 / fan_div of the ensemble's columns.  A round over a short list costs one tile's chain of latencies whatever it holds; spent on G attempts
+  // per particle instead of one it empties the list G times as fast (config 2 mid-run: 4-6 rounds -> 2).  The attempt the NEXT
+  // round starts from travels through att_out / att_in (the width is chosen on the device, from the list's length).
+  int G = 1, lgG = 0, att_base = att;
+  if (!MULTI) {
+    const int64_t slot = T * 16 + nn;
+    int64_t total = n;
+    if (!first) {
+      total = *cnt_in;
+      if (att_out) {
+        att_base = *att_in;
+        while (G < 16 && 2 * (int64_t)fan_div * G * total <= n) { G *= 2; ++lgG; }
+      }
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (att == tries && tick.ctl)          // the redraw probe from ALL particles' first `tries` attempts
+          const_cast<double*>(tick.ctl)[8] = bm_probe((double)total / (double)n, tries);
+        if (att_out) *att_out = att_base + tries * G;
+      }
+      total *= G;
+      if ((int64_t)blockIdx.x * 64 >= total) return;                        // the whole block (uniform): nothing listed for it
+    } else if (att_out && blockIdx.x == 0 && threadIdx.x == 0) {
+      *att_out = tries;
+    }
+    live = slot < total;
+    i = first ? (live ? slot : n - 1) : (int64_t)rows_in[live ? (slot >> lgG) : 0];  // dead columns shadow a particle, never store
+  } else {
+    const int ntiles = mt[0];
+    const int32_t* tiles = mt + 4 + 3 * BM_KMAX;
+    const int32_t* order = tiles + 4 * tiles_max;
+    const bool valid = T < ntiles;
+    const int t4 = valid ? 4 * (int)T : 0;
+    mode = tiles[t4];
+    lbase = tiles[t4 + 3];
+    const int start = tiles[t4 + 1], count = tiles[t4 + 2];
+    if (first) {
+      live = valid && nn < count;
+      i = order[start + (live ? nn : 0)];
+      if (att_out && valid && start == lbase && lane == 0) att_out[mode] = tries;     // (the mode's first tile speaks for it)
+    } else {
+      const int j16 = start - lbase, cm = cnt_in[mode];
+      if (att_out) {                                   // fan-out, per mode: its list against its own particle count
+        att_base = att_in[mode];
+        const int nm = mt[4 + BM_KMAX + mode];
+        while (G < 16 && 2 * (int64_t)fan_div * G * cm <= nm) { G *= 2; ++lgG; }
+        if (valid && j16 == 0 && lane == 0) att_out[mode] = att_base + tries * G;
+      }
+      live = valid && j16 + nn < cm * G;
+      i = live ? (int64_t)rows_in[lbase + ((j16 + nn) >> lgG)] : (int64_t)order[start];
+      if (att == tries && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl) {
+        int64_t total = 0;
+        for (int m = 0; m < mt[1]; ++m) total += cnt_in[m];
+        const_cast<double*>(tick.ctl)[8] = bm_probe((double)total / (double)n, tries);
+      }
+    }
+  }
+  const bool wave_on = __ballot(live) != 0ull;     // a wave without particles skips the arithmetic and only meets the barriers
+  if (!first) {                                   // (uniform) blocks whose four tiles are all beyond their lists
+    if (lane == 0) s_fail[wid] = wave_on;
+    __syncthreads();
+    if (!(s_fail[0] | s_fail[1] | s_fail[2] | s_fail[3])) return;
+    __syncthreads();
+  }
+  const double* __restrict__ means = means_all + (size_t)mode * d;
+  const double* __restrict__ Lm = Lm_all + (size_t)mode * bm_blocks(NP) * 64;
+  const double* __restrict__ Wm = Wm_all + (size_t)mode * bm_blocks(NP) * 64;
+  const int npairs = (d + 1) >> 1;
+  const double sigma = sigmas[mode];
+  const bool carry = KERNEL == TPH_KERNEL_TPCN && tick.carry();
+  const double a_fac = (KERNEL == TPH_KERNEL_TPCN) ? tph_sqrt(1.0 - sigma * sigma) : 1.0;
+  double X[NS];                                  // the B operands: normals (permuted steps), then rows of the proposal (natural steps)
+  bool all_ok = false;
+
+  // sum over the rows of |T x|^2 for the tile (x in X as natural-step operands): every lane ends with ITS column's value
+  auto form = [&](const double* __restrict__ Tb) -> double {
+    double part = 0.0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      bm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4 * p + 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Tb[(size_t)bm_blk(p, s) * 64 + lane], X[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part = fma(acc[q], acc[q], part);
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    return part;
+  };
+
+  double b_fac_s = sigma;
+  if (wave_on) {
+    // ---- round 0: pending accepted move (deferred tph_accept), form at u (first step of a run; afterwards carried), Gamma scale
+    double b_fac = sigma;
+    if (first) {
+      const bool pd = pend && live && pend[i];
+      if (pd || (KERNEL == TPH_KERNEL_TPCN && !carry)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const int r = 4 * s + k;
+          double uj = 0.0;
+          if (r < d) {
+            uj = u[(size_t)r * ld + i];
+            if (pd) { uj = up[(size_t)r * ld + i]; u[(size_t)r * ld + i] = uj; }
+            uj -= (KERNEL == TPH_KERNEL_TPCN) ? means[r] : 0.0;
+          }
+          X[s] = uj;
+        }
+      }
+      if (KERNEL == TPH_KERNEL_TPCN) {
+        double m_u;
+        if (carry) {
+          m_u = maha_u[i];
+        } else {
+          m_u = form(Wm);
+          if (live && k == 0 && maha_u) maha_u[i] = m_u;
+        }
+        const double nu = dof[mode];
+        tph_rng gg(seed, tick, TPH_TAG_GAMMA, (uint64_t)(item0 + i));
+        const double gam = tph_gamma_mt(gg, 0.5 * ((double)d + nu)) * tph_div(2.0, nu + m_u);
+        b_fac = sigma * tph_sqrt(tph_rcp(gam));
+        if (live && k == 0) maha_up[i] = b_fac;        // parked for the later rounds of this particle
+      } else if (live && k == 0 && maha_u) {
+        maha_u[i] = 0.0;
+      }
+      // (the four lanes of a column read the flag in the same instruction of one wave: the store is behind their loads)
+      if (pd && k == 0) pend[i] = 0;
+    } else if (KERNEL == TPH_KERNEL_TPCN) {
+      b_fac = maha_up[i];
+    }
+
+    // ---- the round's attempts att, att + 1, ... att + tries - 1: every column still out of bounds gets the next one IN PLACE (a
+    // tile with one failing column pays a whole pass for it, but late in a run that is a fifth of the tiles for one more pass --
+    // against a list launch, a closing pass and their launch latencies for a handful of particles: config 2, 35-70 us per step)
+    // (Written out, not looped: inside a loop the compiler keeps every address of the matrix blocks and of the current point
+    // live across the body -- 256 VGPRs, one wave per SIMD, 705 against 198 us at 131 072 x 100-D -- where the straight-line form
+    // needs 125.)
+    b_fac_s = b_fac;
+  }
+  // ---- the round's ONE attempt, every wave of the workgroup in step (a wave without particles multiplies zeros): the matrix
+  // blocks of a panel are staged in LDS ONCE per workgroup -- loaded into registers while the previous panel's products run,
+  // stored behind them, one barrier per panel, two buffers -- instead of streamed from L1 / L2 by each of the four waves
+  // (512 bytes per instruction and wave: the operand stream, not the matrix cores, bounded the un-staged kernel).
+  {
+    const double b_fac = b_fac_s;
+    bool pending = live;
+    const bool want_form = KERNEL == TPH_KERNEL_TPCN;
+    double stg[NP];                                           // this thread's share of the next panel: (4 p + 4) blocks x 64 / 256 = p + 1 values
+    auto stage_load = [&](const double* __restrict__ Tb, const int p) {
+      const double* src = Tb + (size_t)bm_blk(p, 0) * 64;
+#pragma unroll
+      for (int k = 0; k < NP; ++k)
+        if (k <= p) stg[k] = src[threadIdx.x + 256 * k];
+    };
+    auto stage_store = [&](const int p, const int buf) {
+      double* dst = bm_lds + (size_t)buf * NS * 64;
+#pragma unroll
+      for (int k = 0; k < NP; ++k)
+        if (k <= p) dst[threadIdx.x + 256 * k] = stg[k];
+    };
+    {
+      // the normals of the attempt: lane (k, n) draws pairs k, k + 4, ... of particle n = its operands of steps 2c, 2c + 1
+      stage_load(Lm, NP - 1);
+      tph_rng gz(seed, tick, TPH_TAG_NORMAL, (uint64_t)(item0 + i));
+      const uint32_t d0 = (uint32_t)(att_base + (nn & (G - 1))) * (uint32_t)npairs;
+#pragma unroll
+      for (int c = 0; c < NS / 2; ++c) {
+        const int q = k + 4 * c;
+        double z0 = 0.0, z1 = 0.0;
+        if (pending && q < npairs) gz.normal2(d0 + (uint32_t)q, z0, z1);
+        X[2 * c] = z0;
+        X[2 * c + 1] = z1;
+      }
+      stage_store(NP - 1, 0);
+      __syncthreads();
+    }
+    const double* __restrict__ uq = (const double*)u;
+    const double* __restrict__ mq = means;
+    bool ok = true;
+    int buf = 0;
+#pragma unroll
+    for (int p = NP - 1; p >= 0; --p) {
+      if (p > 0) stage_load(Lm, p - 1);
+      else if (want_form) stage_load(Wm, 0);
+      const double* __restrict__ Ls = bm_lds + (size_t)buf * NS * 64;
+      bm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s2 = 0; s2 < 4 * p + 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[s2 * 64 + lane], X[s2], acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 16 * p + k + 4 * q;
+        double v = 0.0;
+        if (r < d) {
+          const double ur = uq[(size_t)r * ld + i];
+          const double mr = (KERNEL == TPH_KERNEL_TPCN) ? mq[r] : 0.0;
+          const double base = (KERNEL == TPH_KERNEL_TPCN) ? fma(a_fac, ur - mr, mr) : ur;
+          v = fma(b_fac, acc[q], base);
+          const uint8_t f = HAS_BC ? bc[r] : (uint8_t)TPH_BC_STRICT;
+          if (f == TPH_BC_PERIODIC) v = bc_periodic(v);
+          else if (f == TPH_BC_REFLECTIVE) v = bc_reflective(v);
+          else ok = ok && (v >= 0.0) && (v <= 1.0);
+        }
+        X[4 * p + q] = v;
+      }
+      if (p > 0) stage_store(p - 1, buf ^ 1);
+      else if (want_form) stage_store(0, buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+    const unsigned long long okb = __ballot(ok && pending && att_base + (nn & (G - 1)) < PROP_MAX_ATTEMPTS);
+    const unsigned int okt = (unsigned int)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48)) & 0xFFFFu;
+    const unsigned int grp = okt & (((1u << G) - 1u) << (nn & ~(G - 1)));
+    const bool now_ok = ((okt >> nn) & 1u) && (grp & ((1u << nn) - 1u)) == 0u;
+    if (now_ok) {
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        const int r = 4 * s2 + k;
+        if (r < d) up[(size_t)r * ld + i] = X[s2];
+      }
+    }
+    if (want_form) {
+      // |L^-1 (u' - mu)|^2 of every column (those out of bounds are not stored): the panels of L^-1 in ascending order, staged alike
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        const int r = 4 * s2 + k;
+        X[s2] = r < d ? X[s2] - mq[r] : 0.0;
+      }
+      double part = 0.0;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if (p + 1 < NP) stage_load(Wm, p + 1);
+        const double* __restrict__ Ws = bm_lds + (size_t)buf * NS * 64;
+        bm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s2 = 0; s2 < 4 * p + 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[s2 * 64 + lane], X[s2], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part = fma(acc[q], acc[q], part);
+        if (p + 1 < NP) stage_store(p + 1, buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);
+      if (now_ok && k == 0) maha_up[i] = part;
+    } else if (now_ok && k == 0 && maha_up) {
+      maha_up[i] = 0.0;
+    }
+    if (grp) { pending = false; all_ok = true; }
+  }
+  {
+    // the block's failures take ONE slot range of their mode's list (an atomic per wave -- 16 384 of them on one address at
+    // 262 144 particles -- cost 110 us of a 195 us launch with a fifth of the first attempts out of bounds); a block whose
+    // four tiles belong to different modes (at most K - 1 of them) falls back to one atomic per wave
+    const unsigned long long failb = __ballot(live && !all_ok && k == 0 && (nn & (G - 1)) == 0);
+    const int nf = __popcll(failb);
+    if (lane == 0) { s_fail[wid] = nf | (__popcll(__ballot(live && k == 0)) << 8); s_mode[wid] = mode; }
+    __syncthreads();
+    int before = 0, nfail = 0, nlive = 0, m0 = mode;
+    bool same = true;
+    if (MULTI) {                                         // the mode of the block's failures (tiles without failures do not count)
+#pragma unroll
+      for (int w = 3; w >= 0; --w) if (s_fail[w] & 255) m0 = s_mode[w];
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int f = s_fail[w] & 255;
+      before += w < wid ? f : 0;
+      nfail += f;
+      nlive += s_fail[w] >> 8;
+      same = same && (!MULTI || f == 0 || s_mode[w] == m0);
+    }
+    int slot0;
+    if (same) {
+      if (threadIdx.x == 0 && nfail) s_base = atomicAdd(cnt_out + m0, nfail);
+      __syncthreads();
+      slot0 = s_base + before;
+    } else {
+      __syncthreads();
+      int b0 = 0;
+      if (lane == 0 && nf) b0 = atomicAdd(cnt_out + mode, nf);
+      slot0 = __shfl(b0, 0, 64);
+    }
+    if ((failb >> lane) & 1ull) rows_out[lbase + slot0 + __popcll(failb & ((1ull << lane) - 1ull))] = (int32_t)i;
+    if (first && blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl) {      // regime probe: mean attempts implied by this block's failures, 1 / (1 - f)
+      const_cast<double*>(tick.ctl)[8] = bm_probe((double)nfail / fmax(1.0, (double)nlive), tries);
+    }
+  }
+}
+
+
 // TPH_OPT_BLK_TRIES (0 = by dimension: a retry in place costs a whole tile pass, which pays below n_dim 64 -- regime sweep:
 // 65 536 x 50-D 71 -> 62 us, 262 144 x 32-D 99 -> 79 us at one attempt per particle; 131 072 x 100-D 479 -> 598 us at 1.13)
 // (With the list rounds fanned out -- TPH_OPT_BLK_FAN -- a retry in place only pays at n_dim <= 32: 65 536 x 50-D at 1.3 / 1.8
@@ -493,6 +808,26 @@ static int blkm_launch(tph_ctx* ctx, int64_t blocks, double* u, int64_t n, int64
     if (tries > 1) { if (bc) TPH_BM(NPV, true, 3); else TPH_BM(NPV, false, 3); }                                         \
     else { if (bc) TPH_BM(NPV, true, 1); else TPH_BM(NPV, false, 1); }                                                   \
   } while (0)
+  if (!MULTI && tries == 1 && ctx->blk_stage) {
+    // TPH_OPT_BLK_STAGE: the panels' matrix blocks staged in LDS once per workgroup (k_propose_blkm_lds)
+    const size_t lds = sizeof(double) * 2 * (size_t)(4 * np) * 64;
+#define TPH_BML(NPV, BC)                                                                                                 \
+  hipLaunchKernelGGL((k_propose_blkm_lds<KERNEL, NPV, BC>), grid, dim3(256), lds, ctx->stream, u, n, ld, d, means, Lm, Wm, dof, \
+                     sigmas, bc, seed, tick, item0, up, mu_, mup, pend, cnt_in, rows_in, att, cnt_out, rows_out, mt, tiles_max, tries, att_in, att_out, fan_div)
+#define TPH_BML_NP(NPV) do { if (bc) TPH_BML(NPV, true); else TPH_BML(NPV, false); } while (0)
+    switch (np) {
+      case 2: TPH_BML_NP(2); break;
+      case 3: TPH_BML_NP(3); break;
+      case 4: TPH_BML_NP(4); break;
+      case 5: TPH_BML_NP(5); break;
+      case 6: TPH_BML_NP(6); break;
+      default: TPH_BML_NP(7); break;
+    }
+#undef TPH_BML_NP
+#undef TPH_BML
+    TPH_LAUNCH_CHECK();
+    return 0;
+  }
   switch (np) {
     case 2: TPH_BM_NP(2); break;
     case 3: TPH_BM_NP(3); break;

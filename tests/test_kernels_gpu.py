@@ -1269,3 +1269,42 @@ def test_stage_machine_odd_sizes_vs_multilane(dev, kernel, d):
         assert np.all((got[5][0] >= 0) & (got[5][0] <= 1))
         if kernel == "tpcn":
             np.testing.assert_allclose(got[5][1], got[3][1], rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+@pytest.mark.parametrize("d,rounds,bc", [(50, 1, None), (100, 3, None), (65, 2, "mixed"), (33, 4, None)])
+def test_blocked_rounds_with_panels_staged_in_lds_equal_the_streamed_ones(dev, kernel, d, rounds, bc):
+    """TPH_OPT_BLK_STAGE: the matrix-core rounds with every panel's blocks of L and L^-1 staged in LDS
+    once per workgroup issue the SAME matrix instructions on the same operands as the kernel that streams the blocks to each wave:
+    proposals, both Mahalanobis forms, the failure counts of the rounds and the redraw probe are bit for bit the same (full
+    ensemble, list rounds with fan-out, stragglers through the screened launch)."""
+    rs = np.random.RandomState(50 + d)
+    n = 3000
+    means = 0.5 + 0.03 * rs.randn(1, d)
+    A = rs.randn(d, d) / np.sqrt(d)
+    covs = ((A @ A.T + np.eye(d)) * (0.10 ** 2 / 2.0))[None]
+    _, chol, inv = ps.mode_statistics(means, covs)
+    u = np.clip(0.5 + 0.22 * rs.randn(n, d), 0.01, 0.99)
+    dof, sigmas = np.array([1e6]), np.array([2.38 / np.sqrt(d)])
+    flags = omc.bc_flags(d, [1], [min(4, d - 1)]) if bc else omc.bc_flags(d)
+    modes = _Modes(means, chol, inv, dof, dev)
+    st, ft = torch.from_numpy(sigmas).to(dev), torch.from_numpy(flags).to(dev)
+    seed, tick, item0 = 77, 3, 1_000_000
+    got = {}
+    for stage in (0, 1):
+        c = ctx_for(d)
+        c.set_option(0, 4)                 # blocked path
+        c.set_option(4, rounds)
+        c.set_option(15, 1)                # matrix cores
+        c.set_option(16, 1)                # one try per round (the staged kernel's case)
+        c.set_option(20, stage)            # TPH_OPT_BLK_STAGE
+        up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+        state = c.zeros(10)
+        c.propose(kernel, soa(u, dev), None, modes, st, ft, seed, tick, item0, up, mu_, mup, ctl=state)
+        got[stage] = (aos(up), mu_.cpu().numpy(), mup.cpu().numpy(), state.cpu().numpy())
+        c.set_option(20, 0); c.set_option(4, 0); c.set_option(16, 0); c.set_option(0, 0)
+    for a, b in zip(got[0], got[1]):
+        np.testing.assert_array_equal(a, b)
+    want_up = omc.propose(kernel, u, np.zeros(n, dtype=np.int32), means, chol, inv, dof, sigmas, flags, seed, tick, item0)[0]
+    np.testing.assert_allclose(got[1][0], want_up, rtol=1e-11, atol=1e-13)
+    assert np.any(np.any(got[1][0] != u, axis=1))
