@@ -266,14 +266,6 @@ int tph_propose_mf_mode_lists(tph_ctx* ctx, int kernel, double* u, int64_t n, in
 #if defined(__HIPCC__)
 
 // np.logaddexp (numpy/core/src/npymath: npy_logaddexp) restated
-__device__ __forceinline__ double tph_logaddexp(double x, double y) {
-  if (x == y) return x + 0.6931471805599453094;  // also equal infinities
-  double t = x - y;
-  if (t > 0) return x + log1p(exp(-t));
-  if (t <= 0) return y + log1p(exp(t));
-  return t;  // NaN
-}
-
 // ---- lean FP64 elementary functions for the proposal kernels (gfx950) ----
 // The library log/sqrt/division are IEEE-complete (denormal scaling, special cases, < 1 ulp through double-double steps):
 // 60-70 VALU instructions for log, ~14 each for sqrt and a/b.  The proposal kernels are VALU-issue-bound and call them on
@@ -317,6 +309,22 @@ __device__ __forceinline__ double tph_log(double x) {
                             6.666666666666735130e-01);
   const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
   return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+
+// log(1 + e) for 0 <= e <= 1 through the lean log: u = fl(1 + e), the rounding error c = e - (u - 1) of that sum is exact, and
+// log(u + c) = log(u) + c / u to second order in c / u < 2^-53 (the library log1p is ~110 FP64 instructions: with the exp in front
+// of it K1 was bound by VALU issue at 0.43 of the HBM rate)
+__device__ __forceinline__ double tph_log1p_unit(double e) {
+  const double u = 1.0 + e;
+  return tph_log(u) + tph_div(e - (u - 1.0), u);
+}
+// np.logaddexp (numpy/_core/src/npymath/npy_math_internal.h.src: npy_logaddexp): max + log1p(exp(-|x - y|))
+__device__ __forceinline__ double tph_logaddexp(double x, double y) {
+  if (x == y) return x + 0.6931471805599453094;  // also equal infinities
+  double t = x - y;
+  if (t > 0) return x + tph_log1p_unit(exp(-t));
+  if (t <= 0) return y + tph_log1p_unit(exp(t));
+  return t;  // NaN
 }
 
 // ---- Philox4x32-10 (twin of oracle/philox.py) ----
@@ -588,6 +596,22 @@ __device__ __forceinline__ double tph_block_sum(double v, double* sh) {
     v = tph_wave_sum(v);
   }
   return v;
+}
+// NV block-wide sums at once (256 threads): out[k] = the value tph_block_sum(acc[k], .) leaves in thread 0, bit for bit -- the
+// same shuffle tree per wave and (w0 + w2) + (w1 + w3) over the four wave sums -- behind ONE barrier pair instead of NV of them
+// (a register-accumulator kernel with 55 or 66 sums spent ~7 us per block in its barriers).  `sh` holds 4 NV doubles.
+template <int NV>
+__device__ __forceinline__ void tph_block_sum_many(double (&acc)[NV], double* __restrict__ sh, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = tph_wave_sum(acc[k]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sh[wid * NV + k] = acc[k];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < NV; k += 256) out[k] = (sh[k] + sh[2 * NV + k]) + (sh[NV + k] + sh[3 * NV + k]);
 }
 __device__ __forceinline__ double tph_block_max(double v, double* sh) {
   v = tph_wave_max(v);

@@ -643,16 +643,33 @@ extern "C" int tph_history_clear(tph_ctx* ctx) {
 }
 
 // K1: log-mixture update.  Old rows fold in the one new term (one logaddexp); new rows take all T terms in iteration order.
-// HBM: old rows 24 B (read l, C; write C); new rows 16 B + T table terms (scalar loads).
+// HBM: old rows 24 B (read l, C; write C); new rows 16 B + T table terms (scalar loads).  The old rows go two to a lane in
+// 16-byte accesses, two such pairs in flight per lane before the first logaddexp (a row at a time the kernel sat at 0.43 of the
+// HBM rate, waiting on one 8-byte load per lane behind ~100 FP64 instructions of exp and log1p).
 __global__ void __launch_bounds__(256) k_logmix_append(const double* __restrict__ logl, double* __restrict__ cmix,
                                                        int64_t size_old, int64_t size_new,
                                                        const double* __restrict__ table, int tcap, int T) {
   const double* beta = table;
   const double* logz = table + tcap;
   const double* logn = table + 2 * (size_t)tcap;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const double bT = beta[T - 1], zT = logz[T - 1], nT = logn[T - 1];
-  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < size_new; s += stride) {
+  const int64_t pairs = size_old >> 1;
+  const double2* __restrict__ l2 = reinterpret_cast<const double2*>(logl);
+  double2* __restrict__ c2 = reinterpret_cast<double2*>(cmix);
+  auto fold = [&](double2 l, double2 c) {
+    c.x = tph_logaddexp(c.x, l.x * bT - zT + nT);
+    c.y = tph_logaddexp(c.y, l.y * bT - zT + nT);
+    return c;
+  };
+  int64_t p = tid;
+  for (; p + stride < pairs; p += 2 * stride) {
+    const double2 la = l2[p], ca = c2[p], lb = l2[p + stride], cb = c2[p + stride];
+    c2[p] = fold(la, ca);
+    c2[p + stride] = fold(lb, cb);
+  }
+  if (p < pairs) c2[p] = fold(l2[p], c2[p]);
+  for (int64_t s = 2 * pairs + tid; s < size_new; s += stride) {
     double l = logl[s];
     if (s < size_old) {
       cmix[s] = tph_logaddexp(cmix[s], l * bT - zT + nT);

@@ -15,8 +15,7 @@
 // All `bins` candidates of the reference's 99 -> 0 percentile walk at once on the sorted weights S with
 // prefix sums P1 (of S) and P2 (of S^2): candidate i keeps {w >= thr_i}; it passes if
 // ESS(kept)/ESS(all) >= ess; the answer is the largest passing i (tools.py:42-53).
-__device__ __forceinline__ void trim_candidate(const double* __restrict__ S, int64_t n, int bins, double step, int i,
-                                               double& thr, int64_t& first_kept) {
+__device__ __forceinline__ void trim_threshold_of(const double* __restrict__ S, int64_t n, int bins, double step, int i, double& thr) {
   double p = (i == bins - 1 && bins > 1) ? 99.0 : __dmul_rn((double)i, step);   // np.linspace(0, 99, bins)[i]
   double q = p / 100.0;                                                         // np.percentile: q / 100
   // numpy method 'linear': virtual index = (n - 1) * q  (lib/_function_base_impl.py, _QuantileMethods)
@@ -31,9 +30,6 @@ __device__ __forceinline__ void trim_candidate(const double* __restrict__ S, int
     double diff = b - a;   // numpy _lerp
     thr = (g >= 0.5) ? __dadd_rn(b, -__dmul_rn(diff, __dadd_rn(1.0, -g))) : __dadd_rn(a, __dmul_rn(diff, g));
   }
-  int64_t lo = 0, hi = n;  // first k with S[k] >= thr
-  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (S[mid] < thr) lo = mid + 1; else hi = mid; }
-  first_kept = lo;
 }
 
 // The pass test needs, per candidate, the sums of w and w^2 over the kept rows [first_kept_i, n) of the sorted array: the
@@ -42,16 +38,34 @@ __device__ __forceinline__ void trim_candidate(const double* __restrict__ S, int
 // per iteration at 1 048 576 particles).  Deterministic: a block sums its contiguous range of rows split at the segment
 // boundaries inside it (slot = block + segment is unique along the staircase of overlapping pairs), a wave per segment adds its
 // slots, suffix sums from the top segment down give the kept sums.
+// (one wave per candidate: its 64 lanes probe the ends of 64 equal stretches of the remaining range at once -- five rounds of
+// one memory round trip each at 2.6 x 10^7 rows, where a lane bisecting alone makes twenty-five; same predicate, same answer)
 __global__ void __launch_bounds__(256) k_trim_bounds(const double* __restrict__ S, int64_t n, int bins, int64_t* __restrict__ first,
                                                      double* __restrict__ thrs) {
   const double step = bins > 1 ? 99.0 / (double)(bins - 1) : 0.0;
-  for (int i = threadIdx.x; i < bins; i += blockDim.x) {
-    double thr; int64_t lo;
-    trim_candidate(S, n, bins, step, i, thr, lo);
-    first[i] = lo;
-    thrs[i] = thr;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0 && threadIdx.x == 0) first[bins] = n;
+  if (i >= bins) return;                               // (the whole wave)
+  double thr;
+  trim_threshold_of(S, n, bins, step, i, thr);
+  int64_t lo = 0, hi = n;                              // first k with S[k] >= thr lies in [lo, hi]
+  for (;;) {
+    const int64_t width = hi - lo;
+    if (width <= 0) break;
+    const int64_t st = (width + 63) / 64;
+    const int64_t end = lo + (int64_t)(lane + 1) * st;                    // one past my stretch
+    const int64_t at = (end < hi ? end : hi) - 1;
+    const bool valid = lo + (int64_t)lane * st < hi;
+    const bool below = valid && S[at] < thr;                              // then the whole stretch is below
+    const int c = __popcll(__ballot(below));                              // S ascending: the first c stretches
+    const int64_t nlo = lo + (int64_t)c * st;
+    if (st == 1) { lo = nlo < hi ? nlo : hi; break; }
+    if (nlo >= hi) { lo = hi; break; }
+    hi = nlo + st < hi ? nlo + st : hi;
+    lo = nlo;
   }
-  if (threadIdx.x == 0) first[bins] = n;
+  if (lane == 0) { first[i] = lo; thrs[i] = thr; }
 }
 
 // segment of row r: the last i with first[i] <= r (first[] is non-decreasing, first[0] = 0)
@@ -178,7 +192,7 @@ extern "C" int tph_trim_threshold(tph_ctx* ctx, const double* w_dev, int64_t n, 
   double* slots = (double*)((char*)thrs + a_thr);
   double* seg = (double*)((char*)slots + a_slots);
   TPH_HIP(rocprim::radix_sort_keys(tmp, temp_bytes, w_dev, S, (size_t)n, 0, 64, ctx->stream));
-  hipLaunchKernelGGL(k_trim_bounds, dim3(1), dim3(256), 0, ctx->stream, S, n, bins, first, thrs);
+  hipLaunchKernelGGL(k_trim_bounds, dim3((bins + 3) / 4), dim3(256), 0, ctx->stream, S, n, bins, first, thrs);
   hipLaunchKernelGGL(k_trim_segsums, dim3(nblk), dim3(256), 0, ctx->stream, S, n, per, first, bins, slots);
   hipLaunchKernelGGL(k_trim_segreduce, dim3(bins), dim3(64), 0, ctx->stream, slots, first, per, seg);
   if (lds > 64 * 1024)
@@ -278,7 +292,7 @@ __device__ __forceinline__ double trim_lerp(const long long* __restrict__ n_glob
   const double a = __longlong_as_double((long long)keys[2 * i]), b = __longlong_as_double((long long)keys[2 * i + 1]);
   if (vi >= (double)(n - 1)) return b;
   if (vi < 0.0) return a;
-  const double g = vi - floor(vi), diff = b - a;   // numpy _lerp, as trim_candidate
+  const double g = vi - floor(vi), diff = b - a;   // numpy _lerp, as trim_threshold_of
   return (g >= 0.5) ? __dadd_rn(b, -__dmul_rn(diff, __dadd_rn(1.0, -g))) : __dadd_rn(a, __dmul_rn(diff, g));
 }
 // part[3 i ..] = local (count, sum w, sum w^2) of the weights >= threshold_i ; part[3 bins ..] = local (sum w, sum w^2)
@@ -866,13 +880,8 @@ __global__ void __launch_bounds__(256) k_wcov_small(const double* __restrict__ h
       }
     }
   }
-  __shared__ double sh[4];
-  double* mine = partials + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * NPL;
-#pragma unroll
-  for (int k = 0; k < NPL; ++k) {
-    double t = tph_block_sum(acc[k], sh);
-    if (threadIdx.x == 0) mine[k] = t;
-  }
+  __shared__ double sh[4 * NPL];
+  tph_block_sum_many<NPL>(acc, sh, partials + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * NPL);
 }
 
 // grid of the register kernel: at 168 VGPRs three of its blocks fit a CU, and a grid past the 768 resident ones only adds
@@ -926,13 +935,8 @@ __global__ void __launch_bounds__(256) k_wmom_small(const double* __restrict__ h
     }
     acc[NPL] += w;
   }
-  __shared__ double sh[4];
-  double* mine = partials + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * NC;
-#pragma unroll
-  for (int k = 0; k < NC; ++k) {
-    double t = tph_block_sum(acc[k], sh);
-    if (threadIdx.x == 0) mine[k] = t;
-  }
+  __shared__ double sh[4 * NC];
+  tph_block_sum_many<NC>(acc, sh, partials + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * NC);
 }
 // out = (S0, mean[d], cov[d][d]) from the column sums csum = (S2 lower triangle, S0, S1[d])
 __global__ void k_wmom_finish(const double* __restrict__ csum, const double* __restrict__ centre, int d, double* __restrict__ out) {
@@ -1380,23 +1384,46 @@ __global__ void __launch_bounds__(256) k_nz_count(const int32_t* __restrict__ co
   __syncthreads();
   if (threadIdx.x == 0) blockcnt[blockIdx.x] = s_c;
 }
-// exclusive scan of the block counts in place (one block); total[0] = number of kept rows
+// exclusive scan of the block counts in place (one block); total[0] = number of kept rows.  A thread owns a run of consecutive
+// blocks; it requests them eight at a time (one by one the run is a chain of memory round trips: 44 us at 25 600 blocks)
 __global__ void __launch_bounds__(1024) k_nz_offsets(int* __restrict__ blockcnt, int nblocks, long long* __restrict__ total) {
   __shared__ long long s_part[1024];
   const int per = (nblocks + 1023) / 1024;
   const int lo = threadIdx.x * per, hi = lo + per < nblocks ? lo + per : nblocks;
   long long sum = 0;
-  for (int b = lo; b < hi; ++b) sum += blockcnt[b];
+  for (int b = lo; b < hi; b += 8) {
+    int v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = b + k < hi ? blockcnt[b + k] : 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += v[k];
+  }
   s_part[threadIdx.x] = sum;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    long long run = 0;
-    for (int t = 0; t < 1024; ++t) { long long v = s_part[t]; s_part[t] = run; run += v; }
-    total[0] = run;
+  // exclusive scan of the 1024 run totals: inside each wave by shuffles, the 16 wave totals by the first lanes
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  long long incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const long long up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
   }
+  __shared__ long long s_wtot[16];
+  if (lane == 63) s_wtot[wid] = incl;
   __syncthreads();
-  long long run = s_part[threadIdx.x];
-  for (int b = lo; b < hi; ++b) { int v = blockcnt[b]; blockcnt[b] = (int)run; run += v; }
+  long long woff = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { const long long v = s_wtot[w]; if (w < wid) woff += v; all += v; }
+  if (threadIdx.x == 0) total[0] = all;
+  long long run = woff + incl - sum;
+  for (int b = lo; b < hi; b += 8) {
+    int v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = b + k < hi ? blockcnt[b + k] : 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (b + k < hi) { blockcnt[b + k] = (int)run; run += v[k]; }
+  }
 }
 // seg[2 v], seg[2 v + 1] = first kept row and number of kept rows of shard v (from the exclusive offsets of its first block)
 __global__ void k_nz_segments(const int* __restrict__ offsets, const long long* __restrict__ total, int vl, int per_shard,
@@ -1408,42 +1435,60 @@ __global__ void k_nz_segments(const int* __restrict__ offsets, const long long* 
   seg[2 * v + 1] = b - a;
 }
 __global__ void k_seg_whole(long long n, long long* __restrict__ seg) { if (!threadIdx.x && !blockIdx.x) { seg[0] = 0; seg[1] = n; } }
+// A block first lists its kept rows in LDS (order preserved: ballots and the 16 wave counts), then moves them with EVERY lane
+// busy: lane k of a pass takes kept row k -- neighbouring lanes read neighbouring kept rows of one coordinate and write
+// neighbouring elements of the working set.  (With one lane per HISTORY row, as until round 5, a wave's load instruction carried
+// as many useful loads as the wave had kept rows: 8 of 64 where 13 % of the rows are kept.)
 __global__ void __launch_bounds__(256) k_nz_scatter(const double* __restrict__ u, int64_t cap, int d,
                                                     const int32_t* __restrict__ counts, const int32_t* __restrict__ labels,
                                                     nz_geom g, const int* __restrict__ offsets, double* __restrict__ uc,
                                                     int64_t ldc, int32_t* __restrict__ cc, int32_t* __restrict__ lc) {
-  __shared__ int s_wave[4];
+  constexpr int NT = NZ_ROWS / 256;
+  __shared__ int s_wave[NT * 4];
+  __shared__ int s_row[NZ_ROWS];
+  __shared__ int s_cnt[NZ_ROWS];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  int64_t out = offsets[blockIdx.x];
+  const int64_t out = offsets[blockIdx.x];
   long long base; int rows;
   nz_block_rows(g, blockIdx.x, base, rows);
-  for (int t = 0; t < NZ_ROWS / 256; ++t) {
+  int cnt[NT], below[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
     const int q = t * 256 + threadIdx.x;
-    const int64_t i = base + q;
-    const int cnt = q < rows ? counts[i] : 0;
-    const bool keep = cnt > 0;
-    const unsigned long long mask = __ballot(keep);
-    const int below = __popcll(mask & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave[wid] = __popcll(mask);
-    __syncthreads();
-    int woff = 0, tot = 0;
+    cnt[t] = q < rows ? counts[base + q] : 0;
+  }
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { if (w < wid) woff += s_wave[w]; tot += s_wave[w]; }
-    if (keep) {
-      const int64_t pos = out + woff + below;
-      cc[pos] = cnt;
-      if (lc) lc[pos] = labels[i];
-      for (int j0 = 0; j0 < d; j0 += 8) {        // eight coordinates in flight per kept row
-        double v[8];
+  for (int t = 0; t < NT; ++t) {
+    const unsigned long long mask = __ballot(cnt[t] > 0);
+    below[t] = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[t * 4 + wid] = __popcll(mask);
+  }
+  __syncthreads();
+  int nk = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = j0 + k < d ? u[(size_t)(j0 + k) * cap + i] : 0.0;
+  for (int t = 0; t < NT; ++t) {
+    int before = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (j0 + k < d) uc[(size_t)(j0 + k) * ldc + pos] = v[k];
-      }
+    for (int w = 0; w < 4; ++w) { const int c = s_wave[t * 4 + w]; if (w < wid) before += c; nk += c; }
+    if (cnt[t] > 0) {
+      const int k = nk - (s_wave[t * 4] + s_wave[t * 4 + 1] + s_wave[t * 4 + 2] + s_wave[t * 4 + 3]) + before + below[t];
+      s_row[k] = t * 256 + threadIdx.x;
+      s_cnt[k] = cnt[t];
     }
-    out += tot;
-    __syncthreads();
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < nk; k += 256) {
+    const int64_t i = base + s_row[k], pos = out + k;
+    cc[pos] = s_cnt[k];
+    if (lc) lc[pos] = labels[i];
+    for (int j0 = 0; j0 < d; j0 += 8) {          // eight coordinates in flight per kept row
+      double v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = j0 + c < d ? u[(size_t)(j0 + c) * cap + i] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (j0 + c < d) uc[(size_t)(j0 + c) * ldc + pos] = v[c];
+    }
   }
 }
 

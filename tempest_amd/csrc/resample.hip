@@ -177,25 +177,49 @@ __global__ void __launch_bounds__(256) k_seg_totals(const double* __restrict__ t
 // (pieces: a rank holds vl virtual shards of every iteration -- common.h: tph_part --, its piece (t, v') is entry t * vl + v' of
 // its list; the global order is iteration, rank, shard.  The totals are added in that order whatever G is: the table, and with it
 // every cumulative weight, is the same on any number of GPUs that divides V.)
-// (the totals are staged in LDS by the whole workgroup first -- one thread walking G x P dependent global loads took 33 us at
-// 40 iterations x 16 shards --; the running sum itself stays ONE thread's serial chain: that order is the definition)
+// (the running sum is ONE thread's serial chain: that order is the definition.  Everything around the chain is done by the
+// whole workgroup: the totals are staged in LDS in the global order, thread 0 turns them into running sums in place -- eight
+// LDS reads requested ahead of the eight dependent additions --, and the entries of this rank are written out by all lanes.
+// One thread doing loads, index arithmetic and stores around each addition took 64 us at 25 iterations x 16 shards.)
 __global__ void __launch_bounds__(256) k_block_table(const double* __restrict__ all, int G, int T, int vl, int rank, double* __restrict__ table) {
-  extern __shared__ double s_all[];
+  extern __shared__ double s_run[];
   const int P = T * vl, tot = G * P;
-  const bool staged = tot <= 8000;
-  if (staged) {
-    for (int e = threadIdx.x; e < tot; e += blockDim.x) s_all[e] = all[e];
+  if (tot <= 8000) {
+    // position i of the global order <-> (t, g, v): i = (t * G + g) * vl + v
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) {
+      const int v = i % vl, tg = i / vl, g = tg % G, t = tg / G;
+      s_run[i] = all[(size_t)g * P + t * vl + v];
+    }
     __syncthreads();
+    if (threadIdx.x == 0) {
+      double run = 0.0;
+      int i = 0;
+      for (; i + 8 <= tot; i += 8) {
+        double a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = s_run[i + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { run += a[k]; s_run[i + k] = run; }
+      }
+      for (; i < tot; ++i) { run += s_run[i]; s_run[i] = run; }
+      table[2 * P] = run;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+      const int t = p / vl, v = p - t * vl, i = (t * G + rank) * vl + v;
+      table[p] = i > 0 ? s_run[i - 1] : 0.0;
+      table[P + p] = s_run[i];
+    }
+    return;
   }
   if (threadIdx.x) return;
-  const double* src = staged ? s_all : all;
   double run = 0.0;
   for (int t = 0; t < T; ++t)
     for (int g = 0; g < G; ++g)
       for (int v = 0; v < vl; ++v) {
         const int p = t * vl + v;
         if (g == rank) table[p] = run;
-        run += src[(size_t)g * P + p];
+        run += all[(size_t)g * P + p];
         if (g == rank) table[P + p] = run;
       }
   table[2 * P] = run;
@@ -392,6 +416,7 @@ extern "C" int tph_multinomial_counts_global(tph_ctx* ctx, const double* cdf_dev
   if (!ctx->comm_active())
     return tph_multinomial_counts(ctx, cdf_dev, n, kept_count_dev, factor, n_draw_max, seed, tick, tag, counts_dev);
   TPH_REQUIRE(ctx->blk_T > 0 && (int64_t)ctx->blk_T * ctx->blk_rows == n, "tph_multinomial_counts_global: call tph_cdf_global on this history first");
+  TPH_HIP(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * (size_t)n, ctx->stream));
   TPH_HIP(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * (size_t)n, ctx->stream));
   if (tph_scratch_reserve(ctx, sizeof(double) * tph_cdf_index_doubles(n))) return -1;
   tph_cdf_index ix;
@@ -678,13 +703,20 @@ __global__ void __launch_bounds__(256) k_multinomial_counts(tph_cdf_index ix,
 
 // Many draws (millions: the x4 up-sampling of a 10^6-particle run): each lookup above is ~4.7 random 64-byte sectors
 // (FETCH_SIZE: 3.0 GB per call at 2.6 x 10^7 rows) and the kernel is bound by exactly that.  The counts do not depend on the
-// ORDER of the draws, so they are generated as their 53-bit integers k (U = k 2^-53, tph_k53), sorted on their top 32 bits and
-// merged against the cdf: a thread walks 16 consecutive sorted draws, the first through the index, the others by a galloping
-// search from the previous row (same predicate on the same values => same row; a draw out of order inside its 2^-32 bucket
-// gallops backwards), equal rows are added once.  The reads of neighbouring threads share lines.
-constexpr int MC_CHUNK = 16;
+// ORDER of the draws, so they are generated as their 53-bit integers k (U = k 2^-53, tph_k53), sorted on their top MC_SORT_BITS
+// bits, and counted by the OWNERS of the rows: a workgroup takes a tile of MC_TILE consecutive rows of the cdf into LDS, reads
+// the stretch of the sorted draws that can fall into it (k_mc_bounds: the buckets of the tile's first and last cumulative weight,
+// one bucket of margin either side -- inside a bucket the draws are in no order, and the bucket of a cumulative weight is only
+// known to rounding), keeps those whose row IS in the tile (the predicate of every other lookup: a_i <= U total, the tile's first
+// and last rows decide membership, so a draw is counted by exactly one tile), finds the row by bisection in LDS and counts it with
+// an LDS atomic; the tile's counts leave in one coalesced store.  Every byte of the cdf, of the draws and of the counts crosses
+// HBM once, in streams (the draws of the margins twice); no global atomic, no dependent global load outside k_mc_bounds.  (Until
+// round 5 a thread walked 16 consecutive sorted draws by galloping searches in global memory: 482 us at 2.6 x 10^7 rows, 0.12 of
+// the HBM rate.)
+constexpr int MC_TILE = 2048;             // rows of the cdf per workgroup: 16 KiB + 8 KiB of counters in LDS, six workgroups per CU
 constexpr int64_t MC_SORT_MIN = 1 << 23;      // below ~7 x 10^6 draws the sort's launches and the host read cost more than they save
-constexpr int MC_SORT_LO = 29;            // the draws are sorted on bits [MC_SORT_LO, 53) of their integers
+constexpr int MC_SORT_BITS = 16;          // the draws are sorted on the top MC_SORT_BITS bits of their 53-bit integers ...
+constexpr int MC_SORT_LO = 53 - MC_SORT_BITS;      // ... i.e. on bits [MC_SORT_LO, 53): 2^16 buckets, two passes of the radix sort
 __global__ void __launch_bounds__(256) k_mc_draws(int64_t n_draw, uint64_t seed, uint32_t tick, uint32_t tag,
                                                   uint64_t* __restrict__ keys) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_draw; r += (int64_t)gridDim.x * blockDim.x) {
@@ -693,77 +725,99 @@ __global__ void __launch_bounds__(256) k_mc_draws(int64_t n_draw, uint64_t seed,
     keys[r] = ((uint64_t)(q.x >> 5) << 26) | (uint64_t)(q.y >> 6);
   }
 }
-__global__ void __launch_bounds__(256) k_mc_merge(tph_cdf_index ix, const uint64_t* __restrict__ keys, int64_t n_draw,
-                                                  int32_t* __restrict__ counts) {
-  const int64_t r0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * MC_CHUNK;
-  if (r0 >= n_draw) return;
-  const int64_t n = ix.n[0];
-  const double* __restrict__ a = ix.lvl[0];
+// first position of the sorted draws whose bucket is >= b
+__device__ __forceinline__ int64_t mc_lower_bound(const uint64_t* __restrict__ keys, int64_t n_draw, int64_t b) {
+  int64_t lo = 0, hi = n_draw;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)(keys[mid] >> MC_SORT_LO) < b) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// pos[2 j], pos[2 j + 1]: where the draws that may belong to the tiles below / above boundary j (between rows j MC_TILE - 1 and
+// j MC_TILE) end / begin.  The boundary's cumulative weight v lies in bucket floor(v / total 2^53) >> MC_SORT_LO up to a few units
+// of 2^-53 (the predicate rounds U total once): tiles below it read through the NEXT bucket, tiles above it from the one BEFORE.
+__global__ void __launch_bounds__(256) k_mc_bounds(const double* __restrict__ a, int64_t n, int64_t ntiles,
+                                                   const uint64_t* __restrict__ keys, int64_t n_draw, int64_t* __restrict__ pos) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * (ntiles + 1)) return;
+  const int64_t j = e >> 1;
+  const bool upper = e & 1;                     // 0: end of the tiles below; 1: start of the tiles above
   const double total = a[n - 1];
-  int64_t K = 0, kp = -1;            // K = #{i : a_i / total <= U} of the previous draw; kp = the row being counted
-  int run = 0;
-  auto draw = [&](const uint64_t key, const bool first) {
-    const double U = (double)key * 0x1.0p-53;
-    const double pp = U * total;                                          // (as k_counts_global: one predicate on any number of GPUs)
-    auto below = [&](int64_t i) { return a[i] <= pp; };
-    int64_t lo, hi;                                                       // the count lies in [lo, hi]
-    if (first) {
-      lo = hi = tph_count_below<false>(ix, 1.0, pp);
-    } else if (K < n && below(K)) {                                       // beyond the previous row: gallop forward
-      lo = K + 1;
-      int64_t step = 1;
-      while (lo + step <= n && below(lo + step - 1)) { lo += step; step *= 2; }
-      hi = lo + step - 1 < n ? lo + step - 1 : n;
-    } else if (K == 0 || below(K - 1)) {                                  // the previous row again
-      lo = hi = K;
-    } else {                                                              // a draw out of order inside its bucket: backwards
-      hi = K - 1;
-      int64_t step = 1;
-      for (;;) {
-        const int64_t p = hi - step;
-        if (p < 0) { lo = 0; break; }
-        if (below(p)) { lo = p + 1; break; }
-        hi = p;
-        step *= 2;
+  if (j == 0 || j == ntiles || !(total > 0.0) || !(total < INFINITY)) {      // the ends; a degenerate cdf: every tile reads every draw
+    pos[e] = (j == 0 || (j < ntiles && upper)) ? 0 : n_draw;
+    return;
+  }
+  const double f = (a[j * MC_TILE - 1] / total) * 0x1.0p53;
+  const int64_t kb = (f >= 0x1.0p53 ? ((int64_t)1 << 53) - 1 : (int64_t)f) >> MC_SORT_LO;
+  pos[e] = upper ? mc_lower_bound(keys, n_draw, kb - 1) : mc_lower_bound(keys, n_draw, kb + 2);
+}
+constexpr int MC_BATCH = 8;               // draws a lane requests before it waits for the first (a tile's stretch is ~2 x 10^3 draws)
+__global__ void __launch_bounds__(256) k_mc_tiles(const double* __restrict__ a, int64_t n, const uint64_t* __restrict__ keys,
+                                                  const int64_t* __restrict__ pos, int32_t* __restrict__ counts) {
+  __shared__ double s_a[MC_TILE];
+  __shared__ int s_c[MC_TILE];
+  const int64_t t = blockIdx.x, r0 = t * MC_TILE;
+  const int rows = (int)(n - r0 < MC_TILE ? n - r0 : MC_TILE);
+  const int64_t k0 = pos[2 * t + 1], k1 = pos[2 * (t + 1)];
+  if (k0 >= k1) {                                           // no draw can fall here (the flat stretches of a trimmed history)
+    for (int i = threadIdx.x; i < rows; i += 256) counts[r0 + i] = 0;
+    return;
+  }
+  // the first batch of draws is requested together with the tile (one memory round trip for both)
+  uint64_t kv[MC_BATCH];
+#pragma unroll
+  for (int j = 0; j < MC_BATCH; ++j) {
+    const int64_t k = k0 + threadIdx.x + (int64_t)j * 256;
+    kv[j] = k < k1 ? keys[k] : ~0ull;
+  }
+  for (int i = threadIdx.x; i < MC_TILE; i += 256) {
+    s_a[i] = i < rows ? a[r0 + i] : INFINITY;               // (beyond the end: never <= a draw)
+    s_c[i] = 0;
+  }
+  const double total = a[n - 1];
+  const bool has_below = r0 > 0, last = r0 + rows >= n;
+  const double below = has_below ? a[r0 - 1] : 0.0;
+  __syncthreads();
+  const double top = s_a[rows - 1];
+  for (int64_t kb = k0; kb < k1; kb += 256 * MC_BATCH) {
+    // the batch's bisections side by side, a fixed eleven steps each (the tile is padded with +inf): eight independent LDS reads
+    // per step instead of a chain of eleven per draw
+    double pp[MC_BATCH];
+    bool mine[MC_BATCH];
+    int lo[MC_BATCH];
+#pragma unroll
+    for (int j = 0; j < MC_BATCH; ++j) {
+      pp[j] = ((double)kv[j] * 0x1.0p-53) * total;          // (as k_counts_global: one predicate on any number of GPUs)
+      mine[j] = kv[j] != ~0ull                              // (a draw is < 2^53)
+                && !(has_below && !(below <= pp[j]))        // else its row lies in a tile below
+                && !(!last && top <= pp[j]);                // ... above
+      lo[j] = 0;                                            // #{i in the tile : a_i <= pp}
+    }
+#pragma unroll
+    for (int half = MC_TILE / 2; half >= 1; half >>= 1)
+#pragma unroll
+      for (int j = 0; j < MC_BATCH; ++j) lo[j] += (s_a[lo[j] + half - 1] <= pp[j]) ? half : 0;
+#pragma unroll
+    for (int j = 0; j < MC_BATCH; ++j)
+      if (mine[j]) atomicAdd(&s_c[lo[j] < rows ? lo[j] : rows - 1], 1);     // (only the last tile: a draw at the very top counts for the last row)
+    const int64_t nb = kb + 256 * MC_BATCH;
+    if (nb < k1) {
+#pragma unroll
+      for (int j = 0; j < MC_BATCH; ++j) {
+        const int64_t k = nb + threadIdx.x + (int64_t)j * 256;
+        kv[j] = k < k1 ? keys[k] : ~0ull;
       }
     }
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (below(mid)) lo = mid + 1; else hi = mid;
-    }
-    K = lo;
-    const int64_t kc = K >= n ? n - 1 : K;
-    if (kc == kp) {
-      ++run;
-    } else {
-      if (run) atomicAdd(&counts[kp], run);
-      kp = kc;
-      run = 1;
-    }
-  };
-  if (r0 + MC_CHUNK <= n_draw) {
-    // the thread's 128 bytes of keys in 16-byte loads issued together (8-byte loads spread over the loop fetch every sector
-    // eight times: the lines of 64 threads x 128 B do not survive in L1 between them)
-    const ulonglong2* __restrict__ kv = reinterpret_cast<const ulonglong2*>(keys + r0);      // r0 is a multiple of 16
-    ulonglong2 v[MC_CHUNK / 2];
-#pragma unroll
-    for (int j = 0; j < MC_CHUNK / 2; ++j) v[j] = kv[j];
-#pragma unroll
-    for (int j = 0; j < MC_CHUNK / 2; ++j) {
-      draw(v[j].x, j == 0);
-      draw(v[j].y, false);
-    }
-  } else {
-    for (int j = 0; r0 + j < n_draw; ++j) draw(keys[r0 + j], j == 0);
   }
-  if (run) atomicAdd(&counts[kp], run);
+  __syncthreads();
+  for (int i = threadIdx.x; i < rows; i += 256) counts[r0 + i] = s_c[i];
 }
 
 extern "C" int tph_multinomial_counts(tph_ctx* ctx, const double* cdf_dev, int64_t n, const double* kept_count_dev,
                                       int factor, int64_t n_draw_max, uint64_t seed, uint32_t tick, uint32_t tag,
                                       int32_t* counts_dev) {
   TPH_REQUIRE(ctx && cdf_dev && counts_dev && n > 0 && n_draw_max > 0, "tph_multinomial_counts: bad argument");
-  TPH_HIP(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * (size_t)n, ctx->stream));
   const int64_t sort_min = ctx->mc_sorted > 1 ? (int64_t)ctx->mc_sorted : MC_SORT_MIN;     // > 1: the threshold itself (tests)
   if (ctx->mc_sorted && n_draw_max >= sort_min) {
     // the sort is sized on the host: one 8-byte read of the count (the stream has to drain once; ~20 us against ~1 ms)
@@ -774,31 +828,36 @@ extern "C" int tph_multinomial_counts(tph_ctx* ctx, const double* cdf_dev, int64
       n_draw = (int64_t)ctx->pinned[0] * factor;
       if (n_draw > n_draw_max) n_draw = n_draw_max;
     }
-    if (n_draw <= 0) return 0;
-    if (n_draw >= sort_min) {
+    if (n_draw <= 0) {
+      TPH_HIP(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * (size_t)n, ctx->stream));
+      return 0;
+    }
+    if (n_draw >= sort_min) {                               // (the tiles' owners write every row's count: no clearing)
       size_t temp_bytes = 0;
       uint64_t* nullk = nullptr;
       TPH_HIP(rocprim::radix_sort_keys(nullptr, temp_bytes, nullk, nullk, (size_t)n_draw, MC_SORT_LO, 53, ctx->stream));
-      const size_t a_ix = (sizeof(double) * tph_cdf_index_doubles(n) + 255) / 256 * 256;
+      const int64_t ntiles = (n + MC_TILE - 1) / MC_TILE;
+      const size_t a_pos = (sizeof(int64_t) * 2 * (size_t)(ntiles + 1) + 255) / 256 * 256;
       const size_t a_keys = (sizeof(uint64_t) * (size_t)n_draw + 255) / 256 * 256;
-      if (tph_scratch_reserve(ctx, a_ix + 2 * a_keys + temp_bytes)) return -1;
+      if (tph_scratch_reserve(ctx, a_pos + 2 * a_keys + temp_bytes)) return -1;
       char* base = (char*)ctx->scratch;
-      uint64_t* keys = (uint64_t*)(base + a_ix);
-      uint64_t* sorted = (uint64_t*)(base + a_ix + a_keys);
-      void* tmp = base + a_ix + 2 * a_keys;
-      tph_cdf_index ix;
-      if (tph_cdf_index_build(ctx, cdf_dev, n, (double*)base, &ix)) return -1;
+      int64_t* pos = (int64_t*)base;
+      uint64_t* keys = (uint64_t*)(base + a_pos);
+      uint64_t* sorted = (uint64_t*)(base + a_pos + a_keys);
+      void* tmp = base + a_pos + 2 * a_keys;
       int64_t blocks = (n_draw + 255) / 256;
       if (blocks > 16 * (int64_t)ctx->n_simd) blocks = 16 * (int64_t)ctx->n_simd;
       hipLaunchKernelGGL(k_mc_draws, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_draw, seed, tick, tag, keys);
       TPH_HIP(rocprim::radix_sort_keys(tmp, temp_bytes, keys, sorted, (size_t)n_draw, MC_SORT_LO, 53, ctx->stream));
-      const int64_t threads = (n_draw + MC_CHUNK - 1) / MC_CHUNK;
-      hipLaunchKernelGGL(k_mc_merge, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, ix, sorted, n_draw,
-                         counts_dev);
+      hipLaunchKernelGGL(k_mc_bounds, dim3((unsigned)((2 * (ntiles + 1) + 255) / 256)), dim3(256), 0, ctx->stream, cdf_dev, n, ntiles,
+                         (const uint64_t*)sorted, n_draw, pos);
+      hipLaunchKernelGGL(k_mc_tiles, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, cdf_dev, n, (const uint64_t*)sorted,
+                         (const int64_t*)pos, counts_dev);
       TPH_LAUNCH_CHECK();
       return 0;
     }
   }
+  TPH_HIP(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * (size_t)n, ctx->stream));
   if (tph_scratch_reserve(ctx, sizeof(double) * tph_cdf_index_doubles(n))) return -1;
   tph_cdf_index ix;
   if (tph_cdf_index_build(ctx, cdf_dev, n, (double*)ctx->scratch, &ix)) return -1;

@@ -329,8 +329,8 @@ def test_fit_modes_large_narrow_with_duplicates(dev):
 
 @pytest.mark.parametrize("kept", [True, False])
 def test_multinomial_counts_sorted_draws_equal_the_draw_order_lookups(dev, kept):
-    """TPH_OPT_SORTED_DRAWS: >= 2^23 draws are sorted and merged against the cdf instead of looked up one by one -- the same
-    counts, row by row, on a heavy-tailed trimmed weight vector (flat stretches of the cdf where rows are trimmed away, a
+    """TPH_OPT_SORTED_DRAWS: >= 2^23 draws are sorted and counted by the owners of the cdf's tiles (k_mc_tiles) instead of looked
+    up one by one -- the same counts, row by row, on a heavy-tailed trimmed weight vector (flat stretches of the cdf where rows are trimmed away, a
     few rows that take thousands of draws), with the number of draws on the device (kept rows x 4) or given."""
     from tempest_amd.device import OPT_SORTED_DRAWS
     rs = np.random.RandomState(77)
@@ -358,9 +358,11 @@ def test_multinomial_counts_sorted_draws_equal_the_draw_order_lookups(dev, kept)
 
 
 def test_multinomial_counts_sorted_draws_edge_cases(dev):
-    """The sorted-draw merge at its edges (threshold lowered to 2 draws through the option): fewer draws than one thread's
-    chunk, exactly one chunk, one more, a count that is no multiple of 16; all the mass on one row; weightless rows at both ends
-    of the cdf; two rows; a single row.  Always the counts of the draw-order lookups."""
+    """The count over sorted draws at its edges (threshold lowered to 2 draws through the option): a handful of draws, a count
+    that is no multiple of anything, many more draws than buckets of the sort (several per bucket: the margins of a tile's stretch
+    matter); all the mass on one row, on the last row of a tile, on the first row of the next, on the very last row; weightless
+    rows at both ends of the cdf; row counts of exactly one tile, one more, two tiles, two and one; two rows; a single row.
+    Always the counts of the draw-order lookups."""
     from tempest_amd.device import OPT_SORTED_DRAWS
     rs = np.random.RandomState(5)
     c = ctx_for(3)
@@ -371,9 +373,14 @@ def test_multinomial_counts_sorted_draws_edge_cases(dev):
     cases.append(np.array([0.25, 0.75]))
     cases.append(np.array([1.0]))
     w = np.exp(8.0 * rs.randn(20000)); cases.append(w / w.sum())
+    for n in (2048, 2049, 4096, 4097):
+        w = rs.rand(n) ** 4; cases.append(w / w.sum())
+    for hot in (2047, 2048, 6143):
+        w = 1e-7 * rs.rand(6144); w[hot] = 1.0; cases.append(w / w.sum())
+    w = np.zeros(6144); w[2047] = 0.5; w[2048] = 0.5; cases.append(w)
     for w in cases:
         cdf = c.cdf(torch.from_numpy(w).to(dev))
-        for n_draw in (2, 15, 16, 17, 1000, 4099):
+        for n_draw in (2, 15, 16, 17, 1000, 4099, 300_001):
             got = {}
             for mode in (2, 0):
                 c.set_option(OPT_SORTED_DRAWS, mode)

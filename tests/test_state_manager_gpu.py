@@ -210,7 +210,9 @@ def test_dict_round_trips(tmp_path):
     back.load_state(path)
     assert back.get_history_length() == 3 and back.get_current("beta") == 0.9
     np.testing.assert_array_equal(back.get_history("x", flat=True), st.get_history("x", flat=True))
-    np.testing.assert_array_equal(back.compute_logw_and_logz(1.0)[0], st.compute_logw_and_logz(1.0)[0])
+    # (the loaded state forms its cached log-mixture with one streaming log-sum-exp per row, the running one folded a logaddexp
+    # per iteration: the same value to rounding)
+    np.testing.assert_allclose(back.compute_logw_and_logz(1.0)[0], st.compute_logw_and_logz(1.0)[0], rtol=2e-15, atol=0)
 
 
 def test_results_dict():
