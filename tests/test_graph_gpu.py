@@ -352,3 +352,79 @@ def test_graph_is_captured_again_when_the_redraw_regime_changes_the_proposal_ker
     assert abs(runs[0][0] - runs[1][0]) < 1e-9
     np.testing.assert_array_equal(runs[0][1]["steps"], runs[1][1]["steps"])
     np.testing.assert_allclose(runs[0][1]["logz"], runs[1][1]["logz"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("kernel", ["tpcn", "rwm"])
+def test_regime_probe_driven_across_its_thresholds_on_the_gpu(kernel, monkeypatch):
+    """VERDICT r04 item 8, on the device: the redraw probe of a 40-dimensional run is REPLACED by a script while the steps really
+    run -- captured graphs, real kernels on both sides of every switch.  The band of mcmc.REGIME_THRESHOLDS at 40-D: the blocked
+    rounds are left at a geometric ESTIMATE of 3.4 attempts, the screened batches at a TRUE mean below 5.5 (the two kernels report
+    different probes, the true mean the larger; a script entry holds both).  The script
+      (a) sits below both thresholds, (b) rises above both, (c) falls INTO the band (estimate below 3.4, true mean above 5.5: the
+      screened batches must stay), (d) falls below both, (c') returns into the band (now the blocked rounds must stay: the same
+      probes as in (c), the other kernel), (e) then sits ON the thresholds so that either kernel asks for the other at every
+      reading, forty times.
+    Asserted: exactly one switch up and one down in (a)-(c'), none inside the band from either side; the forty flips cost a handful
+    of switches with growing waits (the dwell rule); every switch under a graph retires exactly that graph and every graph that
+    ever existed was captured once; and the run with graphs IS the step-by-step run under the same script: same kernels at every
+    reading, same steps, same evidence, bit for bit (the kernels either side of a threshold agree with the oracle to rounding:
+    tests/test_screened_gpu.py, test_kernels_gpu.py::test_blocked_*)."""
+    import tempest_amd as tp
+    from tempest_amd import mcmc
+    d = 40
+    up_est, down_true, _, _ = mcmc.regime_band("screened", d)
+    script = [(1.3, 1.3)] * 6 + [(up_est + 3.0, down_true + 4.0)] * 6 + [(up_est - 0.4, down_true + 0.3)] * 8 + [(1.3, 1.3)] * 6
+    script += [(up_est - 0.4, down_true + 0.3)] * 8
+    phases_end = len(script)
+    script += [(up_est + 0.05, down_true - 0.05)] * 40
+
+    def gauss(x):
+        return -0.5 * (x ** 2).sum(dim=1)
+    orig_regime, orig_capture = mcmc.StepEngine._regime, mcmc.StepEngine._capture
+    runs = []
+    for graph in (True, False):
+        seen, captures = [], []
+
+        def scripted(self, mean_attempts, seen=seen):
+            i = len(seen)
+            est, true_mean = script[i] if i < len(script) else (1.3, 1.3)
+            orig_regime(self, est if self.blocked > 0 else true_mean)
+            seen.append((self.blocked > 0, bool(self.staged), len(self._retired_graphs), self.graph is not None))
+
+        def capture(self, captures=captures):
+            captures.append(1)
+            return orig_capture(self)
+        monkeypatch.setattr(mcmc.StepEngine, "_regime", scripted)
+        monkeypatch.setattr(mcmc.StepEngine, "_capture", capture)
+        s = tp.Sampler(prior20, gauss, d, n_particles=1024, vectorize=True, clustering=False, random_state=5, sample=kernel,
+                       graph=graph)
+        s.run(n_total=98304, progress=False)
+        assert len(seen) > len(script), ("the run was too short for the script", len(seen))
+        runs.append((s.evidence()[0], _history(s), list(seen), len(captures), s))
+    monkeypatch.setattr(mcmc.StepEngine, "_regime", orig_regime)
+    monkeypatch.setattr(mcmc.StepEngine, "_capture", orig_capture)
+    seen = runs[0][2]
+    kern = [(b, st) for b, st, _, _ in seen]
+    assert kern == [(b, st) for b, st, _, _ in runs[1][2]]                 # the rule does not depend on the launch path
+    switches = [i for i in range(1, len(kern)) if kern[i] != kern[i - 1]]
+    early = [i for i in switches if i < phases_end]
+    assert len(early) == 2, (early, kern[:phases_end])
+    assert 6 <= early[0] < 12 and kern[early[0]] == (False, True)           # up: onto the screened batches, in phase (b)
+    assert 20 <= early[1] < 26 and kern[early[1]] == (True, False)          # down: only below BOTH thresholds, phase (d)
+    assert all(k == (False, True) for k in kern[early[0]:20])               # inside the band nothing moves, from above ...
+    assert all(k == (True, False) for k in kern[early[1]:phases_end])       # ... nor from below
+    flips = [i for i in switches if phases_end <= i < len(script)]
+    assert 1 <= len(flips) <= 8, flips                                      # forty crossings, a handful of switches
+    gaps = np.diff(flips)
+    assert len(gaps) < 3 or gaps[-1] >= 4                                   # ... and the waits grow
+    # graphs: one retired per switch made under a graph, one capture per graph that ever existed
+    eng = list(runs[0][4]._core.mutator._engines.values())
+    retired = sum(len(e._retired_graphs) for e in eng)
+    assert retired >= len(early) and retired <= len(switches)
+    assert runs[0][3] == retired + sum(1 for e in eng if e.graph is not None)
+    assert runs[1][3] == 0
+    # and the samples: the captured run is the step-by-step run
+    assert runs[0][0] == runs[1][0]
+    for k in ("beta", "logz", "steps", "acceptance"):
+        np.testing.assert_array_equal(runs[0][1][k], runs[1][1][k])
+    assert np.isfinite(runs[0][0])

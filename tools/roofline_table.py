@@ -42,10 +42,13 @@ ALGO = {
     "k_weights": ("K3 weights", 24.0 * NH, "24 B per history row", "stream"),
     "void tph_scan::k_tile_sums<0>": ("K6 scan pass 1 (tile sums)", 8.0 * NH, "8 B per row", "stream"),
     "void tph_scan::k_apply<0>": ("K6 scan pass 3 (local scan + offset)", 16.0 * NH, "16 B per row", "stream"),
+    "void k_seg_tile_sums<0>": ("K6 scan over the canonical pieces, pass 1 (tile sums)", 8.0 * NH, "8 B per row", "stream"),
+    "void k_seg_apply<0>": ("K6 scan over the canonical pieces, pass 3 (local scan + offset)", 16.0 * NH, "16 B per row", "stream"),
     "k_resample_multinomial": ("K6 inverse-CDF lookups of the resampling draws", 8.0 * N, "8 B out per draw (+ ~3 index lines read per draw)", "indexed"),
     "k_multinomial_counts": ("K6 x4 up-sampling, one indexed lookup per draw (TPH_OPT_SORTED_DRAWS = 0)", 0.0, "one atomic per draw (+ ~3 index lines read per draw)", "indexed"),
     "k_mc_draws": ("K6 x4 up-sampling: the draws as 53-bit integers", 0.0, "8 B written per draw", "stream"),
-    "k_mc_merge": ("K6 x4 up-sampling: sorted draws merged against the cdf", 0.0, "8 B per draw + 12 B per history row walked", "stream"),
+    "k_mc_bounds": ("K6 x4 up-sampling: the stretch of the sorted draws of every tile of the cdf", 0.0, "two bisections of the sorted draws per 2048 rows", "indexed"),
+    "k_mc_tiles": ("K6 x4 up-sampling: sorted draws counted by the owners of the cdf's tiles", 0.0, "8 B per draw + 12 B per history row", "stream"),
     "k_gather_rows": ("K7 gather of the resampled rows (from the row-major mirror)", 2.0 * (2 * D + 1) * 8.0 * N, "2 (2d+1) 8 B per output row", "indexed"),
     "k_rows_pack": ("K7 mirror fill: the iteration's new rows, dimension-major -> records", 2.0 * (2 * D + 1) * 8.0 * N, "2 (2d+1) 8 B per new row", "stream"),
     "k_gather(": ("K7 gather of the resampled rows (dimension-major history, no mirror)", 2.0 * (2 * D + 1) * 8.0 * N, "2 (2d+1) 8 B per output row", "indexed"),
@@ -55,7 +58,7 @@ ALGO = {
     "void k_wsum<int>": ("K11 first moments of the up-sampled set", (8.0 * D + 4.0) * NH, "8d + 4 B per row (compacted set: fewer rows)", "stream"),
     "void k_wcov_small<int, 10>": ("K11 centred second moments", (8.0 * D + 4.0) * NH, "8d + 4 B per row (compacted set: fewer rows)", "stream"),
     "k_med_hist1": ("K11 median histogram level 1", (8.0 * D + 4.0) * NH, "8d + 4 B per row (compacted set: fewer rows)", "stream"),
-    "k_nz_scatter": ("K11 compaction of the rows with multiplicity > 0", 0.0, "8d B read per history row + 8d B written per kept row", "stream"),
+    "k_nz_scatter": ("K11 compaction of the rows with multiplicity > 0", 0.0, "8d B read per history row + 8d B written per kept row", "indexed"),
     "void k_wmom_small<10>": ("K4 one-pass weighted moments (volume variation)", (8.0 * D + 8.0) * NH, "8d + 8 B per row", "stream"),
     "void k_cv_sum_small<10>": ("K4 |L^-1 (u - mean)|^2 statistic", (8.0 * D + 8.0) * NH, "8d + 8 B per row", "stream"),
     "void k_membw<0>": ("ceiling: streaming read", 8.0 * 2 * NH, "bytes read", "stream"),
@@ -165,9 +168,9 @@ def collect(base, out):
     ALGO["k_multinomial_counts"] = (label, 0.0, f"{meta['draws']} draws: one atomic each (+ ~3 index lines read per draw)", kind)
     label, _, unit, kind = ALGO["k_mc_draws"]
     ALGO["k_mc_draws"] = (label, 8.0 * meta["draws"], f"8 B written per draw ({meta['draws']} draws)", kind)
-    label, _, unit, kind = ALGO["k_mc_merge"]
-    ALGO["k_mc_merge"] = (label, 8.0 * meta["draws"] + 12.0 * NH, f"8 B per draw ({meta['draws']}) + 12 B per history row (an upper bound: "
-                          "rows between two draws are skipped by the galloping search)", kind)
+    label, _, unit, kind = ALGO["k_mc_tiles"]
+    ALGO["k_mc_tiles"] = (label, 8.0 * meta["draws"] + 12.0 * NH, f"8 B per draw ({meta['draws']}) + 12 B per history row (8 B of cdf read, 4 B of "
+                          "count written)", kind)
     dur, _ = _read(os.path.join(base, "trace"))
     _, fetch = _read(os.path.join(base, "fetch"), "FETCH_SIZE")
     _, write = _read(os.path.join(base, "write"), "WRITE_SIZE")
@@ -194,13 +197,19 @@ def collect(base, out):
                "FETCH_SIZE_bytes_x2": f_b, "WRITE_SIZE_bytes": w_b,
                "counter_bytes_per_launch": f_b + w_b, "achieved_GBs_counters": round((f_b + w_b) / t_us / 1e3, 1),
                "traffic_over_algorithmic": round((f_b + w_b) / algo, 3) if algo else None,
+               # indexed kernels: the counter tallies REQUESTS x 64 B and a lone 64-byte sector is one request (profiles/
+               # r05_fetch_calibration.json) -- their read bytes lie between the raw counter and twice it
+               "traffic_over_algorithmic_min": round((f_b / 2.0 + w_b) / algo, 3) if algo and kind == "indexed" else None,
+               "read_requests_per_us": round(f_b / 2.0 / 64.0 / t_us, 1),
                "access": kind}
         rows.append(rec)
     doc = {"problem": {"n_dim": D, "active_particles": N, "history_rows": NH, "iterations": T},
            "peak_GBs": PEAK,
            "how": "rocprofv3: plain --kernel-trace for durations, --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE "
-                  "KB x 1024 x 2 (gfx950: the counter reports half of a wide coalesced read stream; for 'indexed' kernels the x2 is an "
-                  "upper bound), WRITE_SIZE KB x 1024",
+                  "KB x 1024 x 2 (gfx950: the counter is read requests x 64 B and a request for both 64-byte sectors of a 128-byte line is "
+                  "tallied once -- every coalesced stream, 4 / 8 / 16 B per lane, reads exactly half its bytes; a lone sector reads "
+                  "exactly: profiles/r05_fetch_calibration.json; for 'indexed' kernels the x2 is an upper bound and "
+                  "traffic_over_algorithmic_min the lower one; ~48 requests/ns is the most the probe's gathers reach), WRITE_SIZE KB x 1024",
            "kernels": rows}
     json.dump(doc, open(out, "w"), indent=1)
     for r in rows:
