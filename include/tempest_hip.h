@@ -99,10 +99,10 @@ int tph_warmup(tph_ctx* ctx);
  * (VALU), 2 = FP64 matrix cores (v_mfma_f64_16x16x4: the product is a SYRK; measured no faster -- both are bound by the fill of
  * the staged tile); the parity tests run both */
 #define TPH_OPT_COV_KERNEL 7
-/* TPH_OPT_SORTED_DRAWS: 1 (default) = tph_multinomial_counts with >= 2^23 draws generates them as 53-bit integers, sorts them
+/* TPH_OPT_SORTED_DRAWS: 1 (default) = tph_multinomial_counts with >= 2^21 draws generates them as 53-bit integers, sorts them
  * and merges them against the cdf (the counts do not depend on the order of the draws; one 8-byte device-to-host read of the
  * kept count sizes the sort); 0 = one indexed lookup per draw in draw order; a value > 1 = that many draws as the threshold
- * instead of 2^23 (tests).  Same counts either way. */
+ * instead of 2^21 (tests).  Same counts either way. */
 #define TPH_OPT_SORTED_DRAWS 8
 /* TPH_OPT_STAGED_REDRAW: 1 = 16 < n_dim <= 100, one mode, steps that are mostly REDRAWS (mcmc.py:239-249: early iterations of a
  * high-dimensional run): the row-walker kernel (propose_sm.hip: a lane per attempt with its normals in its column of a tile,
@@ -154,6 +154,10 @@ int tph_warmup(tph_ctx* ctx);
  * streaming them to each of its four waves (default, 1: 160 -> 142 us per round at 100-D x 131072, 48.8 -> 47.3 at 50-D x 65536,
  * profiles/r05_blkm_stage.json); 0 = streamed.  Same proposals bit for bit (same instructions on the same operands). */
 #define TPH_OPT_BLK_STAGE 20
+/* TPH_OPT_GMM_KERNEL: the clustering E-step (tph_gmm_estep, tph_gmm_em_run) at 16 <= n_dim <= 48: 0 = automatic (= 1), 1 = one
+ * lane per row (row in LDS, precision matrix through scalar loads), 2 = 16 rows per wave on the FP64 matrix cores (measured slower on config 3: 158 against
+ * 107 us per pass; kept for the parity test).  Same values to rounding (different summation order). */
+#define TPH_OPT_GMM_KERNEL 21
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- multi-GPU: one process per GPU --------------------------------------

@@ -124,6 +124,108 @@ __global__ void __launch_bounds__(GMM_THREADS) k_gmm_estep(const double* __restr
   }
 }
 
+// n_dim >= 16: the same three modes on the FP64 matrix cores.  A wave takes 16 rows; with Xc = X - mu (d x 16) the quadratic forms
+// are the column sums of Xc .* (P Xc), and P Xc is d/16 x d/4 products v_mfma_f64_16x16x4: for the 16 rows rb of P and the four
+// coordinates 4s .. 4s+3, lane (g = lane / 16, c = lane % 16) supplies A = P[16 rb + c][4s + g] -- read as P[4s + g][16 rb + c], P is
+// symmetric: 128 contiguous bytes per lane group -- and B = Xc[4s + g][row c], and receives Y[16 rb + 4v + g][row c], v = 0..3:
+// the very coordinates 4 (4 rb + v) + g whose Xc it already holds as the B operand of step 4 rb + v.  So the lane multiplies its own
+// registers and two shuffles add the four lane groups; no LDS, no barrier, the rows come straight from global memory in 128-byte
+// segments.  (The one-lane-per-row form above keeps a row in LDS and streams P through scalar loads: 107 us per pass at 7 x 10^5
+// rows x 32-D, a third of the VALU issue rate, waves waiting half their cycles.)  NB = ceil(n_dim / 16).
+typedef double gmm_v4d __attribute__((ext_vector_type(4)));
+template <int NB>
+__global__ void __launch_bounds__(256) k_gmm_estep_mf(const double* __restrict__ x, int64_t ld, int64_t n, int d,
+                                                      const double* __restrict__ sw, const int32_t* __restrict__ labels,
+                                                      int label, int K, const double* __restrict__ params, int mode,
+                                                      double eps, const double* __restrict__ shift,
+                                                      const double* __restrict__ scale, double* __restrict__ wr,
+                                                      int32_t* __restrict__ label_out, double* __restrict__ partials,
+                                                      const double* __restrict__ done) {
+  if (done && done[0] != 0.0) return;            // (as k_gmm_estep)
+  constexpr int KS = 4 * NB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const size_t ps = gmm_stride(d);
+  double acc_w = 0.0, acc_u = 0.0, acc_n = 0.0;
+  const int64_t ntiles = (n + 15) / 16;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+    const int64_t i = t * 16 + c;
+    const bool in = i < n;
+    double xr[KS];
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+      const int j = 4 * s_ + g;
+      const double v = (in && j < d) ? x[(size_t)j * ld + i] : 0.0;
+      xr[s_] = (shift && j < d) ? (v - shift[j]) * scale[j] : v;
+    }
+    const bool member = in && (!labels || labels[i] == label);
+    double pk[GMM_KMAX_RESP];
+    double best = -INFINITY, minm = INFINITY;
+    int arg = 0;
+    for (int k = 0; k < K; ++k) {
+      const double* pr = params + (size_t)k * ps;
+      const double* mu = pr + 1;
+      const double* P = pr + 1 + d;
+      double xc[KS];
+#pragma unroll
+      for (int s_ = 0; s_ < KS; ++s_) {
+        const int j = 4 * s_ + g;
+        xc[s_] = j < d ? xr[s_] - mu[j] : 0.0;
+      }
+      double part = 0.0;
+#pragma unroll
+      for (int rb = 0; rb < NB; ++rb) {
+        gmm_v4d y = {0.0, 0.0, 0.0, 0.0};
+        const int r = 16 * rb + c;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+          const int j = 4 * s_ + g;
+          const double a = (j < d && r < d) ? P[(size_t)j * d + r] : 0.0;
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xc[s_], y, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) part = fma(xc[4 * rb + v], y[v], part);
+      }
+      part += __shfl_xor(part, 16, 64);
+      const double maha = part + __shfl_xor(part, 32, 64);
+      const double logpdf = -0.5 * ((double)d * 1.8378770664093454836 + pr[1 + d + d * d] + maha);
+      if (mode == 0) { if (k < GMM_KMAX_RESP) pk[k] = exp(pr[0]) * exp(logpdf); }
+      else if (mode == 1) minm = fmin(minm, maha);
+      else { const double v = pr[0] + logpdf; if (v > best) { best = v; arg = k; } }
+    }
+    if (g != 0 || !in) continue;                   // lanes 0..15 of the wave write the tile's rows
+    if (!member) {
+      if (mode == 0) for (int k = 0; k < K; ++k) wr[(size_t)k * n + i] = 0.0;
+      if (mode == 1) wr[i] = 0.0;
+      if (mode == 2 && label_out) label_out[i] = -1;
+      continue;
+    }
+    const double swi = sw ? sw[i] : 1.0;
+    if (mode == 0) {
+      double tot = 0.0;
+      for (int k = 0; k < K && k < GMM_KMAX_RESP; ++k) tot += pk[k];
+      for (int k = 0; k < K && k < GMM_KMAX_RESP; ++k) wr[(size_t)k * n + i] = swi * (pk[k] / (tot + eps));
+      const double l = log(tot + 1e-10);
+      acc_w += swi * l;
+      acc_u += l;
+      acc_n += 1.0;
+    } else if (mode == 1) {
+      wr[i] = swi * minm;
+    } else {
+      label_out[i] = arg;
+    }
+  }
+  __shared__ double sh[4];
+  acc_w = tph_block_sum(acc_w, sh);
+  acc_u = tph_block_sum(acc_u, sh);
+  acc_n = tph_block_sum(acc_n, sh);
+  if (threadIdx.x == 0) {
+    partials[(size_t)blockIdx.x * 3] = acc_w;
+    partials[(size_t)blockIdx.x * 3 + 1] = acc_u;
+    partials[(size_t)blockIdx.x * 3 + 2] = acc_n;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_colsum3(const double* __restrict__ partials, int nblocks, double* __restrict__ out,
                                                  const double* __restrict__ done) {
   if (done && done[0] != 0.0) return;
@@ -145,6 +247,24 @@ static int gmm_estep_launch(tph_ctx* ctx, const double* x_dev, int64_t ld, int64
   TPH_REQUIRE(mode != 1 || wr_dev, "tph_gmm_estep: mode 1 needs wr");
   TPH_REQUIRE(mode != 2 || label_out_dev, "tph_gmm_estep: mode 2 needs label_out");
   const int d = ctx->d;
+  // matrix cores on request, up to 48-D (TPH_OPT_GMM_KERNEL: 0 auto = 1 one lane per row | 2 MFMA; above 48-D the unrolled products
+  // of a 16-row tile need more than 192 registers).  MEASURED on config 3 (705 passes over ~7 x 10^5 rows x 32-D): 157.6 us per
+  // pass against 107.1 us of the lane-per-row kernel -- 16 rows per wave leave the exp / log epilogue on a quarter of the lanes
+  // and the precision matrix is re-read per tile; the default stays the lane-per-row kernel (profiles/r05_c3_fit_kernels.json)
+  if (d >= 16 && d <= 48 && ctx->gmm_kernel == 2) {
+    const int64_t nt = (n + 63) / 64;
+    const int nb = (int)(nt < 4096 ? nt : 4096);
+    if (tph_scratch_reserve(ctx, sizeof(double) * 3 * (size_t)nb)) return -1;
+    double* part = (double*)ctx->scratch;
+    switch ((d + 15) / 16) {
+#define C(NB_) case NB_: hipLaunchKernelGGL((k_gmm_estep_mf<NB_>), dim3(nb), dim3(256), 0, ctx->stream, x_dev, ld, n, d, sw_dev, labels_dev, label, K, params_dev, mode, eps, shift_dev, scale_dev, wr_dev, label_out_dev, part, done_dev); break;
+      C(1) C(2) C(3)
+#undef C
+    }
+    if (stats_dev) hipLaunchKernelGGL(k_colsum3, dim3(3), dim3(256), 0, ctx->stream, part, nb, stats_dev, done_dev);
+    TPH_LAUNCH_CHECK();
+    return 0;
+  }
   int64_t ntiles = (n + GMM_THREADS - 1) / GMM_THREADS;
   int nblk = (int)(ntiles < 8192 ? ntiles : 8192);
   if (tph_scratch_reserve(ctx, sizeof(double) * 3 * (size_t)nblk)) return -1;

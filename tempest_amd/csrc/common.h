@@ -128,6 +128,7 @@ struct tph_ctx {
   // matrix-core round kernel of the blocked path (propose_blkm.hip): TPH_OPT_BLK_MFMA and its blocked copies of L and L^-1
   int blk_mfma = 1;
   int blk_tries = 0;                // TPH_OPT_BLK_TRIES: attempts a round of the matrix-core kernel gives its failing columns in place (0 = by n_dim)
+  int gmm_kernel = 0;               // TPH_OPT_GMM_KERNEL: clustering E-step at n_dim >= 16: 0 auto (= 1) | 1 one lane per row | 2 matrix cores
   int blk_stage = 1;                // TPH_OPT_BLK_STAGE: 1 (default) = one-try rounds of one mode stage the panels' matrix blocks in LDS (k_propose_blkm_lds; bitwise the same draws)
   int blk_fan = 1;                  // TPH_OPT_BLK_FAN: list rounds give a straggler up to 16 attempts side by side (1 = default)
   void* bm_buf = nullptr;

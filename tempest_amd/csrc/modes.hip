@@ -614,7 +614,10 @@ __host__ __device__ inline int cov_tile_slices(int d) {
   while (sl < 16 && pairs * sl * 2 <= 256) sl *= 2;
   return sl;
 }
-template <typename WT>
+// (NV = columns of the tile a thread carries: ceil(n_dim / 4) rounded up to 8, 16 or 32.  The NEXT tile's columns and weight are
+// requested into registers before the current tile's products start and stored behind them: until round 5 a tile was requested,
+// waited for, stored and used in turn -- two barriers and one exposed memory round trip per 16 KB, 0.9 TB/s.)
+template <typename WT, int NV>
 __global__ void __launch_bounds__(256) k_wcov_tiled(const double* __restrict__ hu, int64_t cap, int d, const WT* __restrict__ wt,
                                                     const int32_t* __restrict__ labels, int label, int64_t n,
                                                     const double* __restrict__ mean, double* __restrict__ partials,
@@ -647,35 +650,30 @@ __global__ void __launch_bounds__(256) k_wcov_tiled(const double* __restrict__ h
       for (int r = 0; r < COV_TB; ++r) acc[k][q][r] = 0.0;
   }
   const int64_t ntiles = (n + COV_ROWS - 1) / COV_ROWS;
+  // the tile's fill: wave w takes columns w, w + 4, ... (lane = row of the tile), all of them requested before the first is used
+  const int fr = threadIdx.x & 63, jw = threadIdx.x >> 6;
+  double nx[NV], nw = 0.0;
+  auto request = [&](int64_t t) {
+    const int64_t i = t * COV_ROWS + fr;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int j = jw + 4 * k;
+      nx[k] = (j < d && i < n) ? hu[(size_t)j * cap + i] : 0.0;
+    }
+    if (jw == 0) nw = (i < n && (!labels || labels[i] == label)) ? (double)wt[i] : 0.0;
+  };
+  if ((int64_t)blockIdx.x < ntiles) request(blockIdx.x);
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int64_t r0 = t * COV_ROWS;
     __syncthreads();
-    {
-      // the tile's fill: wave w takes columns w, w + 4, ..., EIGHT of them requested before the first is stored (as one load and
-      // one store per trip the fill was a chain of d / 4 memory round trips per tile: config 3's launches 150 -> 133 us)
-      const int r = threadIdx.x & 63, jw = threadIdx.x >> 6;
-      const int64_t i = r0 + r;
-      for (int j0 = jw; j0 < d; j0 += 32) {
-        double v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int j = j0 + 4 * k;
-          v[k] = (j < d && i < n) ? hu[(size_t)j * cap + i] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int j = j0 + 4 * k;
-          if (j < d) xs[j * COV_LD + r] = i < n ? v[k] - mean[j] : 0.0;
-        }
-      }
+    for (int k = 0; k < NV; ++k) {
+      const int j = jw + 4 * k;
+      if (j < d) xs[j * COV_LD + fr] = r0 + fr < n ? nx[k] - mean[j] : 0.0;
     }
-    if (threadIdx.x < COV_ROWS) {
-      int64_t i = r0 + threadIdx.x;
-      double w = 0.0;
-      if (i < n && (!labels || labels[i] == label)) w = (double)wt[i];
-      ws[threadIdx.x] = w;
-    }
+    if (jw == 0) ws[fr] = nw;
     __syncthreads();
+    if (t + gridDim.x < ntiles) request(t + gridDim.x);
 #pragma unroll
     for (int k = 0; k < MAXI; ++k) {
       if (ia[k] < 0) continue;
@@ -747,7 +745,7 @@ __global__ void __launch_bounds__(256) k_wcov_tiled(const double* __restrict__ h
 // the VALU kernel.
 typedef double tph_v4d __attribute__((ext_vector_type(4)));
 constexpr int COV_MF_MAXP = 9;                  // block pairs per wave: 36 pairs (n_dim <= 128) over 4 waves
-template <typename WT>
+template <typename WT, int NV>
 __global__ void __launch_bounds__(256) k_wcov_mfma(const double* __restrict__ hu, int64_t cap, int d, const WT* __restrict__ wt,
                                                    const int32_t* __restrict__ labels, int label, int64_t n,
                                                    const double* __restrict__ mean, double* __restrict__ partials,
@@ -773,21 +771,31 @@ __global__ void __launch_bounds__(256) k_wcov_mfma(const double* __restrict__ hu
     acc[k] = tph_v4d{0.0, 0.0, 0.0, 0.0};
   }
   const int64_t ntiles = (n + COV_ROWS - 1) / COV_ROWS;
+  // the tile's fill as in k_wcov_tiled: wave w takes columns w, w + 4, ... of the padded tile (NV = dp / 4 of them), the NEXT
+  // tile's requested before this tile's products start
+  const int fr = threadIdx.x & 63, jw = threadIdx.x >> 6;
+  double nx[NV], nw = 0.0;
+  auto request = [&](int64_t t) {
+    const int64_t i = t * COV_ROWS + fr;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int j = jw + 4 * k;
+      nx[k] = (j < d && i < n) ? hu[(size_t)j * cap + i] : 0.0;
+    }
+    if (jw == 0) nw = (i < n && (!labels || labels[i] == label)) ? (double)wt[i] : 0.0;
+  };
+  if ((int64_t)blockIdx.x < ntiles) request(blockIdx.x);
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int64_t r0 = t * COV_ROWS;
     __syncthreads();
-    for (int e = threadIdx.x; e < dp * COV_ROWS; e += blockDim.x) {
-      const int j = e / COV_ROWS, r = e % COV_ROWS;
-      const int64_t i = r0 + r;
-      xs[j * COV_LD + r] = (j < d && i < n) ? hu[(size_t)j * cap + i] - mean[j] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int j = jw + 4 * k;
+      if (j < dp) xs[j * COV_LD + fr] = (j < d && r0 + fr < n) ? nx[k] - mean[j] : 0.0;
     }
-    if (threadIdx.x < COV_ROWS) {
-      const int64_t i = r0 + threadIdx.x;
-      double w = 0.0;
-      if (i < n && (!labels || labels[i] == label)) w = (double)wt[i];
-      ws[threadIdx.x] = w;
-    }
+    if (jw == 0) ws[fr] = nw;
     __syncthreads();
+    if (t + gridDim.x < ntiles) request(t + gridDim.x);
     for (int r = 0; r < COV_ROWS; r += 4) {
       const double w = ws[r + lk];
 #pragma unroll
@@ -818,18 +826,28 @@ static int launch_wcov(tph_ctx* ctx, const double* src, int64_t src_ld, const WT
   const int d = ctx->d, npl = d * (d + 1) / 2;
   if (d >= 16 && d <= 128 && ctx->cov_kernel == 2) {      // matrix cores on request (TPH_OPT_COV_KERNEL: 0 auto = 1 register blocks | 2 MFMA)
     const size_t lds = sizeof(double) * ((size_t)((d + 15) / 16 * 16) * COV_LD + COV_ROWS);
-    if (lds > 64 * 1024)
-      TPH_HIP(hipFuncSetAttribute((const void*)k_wcov_mfma<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_wcov_mfma<WT>, dim3(nblk, 1, nseg), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials, seg);
+#define TPH_WCOV_MFMA(NV_)                                                                                                    \
+    do {                                                                                                                      \
+      if (lds > 64 * 1024)                                                                                                    \
+        TPH_HIP(hipFuncSetAttribute((const void*)k_wcov_mfma<WT, NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL((k_wcov_mfma<WT, NV_>), dim3(nblk, 1, nseg), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials, seg); \
+    } while (0)
+    if (d <= 32) TPH_WCOV_MFMA(8); else if (d <= 64) TPH_WCOV_MFMA(16); else TPH_WCOV_MFMA(32);
+#undef TPH_WCOV_MFMA
     *rows_per_block = 1;
     return 0;
   }
   if (d >= 16) {
     const int SL = cov_tile_slices(d);
     const size_t lds = sizeof(double) * ((size_t)d * COV_LD + COV_ROWS + (SL > 1 ? npl : 0));
-    if (lds > 64 * 1024)
-      TPH_HIP(hipFuncSetAttribute((const void*)k_wcov_tiled<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_wcov_tiled<WT>, dim3(nblk, 1, nseg), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials, seg);
+#define TPH_WCOV_TILED(NV_)                                                                                                   \
+    do {                                                                                                                      \
+      if (lds > 64 * 1024)                                                                                                    \
+        TPH_HIP(hipFuncSetAttribute((const void*)k_wcov_tiled<WT, NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL((k_wcov_tiled<WT, NV_>), dim3(nblk, 1, nseg), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials, seg); \
+    } while (0)
+    if (d <= 32) TPH_WCOV_TILED(8); else if (d <= 64) TPH_WCOV_TILED(16); else TPH_WCOV_TILED(32);
+#undef TPH_WCOV_TILED
     *rows_per_block = 1;
     return 0;
   }

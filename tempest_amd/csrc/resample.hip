@@ -714,7 +714,8 @@ __global__ void __launch_bounds__(256) k_multinomial_counts(tph_cdf_index ix,
 // round 5 a thread walked 16 consecutive sorted draws by galloping searches in global memory: 482 us at 2.6 x 10^7 rows, 0.12 of
 // the HBM rate.)
 constexpr int MC_TILE = 2048;             // rows of the cdf per workgroup: 16 KiB + 8 KiB of counters in LDS, six workgroups per CU
-constexpr int64_t MC_SORT_MIN = 1 << 23;      // below ~7 x 10^6 draws the sort's launches and the host read cost more than they save
+constexpr int64_t MC_SORT_MIN = 1 << 21;      // from 2 x 10^6 draws on the sorted path wins at every history size (1 - 27 x 10^6 rows:
+                                              // 123-215 us + the host read against 158-307 us; below, the sort alone costs more: profiles/r05_upsample_ab.jsonl)
 constexpr int MC_SORT_BITS = 16;          // the draws are sorted on the top MC_SORT_BITS bits of their 53-bit integers ...
 constexpr int MC_SORT_LO = 53 - MC_SORT_BITS;      // ... i.e. on bits [MC_SORT_LO, 53): 2^16 buckets, two passes of the radix sort
 __global__ void __launch_bounds__(256) k_mc_draws(int64_t n_draw, uint64_t seed, uint32_t tick, uint32_t tag,
