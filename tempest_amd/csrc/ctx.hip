@@ -418,13 +418,18 @@ extern "C" int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void
   }
   c->partials_bytes = sizeof(double) * (size_t)TPH_RED_BLOCKS * 64;
   if (hipMalloc((void**)&c->partials, c->partials_bytes) != hipSuccess ||
-      hipMalloc((void**)&c->small_dev, sizeof(double) * 4096) != hipSuccess ||
+      hipMalloc((void**)&c->small_dev, sizeof(double) * (4096 + 32)) != hipSuccess ||      // [4096]: the ticket of k_reweight_fold
       hipHostMalloc((void**)&c->pinned, sizeof(double) * 4096) != hipSuccess) {
     tph_set_error("tph_ctx_create: scratch allocation failed");
     delete c;
     return -1;
   }
   memset(c->pinned, 0, sizeof(double) * 4096);      // [4095] is the sequence word tph_reweight_eval polls
+  if (hipMemset(c->small_dev + 4096, 0, sizeof(double) * 32) != hipSuccess) {
+    tph_set_error("tph_ctx_create: scratch initialisation failed");
+    delete c;
+    return -1;
+  }
   if (capacity_hint > 0 && history_reserve(c, capacity_hint)) {
     delete c;
     return -1;

@@ -508,6 +508,25 @@ __global__ void __launch_bounds__(256) k_wsum_final(const double* __restrict__ p
   }
 }
 
+// ... with many columns (ncol > 256: the triangle of a covariance at n_dim >= 23): a thread per COLUMN, the rows in order through four
+// interleaved accumulators -- neighbouring lanes read neighbouring columns of a row (coalesced), where a block per column reads one
+// 8-byte word per 64-byte sector and, since the per-shard segments of round 5, runs 16 x ncol blocks of 128 rows each
+// (50-D: 17 -> 111 us, 100-D: 71 -> 316 us per launch before this kernel).  Deterministic: a fixed order per column.
+__global__ void __launch_bounds__(256) k_colsum2_wide(const double* __restrict__ partials, int nblocks, int ncol,
+                                                      double* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncol) return;
+  partials += (size_t)blockIdx.y * nblocks * ncol;      // (blockIdx.y: segment)
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  int b = 0;
+  for (; b + 4 <= nblocks; b += 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] += partials[(size_t)(b + k) * ncol + c];
+  }
+  for (; b < nblocks; ++b) a[b & 3] += partials[(size_t)b * ncol + c];
+  out[(size_t)blockIdx.y * ncol + c] = (a[0] + a[1]) + (a[2] + a[3]);
+}
+static void launch_colsum2(tph_ctx* ctx, const double* partials, int nblocks, int ncol, int nseg, double* out);
 __global__ void __launch_bounds__(256) k_colsum2(const double* __restrict__ partials, int nblocks, int ncol,
                                                  double* __restrict__ out) {
   int c = blockIdx.x;
@@ -518,6 +537,12 @@ __global__ void __launch_bounds__(256) k_colsum2(const double* __restrict__ part
   __shared__ double sh[4];
   s = tph_block_sum(s, sh);
   if (threadIdx.x == 0) out[c] = s;
+}
+
+static void launch_colsum2(tph_ctx* ctx, const double* partials, int nblocks, int ncol, int nseg, double* out) {
+  // (few rows per segment and many columns: the per-shard partials of a fit at n_dim >= 23; one segment of 2048 rows keeps the block per column)
+  if (ncol > 256 && nblocks <= 256) hipLaunchKernelGGL(k_colsum2_wide, dim3((ncol + 255) / 256, nseg), dim3(256), 0, ctx->stream, partials, nblocks, ncol, out);
+  else hipLaunchKernelGGL(k_colsum2, dim3(ncol, nseg), dim3(256), 0, ctx->stream, partials, nblocks, ncol, out);
 }
 
 // mean_j = sums[1+j] / sums[0]
@@ -614,9 +639,7 @@ __host__ __device__ inline int cov_tile_slices(int d) {
   while (sl < 16 && pairs * sl * 2 <= 256) sl *= 2;
   return sl;
 }
-// (NV = columns of the tile a thread carries: ceil(n_dim / 4) rounded up to 8, 16 or 32.  The NEXT tile's columns and weight are
-// requested into registers before the current tile's products start and stored behind them: until round 5 a tile was requested,
-// waited for, stored and used in turn -- two barriers and one exposed memory round trip per 16 KB, 0.9 TB/s.)
+// (NV: see the tile's fill below.)
 template <typename WT, int NV>
 __global__ void __launch_bounds__(256) k_wcov_tiled(const double* __restrict__ hu, int64_t cap, int d, const WT* __restrict__ wt,
                                                     const int32_t* __restrict__ labels, int label, int64_t n,
@@ -650,30 +673,52 @@ __global__ void __launch_bounds__(256) k_wcov_tiled(const double* __restrict__ h
       for (int r = 0; r < COV_TB; ++r) acc[k][q][r] = 0.0;
   }
   const int64_t ntiles = (n + COV_ROWS - 1) / COV_ROWS;
-  // the tile's fill: wave w takes columns w, w + 4, ... (lane = row of the tile), all of them requested before the first is used
+  // the tile's fill: wave w takes columns w, w + 4, ... (lane = row of the tile), eight of them requested before the first is
+  // used.  NV = 8 (n_dim <= 32): all of a thread's columns, and those of the NEXT tile are requested before this tile's products
+  // start (config 3: 132 -> 114 us per launch); NV = 0 (above 32-D): tile by tile -- carrying 16 or 32 columns in registers
+  // across the products costs more occupancy than the overlap returns (measured: 50-D 388 -> 463 us, 100-D 1.6 -> 3.5 ms)
   const int fr = threadIdx.x & 63, jw = threadIdx.x >> 6;
-  double nx[NV], nw = 0.0;
+  constexpr int NVR = NV > 0 ? NV : 1;
+  double nx[NVR], nw = 0.0;
   auto request = [&](int64_t t) {
     const int64_t i = t * COV_ROWS + fr;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
+    for (int k = 0; k < NVR; ++k) {
       const int j = jw + 4 * k;
       nx[k] = (j < d && i < n) ? hu[(size_t)j * cap + i] : 0.0;
     }
     if (jw == 0) nw = (i < n && (!labels || labels[i] == label)) ? (double)wt[i] : 0.0;
   };
-  if ((int64_t)blockIdx.x < ntiles) request(blockIdx.x);
+  if (NV > 0 && (int64_t)blockIdx.x < ntiles) request(blockIdx.x);
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int64_t r0 = t * COV_ROWS;
     __syncthreads();
+    if (NV > 0) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int j = jw + 4 * k;
-      if (j < d) xs[j * COV_LD + fr] = r0 + fr < n ? nx[k] - mean[j] : 0.0;
+      for (int k = 0; k < NVR; ++k) {
+        const int j = jw + 4 * k;
+        if (j < d) xs[j * COV_LD + fr] = r0 + fr < n ? nx[k] - mean[j] : 0.0;
+      }
+      if (jw == 0) ws[fr] = nw;
+    } else {
+      const int64_t i = r0 + fr;
+      for (int j0 = jw; j0 < d; j0 += 32) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int j = j0 + 4 * k;
+          v[k] = (j < d && i < n) ? hu[(size_t)j * cap + i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int j = j0 + 4 * k;
+          if (j < d) xs[j * COV_LD + fr] = i < n ? v[k] - mean[j] : 0.0;
+        }
+      }
+      if (jw == 0) ws[fr] = (i < n && (!labels || labels[i] == label)) ? (double)wt[i] : 0.0;
     }
-    if (jw == 0) ws[fr] = nw;
     __syncthreads();
-    if (t + gridDim.x < ntiles) request(t + gridDim.x);
+    if (NV > 0 && t + gridDim.x < ntiles) request(t + gridDim.x);
 #pragma unroll
     for (int k = 0; k < MAXI; ++k) {
       if (ia[k] < 0) continue;
@@ -771,31 +816,49 @@ __global__ void __launch_bounds__(256) k_wcov_mfma(const double* __restrict__ hu
     acc[k] = tph_v4d{0.0, 0.0, 0.0, 0.0};
   }
   const int64_t ntiles = (n + COV_ROWS - 1) / COV_ROWS;
-  // the tile's fill as in k_wcov_tiled: wave w takes columns w, w + 4, ... of the padded tile (NV = dp / 4 of them), the NEXT
-  // tile's requested before this tile's products start
+  // the tile's fill as in k_wcov_tiled: NV = 8 (n_dim <= 32) carries the next tile's columns in registers, NV = 0 fills tile by tile
   const int fr = threadIdx.x & 63, jw = threadIdx.x >> 6;
-  double nx[NV], nw = 0.0;
+  constexpr int NVR = NV > 0 ? NV : 1;
+  double nx[NVR], nw = 0.0;
   auto request = [&](int64_t t) {
     const int64_t i = t * COV_ROWS + fr;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
+    for (int k = 0; k < NVR; ++k) {
       const int j = jw + 4 * k;
       nx[k] = (j < d && i < n) ? hu[(size_t)j * cap + i] : 0.0;
     }
     if (jw == 0) nw = (i < n && (!labels || labels[i] == label)) ? (double)wt[i] : 0.0;
   };
-  if ((int64_t)blockIdx.x < ntiles) request(blockIdx.x);
+  if (NV > 0 && (int64_t)blockIdx.x < ntiles) request(blockIdx.x);
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int64_t r0 = t * COV_ROWS;
     __syncthreads();
+    if (NV > 0) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int j = jw + 4 * k;
-      if (j < dp) xs[j * COV_LD + fr] = (j < d && r0 + fr < n) ? nx[k] - mean[j] : 0.0;
+      for (int k = 0; k < NVR; ++k) {
+        const int j = jw + 4 * k;
+        if (j < dp) xs[j * COV_LD + fr] = (j < d && r0 + fr < n) ? nx[k] - mean[j] : 0.0;
+      }
+      if (jw == 0) ws[fr] = nw;
+    } else {
+      const int64_t i = r0 + fr;
+      for (int j0 = jw; j0 < dp; j0 += 32) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int j = j0 + 4 * k;
+          v[k] = (j < d && i < n) ? hu[(size_t)j * cap + i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int j = j0 + 4 * k;
+          if (j < dp) xs[j * COV_LD + fr] = (j < d && i < n) ? v[k] - mean[j] : 0.0;
+        }
+      }
+      if (jw == 0) ws[fr] = (i < n && (!labels || labels[i] == label)) ? (double)wt[i] : 0.0;
     }
-    if (jw == 0) ws[fr] = nw;
     __syncthreads();
-    if (t + gridDim.x < ntiles) request(t + gridDim.x);
+    if (NV > 0 && t + gridDim.x < ntiles) request(t + gridDim.x);
     for (int r = 0; r < COV_ROWS; r += 4) {
       const double w = ws[r + lk];
 #pragma unroll
@@ -832,7 +895,7 @@ static int launch_wcov(tph_ctx* ctx, const double* src, int64_t src_ld, const WT
         TPH_HIP(hipFuncSetAttribute((const void*)k_wcov_mfma<WT, NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       hipLaunchKernelGGL((k_wcov_mfma<WT, NV_>), dim3(nblk, 1, nseg), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials, seg); \
     } while (0)
-    if (d <= 32) TPH_WCOV_MFMA(8); else if (d <= 64) TPH_WCOV_MFMA(16); else TPH_WCOV_MFMA(32);
+    if (d <= 32) TPH_WCOV_MFMA(8); else TPH_WCOV_MFMA(0);
 #undef TPH_WCOV_MFMA
     *rows_per_block = 1;
     return 0;
@@ -846,7 +909,7 @@ static int launch_wcov(tph_ctx* ctx, const double* src, int64_t src_ld, const WT
         TPH_HIP(hipFuncSetAttribute((const void*)k_wcov_tiled<WT, NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       hipLaunchKernelGGL((k_wcov_tiled<WT, NV_>), dim3(nblk, 1, nseg), dim3(256), lds, ctx->stream, src, src_ld, d, wt, labels, label, n, mean, partials, seg); \
     } while (0)
-    if (d <= 32) TPH_WCOV_TILED(8); else if (d <= 64) TPH_WCOV_TILED(16); else TPH_WCOV_TILED(32);
+    if (d <= 32) TPH_WCOV_TILED(8); else TPH_WCOV_TILED(0);
 #undef TPH_WCOV_TILED
     *rows_per_block = 1;
     return 0;
@@ -1006,7 +1069,7 @@ static int moments_launch_cov(tph_ctx* ctx, const void* wt, bool wt_is_int, cons
                         : launch_wcov_small<double>(ctx, src, src_ld, (const double*)wt, labels, label, n, mean_dev, partials, nb);
     TPH_REQUIRE(ok, "covariance: no register kernel for n_dim=%d", d);
     double* csum1 = partials + (size_t)nblk * npl;
-    hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, partials, nb, npl, csum1);
+    launch_colsum2(ctx, partials, nb, npl, 1, csum1);
     hipLaunchKernelGGL(k_cov_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum1, sums_dev, d, student, cov_dev);
     TPH_LAUNCH_CHECK();
     return 0;
@@ -1016,7 +1079,7 @@ static int moments_launch_cov(tph_ctx* ctx, const void* wt, bool wt_is_int, cons
                 : launch_wcov<double>(ctx, src, src_ld, (const double*)wt, labels, label, n, mean_dev, partials, nblk, &rpb))
     return -1;
   double* csum = partials + (size_t)nblk * S * npl;
-  hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, partials, nblk * rpb, npl, csum);
+  launch_colsum2(ctx, partials, nblk * rpb, npl, 1, csum);
   hipLaunchKernelGGL(k_cov_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum, sums_dev, d, student, cov_dev);
   TPH_LAUNCH_CHECK();
   return 0;
@@ -1742,7 +1805,7 @@ static int fit_modes_impl(tph_ctx* ctx, const int32_t* counts_dev, const int32_t
       } else {
         if (launch_wcov<int32_t>(ctx, src, src_ld, counts_dev, lab, k, n_work, mean, part_c, nblk, &rows_pb, seg, vl)) return -1;
       }
-      hipLaunchKernelGGL(k_colsum2, dim3(npl, vl), dim3(256), 0, ctx->stream, part_c, nblk * rows_pb, npl, vs);
+      launch_colsum2(ctx, part_c, nblk * rows_pb, npl, vl, vs);
       TPH_LAUNCH_CHECK();
       if (fold_shards(vs, npl, csum)) return -2;
       hipLaunchKernelGGL(k_cov_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum, sums, d, 1, covs_dev + (size_t)k * d * d);
@@ -1913,7 +1976,7 @@ static int moments_shifted(tph_ctx* ctx, const double* w_dev, int64_t n, const d
     C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12)
 #undef C
   }
-  hipLaunchKernelGGL(k_colsum2, dim3(nc), dim3(256), 0, ctx->stream, part, nblk, nc, csum);
+  launch_colsum2(ctx, part, nblk, nc, 1, csum);
   TPH_LAUNCH_CHECK();
   if (global && tph_comm_allreduce(ctx, 0, nc, TPH_DT_F64, TPH_OP_SUM)) return -2;
   hipLaunchKernelGGL(k_wmom_finish, dim3((d * d + 255) / 256), dim3(256), 0, ctx->stream, csum, centre_dev, d, out_dev);
@@ -2206,7 +2269,7 @@ static int vv_reduce(tph_ctx* ctx, const vv_canon& c, const double* partials, in
   const int vl = c.part.vl, T = c.part.T;
   const bool comm = ctx->comm_active();
   const int V = comm ? vl * ctx->world : vl;
-  hipLaunchKernelGGL(k_colsum2, dim3(ncol, c.P), dim3(256), 0, ctx->stream, partials, nblocks, ncol, c.segsums);
+  launch_colsum2(ctx, partials, nblocks, ncol, c.P, c.segsums);
   hipLaunchKernelGGL(k_fold_cols, dim3((ncol + 255) / 256, vl), dim3(256), 0, ctx->stream, (const double*)c.segsums, T, ncol, c.vs);
   TPH_LAUNCH_CHECK();
   const double* rows = c.vs;
@@ -2255,8 +2318,10 @@ extern "C" int tph_volume_variation(tph_ctx* ctx, const double* w_dev, int64_t n
   if (canon) {
     cn.P = cn.part.T * cn.part.vl;
     const int Vt = cn.part.canonical ? cn.part.V : ctx->world;
-    long long b = cn.part.nv / 4096;
-    const long long bcap = 2048 / ((long long)Vt * cn.part.T) > 1 ? 2048 / ((long long)Vt * cn.part.T) : 1;
+    // blocks per piece: >= 1024 rows each, <= 4096 blocks in all (one block per 4096-row piece left a 65 536-particle history of
+    // 46 iterations with 736 blocks -- three per CU -- and the covariance pass at 592 us against 388 us before the partition)
+    long long b = cn.part.nv / 1024;
+    const long long bcap = 4096 / ((long long)Vt * cn.part.T) > 1 ? 4096 / ((long long)Vt * cn.part.T) : 1;
     cn.bps = (int)(b < 1 ? 1 : (b > bcap ? bcap : b));
     const int rp = d <= 12 ? 1 : (d >= 16 ? 1 : cov_slices(npl_));
     size_t per_block = (size_t)(d <= 12 ? ncmax : (rp * npl_ > (1 + d) * 3 ? rp * npl_ : (1 + d) * 3));
@@ -2353,11 +2418,11 @@ extern "C" int tph_volume_variation(tph_ctx* ctx, const double* w_dev, int64_t n
     if (d <= 12) {
       bool ok = launch_wcov_small<double>(ctx, ctx->u, ctx->cap, w_dev, nullptr, 0, n, mean, part, nblk);
       TPH_REQUIRE(ok, "covariance: no register kernel for n_dim=%d", d);
-      hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk, npl, csum);
+      launch_colsum2(ctx, part, nblk, npl, 1, csum);
     } else {
       int rpb = S;
       if (launch_wcov<double>(ctx, ctx->u, ctx->cap, w_dev, (const int32_t*)nullptr, 0, n, mean, part, nblk, &rpb)) return -1;
-      hipLaunchKernelGGL(k_colsum2, dim3(npl), dim3(256), 0, ctx->stream, part, nblk * rpb, npl, csum);
+      launch_colsum2(ctx, part, nblk * rpb, npl, 1, csum);
     }
     TPH_LAUNCH_CHECK();
     if (comm && tph_comm_allreduce(ctx, 4096, npl, TPH_DT_F64, TPH_OP_SUM)) return -2;

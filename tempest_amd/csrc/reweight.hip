@@ -71,7 +71,10 @@ static k2_geom k2_geometry(const tph_ctx* ctx, const tph_part& p) {
   const long long bv_max = cap / p.V > 1 ? cap / p.V : 1;
   long long rb = (p.nv * (long long)p.T + bv_max - 1) / bv_max;
   rb = (rb + 4095) / 4096 * 4096;
-  if (rb < 16384) rb = 16384;
+  // at least 16 384 rows (128 KB of l and of C) per block -- or one whole piece where pieces are smaller: a history of small
+  // pieces must not end up with fewer blocks than the chip has CUs (65 536 particles x 46 iterations: 184 blocks of 16 384 rows ran
+  // the 15-beta pass at 97 us against 47 us before the partition; 736 blocks of one piece each)
+  { const long long floor_rows = p.nv < 16384 ? (p.nv + 4095) / 4096 * 4096 : 16384; if (rb < floor_rows) rb = floor_rows; }
   g.RB = rb;
   if (rb >= p.nv) {
     g.PPB = (int)(rb / p.nv);
@@ -224,39 +227,40 @@ __global__ void __launch_bounds__(1024) k_reweight_vshards(const double* __restr
   if (lane == 0) { double* o = out + ((size_t)v * nb + b) * 3; o[0] = t.m; o[1] = t.s1; o[2] = t.s2; }
 }
 
-// The V per-shard triples folded in shard order.  shards != NULL: the triples as stored (gathered from all ranks, [V][nb][3]);
-// else they are formed here from this rank's block partials (one GPU: the same values, no trip through memory): the 16 waves
-// share the (shard, beta) pairs -- a pair's triple is one wave's work (vshard_triple) --, park the triples in LDS, and wave b's
-// first lane folds beta b's V triples in shard order (V <= 48: a serial chain of merges, ~1 us).  out_host != NULL: results into
-// pinned host memory with a sequence word behind them (system-scope release) -- tph_reweight_eval polls that word instead of
-// queueing a device-to-host copy and waiting on the stream: the ~25 adaptive-beta passes of one PS iteration are latency-bound,
-// and this removes a copy packet and the runtime's completion path from every one of them.
+// The V per-shard triples folded in shard order, one WORKGROUP per beta.  shards != NULL: the triples as stored (gathered from all
+// ranks, [V][nb][3]); else they are formed here from this rank's block partials (one GPU: the same values, no trip through memory):
+// the 16 waves of the beta's workgroup take the shards -- a shard's triple is one wave's work (vshard_triple) --, park them in LDS,
+// and the first lane folds the V triples in shard order (V <= 48: a serial chain of merges, ~1 us).  (One workgroup for ALL betas,
+// as first built, gave a wave 15 (shard, beta) pairs one after the other at 15 betas x 16 shards, each two dependent memory round
+// trips: 40 us per evaluation at 65 536 particles, 291 evaluations per run.)  out_host != NULL: results into pinned host memory
+// with a sequence word behind them, stored by the LAST workgroup to finish (ticket in device memory; every workgroup's results
+// are fenced to system scope before its ticket) -- tph_reweight_eval polls that word instead of queueing a device-to-host copy and
+// waiting on the stream: the ~25 adaptive-beta passes of one PS iteration are latency-bound, and this removes a copy packet and
+// the runtime's completion path from every one of them.
 __global__ void __launch_bounds__(1024) k_reweight_fold(const double* __restrict__ partials, int bv, const double* __restrict__ shards,
-                                                        int V, int nb, double* __restrict__ out, double* __restrict__ seq_host, double seq) {
-  __shared__ double s_t[48 * TPH_MAX_NB * 3];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+                                                        int V, int nb, double* __restrict__ out, double* __restrict__ seq_host, double seq,
+                                                        unsigned int* __restrict__ ticket) {
+  __shared__ double s_t[48 * 3];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6, b = blockIdx.x;
   if (!shards) {
-    for (int p = w; p < V * nb; p += nw) {
-      const int v = p / nb, b = p - v * nb;
+    for (int v = w; v < V; v += nw) {
       const trip t = vshard_triple(partials, v, bv, nb, b, lane);
-      if (lane == 0) { s_t[3 * p] = t.m; s_t[3 * p + 1] = t.s1; s_t[3 * p + 2] = t.s2; }
+      if (lane == 0) { s_t[3 * v] = t.m; s_t[3 * v + 1] = t.s1; s_t[3 * v + 2] = t.s2; }
     }
     __syncthreads();
   }
-  const double* src = shards ? shards : s_t;
-  if (w < nb && lane == 0) {
-    const int b = w;
-    trip acc{src[(size_t)b * 3], src[(size_t)b * 3 + 1], src[(size_t)b * 3 + 2]};
-    for (int v = 1; v < V; ++v) {
-      const double* q = src + ((size_t)v * nb + b) * 3;
-      acc = trip_merge(acc, trip{q[0], q[1], q[2]});
-    }
-    if (acc.m == -DBL_MAX) acc.m = -INFINITY;  // empty input
-    out[b * 3 + 0] = acc.m; out[b * 3 + 1] = acc.s1; out[b * 3 + 2] = acc.s2;
+  if (threadIdx.x != 0) return;
+  trip acc = shards ? trip{shards[(size_t)b * 3], shards[(size_t)b * 3 + 1], shards[(size_t)b * 3 + 2]} : trip{s_t[0], s_t[1], s_t[2]};
+  for (int v = 1; v < V; ++v) {
+    const double* q = shards ? shards + ((size_t)v * nb + b) * 3 : s_t + 3 * v;
+    acc = trip_merge(acc, trip{q[0], q[1], q[2]});
   }
+  if (acc.m == -DBL_MAX) acc.m = -INFINITY;  // empty input
+  out[b * 3 + 0] = acc.m; out[b * 3 + 1] = acc.s1; out[b * 3 + 2] = acc.s2;
   if (seq_host) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    __threadfence_system();
+    if (atomicAdd(ticket, 1u) == (unsigned int)(nb - 1)) {      // every other workgroup's results are out
+      atomicExch(ticket, 0u);
       __threadfence_system();
       __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -308,11 +312,11 @@ static int reweight_pass(tph_ctx* ctx, const tph_betas& bt, int nb, double* out,
     hipLaunchKernelGGL(k_reweight_vshards, dim3(g.vl), dim3(1024), 0, ctx->stream, ctx->partials, g.bv, nb, (double*)(ctx->comm_buf + mine));
     TPH_LAUNCH_CHECK();
     if (tph_comm_allgather(ctx, mine, all, 3 * (int64_t)nb * g.vl, TPH_DT_F64)) return -2;
-    hipLaunchKernelGGL(k_reweight_fold, dim3(1), dim3(1024), 0, ctx->stream, (const double*)nullptr, 0, (const double*)(ctx->comm_buf + all),
-                       g.vl * ctx->world, nb, out, seq_host, seq);
+    hipLaunchKernelGGL(k_reweight_fold, dim3(nb), dim3(64), 0, ctx->stream, (const double*)nullptr, 0, (const double*)(ctx->comm_buf + all),
+                       g.vl * ctx->world, nb, out, seq_host, seq, (unsigned int*)(ctx->small_dev + 4096));
   } else {
-    hipLaunchKernelGGL(k_reweight_fold, dim3(1), dim3(1024), 0, ctx->stream, (const double*)ctx->partials, g.bv, (const double*)nullptr, g.vl, nb,
-                       out, seq_host, seq);
+    hipLaunchKernelGGL(k_reweight_fold, dim3(nb), dim3(1024), 0, ctx->stream, (const double*)ctx->partials, g.bv, (const double*)nullptr, g.vl, nb,
+                       out, seq_host, seq, (unsigned int*)(ctx->small_dev + 4096));
   }
   TPH_LAUNCH_CHECK();
   return 0;
