@@ -89,7 +89,8 @@ class RegimeOptions:
 #   cap, floor: at most `cap` rounds, and only while the expected failure list still holds `floor` particles.
 # All fitted on one MI355X with tools/regime_sweep.py; `source` names the sweep a row came from.
 REGIME_THRESHOLDS = {
-    "screened": {"source": "profiles/r04_regime_sweep.jsonl, profiles/r04_regime_sweep_fan.jsonl (fanned-out list rounds)",
+    "screened": {"source": "profiles/r04_regime_sweep.jsonl, profiles/r04_regime_sweep_fan.jsonl (fanned-out list rounds); the crossover "
+                           "re-measured with the LDS-staged rounds of round 5: profiles/r05_regime_sweep.jsonl (unchanged)",
                  "bands": ((64, 3.0, 5.0, 6, 64.0), (33, 3.4, 5.5, 8, 64.0), (17, 8.0, 13.0, 12, 64.0))},
     "walker": {"source": "profiles/r03_propose_d50_d100.json (screen off: FP64 row walker, multi-lane straggler pass)",
                "bands": ((64, 4.5, 8.0, 24, 24576.0), (17, 3.5, 5.0, 24, 24576.0))},
