@@ -378,6 +378,7 @@ def test_multinomial_counts_sorted_draws_edge_cases(dev):
     for hot in (2047, 2048, 6143):
         w = 1e-7 * rs.rand(6144); w[hot] = 1.0; cases.append(w / w.sum())
     w = np.zeros(6144); w[2047] = 0.5; w[2048] = 0.5; cases.append(w)
+    cases.append(np.zeros(5000))                        # no weight at all (a degenerate cdf): every draw counts for the last row
     for w in cases:
         cdf = c.cdf(torch.from_numpy(w).to(dev))
         for n_draw in (2, 15, 16, 17, 1000, 4099, 300_001):
@@ -387,7 +388,10 @@ def test_multinomial_counts_sorted_draws_edge_cases(dev):
                 got[mode] = c.multinomial_counts(cdf, seed=3, tick=n_draw, kept_count=None, factor=1, n_draw_max=n_draw).cpu().numpy()
             assert got[2].sum() == n_draw
             np.testing.assert_array_equal(got[2], got[0])
-            assert np.all(got[2][w == 0.0] == 0)
+            if w.sum() > 0:
+                assert np.all(got[2][w == 0.0] == 0)
+            else:
+                assert got[2][-1] == n_draw
     kc = torch.tensor([123.0], dtype=torch.float64, device=dev)          # the draw count from the device: 4 x 123
     cdf = c.cdf(torch.from_numpy(cases[0]).to(dev))
     c.set_option(OPT_SORTED_DRAWS, 2)
