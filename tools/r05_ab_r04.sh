@@ -1,6 +1,8 @@
 #!/bin/bash
 # same box, alternating: the configurations end to end with round 4's package (scratch/r04_pkg: commit b07d541 + its library) and
-# with this tree; two runs per process (the second is what a long job sees)
+# with this tree; two runs per process (the second is what a long job sees).  The old package is not kept in the tree; recreate it with
+#   mkdir -p scratch/r04_pkg && git archive b07d541 tempest_amd tools/run_config.py oracle bench.py | tar -x -C scratch/r04_pkg
+#   (cd scratch/r04_pkg/tempest_amd/csrc && make)      # or copy a library built from that commit to libtempest_hip.so there
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 O=gpurun_out/r05/ab_r04; rm -rf $O; mkdir -p $O
