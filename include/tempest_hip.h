@@ -158,6 +158,11 @@ int tph_warmup(tph_ctx* ctx);
  * lane per row (row in LDS, precision matrix through scalar loads), 2 = 16 rows per wave on the FP64 matrix cores (measured slower on config 3: 158 against
  * 107 us per pass; kept for the parity test).  Same values to rounding (different summation order). */
 #define TPH_OPT_GMM_KERNEL 21
+/* TPH_OPT_FORMS_MFMA: 1 = the forms |L^-1 (u' - mu)|^2 behind the screened batches (tpCN, one mode, 16 < n_dim <= 112) come from the
+ * matrix-core blocks of the blocked rounds (the same instructions as the rounds' own forms) instead of the lane-per-particle
+ * pass through the scalar cache; 0 (default) = the latter.  Same values to rounding; measured 49.6 against 54.0 us per launch at
+ * 131 072 x 100-D. */
+#define TPH_OPT_FORMS_MFMA 22
 int tph_set_option(tph_ctx* ctx, int option, int value);
 
 /* ---- multi-GPU: one process per GPU --------------------------------------

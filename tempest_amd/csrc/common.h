@@ -128,6 +128,7 @@ struct tph_ctx {
   // matrix-core round kernel of the blocked path (propose_blkm.hip): TPH_OPT_BLK_MFMA and its blocked copies of L and L^-1
   int blk_mfma = 1;
   int blk_tries = 0;                // TPH_OPT_BLK_TRIES: attempts a round of the matrix-core kernel gives its failing columns in place (0 = by n_dim)
+  int forms_mfma = 0;               // TPH_OPT_FORMS_MFMA: 1 = the forms behind the screened batches (tpCN, one mode) on the matrix cores (tph_blkm_forms)
   int gmm_kernel = 0;               // TPH_OPT_GMM_KERNEL: clustering E-step at n_dim >= 16: 0 auto (= 1) | 1 one lane per row | 2 matrix cores
   int blk_stage = 1;                // TPH_OPT_BLK_STAGE: 1 (default) = one-try rounds of one mode stage the panels' matrix blocks in LDS (k_propose_blkm_lds; bitwise the same draws)
   int blk_fan = 1;                  // TPH_OPT_BLK_FAN: list rounds give a straggler up to 16 attempts side by side (1 = default)
@@ -430,6 +431,10 @@ struct tph_stepctl {
   // recomputing a d x d quadratic form per particle (same formula on the same doubles: bit-identical).
   __device__ __forceinline__ bool carry() const { return ctl && ctl[0] > 0.0; }
 };
+// the forms of a finished step on the matrix cores (propose_blkm.hip)
+int tph_blkm_forms(tph_ctx* ctx, const double* up, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,
+                   double* maha, tph_stepctl tick, const unsigned long long* queue, const int32_t* todo_cnt, const int32_t* todo_rows,
+                   const int32_t* todo_off);
 
 // Gamma(shape,1), Marsaglia-Tsang; attempt a uses draw a (one Philox call: normal and uniform); shape<1 boosted.
 __device__ inline double tph_gamma_mt(const tph_rng& g, double shape, int first_attempt = 0) {

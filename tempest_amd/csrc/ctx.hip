@@ -408,6 +408,7 @@ extern "C" int tph_ctx_create(int device, int n_dim, int64_t capacity_hint, void
   if (const char* env = getenv("TEMPEST_AMD_BLK_STAGE")) c->blk_stage = atoi(env) ? 1 : 0;       // debugging aid (TPH_OPT_BLK_STAGE)
   if (const char* env = getenv("TEMPEST_AMD_COV_KERNEL")) c->cov_kernel = atoi(env);             // debugging aid (TPH_OPT_COV_KERNEL)
   if (const char* env = getenv("TEMPEST_AMD_GMM_KERNEL")) c->gmm_kernel = atoi(env);             // debugging aid (TPH_OPT_GMM_KERNEL)
+  if (const char* env = getenv("TEMPEST_AMD_FORMS_MFMA")) c->forms_mfma = atoi(env) ? 1 : 0;     // debugging aid (TPH_OPT_FORMS_MFMA)
   if (const char* env = getenv("TEMPEST_AMD_MF_DEAL")) c->mf_deal = atoi(env) < 0 ? 0 : (atoi(env) > 2 ? 2 : atoi(env));          // debugging aid (TPH_OPT_MF_DEAL)
   if (const char* env = getenv("TEMPEST_AMD_HISTORY_VM")) c->hist_vm_mode = atoi(env) < 0 ? 0 : (atoi(env) > 2 ? 2 : atoi(env));   // debugging aid (TPH_OPT_HISTORY_VM)
   c->d = n_dim;
@@ -589,6 +590,7 @@ extern "C" int tph_set_option(tph_ctx* ctx, int option, int value) {
     case TPH_OPT_BLK_FAN: ctx->blk_fan = value < 0 ? 0 : (value > 3 ? 3 : value); break;
     case TPH_OPT_BLK_STAGE: ctx->blk_stage = value ? 1 : 0; break;
     case TPH_OPT_GMM_KERNEL: ctx->gmm_kernel = value < 0 || value > 2 ? 0 : value; break;
+    case TPH_OPT_FORMS_MFMA: ctx->forms_mfma = value ? 1 : 0; break;
     case TPH_OPT_MF_DEAL: ctx->mf_deal = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case TPH_OPT_HISTORY_VM: ctx->hist_vm_mode = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     default: TPH_REQUIRE(false, "tph_set_option: unknown option %d", option);

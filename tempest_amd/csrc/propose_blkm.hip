@@ -859,6 +859,74 @@ static int blkm_round(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
                                     cnt_in, rows_in, att, cnt_out, rows_out, nullptr, 0, att_in, att_out);
 }
 
+// ---- the forms |L^-1 (u' - mu)|^2 of a finished step on the matrix cores (tpCN, one mode) -------------------------------------
+// What the closing pass behind the screened batches needs (maha_tile.h, MODE 1: a lane per particle, L^-1 through the scalar cache,
+// waves waiting on it 80 % of their cycles) in the arithmetic of the blocked rounds: a wave per 16 particles, the natural-step
+// blocks of L^-1 (k_blkm_pack, perm = 0), panels ascending -- the `form` of k_propose_blkm instruction for instruction, so that
+// the form of a proposal no longer depends on which kernel found it.  todo_cnt != NULL: the listed particles only.
+// MEASURED on config 5's shard (131 072 x 100-D, 2929 launches): 49.6 us per launch against 54.0 us for the lane-per-particle pass --
+// every wave streams the 57 KB of blocks from L2, 470 MB per launch; with the blocks staged in LDS per workgroup (two workgroups per
+// CU at 100-D) 65.3 us.  A gain of half a per cent of the run: an option (TPH_OPT_FORMS_MFMA), off by default.
+template <int NP>
+__global__ void __launch_bounds__(256) k_forms_mfma(const double* __restrict__ up, int64_t n, int64_t ld, int d, const double* __restrict__ means,
+                                                    const double* __restrict__ Wm, double* __restrict__ maha, tph_stepctl tick,
+                                                    const unsigned long long* __restrict__ queue, const int32_t* __restrict__ todo_cnt,
+                                                    const int32_t* __restrict__ todo_rows, const int32_t* __restrict__ todo_off) {
+  constexpr int NS = 4 * NP;
+  if (todo_off) todo_rows += *todo_off;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, k = lane >> 4, nn = lane & 15;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && tick.ctl && queue)      // the step's mean attempts per particle (regime probe)
+    const_cast<double*>(tick.ctl)[8] = queue[2] ? (double)queue[1] / (double)queue[2] : 0.0;
+  int64_t idx = ((int64_t)blockIdx.x * 4 + wid) * 16 + nn, lim = n;
+  if (todo_cnt) lim = *todo_cnt;
+  if (((int64_t)blockIdx.x * 4 + wid) * 16 >= lim) return;           // (the whole wave)
+  const bool live = idx < lim;
+  int64_t i = live ? idx : lim - 1;
+  if (todo_cnt) i = (int64_t)todo_rows[i];
+  double X[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int r = 4 * s + k;
+    X[s] = r < d ? up[(size_t)r * ld + i] - means[r] : 0.0;
+  }
+  double part = 0.0;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    bm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4 * p + 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wm[(size_t)bm_blk(p, s) * 64 + lane], X[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part = fma(acc[q], acc[q], part);
+  }
+  part += __shfl_xor(part, 16, 64);
+  part += __shfl_xor(part, 32, 64);
+  if (live && k == 0) maha[i] = part;
+}
+
+int tph_blkm_forms(tph_ctx* ctx, const double* up, int64_t n, int64_t ld, const double* means, const double* chol, const double* winv,
+                   double* maha, tph_stepctl tick, const unsigned long long* queue, const int32_t* todo_cnt, const int32_t* todo_rows,
+                   const int32_t* todo_off) {
+  const int d = ctx->d, np = bm_panels(d);
+  TPH_REQUIRE(d > 16 && d <= 112, "tph_blkm_forms: n_dim=%d outside 17..112", d);
+  double *Lm, *Wm;
+  if (blkm_pack<TPH_KERNEL_TPCN>(ctx, 1, chol, winv, &Lm, &Wm)) return -1;
+  bool rebuilt;
+  if (blkm_refresh<TPH_KERNEL_TPCN>(ctx, 1, chol, winv, Lm, Wm, &rebuilt)) return -1;
+  const dim3 grid((unsigned)((n + 63) / 64));
+#define TPH_FM(NPV) hipLaunchKernelGGL((k_forms_mfma<NPV>), grid, dim3(256), 0, ctx->stream, up, n, ld, d, means, (const double*)Wm, maha, tick, queue, todo_cnt, todo_rows, todo_off)
+  switch (np) {
+    case 2: TPH_FM(2); break;
+    case 3: TPH_FM(3); break;
+    case 4: TPH_FM(4); break;
+    case 5: TPH_FM(5); break;
+    case 6: TPH_FM(6); break;
+    default: TPH_FM(7); break;
+  }
+#undef TPH_FM
+  TPH_LAUNCH_CHECK();
+  return 0;
+}
+
 int tph_blkm_tries(const tph_ctx* ctx) { return bm_tries(ctx); }
 
 int tph_blkm_round(tph_ctx* ctx, int kernel, double* u, int64_t n, int64_t ld, const double* means, const double* chol,

@@ -712,6 +712,8 @@ static int propose_mf(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const doub
   if (pend || KERNEL == TPH_KERNEL_TPCN || maha_u)
     if (launch_maha_tile<KERNEL, 0>(ctx, u, n, ld, means, b.Wb, up, maha_u, tick, pend, nullptr, dof, sigmas, seed, item0, maha_up)) return -1;
   if (mf_launch<KERNEL>(ctx, b, u, n, ld, means, sigmas, bc, seed, tick, item0, up, maha_up, nullptr, nullptr, 0)) return -1;
+  if (KERNEL == TPH_KERNEL_TPCN && ctx->forms_mfma && d <= 112)
+    return tph_blkm_forms(ctx, up, n, ld, means, chol, winv, maha_up, tick, b.queue, nullptr, nullptr, nullptr);
   if (KERNEL == TPH_KERNEL_TPCN || maha_up || tick.ctl)
     if (launch_maha_tile<KERNEL, 1>(ctx, u, n, ld, means, b.Wb, up, maha_up, tick, nullptr, b.queue, dof, sigmas, seed, item0, nullptr)) return -1;
   return 0;
@@ -728,6 +730,8 @@ static int propose_mf_list(tph_ctx* ctx, double* u, int64_t n, int64_t ld, const
   mf_bufs b;
   if (mf_prepare<KERNEL>(ctx, chol, winv, &b, !queue_zeroed)) return -1;
   if (mf_launch<KERNEL>(ctx, b, u, n, ld, means, sigmas, bc, seed, tick, item0, up, maha_up, todo_cnt, todo_rows, att0, att0_dev)) return -1;
+  if (KERNEL == TPH_KERNEL_TPCN && ctx->forms_mfma && ctx->d <= 112)
+    return tph_blkm_forms(ctx, up, n, ld, means, chol, winv, maha_up, tick, nullptr, todo_cnt, todo_rows, nullptr);
   if (KERNEL == TPH_KERNEL_TPCN || maha_up)
     if (launch_maha_tile<KERNEL, 1>(ctx, u, n, ld, means, b.Wb, up, maha_up, tick, nullptr, nullptr, dof, sigmas, seed, item0, nullptr,
                                     todo_cnt, todo_rows)) return -1;

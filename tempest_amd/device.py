@@ -35,6 +35,7 @@ OPT_HISTORY_VM = 18            # TPH_OPT_HISTORY_VM
 OPT_MF_DEAL = 19               # TPH_OPT_MF_DEAL
 OPT_BLK_STAGE = 20             # TPH_OPT_BLK_STAGE
 OPT_GMM_KERNEL = 21            # TPH_OPT_GMM_KERNEL
+OPT_FORMS_MFMA = 22            # TPH_OPT_FORMS_MFMA
 BC_STRICT, BC_PERIODIC, BC_REFLECTIVE = 0, 1, 2
 
 TAG_PRIOR, TAG_NORMAL, TAG_GAMMA, TAG_ACCEPT, TAG_RESAMPLE, TAG_UPSAMPLE, TAG_REPAIR, TAG_SYST = 1, 2, 3, 4, 5, 6, 7, 8

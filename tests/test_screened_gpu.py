@@ -299,3 +299,38 @@ def test_screened_kernel_with_several_modes_vs_oracle_and_single_mode_launches(d
             single = _run(6, d, kernel, u[r:r + 1], one, sm, ft, seed, tick, item0 + int(r), dev)
             np.testing.assert_array_equal(single[0][0], g[0][r])
             assert single[2][0] == g[2][r]
+
+
+@pytest.mark.parametrize("bc", [None, "mixed"])
+@pytest.mark.parametrize("d", [19, 33, 50, 65, 100, 112])
+def test_forms_behind_the_screened_batches_on_the_matrix_cores(dev, bc, d):
+    """TPH_OPT_FORMS_MFMA: the forms |L^-1 (u' - mu)|^2 of a screened step from the matrix-core blocks of the blocked rounds
+    (tph_blkm_forms) instead of the lane-per-particle pass: the proposals are untouched (bit for bit), the forms equal the oracle's
+    and the lane-per-particle pass's to rounding, the regime probe is the same number; also with a straggler list behind a
+    blocked round (variant 4: the closing pass over the listed particles)."""
+    from tempest_amd.device import HipContext
+    n = 1300
+    means, chol, inv, u = _ensemble(d, n, 77 + d)
+    dof, sigmas = np.array([1e6]), np.array([2.38 / np.sqrt(d)])
+    flags = omc.bc_flags(d, [1], [min(4, d - 1)]) if bc else omc.bc_flags(d)
+    seed, tick, item0 = 313, 5, 9_000_000
+    want_up, _, want_mup = omc.propose("tpcn", u, np.zeros(n, dtype=np.int32), means, chol, inv, dof, sigmas, flags, seed, tick, item0)
+    modes = _Modes(means, chol, inv, dof, dev)
+    st, ft = torch.from_numpy(sigmas).to(dev), torch.from_numpy(flags).to(dev)
+    for variant, rounds in ((6, 0), (4, 2)):
+        got = {}
+        for mf in (0, 1):
+            c = HipContext(d, device=0)
+            c.set_option(OPT_VARIANT, variant)
+            c.set_option(4, rounds)
+            c.set_option(22, mf)                      # TPH_OPT_FORMS_MFMA
+            up, mu_, mup = c.empty(d, n), c.empty(n), c.empty(n)
+            state = c.zeros(10)
+            c.propose("tpcn", soa(u, dev), None, modes, st, ft, seed, tick, item0, up, mu_, mup, ctl=state)
+            got[mf] = (aos(up), mup.cpu().numpy(), state.cpu().numpy())
+            c.close()
+        np.testing.assert_array_equal(got[1][0], got[0][0])
+        np.testing.assert_allclose(got[1][0], want_up, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(got[1][1], got[0][1], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(got[1][1], want_mup, rtol=1e-8, atol=1e-8)
+        assert got[1][2][8] == got[0][2][8]
